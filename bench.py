@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py — PHJ |R|=64M join |S|=1G per GPU on MI355X (BASELINE.json configs[2];
+with --gpus N: configs[3], build side RCCL-broadcast, probe side sharded).
+
+One "step" = one complete partitioned hash join over HBM-resident columns:
+fused histogram (R,S) -> plan -> scatter pass 1 -> scatter pass 2 -> LDS
+build+probe, aggregates (count + 3 checksums) resident in HBM at the end.
+Nothing is skipped or cached between steps; the join result of every step is
+checked against the analytic aggregates of the generated relations.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task).
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+INNER_FACTOR, OUTER_FACTOR = 0x2545F491, 0x9E3779B1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--algo", choices=["phj", "npj", "cpra"], default="phj")
+    ap.add_argument("--inner", type=int, default=64_000_000, help="|R| build tuples (replicated)")
+    ap.add_argument("--outer", type=int, default=1_000_000_000, help="|S| probe tuples PER GPU")
+    ap.add_argument("--fanout1", type=int, default=0)
+    ap.add_argument("--fanout2", type=int, default=0)
+    ap.add_argument("--cpu-outer", type=int, default=256_000_000,
+                    help="probe tuples of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
+    ap.add_argument("--materialize", action="store_true", help="also time the materialising join once")
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child
+    process group BEFORE anything touches the GPU, and exit with its code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def cpu_baseline(hj, H, args, algo):
+    """The oracle's restatement of the reference's CPU algorithm ("port"), timed on
+    this host's cores on a bounded sample of the same workload shape."""
+    import numpy as np
+    from oracle import oracle as O
+    outer = min(args.cpu_outer, args.outer)
+    inner = max(1, int(args.inner * (outer / args.outer)))
+    threads = args.cpu_threads or (os.cpu_count() or 1)
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(1, inner, outer, 0, outer, INNER_FACTOR, OUTER_FACTOR, ik, iv, ok, ov)
+    hik, hiv, hok, hov = ik.download(), iv.download(), ok.download(), ov.download()
+    sums = hj.column_sums(ok, outer, OUTER_FACTOR, INNER_FACTOR)
+    for c in (ik, iv, ok, ov):
+        c.free()
+    tm = O.Timing()
+    if algo == "npj":
+        res = O.npj(hik, hiv, hok, hov, threads=threads, load=0.90, timing=tm)     # npj.cpp:944
+    elif algo == "cpra":
+        res = O.cpra(hik, hiv, hok, hov, threads=threads, timing=tm)
+    else:
+        res = O.phj(hik, hiv, hok, hov, threads=threads, timing=tm)
+    ok_ = res == (outer, sums[0], sums[1], sums[2])
+    return {"value": outer / tm.seconds / 1e9, "unit": "Gtuples/s", "cores": threads,
+            "kind": "port",
+            "sample": "%s |R|=%d join |S|=%d (same generator, 1/%g of the per-GPU workload), "
+                      "oracle/hj_oracle.c pthreads, %.3f s, checksum %s"
+                      % (algo, inner, outer, args.outer / outer, tm.seconds,
+                         "ok" if ok_ else "MISMATCH"),
+            "seconds": tm.seconds}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        relaunch_under_torchrun(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = max(args.gpus, world)
+
+    import torch
+    import hash_join_codes_knl_amd as H
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if n_gpus > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+
+    hj = H.HjGpu(local_rank)
+    info = hj.device_info()
+    inner, outer = args.inner, args.outer
+    outer_total = outer * n_gpus
+
+    # ---- relations resident in HBM (torch owns the memory; the library borrows pointers)
+    def col(n):
+        return torch.empty(n + 4, dtype=torch.int32, device=dev)
+    rk, rv, sk, sv = col(inner), col(inner), col(outer), col(outer)
+    stream = torch.cuda.current_stream().cuda_stream
+    # every rank generates R (identical) and its own shard of S
+    hj.generate(1, inner, outer_total, rank * outer, outer, INNER_FACTOR, OUTER_FACTOR,
+                rk.data_ptr(), rv.data_ptr(), sk.data_ptr(), sv.data_ptr(), stream)
+    sums = hj.column_sums(sk.data_ptr(), outer, OUTER_FACTOR, INNER_FACTOR, stream)
+    # uint64 aggregates as int64 bit patterns (sums stay far below 2^63 at these sizes)
+    expect_local = [outer, sums[0], sums[1], sums[2]]
+    if dist is not None:
+        e = torch.tensor(expect_local, dtype=torch.int64, device=dev)
+        dist.all_reduce(e)
+        expect_global = [int(x) for x in e.tolist()]
+        # the build side lives on rank 0 and is broadcast each step (measured, not assumed)
+        r_src_k, r_src_v = rk.clone(), rv.clone()
+    else:
+        expect_global = expect_local
+
+    hj.reserve(inner, outer)
+    prm = H.PhjParams(fanout1=args.fanout1, fanout2=args.fanout2)
+    nprm = H.NpjParams(load=0.5)
+    d_result = torch.zeros(4, dtype=torch.int64, device=dev)
+
+    def step():
+        if dist is not None:
+            # exchange step of the multi-GPU path: replicate the build side over xGMI
+            if rank == 0:
+                rk.copy_(r_src_k); rv.copy_(r_src_v)
+            dist.broadcast(rk, 0)
+            dist.broadcast(rv, 0)
+        s = torch.cuda.current_stream().cuda_stream
+        a = (rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer)
+        if args.algo == "phj":
+            hj.phj_async(*a, prm, d_result.data_ptr(), s)
+        elif args.algo == "cpra":
+            hj.cpra_async(*a, prm, d_result.data_ptr(), s)
+        else:
+            hj.npj_async(*a, nprm, d_result.data_ptr(), s)
+        if dist is not None:
+            dist.all_reduce(d_result)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join",
+              "ms_build", "ms_close_gaps"]
+    acc = {p: 0.0 for p in phases}
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    got = [int(x) for x in d_result.tolist()] if args.warmup else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = hj.stats()                 # hipEvent spans of this step's kernels (same stream)
+        for p in phases:
+            acc[p] += st[p]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    got = [int(x) for x in d_result.tolist()]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    checksum_ok = got == expect_global
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = outer_total / (elapsed / args.steps) / 1e9
+    avg = {p: acc[p] / args.steps for p in phases}
+    n_tuples = inner + outer                      # per GPU
+    st = hj.stats()
+
+    # ---- roofline of each kernel: algorithmic bytes / measured time ----
+    def roof(bytes_per_step, ms, launches, bound="hbm"):
+        if ms <= 0:
+            return None
+        gbs = bytes_per_step / (ms * 1e-3) / 1e9
+        return {"bound": bound, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(ms / launches, 4), "launches_per_step": launches,
+                "algorithmic_bytes_per_launch": int(bytes_per_step / launches)}
+    kernels = {}
+    if args.algo in ("phj", "cpra"):
+        two = st["fanout2"] > 1
+        kernels["hist2_kernel"] = roof(4 * n_tuples, avg["ms_histogram"], 2)
+        kernels["scatter_kernel"] = roof((2 if two else 1) * 16 * n_tuples,
+                                         avg["ms_scatter1"] + avg["ms_scatter2"], 4 if two else 2)
+        kernels["join_kernel"] = roof(8 * n_tuples, avg["ms_join"], 1)
+        join_ms = avg["ms_join"]
+    else:
+        kernels["npj_build_kernel"] = roof(8 * inner + 8 * st["buckets"] + 8 * inner, avg["ms_build"], 1)
+        kernels["npj_probe_kernel"] = roof(16 * outer, avg["ms_join"], 1)
+        join_ms = avg["ms_join"]
+    kernels = {k: v for k, v in kernels.items() if v}
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches_per_step"])
+    roofline = dict(kernels[dominant])
+    roofline["kernel"] = dominant
+
+    out = {
+        "metric": "probe Gtuples/s + % HBM roofline, PHJ |R|=64M join |S|=1G, 1/2/4/8 GPU",
+        "value": round(value, 3), "unit": "Gtuples/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s end-to-end (histogram + %s + LDS build/probe, aggregate output), "
+                               "uniform unique 32-bit keys, |R|=%d replicated, |S|=%d per GPU, selectivity 1"
+                               % (args.algo.upper(), "2 scatter passes" if st["fanout2"] > 1 else "1 scatter pass",
+                                  inner, outer),
+                   "algorithm": args.algo, "inner_tuples": inner, "outer_tuples_per_gpu": outer,
+                   "outer_tuples_total": outer_total,
+                   "fanout": [st["fanout1"], st["fanout2"]],
+                   "parallelism": "probe side sharded over %d GPU(s), build side %s"
+                                  % (n_gpus, "RCCL-broadcast each step" if n_gpus > 1 else "local")},
+        "roofline": roofline,
+        "roofline_kernels": kernels,
+        "join_phase": {"gtuples_per_s_per_gpu": round(outer / (join_ms * 1e-3) / 1e9, 2) if join_ms > 0 else None,
+                       "ms": round(join_ms, 4),
+                       "hbm_read_frac": round(8 * n_tuples / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if join_ms > 0 else None},
+        "phase_ms": {k: round(v, 4) for k, v in avg.items()},
+        "checksum_ok": checksum_ok,
+        "result": {"count": got[0], "sum_keys": got[1], "sum_outer_vals": got[2], "sum_inner_vals": got[3]},
+        "device": info["name"], "arch": info["arch"],
+    }
+    if rank == 0 and n_gpus == 1 and args.cpu_outer > 0:
+        try:
+            out["cpu_baseline"] = cpu_baseline(hj, H, args, args.algo)
+        except Exception as ex:          # the baseline is reported, never required
+            out["cpu_baseline"] = {"value": None, "unit": "Gtuples/s", "cores": 0, "kind": "port",
+                                   "sample": "failed: %r" % (ex,)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    hj.close()
+    if not checksum_ok:
+        sys.exit("join result does not match the analytic aggregates: got %r want %r" % (got, expect_global))
+
+
+if __name__ == "__main__":
+    main()

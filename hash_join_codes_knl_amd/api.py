@@ -1,0 +1,310 @@
+"""ctypes binding of the C-ABI in include/hjgpu.h — names, argument meaning and
+error behaviour mirror the header one to one (which in turn cites the reference
+operators each entry point replaces).
+
+There is NO CPU fallback: if libhjgpu.so is missing or no GPU is visible the
+binding raises.  Device memory is owned by the library (hjgpu_malloc) or by the
+caller (any device pointer, e.g. torch.Tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK, EINVAL, EALIGN, ENOMEM, EHIP, EZEROKEY, EOVERFLOW, ENODEVICE = range(8)
+MAX_FANOUT = 1024
+MAX_PARTS = 32768
+
+EXPORTS = [
+    "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
+    "hjgpu_get_device_info", "hjgpu_reserve", "hjgpu_get_stats",
+    "hjgpu_malloc", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
+    "hjgpu_histogram", "hjgpu_partition", "hjgpu_join_partitions",
+    "hjgpu_npj_build", "hjgpu_npj_probe",
+    "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
+    "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async",
+    "hjgpu_join_host", "hjgpu_generate", "hjgpu_column_sums",
+]
+
+
+class Result(C.Structure):
+    _fields_ = [("count", C.c_uint64), ("sum_keys", C.c_uint64),
+                ("sum_outer_vals", C.c_uint64), ("sum_inner_vals", C.c_uint64)]
+
+    def as_tuple(self):
+        return (self.count, self.sum_keys, self.sum_outer_vals, self.sum_inner_vals)
+
+
+class Output(C.Structure):
+    _fields_ = [("d_keys", C.c_void_p), ("d_outer_vals", C.c_void_p), ("d_inner_vals", C.c_void_p),
+                ("capacity", C.c_size_t), ("block_size", C.c_size_t)]
+
+
+class PhjParams(C.Structure):
+    _fields_ = [("fanout1", C.c_uint32), ("fanout2", C.c_uint32),
+                ("factor1", C.c_uint32), ("factor2", C.c_uint32),
+                ("table_factor", C.c_uint32 * 2),
+                ("chunks", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class NpjParams(C.Structure):
+    _fields_ = [("load", C.c_double), ("factor", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_histogram", C.c_float), ("ms_plan", C.c_float),
+                ("ms_scatter1", C.c_float), ("ms_scatter2", C.c_float), ("ms_join", C.c_float),
+                ("ms_build", C.c_float), ("ms_close_gaps", C.c_float),
+                ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("buckets", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int),
+                ("lds_bytes_per_block", C.c_int), ("hbm_bytes", C.c_uint64)]
+
+
+class HjGpuError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("hjgpu status %d (%s)" % (status, text))
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(build_if_missing=True):
+    """Loads hash_join_codes_knl_amd/lib/libhjgpu.so; raises if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.lib_path()
+    if not os.path.exists(so):
+        if not build_if_missing:
+            raise FileNotFoundError(so + " is missing: run `python -m hash_join_codes_knl_amd.build`")
+        _build.build_library(verbose=False)
+    L = C.CDLL(so)
+    vp, sz, u32, u64p = C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64)
+    L.hjgpu_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.hjgpu_destroy.argtypes = [vp]
+    L.hjgpu_last_error.restype = C.c_char_p
+    L.hjgpu_last_error.argtypes = [vp]
+    L.hjgpu_status_string.restype = C.c_char_p
+    L.hjgpu_status_string.argtypes = [C.c_int]
+    L.hjgpu_get_device_info.argtypes = [vp, C.POINTER(DeviceInfo)]
+    L.hjgpu_reserve.argtypes = [vp, sz, sz]
+    L.hjgpu_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.hjgpu_malloc.argtypes = [vp, C.POINTER(vp), sz]
+    L.hjgpu_free.argtypes = [vp, vp]
+    L.hjgpu_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.hjgpu_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.hjgpu_synchronize.argtypes = [vp, vp]
+    L.hjgpu_histogram.argtypes = [vp, vp, sz, u32, u32, vp, vp]
+    L.hjgpu_partition.argtypes = [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]
+    L.hjgpu_join_partitions.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(PhjParams),
+                                        C.POINTER(Result), C.POINTER(Output), vp]
+    L.hjgpu_npj_build.argtypes = [vp, vp, vp, sz, vp, sz, u32, vp]
+    L.hjgpu_npj_probe.argtypes = [vp, vp, vp, sz, vp, sz, u32, C.POINTER(Result),
+                                  C.POINTER(Output), vp]
+    join = [vp, vp, vp, sz, vp, vp, sz]
+    L.hjgpu_npj.argtypes = join + [C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Output), vp]
+    L.hjgpu_phj.argtypes = join + [C.POINTER(PhjParams), C.POINTER(Result), C.POINTER(Output), vp]
+    L.hjgpu_cpra.argtypes = join + [C.POINTER(PhjParams), C.POINTER(Result), C.POINTER(Output), vp]
+    L.hjgpu_npj_async.argtypes = join + [C.POINTER(NpjParams), vp, vp]
+    L.hjgpu_phj_async.argtypes = join + [C.POINTER(PhjParams), vp, vp]
+    L.hjgpu_cpra_async.argtypes = join + [C.POINTER(PhjParams), vp, vp]
+    L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
+                                  C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Stats)]
+    L.hjgpu_generate.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
+    L.hjgpu_column_sums.argtypes = [vp, vp, sz, u32, u32, u64p, vp]
+    for name in EXPORTS:
+        if name not in ("hjgpu_last_error", "hjgpu_status_string"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+class DeviceColumn:
+    """A uint32/uint64 column in HBM owned through hjgpu_malloc."""
+
+    def __init__(self, ctx, n, dtype=np.uint32):
+        self.ctx, self.n, self.dtype = ctx, int(n), np.dtype(dtype)
+        p = C.c_void_p()
+        ctx._check(ctx.lib.hjgpu_malloc(ctx.handle, C.byref(p), self.n * self.dtype.itemsize))
+        self.ptr = p.value
+
+    @property
+    def nbytes(self):
+        return self.n * self.dtype.itemsize
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.size == self.n
+        self.ctx._check(self.ctx.lib.hjgpu_memcpy_h2d(self.ctx.handle, self.ptr,
+                                                      host.ctypes.data, self.nbytes))
+        return self
+
+    def download(self, n=None):
+        n = self.n if n is None else int(n)
+        host = np.empty(n, self.dtype)
+        self.ctx._check(self.ctx.lib.hjgpu_memcpy_d2h(self.ctx.handle, host.ctypes.data,
+                                                      self.ptr, n * self.dtype.itemsize))
+        return host
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.hjgpu_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class HjGpu:
+    """One hjgpu_ctx.  Methods are named after the C entry points (hjgpu_ prefix dropped)."""
+
+    def __init__(self, device=-1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.hjgpu_create(device, C.byref(h))
+        if st != OK:
+            raise HjGpuError(st, self.lib.hjgpu_status_string(st).decode())
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.hjgpu_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st):
+        if st != OK:
+            raise HjGpuError(st, "%s: %s" % (self.lib.hjgpu_status_string(st).decode(),
+                                             self.lib.hjgpu_last_error(self.handle).decode()))
+
+    # ---- helpers -----------------------------------------------------------------
+    def column(self, host_or_n, dtype=np.uint32):
+        if isinstance(host_or_n, (int, np.integer)):
+            return DeviceColumn(self, host_or_n, dtype)
+        host = np.ascontiguousarray(host_or_n, dtype=dtype)
+        return DeviceColumn(self, host.size, dtype).upload(host)
+
+    def device_info(self):
+        info = DeviceInfo()
+        self._check(self.lib.hjgpu_get_device_info(self.handle, C.byref(info)))
+        return {"name": info.name.decode(), "arch": info.arch.decode(),
+                "compute_units": info.compute_units,
+                "lds_bytes_per_block": info.lds_bytes_per_block, "hbm_bytes": info.hbm_bytes}
+
+    def reserve(self, inner, outer):
+        self._check(self.lib.hjgpu_reserve(self.handle, inner, outer))
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.hjgpu_get_stats(self.handle, C.byref(s)))
+        return s.as_dict()
+
+    def synchronize(self, stream=None):
+        self._check(self.lib.hjgpu_synchronize(self.handle, stream))
+
+    @staticmethod
+    def _ptr(x):
+        return x.ptr if isinstance(x, DeviceColumn) else x
+
+    def _out(self, out):
+        if out is None:
+            return None
+        keys, ov, iv, capacity, block_size = out
+        return C.byref(Output(self._ptr(keys), self._ptr(ov), self._ptr(iv), capacity, block_size))
+
+    # ---- operators ------------------------------------------------------------------
+    def histogram(self, d_keys, n, factor, fanout, d_counts, stream=None):
+        self._check(self.lib.hjgpu_histogram(self.handle, self._ptr(d_keys), n, factor, fanout,
+                                             self._ptr(d_counts), stream))
+
+    def partition(self, d_keys, d_vals, n, factor, fanout, d_keys_out, d_vals_out, d_offsets,
+                  stream=None):
+        self._check(self.lib.hjgpu_partition(self.handle, self._ptr(d_keys), self._ptr(d_vals), n,
+                                             factor, fanout, self._ptr(d_keys_out),
+                                             self._ptr(d_vals_out), self._ptr(d_offsets), stream))
+
+    def join_partitions(self, rk, rv, roff, sk, sv, soff, params, out=None, stream=None):
+        r = Result()
+        self._check(self.lib.hjgpu_join_partitions(self.handle, self._ptr(rk), self._ptr(rv),
+                                                   self._ptr(roff), self._ptr(sk), self._ptr(sv),
+                                                   self._ptr(soff), C.byref(params), C.byref(r),
+                                                   self._out(out), stream))
+        return r.as_tuple()
+
+    def npj_build(self, d_keys, d_vals, n, d_table, buckets, factor, stream=None):
+        self._check(self.lib.hjgpu_npj_build(self.handle, self._ptr(d_keys), self._ptr(d_vals), n,
+                                             self._ptr(d_table), buckets, factor, stream))
+
+    def npj_probe(self, d_keys, d_vals, n, d_table, buckets, factor, out=None, stream=None):
+        r = Result()
+        self._check(self.lib.hjgpu_npj_probe(self.handle, self._ptr(d_keys), self._ptr(d_vals), n,
+                                             self._ptr(d_table), buckets, factor, C.byref(r),
+                                             self._out(out), stream))
+        return r.as_tuple()
+
+    # ---- whole joins ------------------------------------------------------------------
+    def _join(self, fn, params, rk, rv, inner, sk, sv, outer, out, stream):
+        r = Result()
+        self._check(fn(self.handle, self._ptr(rk), self._ptr(rv), inner, self._ptr(sk),
+                       self._ptr(sv), outer, C.byref(params) if params is not None else None,
+                       C.byref(r), self._out(out), stream))
+        return r.as_tuple()
+
+    def npj(self, rk, rv, inner, sk, sv, outer, params=None, out=None, stream=None):
+        return self._join(self.lib.hjgpu_npj, params, rk, rv, inner, sk, sv, outer, out, stream)
+
+    def phj(self, rk, rv, inner, sk, sv, outer, params=None, out=None, stream=None):
+        return self._join(self.lib.hjgpu_phj, params, rk, rv, inner, sk, sv, outer, out, stream)
+
+    def cpra(self, rk, rv, inner, sk, sv, outer, params=None, out=None, stream=None):
+        return self._join(self.lib.hjgpu_cpra, params, rk, rv, inner, sk, sv, outer, out, stream)
+
+    def _join_async(self, fn, params, rk, rv, inner, sk, sv, outer, d_result, stream):
+        self._check(fn(self.handle, self._ptr(rk), self._ptr(rv), inner, self._ptr(sk),
+                       self._ptr(sv), outer, C.byref(params) if params is not None else None,
+                       self._ptr(d_result), stream))
+
+    def npj_async(self, rk, rv, inner, sk, sv, outer, params, d_result, stream=None):
+        self._join_async(self.lib.hjgpu_npj_async, params, rk, rv, inner, sk, sv, outer, d_result, stream)
+
+    def phj_async(self, rk, rv, inner, sk, sv, outer, params, d_result, stream=None):
+        self._join_async(self.lib.hjgpu_phj_async, params, rk, rv, inner, sk, sv, outer, d_result, stream)
+
+    def cpra_async(self, rk, rv, inner, sk, sv, outer, params, d_result, stream=None):
+        self._join_async(self.lib.hjgpu_cpra_async, params, rk, rv, inner, sk, sv, outer, d_result, stream)
+
+    def join_host(self, algorithm, ik, iv, ok, ov, phj_params=None, npj_params=None):
+        """algorithm: 0 npj, 1 phj, 2 cpra; host numpy columns in, (result, stats) out."""
+        ik, iv = np.ascontiguousarray(ik, np.uint32), np.ascontiguousarray(iv, np.uint32)
+        ok, ov = np.ascontiguousarray(ok, np.uint32), np.ascontiguousarray(ov, np.uint32)
+        r, s = Result(), Stats()
+        self._check(self.lib.hjgpu_join_host(
+            self.handle, algorithm, ik.ctypes.data, iv.ctypes.data, ik.size,
+            ok.ctypes.data, ov.ctypes.data, ok.size,
+            C.byref(phj_params) if phj_params is not None else None,
+            C.byref(npj_params) if npj_params is not None else None, C.byref(r), C.byref(s)))
+        return r.as_tuple(), s.as_dict()
+
+    # ---- generator --------------------------------------------------------------------
+    def generate(self, seed, inner, outer_total, outer_begin, outer_count, inner_factor,
+                 outer_factor, ik, iv, ok, ov, stream=None):
+        self._check(self.lib.hjgpu_generate(self.handle, seed, inner, outer_total, outer_begin,
+                                            outer_count, inner_factor, outer_factor,
+                                            self._ptr(ik), self._ptr(iv), self._ptr(ok),
+                                            self._ptr(ov), stream))
+
+    def column_sums(self, d_keys, n, fa, fb, stream=None):
+        sums = (C.c_uint64 * 3)()
+        self._check(self.lib.hjgpu_column_sums(self.handle, self._ptr(d_keys), n, fa, fb, sums, stream))
+        return tuple(int(x) for x in sums)

@@ -1,0 +1,96 @@
+"""Builds libhjgpu.so (HIP kernels + C-ABI) and the host CLI programs for gfx950.
+
+hipcc cross-compiles without a GPU.  Artefacts are written in-tree under
+hash_join_codes_knl_amd/lib/ (git-ignored, shipped to the GPU box by gpurun).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB = os.path.join(PKG, "lib")
+ARCH = "gfx950"
+
+KERNEL_SOURCES = ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip",
+                  "gen_kernels.hip", "hjgpu_api.hip"]
+HOST_PROGRAMS = {"npj": "npj_main.cpp", "phj": "phj_main.cpp", "cpra": "cpra_main.cpp",
+                 "write": "write_main.cpp"}
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libhjgpu)")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def lib_path():
+    return os.path.join(LIB, "libhjgpu.so")
+
+
+def build_library(force=False, verbose=True):
+    os.makedirs(LIB, exist_ok=True)
+    so = lib_path()
+    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps.append(os.path.join(ROOT, "include", "hjgpu.h"))
+    if not force and not _newer(so, deps):
+        return so
+    objs = []
+    for src in srcs:
+        obj = os.path.join(LIB, os.path.basename(src) + ".o")
+        if force or _newer(obj, deps):
+            cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
+                   "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return so
+
+
+def build_host(force=False, verbose=True):
+    """The reference's four programs (./npj ./phj ./cpra ./write) as thin C++ hosts
+    over the C-ABI.  Plain g++: they do not include HIP headers."""
+    os.makedirs(LIB, exist_ok=True)
+    built = []
+    common = [os.path.join(HOST, "host_common.hpp"), os.path.join(ROOT, "include", "hjgpu.h")]
+    for name, src in HOST_PROGRAMS.items():
+        srcp = os.path.join(HOST, src)
+        if not os.path.exists(srcp):
+            continue
+        exe = os.path.join(LIB, name)
+        if force or _newer(exe, [srcp, lib_path()] + common):
+            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
+                   srcp, "-o", exe, "-L", LIB, "-lhjgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        built.append(exe)
+    return built
+
+
+def build_all(force=False, verbose=True):
+    so = build_library(force, verbose)
+    build_host(force, verbose)
+    return so
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built", lib_path())

@@ -1,0 +1,130 @@
+// gen_kernels.hip — counter-based relation generator and column checksums.
+//
+// Statistical contract of the reference generator (generate_data_for_join,
+// cpra2.cpp:1578-1696; write.cpp:1482-1646): unique non-zero build keys, probe
+// keys drawn from the build keys (each build key at least once when
+// outer >= inner, the rest uniform picks), payload = key * odd factor, both
+// columns in pseudo-random order.  The reference builds this with a serial
+// MT19937 stream, a CAS hash set and a Fisher-Yates shuffle; here every tuple
+// is a pure function of (seed, position), so any shard of the probe side can
+// be generated independently on its own GPU with no communication
+// (SURVEY.md §8f row 1).  Bit-compatibility with the MT19937 stream is NOT a
+// goal (the host-side oracle generator covers that, oracle/hj_oracle.c).
+#include "hj_device.hpp"
+#include "hj_internal.hpp"
+
+// lowbias32: a bijection on 32-bit integers with mix32(0) == 0, hence
+// mix32(x) != 0 for x != 0 and distinct x give distinct keys.
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ u64 splitmix64(u64 z)
+{
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+struct GenArgs {
+    u64 seed;
+    u64 inner, outer_total, outer_begin, outer_count;
+    u64 distinct;               // min(inner, outer_total)  (write.cpp:1687-1689)
+    u64 mul, add;               // position permutation j' = (j*mul + add) mod outer_total
+    u64 mul_r, add_r;           // same for the build side, mod inner
+    uint32_t key_base;          // build key i = mix32(key_base + i), key_base + i in [1, 2^32)
+    uint32_t inner_factor, outer_factor;
+    uint32_t *ik, *iv, *ok, *ov;
+};
+
+__global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.ik) {
+        for (u64 i = tid; i < a.inner; i += stride) {
+            const u64 ip = (i * a.mul_r + a.add_r) % a.inner;
+            u64 r;
+            if (ip < a.distinct) r = ip;                               // every distinct key once
+            else r = __umul64hi(splitmix64(ip ^ ~a.seed), a.distinct); // then repeats (outer < inner)
+            const uint32_t k = mix32(a.key_base + (uint32_t)r);
+            a.ik[i] = k;
+            a.iv[i] = k * a.inner_factor;
+        }
+    }
+    if (a.ok) {
+        for (u64 j = tid; j < a.outer_count; j += stride) {
+            const u64 pos = a.outer_begin + j;
+            const u64 jp = (pos * a.mul + a.add) % a.outer_total;     // "shuffle": a bijection of positions
+            u64 r;
+            if (jp < a.distinct) r = jp;                               // every distinct key once
+            else r = __umul64hi(splitmix64(jp ^ a.seed), a.distinct);  // then uniform picks
+            const uint32_t k = mix32(a.key_base + (uint32_t)r);
+            a.ok[j] = k;
+            a.ov[j] = k * a.outer_factor;
+        }
+    }
+}
+
+static u64 gcd_u64(u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } return x; }
+
+int hj_launch_generate(u64 seed, size_t inner, size_t outer_total, size_t outer_begin,
+                       size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
+                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream)
+{
+    if (inner == 0 || inner >= 0xFFFFFFFFull) return HJGPU_EINVAL;
+    if (ok && (outer_total == 0 || outer_begin + outer_count > outer_total)) return HJGPU_EINVAL;
+    if (outer_total >= (1ull << 35)) return HJGPU_EINVAL;      // pos*mul must stay below 2^64
+    GenArgs a;
+    a.seed = seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;
+    a.inner = inner; a.outer_total = outer_total ? outer_total : 1;
+    a.outer_begin = outer_begin; a.outer_count = outer_count;
+    u64 mul = 402653189ull;                                    // prime < 2^29
+    while (gcd_u64(mul, a.outer_total) != 1) mul += 2;
+    a.mul = mul;
+    u64 mul_r = 268435459ull;                                  // prime > 2^28
+    while (gcd_u64(mul_r, (u64)inner) != 1) mul_r += 2;
+    a.mul_r = mul_r;
+    a.add_r = (a.seed >> 13) % inner;
+    a.distinct = (outer_total && outer_total < inner) ? outer_total : inner;
+    a.add = (a.seed >> 7) % a.outer_total;
+    a.key_base = 1u + (uint32_t)((a.seed >> 11) % (0xFFFFFFFFull - a.distinct));
+    a.inner_factor = inner_factor | 1u; a.outer_factor = outer_factor | 1u;
+    a.ik = ik; a.iv = iv; a.ok = ok; a.ov = ov;
+    hipLaunchKernelGGL(generate_kernel, dim3(4096), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+// sums[0] += key, sums[1] += key*fa, sums[2] += key*fb  (products mod 2^32)
+__global__ __launch_bounds__(256) void column_sums_kernel(const uint32_t *__restrict__ keys, u64 n,
+                                                          uint32_t fa, uint32_t fb, u64 *sums)
+{
+    __shared__ u64 red[3][4];
+    u64 s0 = 0, s1 = 0, s2 = 0;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t k = keys[i];
+        s0 += k; s1 += (uint32_t)(k * fa); s2 += (uint32_t)(k * fb);
+    }
+    s0 = wave_reduce_sum(s0); s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2);
+    const int wave = threadIdx.x >> 6;
+    if (hj_lane() == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        u64 s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        atomicAdd(&sums[threadIdx.x], s);
+    }
+}
+
+int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
+                          hipStream_t stream)
+{
+    if (hipMemsetAsync(sums3, 0, 3 * sizeof(u64), stream) != hipSuccess) return HJGPU_EHIP;
+    hipLaunchKernelGGL(column_sums_kernel, dim3(2048), dim3(256), 0, stream, keys, (u64)n, fa, fb, sums3);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}

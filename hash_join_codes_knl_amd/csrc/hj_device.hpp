@@ -1,0 +1,77 @@
+// hj_device.hpp — device-side helpers shared by the gfx950 kernels.
+// wave = 64 lanes everywhere (CDNA4); no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+// H(key, f, N) = mulhi32((uint32)(key*f), N)   (npj.cpp:200-201, phj.cpp:721-722)
+__device__ __forceinline__ uint32_t hj_hash(uint32_t key, uint32_t factor, uint32_t n)
+{
+    return __umulhi(key * factor, n);
+}
+
+// Final partition id of a key under the two partitioning passes.
+__device__ __forceinline__ uint32_t hj_part2(uint32_t key, uint32_t f1, uint32_t F1,
+                                             uint32_t f2, uint32_t F2)
+{
+    return hj_hash(key, f1, F1) * F2 + hj_hash(key, f2, F2);
+}
+
+__device__ __forceinline__ int hj_lane() { return threadIdx.x & 63; }
+
+// Inclusive scan across the 64 lanes of a wave.
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T x)
+{
+    const int lane = hj_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_down(x, d, 64);
+    return x;   // valid in lane 0
+}
+
+// Block-wide exclusive scan of one value per thread. `scratch` needs
+// BLOCK/64 + 1 entries of T in LDS; scratch[BLOCK/64] receives the block total.
+// Contains two __syncthreads(); every thread of the block must call it.
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *scratch)
+{
+    constexpr int NW = BLOCK / 64;
+    const int lane = hj_lane();
+    const int wave = threadIdx.x >> 6;
+    T inc = wave_inclusive_scan(v);
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        T w = (lane < NW) ? scratch[lane] : T(0);
+        T winc = wave_inclusive_scan(w);
+        if (lane < NW) scratch[lane] = winc - w;      // exclusive prefix of the wave sums
+        if (lane == NW - 1) scratch[NW] = winc;       // block total
+    }
+    __syncthreads();
+    return inc - v + scratch[wave];
+}
+
+// Largest index s in [0, n) with prefix[s] <= t, given prefix[0] <= t < prefix[n].
+// Wave-uniform when t is (all lanes walk the same path).
+__device__ __forceinline__ uint32_t hj_find_segment(const u64 *__restrict__ prefix, uint32_t n, u64 t)
+{
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}

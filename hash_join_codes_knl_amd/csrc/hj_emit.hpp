@@ -1,0 +1,67 @@
+// hj_emit.hpp — materialised join output: the reference's block protocol
+// (npj.cpp:244-246, 312-316, 426-436) at wave granularity.
+//
+// Every wave owns a 64-bit cursor `o` (kept in LDS so that it stays coherent
+// across the wave's divergent control flow).  A block of `block_size` output
+// slots is claimed with ONE global atomic (fetch_add on the block counter);
+// the lanes that found a match in the same instruction get consecutive slots
+// (ballot + mbcnt prefix), so a wave writes its matches as one contiguous run.
+// When a run fills the current block the wave claims the next one eagerly,
+// exactly like the reference's `if ((o & (block_size-1)) == 0) o = claim()`.
+// The first block is claimed lazily (HJ_NO_CURSOR) so idle waves leave no hole.
+// The partially filled last block of every wave is compacted by K9
+// (close_gaps, npj.cpp:475-514).
+#pragma once
+#include "hj_device.hpp"
+
+#define HJ_NO_CURSOR (~0ull)
+
+struct Emitter {
+    uint32_t *ok, *oov, *oiv;
+    u64 block_size, block_limit;
+    u64 *block_counter;
+    uint32_t *overflow;
+    volatile u64 *cursor;          // this wave's cursor, in LDS
+
+    __device__ __forceinline__ void init(uint32_t *k, uint32_t *ov, uint32_t *iv, u64 bs, u64 bl,
+                                         u64 *bc, uint32_t *ovf, u64 *lds_cursor)
+    {
+        ok = k; oov = ov; oiv = iv; block_size = bs; block_limit = bl;
+        block_counter = bc; overflow = ovf; cursor = lds_cursor;
+    }
+
+    // Called by the lanes that have a match (any subset of the wave).
+    __device__ __forceinline__ void emit(uint32_t key, uint32_t outer_val, uint32_t inner_val)
+    {
+        if (!ok) return;                                   // aggregate-only mode (uniform)
+        const u64 m = __ballot(1);                         // lanes active here = lanes with a match
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                              __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const u64 o = *cursor;                             // same address in every lane: broadcast
+        const u64 room = (o == HJ_NO_CURSOR) ? 0 : ((o & ~(block_size - 1)) + block_size - o);
+        u64 pos, next;
+        if (n < room) {
+            pos = o + rank;
+            next = o + n;
+        } else {
+            // the run fills the current block: claim the next one (one atomic per block)
+            u64 nb = 0;
+            if (rank == 0) nb = atomicAdd(block_counter, 1ull);
+            // broadcast from the first active lane (= the rank-0 lane)
+            nb = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32)) << 32) |
+                 (u64)__builtin_amdgcn_readfirstlane((uint32_t)nb);
+            if (nb >= block_limit) {
+                if (rank == 0) atomicOr(overflow, 1u);
+                nb = block_limit - 1;                      // stay inside the allocation; result is flagged
+            }
+            const u64 base = nb * block_size;
+            pos = (rank < room) ? (o + rank) : (base + (rank - room));
+            next = base + (n - room);
+        }
+        if (rank == 0) *cursor = next;
+        ok[pos] = key;
+        oov[pos] = outer_val;
+        oiv[pos] = inner_val;
+    }
+};

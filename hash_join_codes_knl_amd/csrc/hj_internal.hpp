@@ -1,0 +1,110 @@
+// hj_internal.hpp — launch wrappers shared between the kernel files and the
+// C-ABI layer (hjgpu_api.hip).  Everything here is enqueue-only on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hjgpu.h"
+
+typedef unsigned long long u64;
+
+// Geometry constants (also read by the planner on the host side).
+constexpr int HJ_SCATTER_BLOCK = 512;           // threads per scatter workgroup
+constexpr int HJ_SCATTER_VPT   = 4;             // uint4 vectors per thread per tile
+constexpr int HJ_SCATTER_TILE  = HJ_SCATTER_BLOCK * HJ_SCATTER_VPT * 4;   // 8192 tuples
+constexpr int HJ_JOIN_BLOCK    = 512;
+constexpr int HJ_JOIN_LOG2SLOTS = 13;           // 8192 slots * 8 B = 64 KiB of LDS
+constexpr int HJ_JOIN_SLOTS    = 1 << HJ_JOIN_LOG2SLOTS;
+constexpr int HJ_JOIN_CAP      = HJ_JOIN_SLOTS / 2;     // max build tuples per table fill
+constexpr int HJ_JOIN_SLICE    = 1 << 16;       // probe tuples per work item (target)
+
+// One partitioning pass over `nseg` independent input segments.
+struct ScatterArgs {
+    const uint32_t *kin, *vin;      // input columns
+    uint32_t *kout, *vout;          // output columns (same length)
+    const u64 *seg_off;             // [nseg+1] element offsets of the segments in kin/vin
+    const u64 *tile_prefix;         // [nseg+1] exclusive prefix of tiles per segment
+    u64 *cursors;                   // [nseg*F] absolute output positions, advanced atomically
+    uint32_t nseg, F, factor;
+    uint32_t in_align;              // (address of kin / 4) % 4, same for vin
+};
+
+struct JoinArgs {
+    const uint32_t *rk, *rv, *sk, *sv;   // co-partitioned columns
+    const u64 *roff, *soff;              // [chunks*P + 1] absolute offsets, chunk-major
+    const u64 *slice_prefix;             // [P+1] exclusive prefix of work items per partition
+    const u64 *slices;                   // [P]   work items of partition q
+    uint32_t P, chunks;
+    uint32_t f1, F1, f2, F2;             // the passes that produced the partitions
+    uint32_t tf0, tf1;                   // table hash / step multipliers
+    uint32_t s_align;                    // (address of sk / 4) % 4
+    hjgpu_result *result;                // device, accumulated atomically
+    // materialised output (NULL keys = aggregate only)
+    uint32_t *ok, *oov, *oiv;
+    u64 block_size, block_limit;
+    u64 *block_counter;                  // device
+    u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
+    uint32_t *overflow;                  // device flag
+};
+
+struct PlanArgs {
+    const u64 *counts[2];     // [chunks*P] fused two-level histograms of R (0) and S (1)
+    u64 n[2];                 // relation sizes
+    u64 *off2[2];             // [chunks*P + 1] absolute final offsets
+    u64 *cur2[2];             // [chunks*P]
+    u64 *off1[2];             // [chunks*F1 + 1]
+    u64 *cur1[2];             // [chunks*F1]
+    u64 *tp1[2];              // [chunks + 1] pass-1 tile prefix
+    u64 *seg1[2];             // [chunks + 1] chunk boundaries
+    u64 *tp2[2];              // [chunks*F1 + 1] pass-2 tile prefix
+    u64 *slice_prefix;        // [P + 1]
+    u64 *slices;              // [P]
+    uint32_t chunks, F1, F2;
+    uint32_t in_align[2];     // alignment of the caller's input columns
+    uint32_t tile, slice;
+};
+
+int hj_launch_hist2(const uint32_t *keys, const u64 *seg1_host, uint32_t chunks,
+                    uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
+                    u64 *counts, int cus, hipStream_t stream);
+int hj_launch_plan(const PlanArgs &a, hipStream_t stream);
+int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream);
+int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream);
+int hj_launch_exscan(const u64 *in, u64 *out, uint32_t n, hipStream_t stream);
+int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStream_t stream);
+
+// NPJ
+int hj_launch_npj_build(const uint32_t *keys, const uint32_t *vals, size_t n, u64 *table,
+                        size_t buckets, uint32_t factor, uint32_t *zero_key_flag,
+                        int cus, hipStream_t stream);
+struct NpjProbeArgs {
+    const uint32_t *keys, *vals;
+    size_t n;
+    const u64 *table;
+    size_t buckets;
+    uint32_t factor;
+    hjgpu_result *result;
+    uint32_t *ok, *oov, *oiv;
+    u64 block_size, block_limit;
+    u64 *block_counter;
+    u64 *final_offsets;
+    uint32_t *overflow;
+};
+int hj_launch_npj_probe(const NpjProbeArgs &a, int cus, hipStream_t stream, int *grid_out);
+
+// K9: compact the per-wave partially filled tail blocks (npj.cpp:475-514).
+// moves: scratch of 2*HJ_MAX_WORKERS entries of 24 bytes.
+constexpr uint32_t HJ_MAX_WORKERS = 8192;
+int hj_launch_close_gaps_ex(uint32_t *k, uint32_t *ov, uint32_t *iv, const u64 *final_offsets,
+                            uint32_t nworkers, u64 block_size, const u64 *block_counter,
+                            const uint32_t *overflow, void *moves, uint32_t *nmoves,
+                            u64 *dense_count, int cus, hipStream_t stream);
+int hj_join_grid(int cus);
+int hj_join_workers(int cus);
+int hj_npj_probe_grid(int cus, size_t n);
+
+// generator / checksums
+int hj_launch_generate(u64 seed, size_t inner, size_t outer_total, size_t outer_begin,
+                       size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
+                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream);
+int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
+                          hipStream_t stream);

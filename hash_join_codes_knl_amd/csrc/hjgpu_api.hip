@@ -1,0 +1,875 @@
+// hjgpu_api.hip — the C-ABI of include/hjgpu.h: context, workspace, launch
+// sequencing.  This file is the MI355X counterpart of the reference's thread
+// orchestration run()/run_hj() (npj.cpp:769-927, phj.cpp:1646-1949,
+// cpra2.cpp:1697-1986): phase order, pass planning, factor choice.  Barriers
+// between phases become stream order; there is no host round trip inside a join.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "hj_internal.hpp"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// Small device-resident state of one join.
+struct DevState {
+    hjgpu_result result;
+    u64 block_counter;
+    u64 dense;
+    uint32_t overflow;
+    uint32_t zero_key;
+    uint32_t nmoves;
+    uint32_t pad;
+};
+
+enum { EV_BEGIN = 0, EV_HIST, EV_PLAN, EV_SCAT1, EV_SCAT2, EV_JOIN, EV_GAPS, EV_COUNT };
+
+}  // namespace
+
+struct hjgpu_ctx {
+    int device = 0;
+    int cus = 0;
+    hipDeviceProp_t prop;
+    char err[512];
+    DevBuf tmp[8];          // pass-1 / pass-2 twins of the 4 columns (hj.h's [1] scratch columns)
+    DevBuf meta;            // histograms, offsets, cursors, tile / work-item prefixes
+    DevBuf table;           // NPJ table
+    DevBuf state;           // DevState
+    DevBuf moves;           // close_gaps move list
+    DevBuf final_offsets;   // per-wave end cursors
+    hipEvent_t ev[EV_COUNT];
+    bool ev_valid[EV_COUNT];
+    hjgpu_stats stats;
+    int last_algo = -1;     // 0 npj, 1 phj/cpra
+};
+
+namespace {
+
+const uint32_t DEFAULT_F1 = 0x9E3779B1u, DEFAULT_F2 = 0x85EBCA6Bu;
+const uint32_t DEFAULT_TF0 = 0xC2B2AE35u, DEFAULT_TF1 = 0x27D4EB2Fu;
+const uint32_t DEFAULT_NPJ_FACTOR = 0x9E3779B1u;
+
+int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        if (e != hipSuccess)
+            snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
+        else
+            snprintf(ctx->err, sizeof(ctx->err), "%s", what);
+    }
+    return status;
+}
+
+#define HIPCHK(ctx, call)                                                       \
+    do {                                                                        \
+        hipError_t e_ = (call);                                                 \
+        if (e_ != hipSuccess) return fail((ctx), HJGPU_EHIP, #call, e_);        \
+    } while (0)
+
+#define CHK(call)                                                               \
+    do {                                                                        \
+        int s_ = (call);                                                        \
+        if (s_ != HJGPU_OK) return s_;                                          \
+    } while (0)
+
+int ensure(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return HJGPU_OK;
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    // round up so that repeated small growth does not reallocate, and keep a
+    // 16-byte tail so aligned vector reads of the last elements stay inside
+    size_t want = (bytes + 255) / 256 * 256 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return fail(ctx, HJGPU_ENOMEM, "hipMalloc(workspace)", e); }
+    b.cap = want;
+    return HJGPU_OK;
+}
+
+inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) & 3); }
+
+// Carves the meta buffer; must match between sizing and use.
+struct MetaLayout {
+    u64 *counts[2], *off2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
+    u64 *slice_prefix, *slices;
+    size_t counts_bytes;    // both relations, contiguous (zeroed per join)
+    size_t total_bytes;
+};
+
+MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P)
+{
+    MetaLayout m;
+    u64 *p = reinterpret_cast<u64 *>(base);
+    size_t at = 0;
+    auto take = [&](size_t n) { u64 *r = p ? p + at : nullptr; at += (n + 1) & ~size_t(1); return r; };
+    m.counts[0] = take((size_t)C * P);
+    m.counts[1] = take((size_t)C * P);
+    m.counts_bytes = at * sizeof(u64);
+    for (int r = 0; r < 2; ++r) {
+        m.off2[r] = take((size_t)C * P + 1);
+        m.cur2[r] = take((size_t)C * P);
+        m.off1[r] = take((size_t)C * F1 + 1);
+        m.cur1[r] = take((size_t)C * F1);
+        m.tp1[r] = take(C + 1);
+        m.seg1[r] = take(C + 1);
+        m.tp2[r] = take((size_t)C * F1 + 1);
+    }
+    m.slice_prefix = take((size_t)P + 1);
+    m.slices = take(P);
+    m.total_bytes = at * sizeof(u64);
+    return m;
+}
+
+// Pass planning.  The reference sizes partitions for a 6400-tuple L2-resident
+// table and derives 1-4 passes of equal fan-out (phj.cpp:1791-1808); here the
+// partition size comes from the LDS table (HJ_JOIN_CAP tuples at load 0.5) and
+// two passes of ~sqrt(P) reach every |R| the 32768-partition cap allows.
+void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint32_t *F2)
+{
+    uint32_t f1 = prm ? prm->fanout1 : 0, f2 = prm ? prm->fanout2 : 0;
+    if (f1 == 0) {
+        const double target = HJ_JOIN_CAP * 0.85;          // mean fill; Poisson tail stays below CAP
+        double parts = ceil((double)inner / target);
+        if (parts < 2) parts = 2;
+        if (parts > HJGPU_MAX_PARTS) parts = HJGPU_MAX_PARTS;
+        if (parts <= 256) { f1 = (uint32_t)parts; f2 = 1; }
+        else {
+            f1 = (uint32_t)ceil(sqrt(parts));
+            f2 = (uint32_t)ceil(parts / f1);
+            while ((u64)f1 * f2 > HJGPU_MAX_PARTS) --f2;
+        }
+    } else if (f2 == 0) f2 = 1;
+    *F1 = f1; *F2 = f2;
+}
+
+void record(hjgpu_ctx *ctx, int which, hipStream_t s)
+{
+    ctx->ev_valid[which] = (hipEventRecord(ctx->ev[which], s) == hipSuccess);
+}
+
+int check_columns(hjgpu_ctx *ctx, const uint32_t *k, const uint32_t *v, size_t n)
+{
+    if (n == 0) return HJGPU_OK;
+    if (!k || !v) return fail(ctx, HJGPU_EINVAL, "null column pointer");
+    if (((uintptr_t)k & 15) || ((uintptr_t)v & 15))
+        return fail(ctx, HJGPU_EALIGN, "key/payload columns must be 16-byte aligned");
+    return HJGPU_OK;
+}
+
+int setup_output(hjgpu_ctx *ctx, const hjgpu_output *out, uint32_t workers, u64 *block_size,
+                 u64 *block_limit)
+{
+    *block_size = 0; *block_limit = 0;
+    if (!out || !out->d_keys) return HJGPU_OK;
+    if (!out->d_outer_vals || !out->d_inner_vals) return fail(ctx, HJGPU_EINVAL, "output columns");
+    u64 bs = out->block_size ? out->block_size : 65536;
+    if (bs < 256 || (bs & (bs - 1))) return fail(ctx, HJGPU_EINVAL, "block_size must be a power of two >= 256");
+    u64 bl = out->capacity / bs;
+    if (bl == 0) return fail(ctx, HJGPU_EINVAL, "output capacity below one block");
+    if (workers > HJ_MAX_WORKERS) return fail(ctx, HJGPU_EINVAL, "too many workers for close_gaps");
+    CHK(ensure(ctx, ctx->final_offsets, (size_t)workers * sizeof(u64)));
+    CHK(ensure(ctx, ctx->moves, (size_t)2 * HJ_MAX_WORKERS * 24));
+    *block_size = bs; *block_limit = bl;
+    return HJGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// PHJ / CPRA: fused histogram -> plan -> scatter x2 -> LDS join
+// ---------------------------------------------------------------------------
+struct PhjPlan {
+    uint32_t C, F1, F2, P;
+    uint32_t f1, f2, tf0, tf1;
+};
+
+int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm,
+                uint32_t chunks, PhjPlan *pl)
+{
+    pl->C = chunks;
+    choose_fanout(inner, prm, &pl->F1, &pl->F2);
+    pl->P = pl->F1 * pl->F2;
+    if (pl->F1 < 1 || pl->F2 < 1 || pl->F1 > HJGPU_MAX_FANOUT || pl->F2 > HJGPU_MAX_FANOUT ||
+        pl->P < 2 || pl->P > HJGPU_MAX_PARTS)
+        return fail(ctx, HJGPU_EINVAL, "fan-out out of range (need 2 <= fanout1*fanout2 <= 32768, each <= 1024)");
+    pl->f1 = (prm && prm->factor1) ? prm->factor1 : DEFAULT_F1;
+    pl->f2 = (prm && prm->factor2) ? prm->factor2 : DEFAULT_F2;
+    pl->tf0 = (prm && prm->table_factor[0]) ? prm->table_factor[0] : DEFAULT_TF0;
+    pl->tf1 = (prm && prm->table_factor[1]) ? prm->table_factor[1] : DEFAULT_TF1;
+    if (!(pl->f1 & 1) || !(pl->f2 & 1) || !(pl->tf0 & 1) || !(pl->tf1 & 1))
+        return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
+    // workspace: pass-1 twins always, pass-2 twins when there is a second pass
+    const size_t rb = (inner + 4) * sizeof(uint32_t), sb = (outer + 4) * sizeof(uint32_t);
+    CHK(ensure(ctx, ctx->tmp[0], rb)); CHK(ensure(ctx, ctx->tmp[1], rb));
+    CHK(ensure(ctx, ctx->tmp[2], sb)); CHK(ensure(ctx, ctx->tmp[3], sb));
+    if (pl->F2 > 1) {
+        CHK(ensure(ctx, ctx->tmp[4], rb)); CHK(ensure(ctx, ctx->tmp[5], rb));
+        CHK(ensure(ctx, ctx->tmp[6], sb)); CHK(ensure(ctx, ctx->tmp[7], sb));
+    }
+    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P);
+    CHK(ensure(ctx, ctx->meta, sz.total_bytes));
+    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
+    return HJGPU_OK;
+}
+
+void chunk_bounds(size_t n, uint32_t C, u64 *b)
+{
+    // thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
+    const size_t part = (n / C) & ~size_t(15);
+    for (uint32_t c = 0; c < C; ++c) b[c] = part * c;
+    b[C] = n;
+}
+
+int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
+                const uint32_t *rk, const uint32_t *rv, size_t inner,
+                const uint32_t *sk, const uint32_t *sv, size_t outer,
+                const hjgpu_output *out, hipStream_t stream)
+{
+    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P);
+    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
+    u64 bs = 0, bl = 0;
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
+
+    record(ctx, EV_BEGIN, stream);
+    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
+    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+
+    // K4: one read of each key column gives the histograms of both passes
+    u64 rb[9], sbnd[9];
+    chunk_bounds(inner, pl.C, rb);
+    chunk_bounds(outer, pl.C, sbnd);
+    if (inner) CHK(hj_launch_hist2(rk, rb, pl.C, pl.f1, pl.F1, pl.f2, pl.F2, m.counts[0], ctx->cus, stream));
+    if (outer) CHK(hj_launch_hist2(sk, sbnd, pl.C, pl.f1, pl.F1, pl.f2, pl.F2, m.counts[1], ctx->cus, stream));
+    record(ctx, EV_HIST, stream);
+
+    // K5
+    PlanArgs pa;
+    for (int r = 0; r < 2; ++r) {
+        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
+        pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
+        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
+    }
+    pa.n[0] = inner; pa.n[1] = outer;
+    pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
+    pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
+    pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
+    CHK(hj_launch_plan(pa, stream));
+    record(ctx, EV_PLAN, stream);
+
+    // K6 pass 1: caller's columns -> tmp[0..3]
+    uint32_t *t1[4] = {(uint32_t *)ctx->tmp[0].p, (uint32_t *)ctx->tmp[1].p,
+                       (uint32_t *)ctx->tmp[2].p, (uint32_t *)ctx->tmp[3].p};
+    const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
+    const size_t nn[2] = {inner, outer};
+    for (int r = 0; r < 2; ++r) {
+        if (!nn[r]) continue;
+        ScatterArgs sa;
+        sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
+        sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
+        sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
+        CHK(hj_launch_scatter(sa, ctx->cus, stream));
+    }
+    record(ctx, EV_SCAT1, stream);
+
+    // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
+    const uint32_t *fin[4] = {t1[0], t1[1], t1[2], t1[3]};
+    if (pl.F2 > 1) {
+        uint32_t *t2[4] = {(uint32_t *)ctx->tmp[4].p, (uint32_t *)ctx->tmp[5].p,
+                           (uint32_t *)ctx->tmp[6].p, (uint32_t *)ctx->tmp[7].p};
+        for (int r = 0; r < 2; ++r) {
+            if (!nn[r]) continue;
+            ScatterArgs sa;
+            sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
+            sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r];
+            sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
+            CHK(hj_launch_scatter(sa, ctx->cus, stream));
+        }
+        for (int i = 0; i < 4; ++i) fin[i] = t2[i];
+    }
+    record(ctx, EV_SCAT2, stream);
+
+    // K7+K8
+    if (inner && outer) {
+        JoinArgs ja;
+        memset(&ja, 0, sizeof(ja));
+        ja.rk = fin[0]; ja.rv = fin[1]; ja.sk = fin[2]; ja.sv = fin[3];
+        ja.roff = m.off2[0]; ja.soff = m.off2[1];
+        ja.slice_prefix = m.slice_prefix; ja.slices = m.slices;
+        ja.P = pl.P; ja.chunks = pl.C;
+        ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2;
+        ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
+        ja.s_align = 0;
+        ja.result = &st->result;
+        if (bs) {
+            ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
+            ja.block_size = bs; ja.block_limit = bl;
+            ja.block_counter = &st->block_counter;
+            ja.final_offsets = (u64 *)ctx->final_offsets.p;
+            ja.overflow = &st->overflow;
+        }
+        CHK(hj_launch_join(ja, ctx->cus, stream));
+    }
+    record(ctx, EV_JOIN, stream);
+    if (bs && inner && outer) {
+        CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
+                                    (const u64 *)ctx->final_offsets.p,
+                                    (uint32_t)hj_join_workers(ctx->cus), bs, &st->block_counter,
+                                    &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
+    }
+    record(ctx, EV_GAPS, stream);
+    ctx->stats.fanout1 = pl.F1; ctx->stats.fanout2 = pl.F2; ctx->stats.buckets = 0;
+    ctx->last_algo = 1;
+    return HJGPU_OK;
+}
+
+int finish_blocking(hjgpu_ctx *ctx, hjgpu_result *result, const hjgpu_output *out, hipStream_t stream)
+{
+    DevState h;
+    HIPCHK(ctx, hipMemcpyAsync(&h, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    if (result) *result = h.result;
+    if (h.zero_key) return fail(ctx, HJGPU_EZEROKEY, "NPJ: a build key is 0, the empty-bucket sentinel");
+    if (h.overflow) return fail(ctx, HJGPU_EOVERFLOW, "materialised output exceeded its capacity");
+    if (out && out->d_keys && h.dense != h.result.count && (h.result.count != 0 || h.dense != 0))
+        return fail(ctx, HJGPU_EHIP, "internal: dense length != match count after close_gaps");
+    return HJGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// NPJ
+// ---------------------------------------------------------------------------
+int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_t *buckets,
+                uint32_t *factor)
+{
+    double load = (prm && prm->load > 0) ? prm->load : 0.5;
+    if (load > 0.99) return fail(ctx, HJGPU_EINVAL, "load factor must be <= 0.99");
+    size_t b = (size_t)((double)inner / load);             // npj.cpp:947
+    if (b <= inner) b = inner + 1;
+    if (b < 16) b = 16;
+    *buckets = b;
+    *factor = (prm && prm->factor) ? prm->factor : DEFAULT_NPJ_FACTOR;
+    if (!(*factor & 1)) return fail(ctx, HJGPU_EINVAL, "hash factor must be odd");
+    CHK(ensure(ctx, ctx->table, b * sizeof(u64)));
+    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
+    return HJGPU_OK;
+}
+
+int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, size_t outer,
+                      const u64 *table, size_t buckets, uint32_t factor, const hjgpu_output *out,
+                      hipStream_t stream)
+{
+    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
+    u64 bs = 0, bl = 0;
+    const int grid = hj_npj_probe_grid(ctx->cus, outer);
+    CHK(setup_output(ctx, out, (uint32_t)grid * 4, &bs, &bl));
+    if (outer) {
+        NpjProbeArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.keys = sk; pa.vals = sv; pa.n = outer; pa.table = table; pa.buckets = buckets;
+        pa.factor = factor; pa.result = &st->result;
+        if (bs) {
+            pa.ok = out->d_keys; pa.oov = out->d_outer_vals; pa.oiv = out->d_inner_vals;
+            pa.block_size = bs; pa.block_limit = bl; pa.block_counter = &st->block_counter;
+            pa.final_offsets = (u64 *)ctx->final_offsets.p; pa.overflow = &st->overflow;
+        }
+        CHK(hj_launch_npj_probe(pa, ctx->cus, stream, nullptr));
+    }
+    record(ctx, EV_JOIN, stream);
+    if (bs && outer) {
+        CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
+                                    (const u64 *)ctx->final_offsets.p, (uint32_t)grid * 4, bs,
+                                    &st->block_counter, &st->overflow, ctx->moves.p, &st->nmoves, &st->dense,
+                                    ctx->cus, stream));
+    }
+    record(ctx, EV_GAPS, stream);
+    return HJGPU_OK;
+}
+
+int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+                const uint32_t *sk, const uint32_t *sv, size_t outer,
+                size_t buckets, uint32_t factor, const hjgpu_output *out, hipStream_t stream)
+{
+    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
+    u64 *table = reinterpret_cast<u64 *>(ctx->table.p);
+    record(ctx, EV_BEGIN, stream);
+    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+    // K1 set() npj.cpp:865-868 ; K2 build() 871-877
+    HIPCHK(ctx, hipMemsetAsync(table, 0, buckets * sizeof(u64), stream));
+    if (inner) CHK(hj_launch_npj_build(rk, rv, inner, table, buckets, factor, &st->zero_key, ctx->cus, stream));
+    record(ctx, EV_HIST, stream);       // reused as "end of build"
+    ctx->ev_valid[EV_PLAN] = ctx->ev_valid[EV_SCAT1] = ctx->ev_valid[EV_SCAT2] = false;
+    CHK(npj_probe_enqueue(ctx, sk, sv, outer, table, buckets, factor, out, stream));
+    ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets;
+    ctx->last_algo = 0;
+    return HJGPU_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// extern "C"
+// ===========================================================================
+extern "C" {
+
+const char *hjgpu_status_string(int s)
+{
+    switch (s) {
+    case HJGPU_OK: return "ok";
+    case HJGPU_EINVAL: return "invalid argument";
+    case HJGPU_EALIGN: return "column not 16-byte aligned";
+    case HJGPU_ENOMEM: return "out of device memory";
+    case HJGPU_EHIP: return "HIP runtime error";
+    case HJGPU_EZEROKEY: return "key 0 is reserved by NPJ";
+    case HJGPU_EOVERFLOW: return "output capacity exceeded";
+    case HJGPU_ENODEVICE: return "no GPU device";
+    default: return "unknown status";
+    }
+}
+
+int hjgpu_create(int device, hjgpu_ctx **out)
+{
+    if (!out) return HJGPU_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return HJGPU_ENODEVICE;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return HJGPU_ENODEVICE; }
+    if (device >= n) return HJGPU_EINVAL;
+    hjgpu_ctx *ctx = new hjgpu_ctx();
+    ctx->err[0] = 0;
+    ctx->device = device;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    if (hipSetDevice(device) != hipSuccess ||
+        hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) { delete ctx; return HJGPU_ENODEVICE; }
+    ctx->cus = ctx->prop.multiProcessorCount;
+    for (int i = 0; i < EV_COUNT; ++i) {
+        ctx->ev_valid[i] = false;
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return HJGPU_EHIP; }
+    }
+    *out = ctx;
+    return HJGPU_OK;
+}
+
+int hjgpu_destroy(hjgpu_ctx *ctx)
+{
+    if (!ctx) return HJGPU_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *all[] = {&ctx->tmp[0], &ctx->tmp[1], &ctx->tmp[2], &ctx->tmp[3], &ctx->tmp[4], &ctx->tmp[5],
+                     &ctx->tmp[6], &ctx->tmp[7], &ctx->meta, &ctx->table, &ctx->state, &ctx->moves,
+                     &ctx->final_offsets};
+    for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+    return HJGPU_OK;
+}
+
+const char *hjgpu_last_error(const hjgpu_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info)
+{
+    if (!ctx || !info) return HJGPU_EINVAL;
+    memset(info, 0, sizeof(*info));
+    snprintf(info->name, sizeof(info->name), "%s", ctx->prop.name);
+    snprintf(info->arch, sizeof(info->arch), "%s", ctx->prop.gcnArchName);
+    info->compute_units = ctx->cus;
+    info->lds_bytes_per_block = (int)ctx->prop.sharedMemPerBlock;
+    info->hbm_bytes = ctx->prop.totalGlobalMem;
+    return HJGPU_OK;
+}
+
+int hjgpu_reserve(hjgpu_ctx *ctx, size_t inner, size_t outer)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PhjPlan pl;
+    hjgpu_phj_params prm;
+    memset(&prm, 0, sizeof(prm));
+    CHK(phj_prepare(ctx, inner, outer, &prm, 8, &pl));     // 8 chunks = largest meta
+    size_t buckets; uint32_t factor;
+    CHK(npj_prepare(ctx, inner, nullptr, &buckets, &factor));
+    return HJGPU_OK;
+}
+
+int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
+{
+    if (!ctx || !s) return HJGPU_EINVAL;
+    if (ctx->ev_valid[EV_GAPS]) HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
+    auto span = [&](int a, int b) -> float {
+        float ms = 0;
+        if (ctx->ev_valid[a] && ctx->ev_valid[b] &&
+            hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) == hipSuccess) return ms;
+        return 0.f;
+    };
+    hjgpu_stats r = ctx->stats;
+    r.ms_total = span(EV_BEGIN, EV_GAPS);
+    if (ctx->last_algo == 0) {
+        r.ms_build = span(EV_BEGIN, EV_HIST);
+        r.ms_join = span(EV_HIST, EV_JOIN);
+        r.ms_histogram = r.ms_plan = r.ms_scatter1 = r.ms_scatter2 = 0;
+    } else {
+        r.ms_histogram = span(EV_BEGIN, EV_HIST);
+        r.ms_plan = span(EV_HIST, EV_PLAN);
+        r.ms_scatter1 = span(EV_PLAN, EV_SCAT1);
+        r.ms_scatter2 = span(EV_SCAT1, EV_SCAT2);
+        r.ms_join = span(EV_SCAT2, EV_JOIN);
+        r.ms_build = 0;
+    }
+    r.ms_close_gaps = span(EV_JOIN, EV_GAPS);
+    *s = r;
+    return HJGPU_OK;
+}
+
+// ---- memory helpers ---------------------------------------------------------
+int hjgpu_malloc(hjgpu_ctx *ctx, void **p, size_t bytes)
+{
+    if (!ctx || !p) return HJGPU_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(p, bytes ? bytes + 16 : 16);   // 16-byte tail for aligned vector reads
+    if (e != hipSuccess) { *p = nullptr; return fail(ctx, HJGPU_ENOMEM, "hipMalloc", e); }
+    return HJGPU_OK;
+}
+int hjgpu_free(hjgpu_ctx *ctx, void *p)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (p) HIPCHK(ctx, hipFree(p));
+    return HJGPU_OK;
+}
+int hjgpu_memcpy_h2d(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (bytes) HIPCHK(ctx, hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    return HJGPU_OK;
+}
+int hjgpu_memcpy_d2h(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (bytes) HIPCHK(ctx, hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+    return HJGPU_OK;
+}
+int hjgpu_synchronize(hjgpu_ctx *ctx, void *stream)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return HJGPU_OK;
+}
+
+// ---- partition operators ------------------------------------------------------
+int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t factor,
+                    uint32_t fanout, uint64_t *d_counts, void *stream_)
+{
+    if (!ctx || !d_counts || (n && !d_keys)) return fail(ctx, HJGPU_EINVAL, "null pointer");
+    if (fanout == 0 || fanout > HJGPU_MAX_PARTS || !(factor & 1))
+        return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 32768] and factor odd");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, (size_t)fanout * sizeof(u64), stream));
+    if (n) {
+        u64 b[9] = {0, n, n, n, n, n, n, n, n};
+        CHK(hj_launch_hist2(d_keys, b, 1, factor, fanout, 1u, 1u, (u64 *)d_counts, ctx->cus, stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    return HJGPU_OK;
+}
+
+int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                    uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
+                    uint64_t *d_offsets, void *stream_)
+{
+    if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
+    if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
+        return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 1024] and factor odd");
+    if (n && (!d_keys_out || !d_vals_out)) return fail(ctx, HJGPU_EINVAL, "null output column");
+    CHK(check_columns(ctx, d_keys, d_vals, n));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    MetaLayout sz = carve(nullptr, 1, fanout, fanout);
+    CHK(ensure(ctx, ctx->meta, sz.total_bytes));
+    MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout);
+    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
+    if (n) {
+        u64 b[9] = {0, n, n, n, n, n, n, n, n};
+        CHK(hj_launch_hist2(d_keys, b, 1, factor, fanout, 1u, 1u, m.counts[0], ctx->cus, stream));
+    }
+    PlanArgs pa;
+    for (int r = 0; r < 2; ++r) {
+        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
+        pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
+        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
+    }
+    pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
+    pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
+    pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
+    CHK(hj_launch_plan(pa, stream));
+    if (n) {
+        ScatterArgs sa;
+        sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
+        sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
+        sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
+        CHK(hj_launch_scatter(sa, ctx->cus, stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
+                               hipMemcpyDeviceToDevice, stream));
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    return HJGPU_OK;
+}
+
+int hjgpu_join_partitions(hjgpu_ctx *ctx,
+                          const uint32_t *rk, const uint32_t *rv, const uint64_t *roff,
+                          const uint32_t *sk, const uint32_t *sv, const uint64_t *soff,
+                          const hjgpu_phj_params *passes, hjgpu_result *result,
+                          const hjgpu_output *out, void *stream_)
+{
+    if (!ctx || !passes || !roff || !soff || !rk || !rv || !sk || !sv)
+        return fail(ctx, HJGPU_EINVAL, "null pointer");
+    if (((uintptr_t)sk & 15) || ((uintptr_t)sv & 15))
+        return fail(ctx, HJGPU_EALIGN, "probe columns must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PhjPlan pl;
+    pl.C = 1;
+    pl.F1 = passes->fanout1; pl.F2 = passes->fanout2 ? passes->fanout2 : 1;
+    pl.P = pl.F1 * pl.F2;
+    if (pl.F1 == 0 || pl.P < 2 || pl.P > HJGPU_MAX_PARTS) return fail(ctx, HJGPU_EINVAL, "fan-out out of range");
+    pl.f1 = passes->factor1 ? passes->factor1 : DEFAULT_F1;
+    pl.f2 = passes->factor2 ? passes->factor2 : DEFAULT_F2;
+    pl.tf0 = passes->table_factor[0] ? passes->table_factor[0] : DEFAULT_TF0;
+    pl.tf1 = passes->table_factor[1] ? passes->table_factor[1] : DEFAULT_TF1;
+    if (!(pl.f1 & 1) || !(pl.f2 & 1) || !(pl.tf0 & 1) || !(pl.tf1 & 1))
+        return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
+    MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P);
+    CHK(ensure(ctx, ctx->meta, sz.total_bytes));
+    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
+    MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P);
+    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
+    u64 bs = 0, bl = 0;
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
+    record(ctx, EV_BEGIN, stream);
+    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+    // counts = adjacent differences of the caller's offsets, then the usual plan
+    // (re-derives identical offsets and the work-item prefix)
+    CHK(hj_launch_offsets_to_counts((const u64 *)roff, m.counts[0], pl.P, stream));
+    CHK(hj_launch_offsets_to_counts((const u64 *)soff, m.counts[1], pl.P, stream));
+    PlanArgs pa;
+    for (int r = 0; r < 2; ++r) {
+        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
+        pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
+        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
+    }
+    pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
+    pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
+    CHK(hj_launch_plan(pa, stream));
+    for (int e : {EV_HIST, EV_PLAN, EV_SCAT1, EV_SCAT2}) record(ctx, e, stream);
+    JoinArgs ja;
+    memset(&ja, 0, sizeof(ja));
+    ja.rk = rk; ja.rv = rv; ja.sk = sk; ja.sv = sv;
+    ja.roff = (const u64 *)roff; ja.soff = (const u64 *)soff;    // caller's offsets (may start at non-zero)
+    ja.slice_prefix = m.slice_prefix; ja.slices = m.slices;
+    ja.P = pl.P; ja.chunks = 1;
+    ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2; ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
+    ja.s_align = 0; ja.result = &st->result;
+    if (bs) {
+        ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
+        ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
+        ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
+    }
+    CHK(hj_launch_join(ja, ctx->cus, stream));
+    record(ctx, EV_JOIN, stream);
+    if (bs)
+        CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
+                                    (const u64 *)ctx->final_offsets.p,
+                                    (uint32_t)hj_join_workers(ctx->cus), bs, &st->block_counter,
+                                    &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
+    record(ctx, EV_GAPS, stream);
+    ctx->last_algo = 1;
+    return finish_blocking(ctx, result, out, stream);
+}
+
+// ---- NPJ operators ------------------------------------------------------------
+int hjgpu_npj_build(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                    uint64_t *d_table, size_t buckets, uint32_t factor, void *stream_)
+{
+    if (!ctx || !d_table || (n && (!d_keys || !d_vals))) return fail(ctx, HJGPU_EINVAL, "null pointer");
+    if (!(factor & 1) || buckets <= n) return fail(ctx, HJGPU_EINVAL, "factor must be odd and buckets > n");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
+    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
+    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+    HIPCHK(ctx, hipMemsetAsync(d_table, 0, buckets * sizeof(u64), stream));
+    if (n) CHK(hj_launch_npj_build(d_keys, d_vals, n, (u64 *)d_table, buckets, factor, &st->zero_key, ctx->cus, stream));
+    return finish_blocking(ctx, nullptr, nullptr, stream);
+}
+
+int hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                    const uint64_t *d_table, size_t buckets, uint32_t factor,
+                    hjgpu_result *result, const hjgpu_output *out, void *stream_)
+{
+    if (!ctx || !d_table || buckets == 0) return fail(ctx, HJGPU_EINVAL, "null pointer");
+    CHK(check_columns(ctx, d_keys, d_vals, n));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(DevState), stream));
+    record(ctx, EV_BEGIN, stream); record(ctx, EV_HIST, stream);
+    CHK(npj_probe_enqueue(ctx, d_keys, d_vals, n, (const u64 *)d_table, buckets, factor, out, stream));
+    ctx->last_algo = 0;
+    return finish_blocking(ctx, result, out, stream);
+}
+
+// ---- whole joins ----------------------------------------------------------------
+int hjgpu_npj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+                    const uint32_t *sk, const uint32_t *sv, size_t outer,
+                    const hjgpu_npj_params *prm, hjgpu_result *d_result, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    CHK(check_columns(ctx, rk, rv, inner));
+    CHK(check_columns(ctx, sk, sv, outer));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t buckets; uint32_t factor;
+    CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
+    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, nullptr, stream));
+    if (d_result)
+        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+    return HJGPU_OK;
+}
+
+int hjgpu_npj(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+              const uint32_t *sk, const uint32_t *sv, size_t outer,
+              const hjgpu_npj_params *prm, hjgpu_result *result, const hjgpu_output *out, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    CHK(check_columns(ctx, rk, rv, inner));
+    CHK(check_columns(ctx, sk, sv, outer));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t buckets; uint32_t factor;
+    CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
+    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream));
+    return finish_blocking(ctx, result, out, stream);
+}
+
+static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
+                    const uint32_t *rk, const uint32_t *rv, size_t inner,
+                    const uint32_t *sk, const uint32_t *sv, size_t outer,
+                    const hjgpu_phj_params *prm, hjgpu_result *result, hjgpu_result *d_result,
+                    const hjgpu_output *out, void *stream_, bool blocking)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    CHK(check_columns(ctx, rk, rv, inner));
+    CHK(check_columns(ctx, sk, sv, outer));
+    if (chunks < 1 || chunks > 8) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 8]");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PhjPlan pl;
+    CHK(phj_prepare(ctx, inner, outer, prm, chunks, &pl));
+    CHK(phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, out, stream));
+    if (d_result)
+        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+    if (blocking) return finish_blocking(ctx, result, out, stream);
+    return HJGPU_OK;
+}
+
+int hjgpu_phj(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+              const uint32_t *sk, const uint32_t *sv, size_t outer,
+              const hjgpu_phj_params *prm, hjgpu_result *result, const hjgpu_output *out, void *stream)
+{
+    return phj_like(ctx, 1, rk, rv, inner, sk, sv, outer, prm, result, nullptr, out, stream, true);
+}
+
+int hjgpu_phj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+                    const uint32_t *sk, const uint32_t *sv, size_t outer,
+                    const hjgpu_phj_params *prm, hjgpu_result *d_result, void *stream)
+{
+    return phj_like(ctx, 1, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false);
+}
+
+int hjgpu_cpra(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+               const uint32_t *sk, const uint32_t *sv, size_t outer,
+               const hjgpu_phj_params *prm, hjgpu_result *result, const hjgpu_output *out, void *stream)
+{
+    const uint32_t chunks = (prm && prm->chunks) ? prm->chunks : 8;
+    return phj_like(ctx, chunks, rk, rv, inner, sk, sv, outer, prm, result, nullptr, out, stream, true);
+}
+
+int hjgpu_cpra_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+                     const uint32_t *sk, const uint32_t *sv, size_t outer,
+                     const hjgpu_phj_params *prm, hjgpu_result *d_result, void *stream)
+{
+    const uint32_t chunks = (prm && prm->chunks) ? prm->chunks : 8;
+    return phj_like(ctx, chunks, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false);
+}
+
+int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
+                    const uint32_t *ik, const uint32_t *iv, size_t inner,
+                    const uint32_t *ok, const uint32_t *ov, size_t outer,
+                    const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
+                    hjgpu_result *result, hjgpu_stats *stats)
+{
+    if (!ctx || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
+    if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return fail(ctx, HJGPU_EINVAL, "null column");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void *h[4] = {ik, iv, ok, ov};
+    const size_t n[4] = {inner, inner, outer, outer};
+    int rc = HJGPU_OK;
+    for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) {
+        rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
+        if (rc == HJGPU_OK) rc = hjgpu_memcpy_h2d(ctx, d[i], h[i], n[i] * sizeof(uint32_t));
+    }
+    if (rc == HJGPU_OK) {
+        // allocate the workspace before the timed region, like the reference's
+        // mamalloc()s before its clock starts (npj.cpp:982-1000 vs 861-863)
+        if (algorithm == 0) { size_t b; uint32_t f; rc = npj_prepare(ctx, inner, np, &b, &f); }
+        else { PhjPlan pl; rc = phj_prepare(ctx, inner, outer, pp, algorithm == 2 ? ((pp && pp->chunks) ? pp->chunks : 8) : 1, &pl); }
+    }
+    if (rc == HJGPU_OK) {
+        const uint32_t *rk = (const uint32_t *)d[0], *rv = (const uint32_t *)d[1];
+        const uint32_t *sk = (const uint32_t *)d[2], *sv = (const uint32_t *)d[3];
+        if (algorithm == 0) rc = hjgpu_npj(ctx, rk, rv, inner, sk, sv, outer, np, result, nullptr, nullptr);
+        else if (algorithm == 1) rc = hjgpu_phj(ctx, rk, rv, inner, sk, sv, outer, pp, result, nullptr, nullptr);
+        else rc = hjgpu_cpra(ctx, rk, rv, inner, sk, sv, outer, pp, result, nullptr, nullptr);
+    }
+    if (rc == HJGPU_OK && stats) rc = hjgpu_get_stats(ctx, stats);
+    for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
+    return rc;
+}
+
+// ---- generator ------------------------------------------------------------------
+int hjgpu_generate(hjgpu_ctx *ctx, uint64_t seed, size_t inner, size_t outer_total,
+                   size_t outer_begin, size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
+                   uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if ((ik && !iv) || (ok && !ov)) return fail(ctx, HJGPU_EINVAL, "key column without payload column");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = hj_launch_generate(seed, inner, outer_total, outer_begin, outer_count, inner_factor,
+                                outer_factor, ik, iv, ok, ov, stream);
+    if (rc != HJGPU_OK) return fail(ctx, rc, "generate: bad sizes or launch failure");
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    return HJGPU_OK;
+}
+
+int hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t fa, uint32_t fb,
+                      uint64_t sums[3], void *stream_)
+{
+    if (!ctx || !sums || (n && !d_keys)) return HJGPU_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->moves, 64));
+    u64 *d = (u64 *)ctx->moves.p;
+    CHK(hj_launch_column_sums(d_keys, n, fa, fb, d, stream));
+    HIPCHK(ctx, hipMemcpyAsync(sums, d, 3 * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    return HJGPU_OK;
+}
+
+}  // extern "C"

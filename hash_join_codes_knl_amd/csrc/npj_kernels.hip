@@ -1,0 +1,264 @@
+// npj_kernels.hip — K2 build, K3 probe, K9 close_gaps for the no-partition join.
+//
+// Replaces build()/probe()/close_gaps() of npj.cpp:190-212, 216-364 (scalar
+// definition 412-445), 475-514.  One global linear-probing table of
+// uint64 (payload << 32 | key), empty = 0, exactly the reference's bucket
+// format, so a table built here can be probed by the oracle and vice versa.
+// Design (not a translation):
+//   * build: one tuple per lane, 64-bit global compare-and-swap against 0; the
+//     key/payload columns are read with 16-byte loads.
+//   * probe: one tuple per lane per chain, four chains per lane from a 16-byte
+//     load, each walking consecutive buckets to the first empty one and
+//     reporting every key match (the reference's "refill finished lanes" loop,
+//     npj.cpp:251-254, exists because its 16 lanes are all it has; here
+//     thousands of resident waves hide the divergence instead).
+//   * The load factor is a free knob (results do not depend on it): the GPU
+//     default is 0.5, the reference's 0.90 (npj.cpp:944) gives ~59-bucket walks.
+#include "hj_device.hpp"
+#include "hj_internal.hpp"
+#include "hj_emit.hpp"
+
+__device__ __forceinline__ u64 npj_bucket(uint32_t key, uint32_t factor, u64 buckets)
+{
+    // h = ((uint64)(uint32)(key*factor) * buckets) >> 32, buckets may exceed 2^32
+    const u64 x = (u64)(uint32_t)(key * factor);
+    return (u64)(((unsigned __int128)x * buckets) >> 32);
+}
+
+__global__ __launch_bounds__(256) void npj_build_kernel(const uint32_t *__restrict__ keys,
+                                                        const uint32_t *__restrict__ vals, u64 n,
+                                                        u64 *table, u64 buckets, uint32_t factor,
+                                                        uint32_t *zero_key_flag)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t key = keys[i];
+        if (key == 0) { atomicOr(zero_key_flag, 1u); continue; }   // npj.cpp:583: 0 is "empty"
+        const u64 pair = ((u64)vals[i] << 32) | key;
+        u64 h = npj_bucket(key, factor, buckets);
+        for (;;) {
+            // claim the first bucket whose low word is empty (npj.cpp:204-210)
+            const u64 old = atomicCAS(&table[h], 0ull, pair);
+            if (old == 0ull) break;
+            if (++h == buckets) h = 0;
+        }
+    }
+}
+
+int hj_launch_npj_build(const uint32_t *keys, const uint32_t *vals, size_t n, u64 *table,
+                        size_t buckets, uint32_t factor, uint32_t *zero_key_flag,
+                        int cus, hipStream_t stream)
+{
+    if (buckets <= n) return HJGPU_EINVAL;       // a walk must always find an empty bucket
+    u64 blocks = (n + 255) / 256;
+    if (blocks > (u64)cus * 16) blocks = (u64)cus * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(npj_build_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, keys, vals,
+                       (u64)n, table, (u64)buckets, factor, zero_key_flag);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+constexpr int NPJ_PROBE_BLOCK = 256;
+
+__global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs a)
+{
+    constexpr int NW = NPJ_PROBE_BLOCK / 64;
+    __shared__ u64 red[4][NW];
+    __shared__ u64 wave_cursor[NW];
+    const int wave = threadIdx.x >> 6;
+    Emitter em;
+    em.init(a.ok, a.oov, a.oiv, a.block_size, a.block_limit, a.block_counter, a.overflow,
+            &wave_cursor[wave]);
+    if (hj_lane() == 0) wave_cursor[wave] = HJ_NO_CURSOR;
+
+    const uint32_t a0 = (uint32_t)(((uintptr_t)a.keys >> 2) & 3);
+    const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(a.keys - a0);
+    const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(a.vals - a0);
+    const u64 gb = a0, ge = a0 + a.n;
+    const u64 nvec = (ge + 3) >> 2;
+    const u64 stride = (u64)gridDim.x * NPJ_PROBE_BLOCK;
+    const u64 *__restrict__ table = a.table;
+    const u64 buckets = a.buckets;
+    const uint32_t factor = a.factor;
+
+    u64 acc_n = 0, acc_k = 0, acc_o = 0, acc_i = 0;
+    for (u64 v = (u64)blockIdx.x * NPJ_PROBE_BLOCK + threadIdx.x; v < nvec; v += stride) {
+        const uint4 kk = k4[v], vv = v4[v];
+        const u64 g = v << 2;
+        const uint32_t key[4] = {kk.x, kk.y, kk.z, kk.w};
+        const uint32_t val[4] = {vv.x, vv.y, vv.z, vv.w};
+        u64 h[4], t[4];
+        bool act[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            act[j] = (g + j >= gb) && (g + j < ge);
+            h[j] = npj_bucket(key[j], factor, buckets);
+            t[j] = act[j] ? table[h[j]] : 0ull;
+        }
+        while (act[0] | act[1] | act[2] | act[3]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (act[j]) {
+                    if ((uint32_t)t[j] == 0u) {
+                        act[j] = false;
+                    } else {
+                        if ((uint32_t)t[j] == key[j]) {
+                            const uint32_t iv = (uint32_t)(t[j] >> 32);
+                            acc_n += 1; acc_k += key[j]; acc_o += val[j]; acc_i += iv;
+                            em.emit(key[j], val[j], iv);
+                        }
+                        if (++h[j] == buckets) h[j] = 0;
+                        t[j] = table[h[j]];
+                    }
+                }
+            }
+        }
+    }
+    if (a.ok && hj_lane() == 0)
+        a.final_offsets[(u64)blockIdx.x * NW + wave] = wave_cursor[wave];
+    acc_n = wave_reduce_sum(acc_n); acc_k = wave_reduce_sum(acc_k);
+    acc_o = wave_reduce_sum(acc_o); acc_i = wave_reduce_sum(acc_i);
+    if (hj_lane() == 0) { red[0][wave] = acc_n; red[1][wave] = acc_k; red[2][wave] = acc_o; red[3][wave] = acc_i; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u64 s = 0;
+        for (int i = 0; i < NW; ++i) s += red[threadIdx.x][i];
+        if (s) atomicAdd(reinterpret_cast<u64 *>(a.result) + threadIdx.x, s);
+    }
+}
+
+int hj_npj_probe_grid(int cus, size_t n)
+{
+    u64 blocks = ((n + 3) / 4 + NPJ_PROBE_BLOCK - 1) / NPJ_PROBE_BLOCK;
+    if (blocks > (u64)cus * 8) blocks = (u64)cus * 8;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int hj_launch_npj_probe(const NpjProbeArgs &a, int cus, hipStream_t stream, int *grid_out)
+{
+    const int grid = hj_npj_probe_grid(cus, a.n);
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL(npj_probe_kernel, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+// --------------------------------------------------------------------------
+// K9 close_gaps (npj.cpp:475-514).  Input: one end cursor per worker (wave);
+// [cursor, end of its block) is a hole.  The filled region is made the dense
+// prefix [0, J): tuples are taken from the highest filled positions and moved
+// into the lowest holes.  Plan kernel (one workgroup): sort the holes (bitonic,
+// LDS), then the reference's two-pointer walk (thread 0; <= 2*#workers steps)
+// emits a move list; copy kernel: the whole chip executes the moves.  J is
+// written to *dense_count.
+// --------------------------------------------------------------------------
+constexpr int CG_BLOCK = 1024;
+constexpr int CG_MAX = 8192;      // max workers (waves) supported
+
+struct Move { u64 dst, src, cnt; };
+
+__global__ __launch_bounds__(CG_BLOCK) void close_gaps_plan_kernel(
+    const u64 *__restrict__ final_offsets, uint32_t nworkers, u64 block_size,
+    const u64 *__restrict__ block_counter, const uint32_t *__restrict__ overflow,
+    Move *moves, uint32_t *nmoves, u64 *dense_count)
+{
+    // an overflowed join left cursors that do not describe disjoint holes: plan nothing
+    if (*overflow) {
+        if (threadIdx.x == 0) { *nmoves = 0; *dense_count = 0; }
+        return;
+    }
+    __shared__ u64 hole_beg[CG_MAX];
+    __shared__ u64 hole_end[CG_MAX];
+    const int tid = threadIdx.x;
+    // holes with no cursor sort to the end (key = ~0)
+    for (uint32_t i = tid; i < CG_MAX; i += CG_BLOCK)
+        hole_beg[i] = (i < nworkers) ? final_offsets[i] : HJ_NO_CURSOR;
+    __syncthreads();
+    for (uint32_t size = 2; size <= CG_MAX; size <<= 1) {
+        for (uint32_t strd = size >> 1; strd > 0; strd >>= 1) {
+            for (uint32_t i = tid; i < CG_MAX / 2; i += CG_BLOCK) {
+                const uint32_t lo = 2 * i - (i & (strd - 1));
+                const uint32_t hi = lo + strd;
+                const bool up = ((lo & size) == 0);
+                const u64 x = hole_beg[lo], y = hole_beg[hi];
+                if ((x > y) == up) { hole_beg[lo] = y; hole_beg[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    // block ends are fixed now; the walk below advances hole_beg only
+    for (uint32_t i = tid; i < CG_MAX; i += CG_BLOCK)
+        hole_end[i] = (hole_beg[i] == HJ_NO_CURSOR) ? HJ_NO_CURSOR
+                                                    : (hole_beg[i] & ~(block_size - 1)) + block_size;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t count = 0;
+        while (count < nworkers && hole_beg[count] != HJ_NO_CURSOR) ++count;
+        uint32_t nm = 0;
+        u64 dense = 0;
+        if (count) {
+            // Two-pointer walk of npj.cpp:486-511 over the holes sorted by position.
+            // The highest claimed block is some worker's last block, so it holds the
+            // highest hole: nothing filled lies above hole_end[count-1].
+            uint32_t l = 0, h = count - 1;
+            u64 src = hole_end[h];
+            uint32_t guard = 4 * count + 4;                 // the walk needs < 3*count steps
+            while (l <= h && guard--) {
+                const u64 fill = src - hole_end[h];         // filled tuples above hole h
+                if (fill == 0) {
+                    src = hole_beg[h];
+                    if (h == 0) break;
+                    --h;
+                    continue;
+                }
+                const u64 hole = hole_end[l] - hole_beg[l];
+                if (hole == 0) { ++l; continue; }
+                const u64 cnt = fill < hole ? fill : hole;
+                moves[nm].dst = hole_beg[l];
+                moves[nm].src = src - cnt;
+                moves[nm].cnt = cnt;
+                ++nm;
+                hole_beg[l] += cnt;
+                src -= cnt;
+            }
+            dense = src;
+        }
+        *nmoves = nm;
+        *dense_count = dense;
+    }
+}
+
+// All workgroups copy the planned moves (sources lie above every remaining
+// hole, so a move never overlaps its destination or another move).
+__global__ __launch_bounds__(256) void close_gaps_copy_kernel(
+    uint32_t *k, uint32_t *ov, uint32_t *iv, const Move *__restrict__ moves,
+    const uint32_t *__restrict__ nmoves)
+{
+    constexpr u64 CH = 2048;
+    const uint32_t nm = *nmoves;
+    for (uint32_t m = 0; m < nm; ++m) {
+        const u64 dst = moves[m].dst, src = moves[m].src, cnt = moves[m].cnt;
+        for (u64 c = (u64)blockIdx.x * CH; c < cnt; c += (u64)gridDim.x * CH) {
+            const u64 e = min(cnt, c + CH);
+            for (u64 i = c + threadIdx.x; i < e; i += 256) {
+                k[dst + i] = k[src + i];
+                ov[dst + i] = ov[src + i];
+                iv[dst + i] = iv[src + i];
+            }
+        }
+    }
+}
+
+int hj_launch_close_gaps_ex(uint32_t *k, uint32_t *ov, uint32_t *iv, const u64 *final_offsets,
+                            uint32_t nworkers, u64 block_size, const u64 *block_counter,
+                            const uint32_t *overflow, void *moves, uint32_t *nmoves,
+                            u64 *dense_count, int cus, hipStream_t stream)
+{
+    if (nworkers > CG_MAX) return HJGPU_EINVAL;
+    hipLaunchKernelGGL(close_gaps_plan_kernel, dim3(1), dim3(CG_BLOCK), 0, stream,
+                       final_offsets, nworkers, block_size, block_counter, overflow,
+                       reinterpret_cast<Move *>(moves), nmoves, dense_count);
+    hipLaunchKernelGGL(close_gaps_copy_kernel, dim3(cus * 4), dim3(256), 0, stream, k, ov, iv,
+                       reinterpret_cast<const Move *>(moves), nmoves);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}

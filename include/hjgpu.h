@@ -1,0 +1,223 @@
+/*
+ * hjgpu.h — C-ABI of libhjgpu: MI355X (gfx950) hash-join operators.
+ *
+ * This is the drop-in boundary for the hot path of xtcyclist/hash_join_codes_KNL.
+ * The reference has no plugin/FFI layer: its "interface" is the operator
+ * functions that run()/run_hj() call (npj.cpp:769-927, phj.cpp:1646-1949,
+ * cpra2.cpp:1697-1986).  Each entry point below names the reference operator(s)
+ * it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - Column layout is hj.h:1-72's: separate uint32 key and payload columns
+ *     (inner = build side R, outer = probe side S).  `d_` pointers are DEVICE
+ *     pointers (HBM); key and payload columns of one relation must be 16-byte
+ *     aligned (the reference requires 64-byte alignment, npj.cpp:118-126).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *     `*_async` entry points only enqueue; everything else returns after the
+ *     work has completed.
+ *   - Every function returns an HJGPU_* status (the reference aborts through
+ *     assert(); a library reports).  hjgpu_last_error() has the detail text.
+ *   - Hash function everywhere: H(key, f, N) = mulhi32((uint32)(key*f), N)
+ *     (npj.cpp:200-201, phj.cpp:83-100, 721-722); factors must be odd.
+ *   - Join result = order-free aggregates over the three output columns
+ *     join_keys / join_outer_vals / join_inner_vals.
+ */
+#ifndef HJGPU_H
+#define HJGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HJGPU_OK          0
+#define HJGPU_EINVAL      1   /* null pointer, even factor, fan-out out of range ...        */
+#define HJGPU_EALIGN      2   /* column pointer not 16-byte aligned                         */
+#define HJGPU_ENOMEM      3   /* device allocation failed                                   */
+#define HJGPU_EHIP        4   /* HIP runtime error (text in hjgpu_last_error)               */
+#define HJGPU_EZEROKEY    5   /* NPJ only: key 0 is the empty-bucket sentinel (npj.cpp:583) */
+#define HJGPU_EOVERFLOW   6   /* materialised output exceeded its capacity
+                                 (reference: assert(o <= block_limit), npj.cpp:245)          */
+#define HJGPU_ENODEVICE   7   /* no gfx950-class device visible                             */
+
+#define HJGPU_MAX_FANOUT  1024u   /* per partitioning pass                                   */
+#define HJGPU_MAX_PARTS   32768u  /* fanout1 * fanout2                                       */
+
+typedef struct hjgpu_ctx hjgpu_ctx;
+
+typedef struct {
+    uint64_t count;            /* J                                                          */
+    uint64_t sum_keys;         /* sum join_keys[j]        mod 2^64                           */
+    uint64_t sum_outer_vals;   /* sum join_outer_vals[j]  (probe-side payload)               */
+    uint64_t sum_inner_vals;   /* sum join_inner_vals[j]  (build-side payload)               */
+} hjgpu_result;
+
+/* Optional materialised output: three device columns of `capacity` uint32.
+ * Blocks of block_size tuples are claimed with one atomic each, exactly the
+ * reference's protocol (npj.cpp:244-246, 312-316); after the join the dense
+ * prefix [0, count) holds the result (close_gaps, npj.cpp:475-514). */
+typedef struct {
+    uint32_t *d_keys;
+    uint32_t *d_outer_vals;
+    uint32_t *d_inner_vals;
+    size_t    capacity;        /* in tuples; multiple of block_size                          */
+    size_t    block_size;      /* power of two; 0 = 65536 (npj.cpp:945)                      */
+} hjgpu_output;
+
+typedef struct {
+    uint32_t fanout1, fanout2; /* pass fan-outs; 0 = choose from |R| and the LDS table size  */
+    uint32_t factor1, factor2; /* odd pass multipliers; 0 = library defaults                 */
+    uint32_t table_factor[2];  /* odd table hash / step multipliers; 0 = defaults            */
+    uint32_t chunks;           /* CPRA only: number of independently partitioned chunks
+                                  (the reference's #threads, cpra2.cpp:1757-1827); 0 = 8     */
+    uint32_t reserved;
+} hjgpu_phj_params;
+
+typedef struct {
+    double   load;             /* buckets = inner/load (npj.cpp:944-947); 0 = 0.5            */
+    uint32_t factor;           /* odd multiplier; 0 = default                                */
+    uint32_t reserved;
+} hjgpu_npj_params;
+
+/* Per-phase device times of the last join on this context (hipEvent based). */
+typedef struct {
+    float    ms_total;
+    float    ms_histogram;     /* K4: fused two-level histogram, R and S                     */
+    float    ms_plan;          /* K5: prefix sums / cursors                                  */
+    float    ms_scatter1;      /* K6 pass 1, R and S                                         */
+    float    ms_scatter2;      /* K6 pass 2, R and S                                         */
+    float    ms_join;          /* K7+K8 (PHJ/CPRA) or K3 probe (NPJ)                         */
+    float    ms_build;         /* NPJ: K1 clear + K2 build                                   */
+    float    ms_close_gaps;    /* K9                                                         */
+    uint32_t fanout1, fanout2; /* what was used                                              */
+    uint64_t buckets;          /* NPJ table size                                             */
+} hjgpu_stats;
+
+typedef struct {
+    char     name[128];
+    char     arch[64];
+    int      compute_units;
+    int      lds_bytes_per_block;
+    uint64_t hbm_bytes;
+} hjgpu_device_info;
+
+/* ---- context ---------------------------------------------------------------- */
+int  hjgpu_create(int device, hjgpu_ctx **ctx);           /* device < 0: current device      */
+int  hjgpu_destroy(hjgpu_ctx *ctx);
+const char *hjgpu_last_error(const hjgpu_ctx *ctx);
+const char *hjgpu_status_string(int status);
+int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
+/* Pre-size the internal workspace (partition scratch twins = hj.h's [1]
+ * columns, NPJ table) so that no allocation happens inside a timed join. */
+int  hjgpu_reserve(hjgpu_ctx *ctx, size_t inner_tuples, size_t outer_tuples);
+int  hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *stats);
+
+/* ---- device memory helpers for hosts that do not link HIP (mamalloc/free,
+ * npj.cpp:118-126, and the fread targets npj.cpp:1013-1039) ------------------- */
+int  hjgpu_malloc(hjgpu_ctx *ctx, void **d_ptr, size_t bytes);
+int  hjgpu_free(hjgpu_ctx *ctx, void *d_ptr);
+int  hjgpu_memcpy_h2d(hjgpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int  hjgpu_memcpy_d2h(hjgpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int  hjgpu_synchronize(hjgpu_ctx *ctx, void *stream);
+
+/* ---- partition operators ------------------------------------------------------ */
+/* histogram(), phj.cpp:693 (shared form 773): d_counts[p] = |{i: H(key_i,f,F)=p}|. */
+int  hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n,
+                     uint32_t factor, uint32_t fanout, uint64_t *d_counts, void *stream);
+/* histogram() + interleave() + partition() (phj.cpp:693, 1263, 1029): permutes
+ * (key, payload) so that partition p occupies [d_offsets[p], d_offsets[p+1]);
+ * order inside a partition is unspecified, as in the reference.
+ * d_offsets: fanout+1 uint64 (64-bit: SURVEY F10). */
+int  hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                     uint32_t factor, uint32_t fanout,
+                     uint32_t *d_keys_out, uint32_t *d_vals_out, uint64_t *d_offsets,
+                     void *stream);
+/* build()+probe() over co-partitioned relations (phj.cpp:307, 399; the commented
+ * join loop phj.cpp:1869-1924 / live cpra2.cpp:1883-1971): for every partition p,
+ * R rows [d_inner_offsets[p], [p+1]) are loaded into an LDS hash table and S rows
+ * [d_outer_offsets[p], [p+1]) probe it.  (factor1, fanout1, factor2, fanout2)
+ * must be the passes that produced the partitions (needed to pick a per-partition
+ * empty sentinel, phj.cpp:1886-1897; fanout2 = 1 for a single pass). */
+int  hjgpu_join_partitions(hjgpu_ctx *ctx,
+                           const uint32_t *d_inner_keys, const uint32_t *d_inner_vals,
+                           const uint64_t *d_inner_offsets,
+                           const uint32_t *d_outer_keys, const uint32_t *d_outer_vals,
+                           const uint64_t *d_outer_offsets,
+                           const hjgpu_phj_params *passes,
+                           hjgpu_result *result, const hjgpu_output *out, void *stream);
+
+/* ---- NPJ operators ------------------------------------------------------------- */
+/* set()+build(), npj.cpp:366, 190: d_table = uint64[buckets] of (val<<32)|key. */
+int  hjgpu_npj_build(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                     uint64_t *d_table, size_t buckets, uint32_t factor, void *stream);
+/* probe()+close_gaps(), npj.cpp:216, 475. */
+int  hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                     const uint64_t *d_table, size_t buckets, uint32_t factor,
+                     hjgpu_result *result, const hjgpu_output *out, void *stream);
+
+/* ---- whole joins on HBM-resident columns (replace run()/run_hj()) ---------------- */
+/* run(), npj.cpp:769-927 */
+int  hjgpu_npj(hjgpu_ctx *ctx,
+               const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+               const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+               const hjgpu_npj_params *params,
+               hjgpu_result *result, const hjgpu_output *out, void *stream);
+/* run_hj(), phj.cpp:1646-1949 */
+int  hjgpu_phj(hjgpu_ctx *ctx,
+               const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+               const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+               const hjgpu_phj_params *params,
+               hjgpu_result *result, const hjgpu_output *out, void *stream);
+/* run_hj(), cpra2.cpp:1697-1986 (chunked partitioning, owner gathers slices) */
+int  hjgpu_cpra(hjgpu_ctx *ctx,
+                const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+                const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+                const hjgpu_phj_params *params,
+                hjgpu_result *result, const hjgpu_output *out, void *stream);
+/* Enqueue-only forms: the aggregates land in d_result (device memory, 32 bytes);
+ * no host synchronisation, so a caller can time with its own events or capture
+ * the sequence.  Workspace must have been reserved (hjgpu_reserve). */
+int  hjgpu_npj_async(hjgpu_ctx *ctx,
+                     const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+                     const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+                     const hjgpu_npj_params *params, hjgpu_result *d_result, void *stream);
+int  hjgpu_phj_async(hjgpu_ctx *ctx,
+                     const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+                     const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+                     const hjgpu_phj_params *params, hjgpu_result *d_result, void *stream);
+int  hjgpu_cpra_async(hjgpu_ctx *ctx,
+                      const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+                      const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+                      const hjgpu_phj_params *params, hjgpu_result *d_result, void *stream);
+
+/* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
+ * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates. ---------- */
+int  hjgpu_join_host(hjgpu_ctx *ctx, int algorithm /* 0 npj, 1 phj, 2 cpra */,
+                     const uint32_t *inner_keys, const uint32_t *inner_vals, size_t inner,
+                     const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
+                     const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
+                     hjgpu_result *result, hjgpu_stats *stats);
+
+/* ---- data generator (write.cpp / generate_data_for_join, cpra2.cpp:1578-1696):
+ * statistical contract only — unique non-zero build keys, probe keys drawn from
+ * them (every build key at least once when outer >= inner), payload = key*factor,
+ * both sides in pseudo-random order; counter-based, so any shard
+ * [outer_begin, outer_begin+outer_count) of the probe side can be produced
+ * independently on its own GPU. */
+int  hjgpu_generate(hjgpu_ctx *ctx, uint64_t seed, size_t inner, size_t outer_total,
+                    size_t outer_begin, size_t outer_count,
+                    uint32_t inner_factor, uint32_t outer_factor,
+                    uint32_t *d_inner_keys, uint32_t *d_inner_vals,   /* may be NULL */
+                    uint32_t *d_outer_keys, uint32_t *d_outer_vals,   /* may be NULL */
+                    void *stream);
+/* sum over a column of key, key*f_a, key*f_b (mod 2^32 per term, uint64 sums):
+ * the analytic join aggregates of a selectivity-1 workload. */
+int  hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n,
+                       uint32_t f_a, uint32_t f_b, uint64_t sums[3], void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HJGPU_H */

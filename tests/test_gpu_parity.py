@@ -1,0 +1,304 @@
+"""GPU parity tests: every HIP operator / whole join, called through the C-ABI
+(include/hjgpu.h via ctypes), against the CPU oracle on the same seeded inputs.
+Integer work: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+import hash_join_codes_knl_amd as H
+from helpers import mulhi_hash, pairs, numpy_join, materialised_rows, sort_rows
+
+pytestmark = pytest.mark.gpu
+
+F_A, F_B = 0x9E3779B1, 0x85EBCA6B
+
+
+def _cols(hj, *arrays):
+    return [hj.column(a) for a in arrays]
+
+
+def _free(*cols):
+    for c in cols:
+        c.free()
+
+
+# ---------------------------------------------------------------- K4 histogram
+@pytest.mark.parametrize("n,fanout", [(0, 8), (1, 1), (5, 3), (1000, 7), (100003, 64),
+                                      (1 << 20, 1000), (3_000_017, 17000), (50_000, 32768)])
+def test_histogram_matches_oracle(hj, oracle, n, fanout):
+    rng = np.random.default_rng(n + fanout)
+    keys = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    want = oracle.histogram(keys, F_A, fanout).astype(np.uint64)
+    dk = hj.column(keys) if n else hj.column(1)
+    dc = hj.column(fanout, np.uint64)
+    hj.histogram(dk, n, F_A, fanout, dc)
+    got = dc.download()
+    _free(dk, dc)
+    assert got.sum() == n
+    assert np.array_equal(got, want)
+
+
+def test_histogram_unaligned_view(hj, oracle):
+    """Sub-ranges that do not start on a 16-byte boundary (pass-2 segments do not)."""
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 2**32, size=10_000, dtype=np.uint64).astype(np.uint32)
+    dk = hj.column(keys)
+    dc = hj.column(37, np.uint64)
+    for off, n in [(1, 999), (2, 4097), (3, 1), (7, 8190), (5, 0)]:
+        hj.histogram(dk.ptr + 4 * off, n, F_B, 37, dc)
+        assert np.array_equal(dc.download(), oracle.histogram(keys[off:off + n], F_B, 37).astype(np.uint64))
+    _free(dk, dc)
+
+
+# ---------------------------------------------------------------- K5+K6 partition
+@pytest.mark.parametrize("n,fanout", [(0, 4), (1, 2), (17, 5), (8192, 64), (8193, 64),
+                                      (100_003, 128), (1_000_000, 1000), (2_500_000, 1024),
+                                      (300_000, 1)])
+def test_partition_matches_oracle(hj, oracle, n, fanout):
+    rng = np.random.default_rng(n * 31 + fanout)
+    keys = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    vals = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    counts, ko_ref, vo_ref = oracle.partition(keys, vals, F_A, fanout)
+    dk, dv = (hj.column(keys), hj.column(vals)) if n else (hj.column(1), hj.column(1))
+    dko, dvo = hj.column(max(n, 1)), hj.column(max(n, 1))
+    doff = hj.column(fanout + 1, np.uint64)
+    hj.partition(dk, dv, n, F_A, fanout, dko, dvo, doff)
+    off = doff.download().astype(np.int64)
+    ko, vo = dko.download(n), dvo.download(n)
+    _free(dk, dv, dko, dvo, doff)
+    want_off = np.concatenate([[0], np.cumsum(counts.astype(np.int64))])
+    assert np.array_equal(off, want_off)                      # histogram + prefix: exact
+    # every tuple lies in its hash partition
+    part_of_pos = np.searchsorted(off, np.arange(n), side="right") - 1
+    assert np.array_equal(mulhi_hash(ko, F_A, fanout), part_of_pos)
+    # per-partition multiset equality with the oracle (order inside a partition is free)
+    got = pairs(ko, vo); ref = pairs(ko_ref, vo_ref)
+    key = part_of_pos.astype(np.uint64)
+    got_sorted = got[np.lexsort((got, key))]
+    ref_sorted = ref[np.lexsort((ref, key))]
+    assert np.array_equal(got_sorted, ref_sorted)
+
+
+def test_partition_skewed_all_one_partition(hj, oracle):
+    n = 50_000
+    keys = np.full(n, 12345, np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    dk, dv, dko, dvo = hj.column(keys), hj.column(vals), hj.column(n), hj.column(n)
+    doff = hj.column(65, np.uint64)
+    hj.partition(dk, dv, n, F_A, 64, dko, dvo, doff)
+    off = doff.download()
+    p = int(mulhi_hash(keys[:1], F_A, 64)[0])
+    assert off[p] == 0 and off[p + 1] == n
+    assert np.array_equal(np.sort(dvo.download()), vals)
+    assert (dko.download() == 12345).all()
+    _free(dk, dv, dko, dvo, doff)
+
+
+# ---------------------------------------------------------------- whole joins
+CASES = {
+    # name: (outer, inner, selectivity, seed)
+    "tiny": (10, 3, 1.0, 1),
+    "small_unique": (4096, 1024, 1.0, 2),
+    "mid_unique": (65_536, 4_096, 1.0, 3),
+    "build_dups_16x": (1_000, 16_000, 1.0, 4),         # config-1 shape: 16 copies per build key
+    "selectivity_half": (50_000, 20_000, 0.5, 5),
+    "selectivity_zero": (5_000, 5_000, 0.0, 6),
+    "large": (2_000_000, 250_000, 1.0, 7),
+}
+
+
+def _join_all(hj, ik, iv, ok, ov, phj_params=None, npj_params=None, algos=("npj", "phj", "cpra")):
+    rk, rv, sk, sv = _cols(hj, ik if len(ik) else np.zeros(1, np.uint32), iv if len(iv) else np.zeros(1, np.uint32),
+                           ok if len(ok) else np.zeros(1, np.uint32), ov if len(ov) else np.zeros(1, np.uint32))
+    out = {}
+    if "npj" in algos:
+        out["npj"] = hj.npj(rk, rv, len(ik), sk, sv, len(ok), npj_params)
+    if "phj" in algos:
+        out["phj"] = hj.phj(rk, rv, len(ik), sk, sv, len(ok), phj_params)
+    if "cpra" in algos:
+        out["cpra"] = hj.cpra(rk, rv, len(ik), sk, sv, len(ok), phj_params)
+    _free(rk, rv, sk, sv)
+    return out
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_joins_match_oracle(hj, oracle, name):
+    outer, inner, sel, seed = CASES[name]
+    ik, iv, ok, ov = oracle.generate(outer, inner, selectivity=sel, seed=seed)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    assert want == numpy_join(ik, iv, ok, ov)
+    # the oracle's own three algorithms agree with the definition (restated reference)
+    assert oracle.npj(ik, iv, ok, ov, threads=2) == want
+    assert oracle.phj(ik, iv, ok, ov, threads=2, hash_table_limit=max(8, inner // 50)) == want
+    got = _join_all(hj, ik, iv, ok, ov)
+    for algo, res in got.items():
+        assert res == want, "%s on %s: got %r want %r" % (algo, name, res, want)
+
+
+@pytest.mark.parametrize("f1,f2", [(2, 1), (3, 1), (64, 1), (5, 7), (64, 64), (128, 100), (1000, 32)])
+def test_phj_cpra_any_fanout(hj, oracle, f1, f2):
+    ik, iv, ok, ov = oracle.generate(200_000, 30_000, seed=11)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    for chunks in (1, 3, 8):
+        prm = H.PhjParams(fanout1=f1, fanout2=f2, chunks=chunks)
+        got = _join_all(hj, ik, iv, ok, ov, phj_params=prm, algos=("phj", "cpra"))
+        assert got["phj"] == want and got["cpra"] == want, (f1, f2, chunks, got, want)
+
+
+def test_phj_overflow_partitions_multi_fill(hj, oracle):
+    """Partitions far larger than one LDS table fill (duplicate-heavy build side):
+    the join must re-fill the table and re-stream the probe slice."""
+    ik, iv, ok, ov = oracle.generate(3_000, 96_000, seed=12)       # 32 copies per key
+    want = oracle.join_definition(ik, iv, ok, ov)
+    prm = H.PhjParams(fanout1=2, fanout2=1)                        # ~48K build rows per partition
+    got = _join_all(hj, ik, iv, ok, ov, phj_params=prm, algos=("phj", "cpra"))
+    assert got["phj"] == want and got["cpra"] == want
+
+
+def test_phj_key_zero_is_legal(hj, oracle):
+    """PHJ/CPRA accept key 0 (per-partition sentinel, phj.cpp:1886-1897)."""
+    ik, iv, ok, ov = oracle.generate(20_000, 5_000, seed=13)
+    ik = ik.copy(); ok = ok.copy()
+    victim = ik[0]
+    ik[0] = 0; iv[0] = 777
+    ok[ok == victim] = 0
+    ok[:5] = 0
+    ov = (ok.astype(np.uint64) * 3 + 1).astype(np.uint32)
+    want = numpy_join(ik, iv, ok, ov)
+    assert want[0] > 0
+    got = _join_all(hj, ik, iv, ok, ov, algos=("phj", "cpra"))
+    assert got["phj"] == want and got["cpra"] == want
+
+
+def test_npj_rejects_key_zero(hj, oracle):
+    ik, iv, ok, ov = oracle.generate(1000, 1000, seed=14)
+    ik = ik.copy(); ik[10] = 0
+    with pytest.raises(H.HjGpuError) as e:
+        _join_all(hj, ik, iv, ok, ov, algos=("npj",))
+    assert e.value.status == H.api.EZEROKEY
+
+
+def test_empty_sides(hj, oracle):
+    ik, iv, ok, ov = oracle.generate(1000, 500, seed=15)
+    e = np.zeros(0, np.uint32)
+    for a, b, c, d in [(e, e, ok, ov), (ik, iv, e, e), (e, e, e, e)]:
+        got = _join_all(hj, a, b, c, d)
+        for res in got.values():
+            assert res == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("load", [0.25, 0.5, 0.9])
+def test_npj_load_factor_is_free(hj, oracle, load):
+    ik, iv, ok, ov = oracle.generate(100_000, 40_000, seed=16)
+    want = oracle.npj(ik, iv, ok, ov, threads=2, load=0.9)        # reference load (npj.cpp:944)
+    got = _join_all(hj, ik, iv, ok, ov, npj_params=H.NpjParams(load=load), algos=("npj",))
+    assert got["npj"] == want
+
+
+def test_npj_table_is_reference_format(hj, oracle):
+    """A table built on the GPU is probe-able by the oracle's probe and vice versa:
+    same bucket format (val<<32|key), same hash, same walk (npj.cpp:190-212, 412-445)."""
+    import ctypes as C
+    ik, iv, ok, ov = oracle.generate(30_000, 10_000, seed=17)
+    buckets = int(len(ik) / 0.5)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    rk, rv, sk, sv = _cols(hj, ik, iv, ok, ov)
+    dt = hj.column(buckets, np.uint64)
+    hj.npj_build(rk, rv, len(ik), dt, buckets, F_A)
+    table = dt.download()
+    # GPU table -> oracle probe
+    r = oracle.Result()
+    oracle.lib().hjo_npj_probe(ok, ov, len(ok), table, buckets, F_A, 0, C.byref(r), None, None)
+    assert r.as_tuple() == want
+    # same multiset of buckets as the oracle's build (placement may differ by insert order)
+    t2 = np.zeros(buckets, np.uint64)
+    oracle.lib().hjo_npj_build(ik, iv, len(ik), t2, buckets, F_A, 0)
+    assert np.array_equal(np.sort(table), np.sort(t2))
+    # oracle table -> GPU probe
+    dt.upload(t2)
+    assert hj.npj_probe(sk, sv, len(ok), dt, buckets, F_A) == want
+    _free(rk, rv, sk, sv, dt)
+
+
+# ---------------------------------------------------------------- materialised output (K9)
+@pytest.mark.parametrize("algo", ["npj", "phj", "cpra"])
+@pytest.mark.parametrize("case", ["mid_unique", "build_dups_16x", "selectivity_half"])
+def test_materialised_rows_match(hj, oracle, algo, case):
+    outer, inner, sel, seed = CASES[case]
+    ik, iv, ok, ov = oracle.generate(outer, inner, selectivity=sel, seed=seed)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    wk, wo, wi = materialised_rows(ik, iv, ok, ov)
+    block = 256
+    capacity = (want[0] // block + 8192 + 8) * block
+    rk, rv, sk, sv = _cols(hj, ik, iv, ok, ov)
+    jk, jo, ji = hj.column(capacity), hj.column(capacity), hj.column(capacity)
+    res = getattr(hj, algo)(rk, rv, len(ik), sk, sv, len(ok), None, out=(jk, jo, ji, capacity, block))
+    assert res == want
+    n = res[0]
+    gk, go, gi = sort_rows(jk.download(n), jo.download(n), ji.download(n))
+    _free(rk, rv, sk, sv, jk, jo, ji)
+    assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi)
+
+
+def test_materialised_overflow_is_reported(hj, oracle):
+    ik, iv, ok, ov = oracle.generate(50_000, 10_000, seed=21)
+    rk, rv, sk, sv = _cols(hj, ik, iv, ok, ov)
+    cap = 256 * 4
+    jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+    with pytest.raises(H.HjGpuError) as e:
+        hj.phj(rk, rv, len(ik), sk, sv, len(ok), None, out=(jk, jo, ji, cap, 256))
+    assert e.value.status == H.api.EOVERFLOW
+    _free(rk, rv, sk, sv, jk, jo, ji)
+
+
+# ---------------------------------------------------------------- argument checking
+def test_bad_arguments(hj):
+    d = hj.column(np.arange(64, dtype=np.uint32))
+    with pytest.raises(H.HjGpuError) as e:
+        hj.phj(d.ptr + 4, d.ptr + 4, 8, d, d, 8)                   # misaligned column
+    assert e.value.status == H.api.EALIGN
+    with pytest.raises(H.HjGpuError) as e:
+        hj.phj(d, d, 8, d, d, 8, H.PhjParams(fanout1=4, fanout2=1, factor1=2))   # even factor
+    assert e.value.status == H.api.EINVAL
+    with pytest.raises(H.HjGpuError) as e:
+        hj.phj(d, d, 8, d, d, 8, H.PhjParams(fanout1=2000, fanout2=1))
+    assert e.value.status == H.api.EINVAL
+    d.free()
+
+
+# ---------------------------------------------------------------- generator
+def test_device_generator_contract(hj):
+    inner, outer = 100_000, 1_000_000
+    fi, fo = 0x0F0F0F0F | 1, 0x12345679
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(42, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    hik, hiv, hok, hov = ik.download(), iv.download(), ok.download(), ov.download()
+    assert (hik != 0).all() and len(np.unique(hik)) == inner          # unique non-zero build keys
+    assert np.array_equal(hiv, (hik.astype(np.uint64) * fi).astype(np.uint32))
+    assert np.array_equal(hov, (hok.astype(np.uint64) * fo).astype(np.uint32))
+    assert np.isin(hok, hik).all()                                     # selectivity 1
+    assert len(np.unique(hok)) == inner                                # every build key probed
+    # shards are position-pure: generating [a, a+c) alone gives the same tuples
+    sk, sv = hj.column(1000), hj.column(1000)
+    hj.generate(42, inner, outer, 123_456, 1000, fi, fo, None, None, sk, sv)
+    assert np.array_equal(sk.download(), hok[123_456:124_456])
+    # analytic aggregates == join result
+    want = numpy_join(hik, hiv, hok, hov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    assert (outer, sums[0], sums[1], sums[2]) == want
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    _free(ik, iv, ok, ov, sk, sv)
+
+
+def test_device_generator_duplicate_build_side(hj):
+    """outer < inner: min(inner, outer) distinct keys, build side repeats them (write.cpp:1687-1689)."""
+    inner, outer = 160_000, 10_000
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(7, inner, outer, 0, outer, 3, 5, ik, iv, ok, ov)
+    hik, hiv, hok, hov = ik.download(), iv.download(), ok.download(), ov.download()
+    assert len(np.unique(hik)) == outer and len(np.unique(hok)) == outer
+    want = numpy_join(hik, hiv, hok, hov)
+    assert want[0] == inner
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    assert hj.cpra(ik, iv, inner, ok, ov, outer) == want
+    _free(ik, iv, ok, ov)
