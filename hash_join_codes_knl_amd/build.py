@@ -51,7 +51,7 @@ def build_library(force=False, verbose=True):
     for src in srcs:
         obj = os.path.join(LIB, os.path.basename(src) + ".o")
         if force or _newer(obj, deps):
-            cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
+            cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++20", "-fPIC",
                    "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
@@ -76,7 +76,7 @@ def build_host(force=False, verbose=True):
             continue
         exe = os.path.join(LIB, name)
         if force or _newer(exe, [srcp, lib_path()] + common):
-            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
+            cmd = ["g++", "-O2", "-std=c++20", "-Wall", "-I", os.path.join(ROOT, "include"),
                    srcp, "-o", exe, "-L", LIB, "-lhjgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
             if verbose:
                 print(" ".join(cmd), flush=True)

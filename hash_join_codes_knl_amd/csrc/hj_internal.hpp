@@ -11,11 +11,39 @@ typedef unsigned long long u64;
 constexpr int HJ_SCATTER_BLOCK = 512;           // threads per scatter workgroup
 constexpr int HJ_SCATTER_VPT   = 4;             // uint4 vectors per thread per tile
 constexpr int HJ_SCATTER_TILE  = HJ_SCATTER_BLOCK * HJ_SCATTER_VPT * 4;   // 8192 tuples
-constexpr int HJ_JOIN_BLOCK    = 512;
-constexpr int HJ_JOIN_LOG2SLOTS = 13;           // 8192 slots * 8 B = 64 KiB of LDS
-constexpr int HJ_JOIN_SLOTS    = 1 << HJ_JOIN_LOG2SLOTS;
-constexpr int HJ_JOIN_CAP      = HJ_JOIN_SLOTS / 2;     // max build tuples per table fill
 constexpr int HJ_JOIN_SLICE    = 1 << 16;       // probe tuples per work item (target)
+
+// Join-kernel geometry: threads per workgroup, log2 of the LDS table slots, and
+// probe vectors each lane keeps in flight.  Default 512 / 8192 slots (64 KiB) / 4;
+// HJGPU_JOIN_CFG="block,log2slots,batch" selects another built variant (tuning).
+struct JoinConfig {
+    int block, log2slots, batch;
+    int slots() const { return 1 << log2slots; }
+    int cap() const { return slots() / 2; }      // max build tuples per table fill (load <= 0.5)
+};
+const JoinConfig &hj_join_config();
+
+// Geometry of partitioning pass 1, known on the host (sizes + alignment only):
+// each chunk (segment) is cut into `ranges_per_chunk` contiguous ranges of whole
+// tiles.  K4 counts per range, K5 turns the counts into per-range write bases,
+// and K6 pass 1 walks the same ranges with private cursors - no global atomics.
+constexpr uint32_t HJ_RANGES = 1024;            // total ranges (all chunks)
+struct Pass1Geom {
+    u64 b[9];                       // chunk boundaries b[0..chunks]
+    uint32_t chunks;
+    uint32_t align;                 // (address of the key column / 4) % 4
+    uint32_t ranges_per_chunk;      // HJ_RANGES / chunks
+    uint32_t tile;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline u64 hj_tiles_of(u64 b, u64 e, uint32_t align, uint32_t tile)
+{
+    if (e <= b) return 0;
+    const u64 gb = (align + b) & ~3ull, ge = align + e;
+    return (ge - gb + tile - 1) / tile;
+}
 
 // One partitioning pass over `nseg` independent input segments.
 struct ScatterArgs {
@@ -26,6 +54,11 @@ struct ScatterArgs {
     u64 *cursors;                   // [nseg*F] absolute output positions, advanced atomically
     uint32_t nseg, F, factor;
     uint32_t in_align;              // (address of kin / 4) % 4, same for vin
+    uint32_t exp;                   // timing-experiment bits (0 in production)
+    // pass 1 only (ranged == 1): per-range bases instead of atomic cursors
+    uint32_t ranged;
+    Pass1Geom geom;
+    const u64 *range_base;          // [ranges][F] absolute output position of each (range, partition)
 };
 
 struct JoinArgs {
@@ -44,6 +77,7 @@ struct JoinArgs {
     u64 *block_counter;                  // device
     u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
     uint32_t *overflow;                  // device flag
+    uint32_t exp;                        // timing-experiment bits (0 in production)
 };
 
 struct PlanArgs {
@@ -63,9 +97,11 @@ struct PlanArgs {
     uint32_t tile, slice;
 };
 
-int hj_launch_hist2(const uint32_t *keys, const u64 *seg1_host, uint32_t chunks,
+int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-                    u64 *counts, int cus, hipStream_t stream);
+                    u64 *counts, uint32_t *range_counts, int cus, hipStream_t stream);
+int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
+                         uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream);
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream);
 int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream);
 int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream);

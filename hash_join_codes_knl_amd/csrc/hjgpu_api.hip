@@ -98,6 +98,8 @@ inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) 
 struct MetaLayout {
     u64 *counts[2], *off2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
     u64 *slice_prefix, *slices;
+    uint32_t *range_counts[2];   // [ranges][F1] pass-1 counts per range (K4 -> K5b)
+    u64 *range_base[2];          // [ranges][F1] pass-1 write bases per range (K5b -> K6)
     size_t counts_bytes;    // both relations, contiguous (zeroed per join)
     size_t total_bytes;
 };
@@ -122,6 +124,11 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P)
     }
     m.slice_prefix = take((size_t)P + 1);
     m.slices = take(P);
+    const size_t ranges = (size_t)(HJ_RANGES / C) * C;
+    for (int r = 0; r < 2; ++r) {
+        m.range_counts[r] = reinterpret_cast<uint32_t *>(take((ranges * F1 + 1) / 2));
+        m.range_base[r] = take(ranges * F1);
+    }
     m.total_bytes = at * sizeof(u64);
     return m;
 }
@@ -134,7 +141,7 @@ void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint
 {
     uint32_t f1 = prm ? prm->fanout1 : 0, f2 = prm ? prm->fanout2 : 0;
     if (f1 == 0) {
-        const double target = HJ_JOIN_CAP * 0.85;          // mean fill; Poisson tail stays below CAP
+        const double target = hj_join_config().cap() * 0.85;   // mean fill; Poisson tail stays below CAP
         double parts = ceil((double)inner / target);
         if (parts < 2) parts = 2;
         if (parts > HJGPU_MAX_PARTS) parts = HJGPU_MAX_PARTS;
@@ -216,12 +223,18 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     return HJGPU_OK;
 }
 
-void chunk_bounds(size_t n, uint32_t C, u64 *b)
+Pass1Geom make_geom(const void *keys, size_t n, uint32_t C)
 {
-    // thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
+    // chunk ranges = thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
+    Pass1Geom g;
     const size_t part = (n / C) & ~size_t(15);
-    for (uint32_t c = 0; c < C; ++c) b[c] = part * c;
-    b[C] = n;
+    for (uint32_t c = 0; c < C; ++c) g.b[c] = part * c;
+    for (uint32_t c = C; c < 9; ++c) g.b[c] = n;
+    g.chunks = C;
+    g.align = align_of(keys);
+    g.ranges_per_chunk = HJ_RANGES / C;
+    g.tile = HJ_SCATTER_TILE;
+    return g;
 }
 
 int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
@@ -239,11 +252,9 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
 
     // K4: one read of each key column gives the histograms of both passes
-    u64 rb[9], sbnd[9];
-    chunk_bounds(inner, pl.C, rb);
-    chunk_bounds(outer, pl.C, sbnd);
-    if (inner) CHK(hj_launch_hist2(rk, rb, pl.C, pl.f1, pl.F1, pl.f2, pl.F2, m.counts[0], ctx->cus, stream));
-    if (outer) CHK(hj_launch_hist2(sk, sbnd, pl.C, pl.f1, pl.F1, pl.f2, pl.F2, m.counts[1], ctx->cus, stream));
+    const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C), make_geom(sk, outer, pl.C)};
+    if (inner) CHK(hj_launch_hist2(rk, geom[0], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[0], m.range_counts[0], ctx->cus, stream));
+    if (outer) CHK(hj_launch_hist2(sk, geom[1], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[1], m.range_counts[1], ctx->cus, stream));
     record(ctx, EV_HIST, stream);
 
     // K5
@@ -259,6 +270,11 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
     pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
     CHK(hj_launch_plan(pa, stream));
+    // K5b: per-range write bases of pass 1
+    const size_t nn0[2] = {inner, outer};
+    for (int r = 0; r < 2; ++r)
+        if (nn0[r]) CHK(hj_launch_range_base(m.range_counts[r], m.off1[r], m.range_base[r], pl.C,
+                                             geom[r].ranges_per_chunk, pl.F1, stream));
     record(ctx, EV_PLAN, stream);
 
     // K6 pass 1: caller's columns -> tmp[0..3]
@@ -272,6 +288,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
         sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
         sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
+        sa.exp = 0; sa.ranged = 1; sa.geom = geom[r]; sa.range_base = m.range_base[r];
         CHK(hj_launch_scatter(sa, ctx->cus, stream));
     }
     record(ctx, EV_SCAT1, stream);
@@ -287,6 +304,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
             sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r];
             sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
+            sa.exp = 0; sa.ranged = 0; sa.geom = geom[r]; sa.range_base = nullptr;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
         for (int i = 0; i < 4; ++i) fin[i] = t2[i];
@@ -569,8 +587,12 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(d_counts, 0, (size_t)fanout * sizeof(u64), stream));
     if (n) {
-        u64 b[9] = {0, n, n, n, n, n, n, n, n};
-        CHK(hj_launch_hist2(d_keys, b, 1, factor, fanout, 1u, 1u, (u64 *)d_counts, ctx->cus, stream));
+        // the per-range counts are a by-product here; they go to scratch
+        CHK(ensure(ctx, ctx->moves, (size_t)HJ_RANGES * sizeof(uint32_t)));
+        // (F1 = 1, F2 = fanout): the fused LDS histogram carries the counts, the
+        // per-range pass-1 rows degenerate to one counter each
+        CHK(hj_launch_hist2(d_keys, make_geom(d_keys, n, 1), 1u, 1u, factor, fanout, (u64 *)d_counts,
+                            (uint32_t *)ctx->moves.p, ctx->cus, stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(stream));
     return HJGPU_OK;
@@ -591,10 +613,8 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout);
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
-    if (n) {
-        u64 b[9] = {0, n, n, n, n, n, n, n, n};
-        CHK(hj_launch_hist2(d_keys, b, 1, factor, fanout, 1u, 1u, m.counts[0], ctx->cus, stream));
-    }
+    const Pass1Geom geom = make_geom(d_keys, n, 1);
+    if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], ctx->cus, stream));
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
         pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
@@ -607,10 +627,13 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
     CHK(hj_launch_plan(pa, stream));
     if (n) {
+        CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
+                                 geom.ranges_per_chunk, fanout, stream));
         ScatterArgs sa;
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
         sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
+        sa.exp = 0; sa.ranged = 1; sa.geom = geom; sa.range_base = m.range_base[0];
         CHK(hj_launch_scatter(sa, ctx->cus, stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),

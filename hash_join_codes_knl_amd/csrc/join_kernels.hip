@@ -3,25 +3,31 @@
 // Replaces build()/probe() of phj.cpp:307-397 / 399-571 (scalar definitions
 // 577-647) and the join loop phj.cpp:1869-1924 / cpra2.cpp:1883-1971.
 // Design (not a translation):
-//   * The reference keeps a ~128 KB table per thread in L2 (phj.cpp:1976-1977);
-//     here each 512-thread workgroup owns a 64 KiB open-addressing table in LDS
-//     (8192 slots of {key, payload}), two workgroups per CU so that one
-//     workgroup's table fill/build overlaps the other's probe stream.
-//   * Double hashing like the reference, but over a power-of-two table with an
-//     odd step: slot = top bits of key*tf0, step = (top bits of key*tf1) | 1.
-//     Load factor <= 0.5 by construction (at most SLOTS/2 build tuples per fill;
-//     larger partitions are processed in several fills, re-streaming the probe
-//     slice — the overflow path for skewed / duplicate-heavy build sides).
-//   * Insert = LDS compare-and-swap on the key word against the empty sentinel
-//     (the reference serialises lane conflicts by scatter/gather-back,
-//     phj.cpp:349-353); the sentinel of partition q is the smallest value that
-//     does NOT hash to q (generalises phj.cpp:1886-1897), so key 0 is legal.
-//   * Probe streams the S slice with aligned 16-byte loads, four independent
-//     chains per lane, walking to the first empty slot and reporting every
-//     match (no _UNIQUE, phj.cpp:616-644).
-//   * A work item is (partition, slice of its probe rows); CPRA's per-chunk
-//     pieces (cpra2.cpp:1891-1959 memcpy gather) are walked in place: the
-//     "gather" is just the loop over chunk offsets.
+//   * The reference keeps a ~128 KB double-hashing table per thread in L2
+//     (phj.cpp:1976-1977); here each workgroup owns an 8192-slot table of
+//     {key, payload} words in LDS (64 KiB, two workgroups per CU so that one
+//     workgroup's clear/build overlaps the other's probe stream).
+//   * FAST PATH - 2-choice cuckoo table.  rocprof PMC showed the open-addressing
+//     probe loop was instruction-bound (127 VALU + 77 SALU wave-instructions per
+//     probe key: 64 lanes x 4 chains wait for the longest chain), not memory-bound.
+//     In a cuckoo table a key lives in exactly one of two slots
+//     a1 = top bits of key*tf0, a2 = a1 + odd offset from key*tf1, so a probe is two
+//     independent ds_read_b64 and two compares: no loop, no divergence, and up
+//     to two copies of a build key are reported naturally (multi-match).
+//     Build = ds_wrxchg_rtn_b64 eviction walk, bounded; at load <= 0.5 it succeeds
+//     with overwhelming probability for unique keys.
+//   * FALLBACK - double-hashing chains (the reference's scheme over a power-of-two
+//     table, odd step) when the cuckoo build does not converge: >= 3 copies of a
+//     build key (config-1-like duplicate-heavy build sides) or an unlucky cycle.
+//     Probe walks to the first empty slot and reports every match (no _UNIQUE,
+//     phj.cpp:616-644).
+//   * At most SLOTS/2 build tuples per table fill; larger partitions are processed
+//     in several fills, re-streaming the probe slice (skew overflow path).
+//   * The empty sentinel of partition q is the smallest value that does NOT hash to
+//     q (generalises phj.cpp:1886-1897), so key 0 is legal.
+//   * A work item is (partition, slice of its probe rows); CPRA's per-chunk pieces
+//     (cpra2.cpp:1891-1959 memcpy gather) are walked in place: the "gather" is
+//     just the loop over chunk offsets.
 //   * Results: register aggregates (count + 3 sums) reduced per workgroup, or
 //     materialised rows through per-wave 64-bit cursors into atomically claimed
 //     blocks (the reference's block protocol, npj.cpp:244-246, 312-316).
@@ -29,17 +35,21 @@
 #include "hj_internal.hpp"
 #include "hj_emit.hpp"
 
-template <int BLOCK, int LOG2SLOTS>
-__global__ __launch_bounds__(BLOCK) void join_kernel(JoinArgs a)
+template <int BLOCK, int LOG2SLOTS, int BATCH>
+__global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 {
     constexpr uint32_t SLOTS = 1u << LOG2SLOTS;
     constexpr uint32_t MASK = SLOTS - 1;
     constexpr uint32_t CAP = SLOTS / 2;
     constexpr int SHIFT = 32 - LOG2SLOTS;
     constexpr int NW = BLOCK / 64;
-    __shared__ uint2 tab[SLOTS];                 // .x = key, .y = build payload
+    constexpr int RB = 8;                        // build rows a lane loads before inserting
+    constexpr int CUCKOO_MAX_EVICTIONS = 64;
+    __shared__ u64 tab64[SLOTS];                 // low word = key, high word = build payload
     __shared__ u64 red[4][NW];
     __shared__ u64 wave_cursor[NW];
+    __shared__ uint32_t cuckoo_failed;
+    uint2 *tab = reinterpret_cast<uint2 *>(tab64);   // chained view: .x = key, .y = payload
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -55,15 +65,142 @@ __global__ __launch_bounds__(BLOCK) void join_kernel(JoinArgs a)
     if (hj_lane() == 0) wave_cursor[wave] = HJ_NO_CURSOR;
 
     u64 acc_n = 0, acc_k = 0, acc_o = 0, acc_i = 0;
+    uint32_t empty = 0;
+    uint32_t q = 0;
+
+    // ---- visit rows [fill_beg, fill_end) of the chunk-concatenated build partition q ----
+    auto for_each_build_row = [&](u64 fill_beg, u64 fill_end, auto insert) {
+        u64 seen = 0;
+        for (uint32_t c = 0; c < C; ++c) {
+            const u64 b = a.roff[(u64)c * P + q], e = a.roff[(u64)c * P + q + 1];
+            const u64 len = e - b;
+            const u64 lo = max(seen, fill_beg), hi = min(seen + len, fill_end);
+            for (u64 base = lo; base < hi; base += (u64)BLOCK * RB) {
+                uint32_t k[RB], v[RB];
+                // all loads of the batch are issued before the first insert
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const u64 i = base + (u64)j * BLOCK + tid;
+                    k[j] = 0; v[j] = 0;
+                    if (i < hi) { k[j] = a.rk[b + (i - seen)]; v[j] = a.rv[b + (i - seen)]; }
+                }
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const u64 i = base + (u64)j * BLOCK + tid;
+                    if (i < hi) insert(k[j], v[j]);
+                }
+            }
+            seen += len;
+        }
+    };
+
+    // ---- stream the S rows [gb, ge): BATCH key + BATCH payload vectors in flight per lane ----
+    auto for_each_probe_vector = [&](u64 gb, u64 ge, auto probe4) {
+        for (u64 g0 = (gb & ~3ull) + (u64)tid * 4; g0 < ge; g0 += (u64)BLOCK * 4 * BATCH) {
+            uint4 kk[BATCH], vv[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const u64 g = g0 + (u64)u * BLOCK * 4;
+                kk[u] = make_uint4(0, 0, 0, 0); vv[u] = kk[u];
+                if (g < ge) { kk[u] = sk4[g >> 2]; vv[u] = sv4[g >> 2]; }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const u64 g = g0 + (u64)u * BLOCK * 4;
+                if (g >= ge) break;
+                const uint32_t key[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w};
+                const uint32_t val[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+                bool valid[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) valid[j] = (g + j >= gb) && (g + j < ge);
+                probe4(key, val, valid);
+            }
+        }
+    };
+
+    // cuckoo probe: two independent slot reads per key, no loop
+    auto probe4_cuckoo = [&](const uint32_t (&key)[4], const uint32_t (&val)[4], const bool (&valid)[4]) {
+        u64 t1[4], t2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a1 = (key[j] * tf0) >> SHIFT;
+            const uint32_t a2 = (a1 + (((key[j] * tf1) >> SHIFT) | 1u)) & MASK;
+            t1[j] = tab64[a1];
+            t2[j] = tab64[a2];
+        }
+        u64 sk_ = 0, so_ = 0, si_ = 0;
+        uint32_t n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
+            const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]);
+            const uint32_t m = (h1 ? 1u : 0u) + (h2 ? 1u : 0u);
+            n += m;
+            sk_ += (u64)key[j] * m;
+            so_ += (u64)val[j] * m;
+            si_ += (h1 ? (uint32_t)(t1[j] >> 32) : 0u);
+            si_ += (h2 ? (uint32_t)(t2[j] >> 32) : 0u);
+            if (a.ok) {
+                if (h1) em.emit(key[j], val[j], (uint32_t)(t1[j] >> 32));
+                if (h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
+            }
+        }
+        acc_n += n; acc_k += sk_; acc_o += so_; acc_i += si_;
+    };
+
+    // chained probe: 4 chains per lane advanced in lock step to the first empty slot
+    auto probe4_chained = [&](const uint32_t (&key)[4], const uint32_t (&val)[4], const bool (&valid)[4]) {
+        uint32_t slot[4], step[4];
+        uint2 t[4];
+        bool live[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            live[j] = valid[j];
+            slot[j] = (key[j] * tf0) >> SHIFT;
+            step[j] = ((key[j] * tf1) >> SHIFT) | 1u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t[j] = make_uint2(empty, 0u); if (live[j]) t[j] = tab[slot[j]]; }
+        for (;;) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool hit = live[j] && (t[j].x == key[j]);
+                acc_n += hit ? 1u : 0u;
+                acc_k += hit ? key[j] : 0u;
+                acc_o += hit ? val[j] : 0u;
+                acc_i += hit ? t[j].y : 0u;
+                if (a.ok) { if (hit) em.emit(key[j], val[j], t[j].y); }
+                live[j] = live[j] && (t[j].x != empty);
+                slot[j] = (slot[j] + step[j]) & MASK;
+            }
+            if (!(live[0] | live[1] | live[2] | live[3])) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (live[j]) t[j] = tab[slot[j]];
+        }
+    };
+
+    auto probe_item = [&](u64 slice, u64 nslices, auto probe4) {
+        for (uint32_t c = 0; c < C; ++c) {
+            const u64 b = a.soff[(u64)c * P + q], e = a.soff[(u64)c * P + q + 1];
+            const u64 len = e - b;
+            if (len == 0) continue;
+            // sub-range `slice` of `nslices` equal parts (len < 2^40, slices < 2^24)
+            const u64 sb = b + (len * slice) / nslices;
+            const u64 se = b + (len * (slice + 1)) / nslices;
+            if (se <= sb) continue;
+            for_each_probe_vector(a.s_align + sb, a.s_align + se, probe4);
+        }
+    };
 
     for (u64 w = blockIdx.x; w < total_items; w += gridDim.x) {
-        const uint32_t q = hj_find_segment(a.slice_prefix, P, w);
+        q = hj_find_segment(a.slice_prefix, P, w);
         const u64 slice = w - a.slice_prefix[q];
         const u64 nslices = a.slices[q];
 
         // empty sentinel: smallest value whose partition is not q (P >= 2)
-        uint32_t empty = 0;
+        empty = 0;
         while (hj_part2(empty, a.f1, a.F1, a.f2, a.F2) == q) ++empty;
+        const u64 EMPTY64 = (u64)empty;
 
         // total build rows of q over all chunks
         u64 nr = 0;
@@ -71,20 +208,35 @@ __global__ __launch_bounds__(BLOCK) void join_kernel(JoinArgs a)
 
         for (u64 fill_beg = 0; fill_beg < nr; fill_beg += CAP) {
             const u64 fill_end = min(nr, fill_beg + CAP);
-            // ---- clear --------------------------------------------------------
-            for (uint32_t i = tid; i < SLOTS; i += BLOCK) tab[i] = make_uint2(empty, 0u);
+            // ---- clear + cuckoo build --------------------------------------------
+            for (uint32_t i = tid; i < SLOTS; i += BLOCK) tab64[i] = EMPTY64;
+            if (tid == 0) cuckoo_failed = (a.exp & 8) ? 1u : 0u;
             __syncthreads();
-            // ---- build: rows [fill_beg, fill_end) of the chunk-concatenated R_q --
-            u64 seen = 0;
-            for (uint32_t c = 0; c < C; ++c) {
-                const u64 b = a.roff[(u64)c * P + q], e = a.roff[(u64)c * P + q + 1];
-                const u64 len = e - b;
-                // intersection of [seen, seen+len) with [fill_beg, fill_end)
-                const u64 lo = max(seen, fill_beg), hi = min(seen + len, fill_end);
-                for (u64 i = lo + tid; i < hi; i += BLOCK) {
-                    const u64 row = b + (i - seen);
-                    const uint32_t k = a.rk[row];
-                    const uint32_t v = a.rv[row];
+            for_each_build_row(fill_beg, fill_end, [&](uint32_t k, uint32_t v) {
+                u64 cur = (u64)k | ((u64)v << 32);
+                uint32_t loc = (k * tf0) >> SHIFT;
+                int it = 0;
+                for (; it < CUCKOO_MAX_EVICTIONS; ++it) {
+                    const u64 old = atomicExch(&tab64[loc], cur);            // ds_wrxchg_rtn_b64
+                    if ((uint32_t)old == empty) break;                       // slot was free
+                    // `old` was evicted: it moves to the other one of its two slots
+                    const uint32_t ok_ = (uint32_t)old;
+                    const uint32_t a1 = (ok_ * tf0) >> SHIFT;
+                    const uint32_t a2 = (a1 + (((ok_ * tf1) >> SHIFT) | 1u)) & MASK;
+                    loc = (loc == a1) ? a2 : a1;
+                    cur = old;
+                }
+                if (it == CUCKOO_MAX_EVICTIONS) cuckoo_failed = 1;           // a tuple is left in hand
+            });
+            __syncthreads();
+            if (!cuckoo_failed) {
+                probe_item(slice, nslices, probe4_cuckoo);
+            } else {
+                // ---- fallback: rebuild as double-hashing chains, multi-match probe -----
+                __syncthreads();
+                for (uint32_t i = tid; i < SLOTS; i += BLOCK) tab64[i] = EMPTY64;
+                __syncthreads();
+                for_each_build_row(fill_beg, fill_end, [&](uint32_t k, uint32_t v) {
                     uint32_t slot = (k * tf0) >> SHIFT;
                     const uint32_t step = ((k * tf1) >> SHIFT) | 1u;
                     for (;;) {
@@ -92,62 +244,9 @@ __global__ __launch_bounds__(BLOCK) void join_kernel(JoinArgs a)
                         if (old == empty) { tab[slot].y = v; break; }
                         slot = (slot + step) & MASK;
                     }
-                }
-                seen += len;
-            }
-            __syncthreads();
-            // ---- probe: this item's share of every chunk piece of S_q -----------
-            for (uint32_t c = 0; c < C; ++c) {
-                const u64 b = a.soff[(u64)c * P + q], e = a.soff[(u64)c * P + q + 1];
-                const u64 len = e - b;
-                if (len == 0) continue;
-                // sub-range `slice` of `nslices` equal parts (128-bit safe: len < 2^40, slices < 2^24)
-                const u64 sb = b + (len * slice) / nslices;
-                const u64 se = b + (len * (slice + 1)) / nslices;
-                if (se <= sb) continue;
-                const u64 gb = a.s_align + sb, ge = a.s_align + se;
-                u64 g = (gb & ~3ull) + (u64)tid * 4;
-                bool have = g < ge;
-                uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
-                if (have) { kk = sk4[g >> 2]; vv = sv4[g >> 2]; }
-                while (have) {
-                    // prefetch the next vector before walking the chains of this one
-                    const u64 g2 = g + (u64)BLOCK * 4;
-                    const bool have2 = g2 < ge;
-                    uint4 kk2 = make_uint4(0, 0, 0, 0), vv2 = kk2;
-                    if (have2) { kk2 = sk4[g2 >> 2]; vv2 = sv4[g2 >> 2]; }
-
-                    const uint32_t key[4] = {kk.x, kk.y, kk.z, kk.w};
-                    const uint32_t val[4] = {vv.x, vv.y, vv.z, vv.w};
-                    uint32_t slot[4], step[4];
-                    uint2 t[4];
-                    bool act[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        act[j] = (g + j >= gb) && (g + j < ge);
-                        slot[j] = (key[j] * tf0) >> SHIFT;
-                        step[j] = ((key[j] * tf1) >> SHIFT) | 1u;
-                        t[j] = act[j] ? tab[slot[j]] : make_uint2(empty, 0u);
-                    }
-                    while (act[0] | act[1] | act[2] | act[3]) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (act[j]) {
-                                if (t[j].x == empty) {
-                                    act[j] = false;
-                                } else {
-                                    if (t[j].x == key[j]) {
-                                        acc_n += 1; acc_k += key[j]; acc_o += val[j]; acc_i += t[j].y;
-                                        em.emit(key[j], val[j], t[j].y);
-                                    }
-                                    slot[j] = (slot[j] + step[j]) & MASK;
-                                    t[j] = tab[slot[j]];
-                                }
-                            }
-                        }
-                    }
-                    g = g2; have = have2; kk = kk2; vv = vv2;
-                }
+                });
+                __syncthreads();
+                probe_item(slice, nslices, probe4_chained);
             }
             __syncthreads();   // table is reused by the next fill / work item
         }
@@ -170,13 +269,58 @@ __global__ __launch_bounds__(BLOCK) void join_kernel(JoinArgs a)
     }
 }
 
-int hj_join_grid(int cus) { return cus * 2; }
-int hj_join_workers(int cus) { return hj_join_grid(cus) * (HJ_JOIN_BLOCK / 64); }
+#include <stdlib.h>
+#include <stdio.h>
+
+const JoinConfig &hj_join_config()
+{
+    static JoinConfig cfg = {512, 13, 2};
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char *e = getenv("HJGPU_JOIN_CFG");
+        int b, l, u;
+        if (e && sscanf(e, "%d,%d,%d", &b, &l, &u) == 3) { cfg.block = b; cfg.log2slots = l; cfg.batch = u; }
+    }
+    return cfg;
+}
+
+// workgroups per CU the LDS table allows (160 KiB per CU), capped by 2048 threads per CU
+static int join_wgs_per_cu(const JoinConfig &c)
+{
+    int by_lds = (160 * 1024) / (c.slots() * 8 + 1024);
+    int by_threads = 2048 / c.block;
+    int n = by_lds < by_threads ? by_lds : by_threads;
+    return n < 1 ? 1 : n;
+}
+
+int hj_join_grid(int cus) { return cus * join_wgs_per_cu(hj_join_config()); }
+int hj_join_workers(int cus) { return hj_join_grid(cus) * (hj_join_config().block / 64); }
+
+#define JOIN_CASE(B, L, U)                                                                        \
+    if (c.block == B && c.log2slots == L && c.batch == U) {                                       \
+        hipLaunchKernelGGL((join_kernel<B, L, U>), dim3(hj_join_grid(cus)), dim3(B), 0, stream, a); \
+        return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
+    }
 
 int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream)
 {
     if (a.P < 2 || a.chunks == 0) return HJGPU_EINVAL;
-    hipLaunchKernelGGL((join_kernel<HJ_JOIN_BLOCK, HJ_JOIN_LOG2SLOTS>), dim3(hj_join_grid(cus)),
-                       dim3(HJ_JOIN_BLOCK), 0, stream, a);
-    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+    const JoinConfig &c = hj_join_config();
+    const char *ex = getenv("HJGPU_EXP_JOIN");          // timing experiments only (results are wrong)
+    JoinArgs b = a;
+    b.exp = ex ? (uint32_t)atoi(ex) : 0;
+#define a b
+    JOIN_CASE(512, 13, 4)
+    JOIN_CASE(512, 13, 2)
+    JOIN_CASE(512, 13, 1)
+    JOIN_CASE(1024, 14, 4)
+    JOIN_CASE(1024, 14, 2)
+    JOIN_CASE(1024, 13, 2)
+    JOIN_CASE(256, 12, 4)
+    JOIN_CASE(256, 12, 8)
+    JOIN_CASE(256, 13, 4)
+    JOIN_CASE(512, 12, 4)
+#undef a
+    return HJGPU_EINVAL;
 }

@@ -20,87 +20,132 @@
 // overlaps a valid element never leaves that element's page.
 #include "hj_device.hpp"
 #include "hj_internal.hpp"
+#include <stdlib.h>
 
 // --------------------------------------------------------------------------
-// K4: fused two-level histogram.  grid = (blocks, chunks)
+// K4: fused two-level histogram + per-range pass-1 counts.
+// A workgroup walks whole ranges (Pass1Geom); for every range it leaves the
+// F1 pass-1 counts of that range in range_counts[range][F1] (plain stores), and
+// it accumulates the fused (p1,p2) histogram of everything it saw in LDS, flushed
+// once at the end with one global atomic per non-empty bin.
 // --------------------------------------------------------------------------
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void hist2_kernel(
-    const uint32_t *__restrict__ keys, u64 seg_beg0, u64 seg_beg1, u64 seg_beg2, u64 seg_beg3,
-    u64 seg_beg4, u64 seg_beg5, u64 seg_beg6, u64 seg_beg7, u64 seg_beg8,
-    uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2, u64 *__restrict__ counts)
+    const uint32_t *__restrict__ keys, Pass1Geom geom,
+    uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
+    u64 *__restrict__ counts, uint32_t *__restrict__ range_counts)
 {
-    extern __shared__ uint32_t lds_hist[];
+    extern __shared__ uint32_t lds_hist[];          // [P] fused, then [F1] per-range
     const uint32_t P = F1 * F2;
-    const uint32_t chunk = blockIdx.y;
-    // chunk boundaries arrive by value (<= 8 chunks + end) to avoid a dependent load
-    const u64 bounds[9] = {seg_beg0, seg_beg1, seg_beg2, seg_beg3, seg_beg4,
-                           seg_beg5, seg_beg6, seg_beg7, seg_beg8};
-    u64 beg = 0, end = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        if (c == (int)chunk) { beg = bounds[c]; end = bounds[c + 1]; }
+    uint32_t *range_hist = lds_hist + P;
+    const uint32_t Rc = geom.ranges_per_chunk;         // launched once per chunk: geom.chunks == 1
+    const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(keys - geom.align);
 
     for (uint32_t i = threadIdx.x; i < P; i += BLOCK) lds_hist[i] = 0;
-    __syncthreads();
 
-    const uint32_t a0 = (uint32_t)(((uintptr_t)keys >> 2) & 3);
-    const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(keys - a0);
-    const u64 gb = a0 + beg, ge = a0 + end;          // element coordinates from the aligned base
-    const u64 v_beg = gb >> 2, v_end = (ge + 3) >> 2; // vectors [v_beg, v_end)
-    const u64 stride = (u64)gridDim.x * BLOCK;
-    for (u64 v = v_beg + (u64)blockIdx.x * BLOCK + threadIdx.x; v < v_end; v += stride) {
-        const uint4 k = k4[v];
-        const u64 g = v << 2;
-        const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
-        if (g >= gb && g + 4 <= ge) {
+    for (uint32_t r = blockIdx.x; r < Rc; r += gridDim.x) {
+        const uint32_t j = r;
+        const u64 cb = geom.b[0], ce = geom.b[1];
+        const u64 gb = geom.align + cb, ge = geom.align + ce;
+        const u64 tiles = hj_tiles_of(cb, ce, geom.align, geom.tile);
+        const u64 t_beg = tiles * j / Rc, t_end = tiles * (j + 1) / Rc;
+        const u64 g_lo = (gb & ~3ull) + t_beg * geom.tile;
+        const u64 g_hi = min(ge, (gb & ~3ull) + t_end * geom.tile);
+
+        for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) range_hist[i] = 0;
+        __syncthreads();
+        if (t_end > t_beg) {
+            for (u64 g = g_lo + (u64)threadIdx.x * 4; g < g_hi; g += (u64)BLOCK * 4) {
+                const uint4 k = k4[g >> 2];
+                const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
+                const bool full = (g >= gb) && (g + 4 <= ge);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                atomicAdd(&lds_hist[hj_part2(kk[c], f1, F1, f2, F2)], 1u);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (g + c >= gb && g + c < ge)
-                    atomicAdd(&lds_hist[hj_part2(kk[c], f1, F1, f2, F2)], 1u);
+                for (int e = 0; e < 4; ++e) {
+                    if (full || (g + e >= gb && g + e < ge)) {
+                        const uint32_t p1 = hj_hash(kk[e], f1, F1);
+                        atomicAdd(&range_hist[p1], 1u);
+                        if (F2 > 1) atomicAdd(&lds_hist[p1 * F2 + hj_hash(kk[e], f2, F2)], 1u);
+                    }
+                }
+            }
         }
+        __syncthreads();
+        uint32_t *__restrict__ rc = range_counts + (u64)r * F1;
+        for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) {
+            const uint32_t v = range_hist[i];
+            rc[i] = v;
+            if (F2 == 1 && v) atomicAdd(&lds_hist[i], v);       // single pass: fused == pass-1 histogram
+        }
+        __syncthreads();
     }
     __syncthreads();
-    u64 *__restrict__ out = counts + (u64)chunk * P;
     for (uint32_t i = threadIdx.x; i < P; i += BLOCK) {
-        const uint32_t c = lds_hist[i];
-        if (c) atomicAdd(&out[i], (u64)c);
+        const uint32_t v = lds_hist[i];
+        if (v) atomicAdd(&counts[i], (u64)v);
     }
 }
 
-int hj_launch_hist2(const uint32_t *keys, const u64 *seg1_host, uint32_t chunks,
+// chunks > 1 (CPRA): one launch per chunk keeps the fused LDS histogram per chunk.
+int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-                    u64 *counts, int cus, hipStream_t stream)
+                    u64 *counts, uint32_t *range_counts, int cus, hipStream_t stream)
 {
     constexpr int BLOCK = 1024;
     const uint32_t P = F1 * F2;
-    const size_t lds = (size_t)P * sizeof(uint32_t);
-    if (chunks == 0 || chunks > 8 || lds > 128 * 1024) return HJGPU_EINVAL;
+    const size_t lds = ((size_t)P + F1) * sizeof(uint32_t);
+    if (geom.chunks == 0 || geom.chunks > 8 || lds > 140 * 1024) return HJGPU_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&hist2_kernel<BLOCK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             return HJGPU_EHIP;
         attr_set = true;
     }
-    u64 b[9];
-    for (uint32_t c = 0; c <= 8; ++c) b[c] = seg1_host[c < chunks ? c : chunks];
-    u64 longest = 0;
-    for (uint32_t c = 0; c < chunks; ++c) if (b[c + 1] - b[c] > longest) longest = b[c + 1] - b[c];
-    // enough workgroups to fill the chip (1024-thread workgroups: two per CU while
-    // the histogram fits twice in LDS), never more than there are vectors
-    u64 want = (longest / 4 + BLOCK - 1) / BLOCK;
-    u64 cap = (u64)cus * (lds > 72 * 1024 ? 1 : 2);
-    cap = (cap + chunks - 1) / chunks;
-    if (want > cap) want = cap;
-    if (want < 1) want = 1;
-    dim3 grid((uint32_t)want, chunks);
-    hipLaunchKernelGGL(hist2_kernel<BLOCK>, grid, dim3(BLOCK), lds, stream, keys,
-                       b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], f1, F1, f2, F2, counts);
+    const uint32_t per_cu = (lds > 72 * 1024) ? 1 : 2;
+    for (uint32_t c = 0; c < geom.chunks; ++c) {
+        // present chunk c as a single-chunk geometry so that its fused histogram
+        // lands in its own row of `counts` and its ranges in their own rows
+        Pass1Geom g1 = geom;
+        g1.chunks = 1;
+        g1.b[0] = geom.b[c]; g1.b[1] = geom.b[c + 1];
+        for (int q = 2; q < 9; ++q) g1.b[q] = geom.b[c + 1];
+        uint32_t grid = (uint32_t)cus * per_cu;
+        if (geom.chunks > 1) grid = (grid + geom.chunks - 1) / geom.chunks;
+        if (grid > geom.ranges_per_chunk) grid = geom.ranges_per_chunk;
+        hipLaunchKernelGGL(hist2_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, stream, keys, g1,
+                           f1, F1, f2, F2, counts + (u64)c * P,
+                           range_counts + (u64)c * geom.ranges_per_chunk * F1);
+    }
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+// --------------------------------------------------------------------------
+// K5b: per-range write bases of pass 1.  One workgroup per (chunk, partition):
+// base[range][p] = off1[chunk][p] + sum of the counts of earlier ranges of the chunk.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void range_base_kernel(
+    const uint32_t *__restrict__ range_counts, const u64 *__restrict__ off1,
+    u64 *__restrict__ range_base, uint32_t Rc, uint32_t F1)
+{
+    __shared__ u64 scratch[256 / 64 + 1];
+    const uint32_t c = blockIdx.x / F1, p = blockIdx.x - c * F1;
+    const uint32_t per = (Rc + 255) / 256;
+    const uint32_t lo = min(Rc, threadIdx.x * per), hi = min(Rc, lo + per);
+    const u64 row0 = (u64)c * Rc;
+    u64 sum = 0;
+    for (uint32_t j = lo; j < hi; ++j) sum += range_counts[(row0 + j) * F1 + p];
+    u64 run = off1[(u64)c * F1 + p] + block_exclusive_scan<256, u64>(sum, scratch);
+    for (uint32_t j = lo; j < hi; ++j) {
+        range_base[(row0 + j) * F1 + p] = run;
+        run += range_counts[(row0 + j) * F1 + p];
+    }
+}
+
+int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
+                         uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream)
+{
+    hipLaunchKernelGGL(range_base_kernel, dim3(chunks * F1), dim3(256), 0, stream, range_counts,
+                       off1, range_base, ranges_per_chunk, F1);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
@@ -125,12 +170,6 @@ __device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 
     __syncthreads();
 }
 
-__device__ __forceinline__ u64 tiles_of(u64 b, u64 e, uint32_t align, uint32_t tile)
-{
-    if (e <= b) return 0;
-    const u64 gb = (align + b) & ~3ull, ge = align + e;
-    return (ge - gb + tile - 1) / tile;
-}
 
 __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(PlanArgs a)
 {
@@ -159,11 +198,11 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(PlanArgs a)
         const uint32_t al = a.in_align[r];
         const uint32_t tile = a.tile;
         const u64 *seg1 = a.seg1[r];
-        plan_scan(C, [&](uint32_t i) { return tiles_of(seg1[i], seg1[i + 1], al, tile); },
+        plan_scan(C, [&](uint32_t i) { return hj_tiles_of(seg1[i], seg1[i + 1], al, tile); },
                   a.tp1[r], 0, scratch);
         // pass-2 tiles: segments are the pass-1 partitions inside the (aligned) workspace
         const u64 *off1 = a.off1[r];
-        plan_scan(C * a.F1, [&](uint32_t i) { return tiles_of(off1[i], off1[i + 1], 0, tile); },
+        plan_scan(C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile); },
                   a.tp2[r], 0, scratch);
     } else {
         // join work items: partition q gets ceil(|S_q| / slice) items when both sides are non-empty
@@ -215,9 +254,17 @@ int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStre
 }
 
 // --------------------------------------------------------------------------
-// K6: scatter one pass.  Persistent workgroups walk the tile list.
+// K6: scatter one pass.
+//   RANGED (pass 1): a workgroup walks whole ranges of tiles; the output position
+//     of every (range, partition) was computed by K5b, so the bin-owner thread
+//     keeps the write cursor of its bins in registers - no global atomics (with
+//     one shared cursor per partition, 512 workgroups hammering the same few
+//     cache lines cost 6.5 of 9.7 ms at |S| = 1G).
+//   !RANGED (pass 2): a workgroup owns a contiguous run of tiles, i.e. stays in
+//     the same pass-1 partition for a while, so each partition's F2 cursors are
+//     shared by only a few workgroups; one returning atomic per (tile, partition).
 // --------------------------------------------------------------------------
-template <int BLOCK, int VPT>
+template <int BLOCK, int VPT, bool RANGED>
 __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 {
     constexpr int TILE = BLOCK * VPT * 4;
@@ -232,22 +279,17 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     uint32_t *wsum = svals + TILE;                                  // [NW + 1]
 
     const int tid = threadIdx.x;
-    const u64 total_tiles = a.tile_prefix[a.nseg];
     const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(a.kin - a.in_align);
     const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(a.vin - a.in_align);
     const uint32_t factor = a.factor;
     const uint32_t bpt = (F + BLOCK - 1) / BLOCK;                   // bins per thread in the scan (<= 2)
+    u64 mycur[2] = {0, 0};                                          // RANGED: cursors of my bins
 
-    for (u64 t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-        const uint32_t seg = hj_find_segment(a.tile_prefix, a.nseg, t);
-        const u64 gb = a.in_align + a.seg_off[seg];
-        const u64 ge = a.in_align + a.seg_off[seg + 1];
-        const u64 g0 = (gb & ~3ull) + (t - a.tile_prefix[seg]) * (u64)TILE;
-
+    // ---- one tile: segment [gb, ge) in element coordinates, tile starts at g0 ----
+    auto process_tile = [&](u64 gb, u64 ge, u64 g0, u64 cursor_row) {
         for (uint32_t i = tid; i < F; i += BLOCK) hist[i] = 0;
         __syncthreads();
 
-        // ---- load the tile, rank every tuple inside its partition -----------
         uint32_t key[VPT * 4], val[VPT * 4], pr[VPT * 4];
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
@@ -263,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 uint32_t code = 0xFFFFFFFFu;
                 if (valid) {
                     const uint32_t p = hj_hash(key[j * 4 + c], factor, F);
-                    const uint32_t r = atomicAdd(&hist[p], 1u);     // ds_add_rtn_u32
+                    const uint32_t r = atomicAdd(&hist[p], 1u);     // ds_add_rtn_u32: rank inside p
                     code = (p << 16) | r;
                 }
                 pr[j * 4 + c] = code;
@@ -271,21 +313,25 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         }
         __syncthreads();
 
-        // ---- local bases + one global claim per non-empty partition ----------
+        // ---- local bases + one output run per non-empty partition --------------
         uint32_t cnt[2] = {0, 0};
         uint32_t sum = 0;
-        for (uint32_t i = 0; i < bpt; ++i) {
+#pragma unroll
+        for (uint32_t i = 0; i < 2; ++i) {
             const uint32_t bin = tid * bpt + i;
-            cnt[i] = (bin < F) ? hist[bin] : 0;
+            cnt[i] = (i < bpt && bin < F) ? hist[bin] : 0;
             sum += cnt[i];
         }
         uint32_t run = block_exclusive_scan<BLOCK, uint32_t>(sum, wsum);
-        for (uint32_t i = 0; i < bpt; ++i) {
+#pragma unroll
+        for (uint32_t i = 0; i < 2; ++i) {
             const uint32_t bin = tid * bpt + i;
-            if (bin < F) {
+            if (i < bpt && bin < F) {
                 hist[bin] = run;
                 if (cnt[i]) {
-                    const u64 dst = atomicAdd(&a.cursors[(u64)seg * F + bin], (u64)cnt[i]);
+                    u64 dst;
+                    if (RANGED) { dst = mycur[i]; mycur[i] = dst + cnt[i]; }
+                    else dst = atomicAdd(&a.cursors[cursor_row + bin], (u64)cnt[i]);
                     delta[bin] = dst - run;
                 }
                 run += cnt[i];
@@ -294,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         __syncthreads();
         const uint32_t tile_count = wsum[NW];
 
-        // ---- counting sort inside LDS ----------------------------------------
+        // ---- counting sort inside LDS --------------------------------------------
 #pragma unroll
         for (int e = 0; e < VPT * 4; ++e) {
             if (pr[e] != 0xFFFFFFFFu) {
@@ -305,7 +351,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         }
         __syncthreads();
 
-        // ---- stream out: lane i writes tuple i, runs are contiguous ------------
+        // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
         for (uint32_t i = tid; i < tile_count; i += BLOCK) {
             const uint32_t k = skeys[i];
             const u64 d = delta[hj_hash(k, factor, F)] + i;
@@ -313,25 +359,66 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             a.vout[d] = svals[i];
         }
         __syncthreads();
+    };
+
+    if (RANGED) {
+        const uint32_t Rc = a.geom.ranges_per_chunk;
+        const uint32_t nranges = Rc * a.geom.chunks;
+        for (uint32_t r = blockIdx.x; r < nranges; r += gridDim.x) {
+            const uint32_t c = r / Rc, j = r - c * Rc;
+            u64 cb = 0, ce = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q == (int)c) { cb = a.geom.b[q]; ce = a.geom.b[q + 1]; }
+            const u64 gb = a.geom.align + cb, ge = a.geom.align + ce;
+            const u64 tiles = hj_tiles_of(cb, ce, a.geom.align, TILE);
+            const u64 t_beg = tiles * j / Rc, t_end = tiles * (j + 1) / Rc;
+#pragma unroll
+            for (uint32_t i = 0; i < 2; ++i) {
+                const uint32_t bin = tid * bpt + i;
+                if (i < bpt && bin < F) mycur[i] = a.range_base[(u64)r * F + bin];
+            }
+            for (u64 t = t_beg; t < t_end; ++t)
+                process_tile(gb, ge, (gb & ~3ull) + t * (u64)TILE, 0);
+        }
+    } else {
+        const u64 total_tiles = a.tile_prefix[a.nseg];
+        const u64 t_beg = total_tiles * blockIdx.x / gridDim.x;
+        const u64 t_end = total_tiles * (blockIdx.x + 1) / gridDim.x;
+        if (t_beg < t_end) {
+            uint32_t seg = hj_find_segment(a.tile_prefix, a.nseg, t_beg);
+            for (u64 t = t_beg; t < t_end; ++t) {
+                while (t >= a.tile_prefix[seg + 1]) ++seg;          // skips empty segments too
+                const u64 gb = a.in_align + a.seg_off[seg];
+                const u64 ge = a.in_align + a.seg_off[seg + 1];
+                process_tile(gb, ge, (gb & ~3ull) + (t - a.tile_prefix[seg]) * (u64)TILE, (u64)seg * F);
+            }
+        }
     }
 }
 
-int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream)
+template <bool RANGED>
+static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
 {
     constexpr int BLOCK = HJ_SCATTER_BLOCK, VPT = HJ_SCATTER_VPT;
     constexpr int TILE = BLOCK * VPT * 4;
-    if (a.F == 0 || a.F > 2 * BLOCK || a.F > HJGPU_MAX_FANOUT) return HJGPU_EINVAL;
     const uint32_t Fpad = (a.F + 3) & ~3u;
     const size_t lds = (size_t)Fpad * 12 + (size_t)TILE * 8 + (BLOCK / 64 + 1) * 4 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
             return HJGPU_EHIP;
         attr_set = true;
     }
     // two workgroups per CU fit in LDS (2 * ~77 KiB <= 160 KiB); persistent grid
     const int grid = cus * 2;
-    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT>), dim3(grid), dim3(BLOCK), lds, stream, a);
+    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED>), dim3(grid), dim3(BLOCK), lds, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream)
+{
+    if (a.F == 0 || a.F > 2 * HJ_SCATTER_BLOCK || a.F > HJGPU_MAX_FANOUT) return HJGPU_EINVAL;
+    if (a.ranged && a.geom.tile != (uint32_t)HJ_SCATTER_TILE) return HJGPU_EINVAL;
+    return a.ranged ? launch_scatter_t<true>(a, cus, stream) : launch_scatter_t<false>(a, cus, stream);
 }
