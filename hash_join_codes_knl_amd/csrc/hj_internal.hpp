@@ -8,9 +8,9 @@
 typedef unsigned long long u64;
 
 // Geometry constants (also read by the planner on the host side).
-constexpr int HJ_SCATTER_BLOCK = 512;           // threads per scatter workgroup
-constexpr int HJ_SCATTER_VPT   = 4;             // uint4 vectors per thread per tile
-constexpr int HJ_SCATTER_TILE  = HJ_SCATTER_BLOCK * HJ_SCATTER_VPT * 4;   // 8192 tuples
+// Scatter tile = block * vectors_per_thread * 4 tuples (default 512 * 4 * 4 = 8192);
+// HJGPU_SCATTER_CFG="block,vpt" selects another built variant (tuning).
+int hj_scatter_tile();
 constexpr int HJ_JOIN_SLICE    = 1 << 16;       // probe tuples per work item (target)
 
 // Join-kernel geometry: threads per workgroup, log2 of the LDS table slots, and
@@ -54,7 +54,6 @@ struct ScatterArgs {
     u64 *cursors;                   // [nseg*F] absolute output positions, advanced atomically
     uint32_t nseg, F, factor;
     uint32_t in_align;              // (address of kin / 4) % 4, same for vin
-    uint32_t exp;                   // timing-experiment bits (0 in production)
     // pass 1 only (ranged == 1): per-range bases instead of atomic cursors
     uint32_t ranged;
     Pass1Geom geom;
@@ -77,7 +76,7 @@ struct JoinArgs {
     u64 *block_counter;                  // device
     u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
     uint32_t *overflow;                  // device flag
-    uint32_t exp;                        // timing-experiment bits (0 in production)
+    uint32_t force_chained;              // tests: skip the cuckoo fast path (HJGPU_FORCE_CHAINED=1)
 };
 
 struct PlanArgs {

@@ -233,7 +233,7 @@ Pass1Geom make_geom(const void *keys, size_t n, uint32_t C)
     g.chunks = C;
     g.align = align_of(keys);
     g.ranges_per_chunk = HJ_RANGES / C;
-    g.tile = HJ_SCATTER_TILE;
+    g.tile = (uint32_t)hj_scatter_tile();
     return g;
 }
 
@@ -268,7 +268,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
-    pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
+    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
     CHK(hj_launch_plan(pa, stream));
     // K5b: per-range write bases of pass 1
     const size_t nn0[2] = {inner, outer};
@@ -288,7 +288,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
         sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
         sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
-        sa.exp = 0; sa.ranged = 1; sa.geom = geom[r]; sa.range_base = m.range_base[r];
+        sa.ranged = 1; sa.geom = geom[r]; sa.range_base = m.range_base[r];
         CHK(hj_launch_scatter(sa, ctx->cus, stream));
     }
     record(ctx, EV_SCAT1, stream);
@@ -304,7 +304,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
             sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r];
             sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
-            sa.exp = 0; sa.ranged = 0; sa.geom = geom[r]; sa.range_base = nullptr;
+            sa.ranged = 0; sa.geom = geom[r]; sa.range_base = nullptr;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
         for (int i = 0; i < 4; ++i) fin[i] = t2[i];
@@ -624,7 +624,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
-    pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
+    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
     CHK(hj_launch_plan(pa, stream));
     if (n) {
         CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
@@ -633,7 +633,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
         sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
-        sa.exp = 0; sa.ranged = 1; sa.geom = geom; sa.range_base = m.range_base[0];
+        sa.ranged = 1; sa.geom = geom; sa.range_base = m.range_base[0];
         CHK(hj_launch_scatter(sa, ctx->cus, stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
@@ -686,7 +686,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     }
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
-    pa.tile = HJ_SCATTER_TILE; pa.slice = HJ_JOIN_SLICE;
+    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
     CHK(hj_launch_plan(pa, stream));
     for (int e : {EV_HIST, EV_PLAN, EV_SCAT1, EV_SCAT2}) record(ctx, e, stream);
     JoinArgs ja;

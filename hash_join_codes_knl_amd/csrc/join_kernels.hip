@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             const u64 fill_end = min(nr, fill_beg + CAP);
             // ---- clear + cuckoo build --------------------------------------------
             for (uint32_t i = tid; i < SLOTS; i += BLOCK) tab64[i] = EMPTY64;
-            if (tid == 0) cuckoo_failed = (a.exp & 8) ? 1u : 0u;
+            if (tid == 0) cuckoo_failed = a.force_chained;
             __syncthreads();
             for_each_build_row(fill_beg, fill_end, [&](uint32_t k, uint32_t v) {
                 u64 cur = (u64)k | ((u64)v << 32);
@@ -307,9 +307,9 @@ int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream)
 {
     if (a.P < 2 || a.chunks == 0) return HJGPU_EINVAL;
     const JoinConfig &c = hj_join_config();
-    const char *ex = getenv("HJGPU_EXP_JOIN");          // timing experiments only (results are wrong)
+    const char *ex = getenv("HJGPU_FORCE_CHAINED");     // tests: exercise the fallback table everywhere
     JoinArgs b = a;
-    b.exp = ex ? (uint32_t)atoi(ex) : 0;
+    b.force_chained = (ex && atoi(ex)) ? 1u : 0u;
 #define a b
     JOIN_CASE(512, 13, 4)
     JOIN_CASE(512, 13, 2)

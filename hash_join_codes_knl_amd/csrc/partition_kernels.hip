@@ -21,6 +21,7 @@
 #include "hj_device.hpp"
 #include "hj_internal.hpp"
 #include <stdlib.h>
+#include <stdio.h>
 
 // --------------------------------------------------------------------------
 // K4: fused two-level histogram + per-range pass-1 counts.
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 {
     constexpr int TILE = BLOCK * VPT * 4;
     constexpr int NW = BLOCK / 64;
+    constexpr int BPT = (1024 + BLOCK - 1) / BLOCK;                 // max bins per thread (F <= 1024)
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t F = a.F;
     const uint32_t Fpad = (F + 3) & ~3u;
@@ -282,30 +284,99 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(a.kin - a.in_align);
     const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(a.vin - a.in_align);
     const uint32_t factor = a.factor;
-    const uint32_t bpt = (F + BLOCK - 1) / BLOCK;                   // bins per thread in the scan (<= 2)
-    u64 mycur[2] = {0, 0};                                          // RANGED: cursors of my bins
+    const uint32_t bpt = (F + BLOCK - 1) / BLOCK;                   // bins per thread in the scan
+    u64 mycur[BPT];                                                 // RANGED: cursors of my bins
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) mycur[i] = 0;
 
-    // ---- one tile: segment [gb, ge) in element coordinates, tile starts at g0 ----
-    auto process_tile = [&](u64 gb, u64 ge, u64 g0, u64 cursor_row) {
+    // ---- the sequence of tiles this workgroup owns -------------------------------
+    struct Tile { u64 gb, ge, g0, cursor_row; uint32_t range; bool new_range, valid; };
+    // RANGED state
+    uint32_t r_cur = blockIdx.x;
+    u64 rt = 0, rt_end = 0, r_gb = 0, r_ge = 0;
+    bool r_open = false;
+    // !RANGED state
+    u64 t_cur = 0, t_end = 0;
+    uint32_t seg = 0;
+    if (!RANGED) {
+        const u64 total_tiles = a.tile_prefix[a.nseg];
+        t_cur = total_tiles * blockIdx.x / gridDim.x;
+        t_end = total_tiles * (blockIdx.x + 1) / gridDim.x;
+        if (t_cur < t_end) seg = hj_find_segment(a.tile_prefix, a.nseg, t_cur);
+    }
+    auto next_tile = [&]() -> Tile {
+        Tile t;
+        t.valid = false; t.new_range = false; t.range = 0; t.gb = t.ge = t.g0 = t.cursor_row = 0;
+        if (RANGED) {
+            const uint32_t Rc = a.geom.ranges_per_chunk;
+            const uint32_t nranges = Rc * a.geom.chunks;
+            while (!r_open || rt >= rt_end) {
+                if (r_open) { r_cur += gridDim.x; r_open = false; }
+                if (r_cur >= nranges) return t;
+                const uint32_t c = r_cur / Rc, j = r_cur - c * Rc;
+                u64 cb = 0, ce = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q == (int)c) { cb = a.geom.b[q]; ce = a.geom.b[q + 1]; }
+                r_gb = a.geom.align + cb; r_ge = a.geom.align + ce;
+                const u64 tiles = hj_tiles_of(cb, ce, a.geom.align, TILE);
+                rt = tiles * j / Rc; rt_end = tiles * (j + 1) / Rc;
+                r_open = true;
+                t.new_range = true;
+            }
+            t.gb = r_gb; t.ge = r_ge; t.g0 = (r_gb & ~3ull) + rt * (u64)TILE;
+            t.range = r_cur; t.valid = true;
+            ++rt;
+        } else {
+            if (t_cur >= t_end) return t;
+            while (t_cur >= a.tile_prefix[seg + 1]) ++seg;          // skips empty segments too
+            t.gb = a.in_align + a.seg_off[seg];
+            t.ge = a.in_align + a.seg_off[seg + 1];
+            t.g0 = (t.gb & ~3ull) + (t_cur - a.tile_prefix[seg]) * (u64)TILE;
+            t.cursor_row = (u64)seg * F;
+            t.valid = true;
+            ++t_cur;
+        }
+        return t;
+    };
+
+    uint32_t key[VPT * 4], val[VPT * 4];
+    auto load_tile = [&](const Tile &t) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const u64 g = t.g0 + (u64)(j * BLOCK + tid) * 4;
+            uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if ((g < t.ge) && (g + 4 > t.gb)) { kk = k4[g >> 2]; vv = v4[g >> 2]; }
+            key[j * 4 + 0] = kk.x; key[j * 4 + 1] = kk.y; key[j * 4 + 2] = kk.z; key[j * 4 + 3] = kk.w;
+            val[j * 4 + 0] = vv.x; val[j * 4 + 1] = vv.y; val[j * 4 + 2] = vv.z; val[j * 4 + 3] = vv.w;
+        }
+    };
+
+    Tile cur = next_tile();
+    if (!cur.valid) return;
+    load_tile(cur);
+    for (;;) {
+        if (RANGED && cur.new_range) {
+#pragma unroll
+            for (int i = 0; i < BPT; ++i) {
+                const uint32_t bin = tid * bpt + i;
+                if ((uint32_t)i < bpt && bin < F) mycur[i] = a.range_base[(u64)cur.range * F + bin];
+            }
+        }
         for (uint32_t i = tid; i < F; i += BLOCK) hist[i] = 0;
         __syncthreads();
 
-        uint32_t key[VPT * 4], val[VPT * 4], pr[VPT * 4];
+        // ---- rank every tuple inside its partition (ds_add_rtn_u32) --------------
+        uint32_t pr[VPT * 4];
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
-            const u64 g = g0 + (u64)(j * BLOCK + tid) * 4;
-            uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            const bool touch = (g < ge) && (g + 4 > gb);
-            if (touch) { kk = k4[g >> 2]; vv = v4[g >> 2]; }
-            key[j * 4 + 0] = kk.x; key[j * 4 + 1] = kk.y; key[j * 4 + 2] = kk.z; key[j * 4 + 3] = kk.w;
-            val[j * 4 + 0] = vv.x; val[j * 4 + 1] = vv.y; val[j * 4 + 2] = vv.z; val[j * 4 + 3] = vv.w;
+            const u64 g = cur.g0 + (u64)(j * BLOCK + tid) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const bool valid = touch && (g + c >= gb) && (g + c < ge);
+                const bool valid = (g + c >= cur.gb) && (g + c < cur.ge);
                 uint32_t code = 0xFFFFFFFFu;
                 if (valid) {
                     const uint32_t p = hj_hash(key[j * 4 + c], factor, F);
-                    const uint32_t r = atomicAdd(&hist[p], 1u);     // ds_add_rtn_u32: rank inside p
+                    const uint32_t r = atomicAdd(&hist[p], 1u);
                     code = (p << 16) | r;
                 }
                 pr[j * 4 + c] = code;
@@ -314,24 +385,24 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         __syncthreads();
 
         // ---- local bases + one output run per non-empty partition --------------
-        uint32_t cnt[2] = {0, 0};
+        uint32_t cnt[BPT];
         uint32_t sum = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < 2; ++i) {
+        for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
-            cnt[i] = (i < bpt && bin < F) ? hist[bin] : 0;
+            cnt[i] = ((uint32_t)i < bpt && bin < F) ? hist[bin] : 0;
             sum += cnt[i];
         }
         uint32_t run = block_exclusive_scan<BLOCK, uint32_t>(sum, wsum);
 #pragma unroll
-        for (uint32_t i = 0; i < 2; ++i) {
+        for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
-            if (i < bpt && bin < F) {
+            if ((uint32_t)i < bpt && bin < F) {
                 hist[bin] = run;
                 if (cnt[i]) {
                     u64 dst;
                     if (RANGED) { dst = mycur[i]; mycur[i] = dst + cnt[i]; }
-                    else dst = atomicAdd(&a.cursors[cursor_row + bin], (u64)cnt[i]);
+                    else dst = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
                     delta[bin] = dst - run;
                 }
                 run += cnt[i];
@@ -349,6 +420,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 svals[pos] = val[e];
             }
         }
+        // The input registers are dead now: start the next tile's loads so that they
+        // are in flight during the stream-out below (no extra registers needed).
+        const Tile nxt = next_tile();
+        if (nxt.valid) load_tile(nxt);
         __syncthreads();
 
         // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
@@ -359,66 +434,64 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             a.vout[d] = svals[i];
         }
         __syncthreads();
-    };
-
-    if (RANGED) {
-        const uint32_t Rc = a.geom.ranges_per_chunk;
-        const uint32_t nranges = Rc * a.geom.chunks;
-        for (uint32_t r = blockIdx.x; r < nranges; r += gridDim.x) {
-            const uint32_t c = r / Rc, j = r - c * Rc;
-            u64 cb = 0, ce = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) if (q == (int)c) { cb = a.geom.b[q]; ce = a.geom.b[q + 1]; }
-            const u64 gb = a.geom.align + cb, ge = a.geom.align + ce;
-            const u64 tiles = hj_tiles_of(cb, ce, a.geom.align, TILE);
-            const u64 t_beg = tiles * j / Rc, t_end = tiles * (j + 1) / Rc;
-#pragma unroll
-            for (uint32_t i = 0; i < 2; ++i) {
-                const uint32_t bin = tid * bpt + i;
-                if (i < bpt && bin < F) mycur[i] = a.range_base[(u64)r * F + bin];
-            }
-            for (u64 t = t_beg; t < t_end; ++t)
-                process_tile(gb, ge, (gb & ~3ull) + t * (u64)TILE, 0);
-        }
-    } else {
-        const u64 total_tiles = a.tile_prefix[a.nseg];
-        const u64 t_beg = total_tiles * blockIdx.x / gridDim.x;
-        const u64 t_end = total_tiles * (blockIdx.x + 1) / gridDim.x;
-        if (t_beg < t_end) {
-            uint32_t seg = hj_find_segment(a.tile_prefix, a.nseg, t_beg);
-            for (u64 t = t_beg; t < t_end; ++t) {
-                while (t >= a.tile_prefix[seg + 1]) ++seg;          // skips empty segments too
-                const u64 gb = a.in_align + a.seg_off[seg];
-                const u64 ge = a.in_align + a.seg_off[seg + 1];
-                process_tile(gb, ge, (gb & ~3ull) + (t - a.tile_prefix[seg]) * (u64)TILE, (u64)seg * F);
-            }
-        }
+        if (!nxt.valid) break;
+        cur = nxt;
     }
 }
 
-template <bool RANGED>
+struct ScatterConfig { int block, vpt; };
+static const ScatterConfig &scatter_config()
+{
+    static ScatterConfig cfg = {1024, 4};
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char *e = getenv("HJGPU_SCATTER_CFG");       // "block,vectors_per_thread" (tuning)
+        int b, v;
+        if (e && sscanf(e, "%d,%d", &b, &v) == 2) { cfg.block = b; cfg.vpt = v; }
+    }
+    return cfg;
+}
+
+int hj_scatter_tile() { return scatter_config().block * scatter_config().vpt * 4; }
+
+template <int BLOCK, int VPT, bool RANGED>
 static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
 {
-    constexpr int BLOCK = HJ_SCATTER_BLOCK, VPT = HJ_SCATTER_VPT;
     constexpr int TILE = BLOCK * VPT * 4;
     const uint32_t Fpad = (a.F + 3) & ~3u;
     const size_t lds = (size_t)Fpad * 12 + (size_t)TILE * 8 + (BLOCK / 64 + 1) * 4 + 16;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return HJGPU_EHIP;
         attr_set = true;
     }
-    // two workgroups per CU fit in LDS (2 * ~77 KiB <= 160 KiB); persistent grid
-    const int grid = cus * 2;
+    // persistent grid: as many workgroups per CU as LDS (160 KiB) and threads (2048) allow
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    if (per_cu > 2048 / BLOCK) per_cu = 2048 / BLOCK;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = cus * per_cu;
     hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED>), dim3(grid), dim3(BLOCK), lds, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
+#define SCATTER_CASE(B, V)                                                                   \
+    if (c.block == B && c.vpt == V)                                                          \
+        return a.ranged ? launch_scatter_t<B, V, true>(a, cus, stream)                       \
+                        : launch_scatter_t<B, V, false>(a, cus, stream);
+
 int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream)
 {
-    if (a.F == 0 || a.F > 2 * HJ_SCATTER_BLOCK || a.F > HJGPU_MAX_FANOUT) return HJGPU_EINVAL;
-    if (a.ranged && a.geom.tile != (uint32_t)HJ_SCATTER_TILE) return HJGPU_EINVAL;
-    return a.ranged ? launch_scatter_t<true>(a, cus, stream) : launch_scatter_t<false>(a, cus, stream);
+    if (a.F == 0 || a.F > HJGPU_MAX_FANOUT) return HJGPU_EINVAL;
+    if (a.ranged && a.geom.tile != (uint32_t)hj_scatter_tile()) return HJGPU_EINVAL;
+    const ScatterConfig &c = scatter_config();
+    SCATTER_CASE(512, 4)
+    SCATTER_CASE(256, 4)
+    SCATTER_CASE(256, 8)
+    SCATTER_CASE(1024, 2)
+    SCATTER_CASE(1024, 4)
+    SCATTER_CASE(512, 2)
+    return HJGPU_EINVAL;
 }

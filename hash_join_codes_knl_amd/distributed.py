@@ -1,0 +1,131 @@
+"""Multi-GPU orchestration of the joins: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X nodes).
+
+This is the distributed counterpart of the reference's thread orchestration:
+  * PHJ / NPJ (phj.cpp:1715-1770 exchanges both relations between threads; the
+    cheaper decomposition here replicates the build side and shards the probe
+    side, valid because R join S = union_g (R join S_g)):
+        broadcast(R)  ->  local join on (R, S_g)  ->  all_reduce(count, 3 sums)
+  * CPRA (cpra2.cpp:1757-1827 partitions each thread's own chunk, then thread t
+    gathers partitions [t*P/T, (t+1)*P/T) from every chunk by memcpy,
+    cpra2.cpp:1868-1904, 1946-1959):
+        local partition of the own chunk with top-level fan-out = #GPUs
+        ->  all_gather(counts)  ->  all_to_all_v(keys), all_to_all_v(payloads)
+        ->  local PHJ on the received tuples  ->  all_reduce(count, 3 sums)
+    Every GPU pair exchanges 1/G of a chunk over its direct xGMI link.
+
+The data path operators are injected (`ops`): on a GPU box they are the C-ABI
+entry points (hjgpu_partition / hjgpu_phj through `GpuOps`); the CPU tests inject
+the oracle so that the host logic (ownership, split sizes, reductions) is covered
+with the gloo backend.  Nothing here computes on tuples itself.
+"""
+import numpy as np
+
+TOP_LEVEL_FACTOR = 0x2C1B3C6D | 1      # odd multiplier of the exchange-level partitioning
+
+
+def shard_bounds(n, parts, alignment=16):
+    """thread_beg/thread_end (npj.cpp:516-529): contiguous, `alignment`-aligned ranges."""
+    part = (n // parts) & ~(alignment - 1)
+    return [(part * t, n if t + 1 == parts else part * (t + 1)) for t in range(parts)]
+
+
+def owner_of_partition(p, partitions, world):
+    """cpra2.cpp:1868-1872: rank t owns partitions [t*(P//T), (t+1)*(P//T)), the last rank the tail."""
+    per = max(1, partitions // world)
+    return min(p // per, world - 1)
+
+
+def _u64_tensor(torch, values, device):
+    # uint64 aggregates travel as int64 bit patterns (wrap-around addition is identical)
+    return torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in values],
+                        dtype=torch.int64, device=device)
+
+
+def _from_i64(values):
+    return tuple(int(v) & ((1 << 64) - 1) for v in values)
+
+
+def all_reduce_result(dist, torch, result, device):
+    t = _u64_tensor(torch, result, device)
+    dist.all_reduce(t)
+    return _from_i64(t.tolist())
+
+
+def phj_replicated_build(dist, torch, ops, r_keys, r_vals, s_keys_local, s_vals_local, src=0):
+    """Build side lives on `src`; every rank holds its own probe shard.
+    r_keys/r_vals: tensors of |R| elements on every rank (contents only valid on src).
+    Returns the global (count, sum_keys, sum_outer, sum_inner)."""
+    dist.broadcast(r_keys, src)
+    dist.broadcast(r_vals, src)
+    local = ops.join(r_keys, r_vals, s_keys_local, s_vals_local)
+    return all_reduce_result(dist, torch, local, r_keys.device)
+
+
+def cpra_exchange(dist, torch, ops, keys, vals, world, rank):
+    """Co-partition one relation: local top-level partition + all-to-all-v.
+    Returns (keys, vals) tensors holding every tuple whose top-level partition this rank owns."""
+    pk, pv, offsets = ops.partition(keys, vals, TOP_LEVEL_FACTOR, world)   # offsets: world+1 ints
+    send_counts = [int(offsets[g + 1] - offsets[g]) for g in range(world)]
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=keys.device)
+    rc = torch.empty(world, dtype=torch.int64, device=keys.device)
+    dist.all_to_all_single(rc, sc)                       # counts first, payload second
+    recv_counts = [int(x) for x in rc.tolist()]
+    out_k = torch.empty(sum(recv_counts), dtype=keys.dtype, device=keys.device)
+    out_v = torch.empty(sum(recv_counts), dtype=vals.dtype, device=vals.device)
+    dist.all_to_all_single(out_k, pk, recv_counts, send_counts)
+    dist.all_to_all_single(out_v, pv, recv_counts, send_counts)
+    return out_k, out_v
+
+
+def cpra_copartitioned(dist, torch, ops, r_keys_local, r_vals_local, s_keys_local, s_vals_local):
+    """Both relations chunked over the ranks; one exchange step, then a local join."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    rk, rv = cpra_exchange(dist, torch, ops, r_keys_local, r_vals_local, world, rank)
+    sk, sv = cpra_exchange(dist, torch, ops, s_keys_local, s_vals_local, world, rank)
+    local = ops.join(rk, rv, sk, sv)
+    return all_reduce_result(dist, torch, local, r_keys_local.device)
+
+
+class GpuOps:
+    """Data-path operators on device tensors through the C-ABI (no CPU fallback)."""
+
+    def __init__(self, hj, torch, algorithm="phj", params=None):
+        self.hj, self.torch, self.algorithm, self.params = hj, torch, algorithm, params
+
+    def _stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def join(self, rk, rv, sk, sv):
+        fn = {"phj": self.hj.phj, "npj": self.hj.npj, "cpra": self.hj.cpra}[self.algorithm]
+        return fn(rk.data_ptr(), rv.data_ptr(), rk.numel(), sk.data_ptr(), sv.data_ptr(), sk.numel(),
+                  self.params, None, self._stream())
+
+    def partition(self, keys, vals, factor, fanout):
+        torch = self.torch
+        n = keys.numel()
+        pk = torch.empty(n + 4, dtype=keys.dtype, device=keys.device)[:n]
+        pv = torch.empty(n + 4, dtype=vals.dtype, device=vals.device)[:n]
+        off = torch.empty(fanout + 1, dtype=torch.int64, device=keys.device)
+        self.hj.partition(keys.data_ptr(), vals.data_ptr(), n, factor, fanout,
+                          pk.data_ptr(), pv.data_ptr(), off.data_ptr(), self._stream())
+        return pk, pv, [int(x) for x in off.tolist()]
+
+
+class OracleOps:
+    """TEST ONLY: the same interface over the CPU oracle (used by the gloo tests)."""
+
+    def __init__(self, oracle, torch):
+        self.O, self.torch = oracle, torch
+
+    def _np(self, t):
+        return t.numpy().view(np.uint32)
+
+    def join(self, rk, rv, sk, sv):
+        return self.O.join_definition(self._np(rk), self._np(rv), self._np(sk), self._np(sv))
+
+    def partition(self, keys, vals, factor, fanout):
+        counts, ko, vo = self.O.partition(self._np(keys), self._np(vals), factor, fanout)
+        off = np.concatenate([[0], np.cumsum(counts.astype(np.int64))])
+        return (self.torch.from_numpy(ko.view(np.int32)), self.torch.from_numpy(vo.view(np.int32)),
+                [int(x) for x in off])

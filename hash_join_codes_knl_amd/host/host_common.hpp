@@ -1,0 +1,156 @@
+// host_common.hpp — shared by the npj / phj / cpra / write host programs.
+//
+// These programs keep the reference's command lines and file format
+// (npj.cpp:929-1125, phj.cpp:1959-2231, cpra2.cpp:2017-2231, write.cpp:1677-1888):
+//     ./npj|phj|cpra [#threads] [outer_tuples] [inner_tuples] [ratio]
+//     ./write        [#threads] [outer_tuples] [inner_tuples] [selectivity] [zipf]
+// reading / writing raw little-endian uint32 columns ./ik_<inner>.txt ./iv_<inner>.txt
+// ./ok_<outer>.txt ./ov_<outer>.txt in the current directory.  Everything below
+// the fread()s is replaced by one call into libhjgpu (include/hjgpu.h); no HIP
+// header is needed here.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "hjgpu.h"
+
+namespace hjhost {
+
+struct Args {
+    int threads;          // accepted for CLI compatibility; the GPU path does not use it
+    size_t outer, inner;
+    double extra;         // ratio (join programs) / selectivity (write)
+    double zipf;
+};
+
+inline Args parse(int argc, char **argv, double extra_default)
+{
+    Args a;
+    // defaults of the reference: hardware_threads(), 200 M, 200 M (npj.cpp:932-935)
+    a.threads = argc > 1 ? atoi(argv[1]) : 1;
+    a.outer = argc > 2 ? (size_t)atoll(argv[2]) : (size_t)200 * 1000 * 1000;
+    a.inner = argc > 3 ? (size_t)atoll(argv[3]) : (size_t)200 * 1000 * 1000;
+    a.extra = argc > 4 ? atof(argv[4]) : extra_default;
+    a.zipf = argc > 5 ? atof(argv[5]) : 0.0;
+    return a;
+}
+
+inline std::string column_path(const char *prefix, size_t tuples)
+{
+    return std::string("./") + prefix + "_" + std::to_string(tuples) + ".txt";
+}
+
+// The reference does not check fopen/fread (a missing file segfaults); a host
+// program reports and exits with status 2 instead.
+inline bool read_column(const std::string &path, size_t tuples, std::vector<uint32_t> &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot open %s (generate it with ./write)\n", path.c_str()); return false; }
+    out.resize(tuples);
+    const size_t got = tuples ? fread(out.data(), sizeof(uint32_t), tuples, f) : 0;
+    fclose(f);
+    if (got != tuples) { fprintf(stderr, "%s: expected %zu tuples, read %zu\n", path.c_str(), tuples, got); return false; }
+    return true;
+}
+
+inline bool write_column(const std::string &path, const std::vector<uint32_t> &col)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { fprintf(stderr, "cannot create %s\n", path.c_str()); return false; }
+    const size_t put = col.empty() ? 0 : fwrite(col.data(), sizeof(uint32_t), col.size(), f);
+    fclose(f);
+    return put == col.size();
+}
+
+struct Relations {
+    std::vector<uint32_t> ik, iv, ok, ov;
+};
+
+inline bool load_relations(const Args &a, Relations &r)
+{
+    return read_column(column_path("ik", a.inner), a.inner, r.ik) &&
+           read_column(column_path("iv", a.inner), a.inner, r.iv) &&
+           read_column(column_path("ok", a.outer), a.outer, r.ok) &&
+           read_column(column_path("ov", a.outer), a.outer, r.ov);
+}
+
+// Runs one join on the GPU and prints the extended report on stderr; the
+// reference's own stdout line is printed by each main in its own format.
+inline int run_join(int algorithm, const Args &a, const Relations &r, hjgpu_result *res,
+                    hjgpu_stats *st)
+{
+    hjgpu_ctx *ctx = nullptr;
+    int rc = hjgpu_create(-1, &ctx);
+    if (rc != HJGPU_OK) { fprintf(stderr, "hjgpu_create: %s\n", hjgpu_status_string(rc)); return rc; }
+    hjgpu_phj_params pp;
+    memset(&pp, 0, sizeof(pp));
+    if (algorithm == 2) pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 8 ? a.threads : 8);
+    hjgpu_npj_params np;
+    memset(&np, 0, sizeof(np));
+    rc = hjgpu_join_host(ctx, algorithm, r.ik.data(), r.iv.data(), r.ik.size(),
+                         r.ok.data(), r.ov.data(), r.ok.size(), &pp, &np, res, st);
+    if (rc != HJGPU_OK)
+        fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_last_error(ctx));
+    hjgpu_device_info info;
+    if (rc == HJGPU_OK && hjgpu_get_device_info(ctx, &info) == HJGPU_OK) {
+        const double sec = st->ms_total * 1e-3;
+        const double n = (double)r.ik.size() + (double)r.ok.size();
+        fprintf(stderr, "device: %s (%s, %d CUs)\n", info.name, info.arch, info.compute_units);
+        fprintf(stderr, "join_tuples=%llu sum_keys=%llu sum_outer_vals=%llu sum_inner_vals=%llu\n",
+                (unsigned long long)res->count, (unsigned long long)res->sum_keys,
+                (unsigned long long)res->sum_outer_vals, (unsigned long long)res->sum_inner_vals);
+        fprintf(stderr, "device time %.4f s: %.2f Gtuples/s probe-side, %.1f GB/s of input columns\n",
+                sec, sec > 0 ? r.ok.size() / sec / 1e9 : 0.0, sec > 0 ? 8.0 * n / sec / 1e9 : 0.0);
+    }
+    hjgpu_destroy(ctx);
+    return rc;
+}
+
+// ---- generator pieces for ./write (own restatement of write.cpp's intent) -------
+// MT19937 exactly as seeded by the reference (rand32_init, npj.cpp:138-148).
+struct Rand32 {
+    uint32_t num[625];
+    size_t index;
+    explicit Rand32(uint32_t seed)
+    {
+        num[0] = seed;
+        for (size_t i = 0; i != 623; ++i) num[i + 1] = 0x6c078965u * (num[i] ^ (num[i] >> 30));
+        index = 624;
+    }
+    uint32_t next()
+    {
+        if (index == 624) {
+            size_t i = 0;
+            for (; i != 227; ++i) {
+                const uint32_t y = (num[i] & 0x80000000u) + (num[i + 1] & 0x7fffffffu);
+                num[i] = num[i + 397] ^ (y >> 1) ^ (0x9908b0dfu & (0u - (y & 1u)));
+            }
+            num[624] = num[0];
+            for (; i != 624; ++i) {
+                const uint32_t y = (num[i] & 0x80000000u) + (num[i + 1] & 0x7fffffffu);
+                num[i] = num[i - 227] ^ (y >> 1) ^ (0x9908b0dfu & (0u - (y & 1u)));
+            }
+            index = 0;
+        }
+        uint32_t y = num[index++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+};
+
+inline bool odd_prime(uint64_t x)
+{
+    for (uint64_t d = 3; d * d <= x; d += 2)
+        if (x % d == 0) return false;
+    return true;
+}
+
+}  // namespace hjhost

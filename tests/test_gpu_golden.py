@@ -1,0 +1,116 @@
+"""GPU tests against the committed golden vectors (outputs of the reference's own
+scalar operator code, tests/golden/make_golden.py) and size-independent
+properties at BASELINE.json's full sizes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import hash_join_codes_knl_amd as H
+from helpers import mulhi_hash
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HIST_CASES = [(0x9E3779B1, 7), (0x85EBCA6B, 64), (0x9E3779B1, 1000)]
+PART_CASES = [(0x9E3779B1, 7), (0x85EBCA6B, 64)]
+NPJ_FACTOR, NPJ_LOAD = 0x9E3779B1, 0.90
+FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+                  if not os.path.basename(p).startswith("rand32"))
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hip_operators_reproduce_reference_outputs(hj, name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    ik, iv, ok, ov = g["inner_keys"], g["inner_vals"], g["outer_keys"], g["outer_vals"]
+    rk, rv, sk, sv = hj.column(ik), hj.column(iv), hj.column(ok), hj.column(ov)
+    # K4
+    for idx, (f, F) in enumerate(HIST_CASES):
+        dc = hj.column(F, np.uint64)
+        hj.histogram(sk, len(ok), f, F, dc)
+        assert np.array_equal(dc.download(), g["hist_%d" % idx].astype(np.uint64))
+        dc.free()
+    # K5 + K6
+    for idx, (f, F) in enumerate(PART_CASES):
+        dko, dvo, doff = hj.column(len(ok)), hj.column(len(ok)), hj.column(F + 1, np.uint64)
+        hj.partition(sk, sv, len(ok), f, F, dko, dvo, doff)
+        off = doff.download().astype(np.int64)
+        ko, vo = dko.download(), dvo.download()
+        assert np.array_equal(np.diff(off), g["part_%d_counts" % idx].astype(np.int64))
+        for p in range(F):
+            assert int(ko[off[p]:off[p + 1]].astype(np.uint64).sum()) == int(g["part_%d_sum_keys" % idx][p])
+            assert int(vo[off[p]:off[p + 1]].astype(np.uint64).sum()) == int(g["part_%d_sum_vals" % idx][p])
+        for c in (dko, dvo, doff):
+            c.free()
+    want = tuple(int(x) for x in g["phj_result"])
+    # K1-K3 with the reference's load factor and hash factor: same bucket multiset, same result
+    if "npj_result" in g:
+        buckets = int(len(ik) / NPJ_LOAD)
+        dt = hj.column(buckets, np.uint64)
+        hj.npj_build(rk, rv, len(ik), dt, buckets, NPJ_FACTOR)
+        assert np.array_equal(np.sort(dt.download()), g["npj_table_sorted"])
+        assert hj.npj_probe(sk, sv, len(ok), dt, buckets, NPJ_FACTOR) == tuple(int(x) for x in g["npj_result"])
+        dt.free()
+        assert hj.npj(rk, rv, len(ik), sk, sv, len(ok), H.NpjParams(load=NPJ_LOAD, factor=NPJ_FACTOR)) == want
+    # K7 + K8 (cuckoo fast path, then the chained fallback forced everywhere)
+    for prm in (None, H.PhjParams(fanout1=5, fanout2=3), H.PhjParams(fanout1=64, fanout2=1, chunks=4)):
+        assert hj.phj(rk, rv, len(ik), sk, sv, len(ok), prm) == want
+        assert hj.cpra(rk, rv, len(ik), sk, sv, len(ok), prm) == want
+    os.environ["HJGPU_FORCE_CHAINED"] = "1"
+    try:
+        assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == want
+        assert hj.cpra(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(fanout1=7, fanout2=2, chunks=3)) == want
+    finally:
+        del os.environ["HJGPU_FORCE_CHAINED"]
+    for c in (rk, rv, sk, sv):
+        c.free()
+
+
+def test_full_size_properties_64m_1g(hj):
+    """BASELINE.json configs[1]/[2] sizes: |R| = 64 M, |S| = 1 G, selectivity 1.
+    Size-independent properties: (i) join count = |S| and the three sums equal the
+    column checksums of S (every probe key matches exactly one build key);
+    (ii) partitioning preserves the column checksums (linearity) and every sampled
+    partition range holds only keys of that partition; (iii) NPJ, PHJ and CPRA agree."""
+    inner, outer = 64_000_000, 1_000_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(1, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    hj.reserve(inner, outer)
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    st = hj.stats()
+    assert st["fanout1"] * st["fanout2"] >= 15_000
+    assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=8)) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    # (ii) one pass over S with fan-out 1000
+    F, f = 1000, 0x85EBCA6B
+    pk, pv, off = hj.column(outer), hj.column(outer), hj.column(F + 1, np.uint64)
+    hj.partition(ok, ov, outer, f, F, pk, pv, off)
+    assert hj.column_sums(pk, outer, fo, fi) == sums
+    o = off.download().astype(np.int64)
+    assert o[0] == 0 and o[-1] == outer and (np.diff(o) > 0).all()
+    cnt = hj.column(F, np.uint64)
+    for p in (0, 1, 499, 998, 999):
+        n = int(o[p + 1] - o[p])
+        hj.histogram(pk.ptr + 4 * int(o[p]), n, f, F, cnt)
+        c = cnt.download()
+        assert c[p] == n and c.sum() == n
+    for c in (ik, iv, ok, ov, pk, pv, off, cnt):
+        c.free()
+
+
+def test_partition_sample_is_in_partition(hj):
+    rng = np.random.default_rng(3)
+    keys = rng.integers(0, 2**32, size=5_000_000, dtype=np.uint64).astype(np.uint32)
+    dk, dv = hj.column(keys), hj.column(keys)
+    pk, pv, off = hj.column(len(keys)), hj.column(len(keys)), hj.column(513, np.uint64)
+    hj.partition(dk, dv, len(keys), 0x9E3779B1, 512, pk, pv, off)
+    o = off.download().astype(np.int64)
+    ko = pk.download()
+    assert np.array_equal(mulhi_hash(ko, 0x9E3779B1, 512), np.searchsorted(o, np.arange(len(keys)), side="right") - 1)
+    assert np.array_equal(pv.download(), ko)
+    for c in (dk, dv, pk, pv, off):
+        c.free()
