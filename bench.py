@@ -158,6 +158,7 @@ def main():
     phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join",
               "ms_build", "ms_close_gaps"]
     acc = {p: 0.0 for p in phases}
+    per_step = {p: [] for p in phases}
     for _ in range(args.warmup):
         step()
     barrier()
@@ -168,6 +169,7 @@ def main():
         st = hj.stats()                 # hipEvent spans of this step's kernels (same stream)
         for p in phases:
             acc[p] += st[p]
+            per_step[p].append(st[p])
     barrier()
     elapsed = time.perf_counter() - t0
     got = [int(x) for x in d_result.tolist()]
@@ -230,6 +232,8 @@ def main():
                        "ms": round(join_ms, 4),
                        "hbm_read_frac": round(8 * n_tuples / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if join_ms > 0 else None},
         "phase_ms": {k: round(v, 4) for k, v in avg.items()},
+        "phase_ms_min": {k: round(min(v), 4) for k, v in per_step.items() if v},
+        "phase_ms_max": {k: round(max(v), 4) for k, v in per_step.items() if v},
         "checksum_ok": checksum_ok,
         "result": {"count": got[0], "sum_keys": got[1], "sum_outer_vals": got[2], "sum_inner_vals": got[3]},
         "device": info["name"], "arch": info["arch"],

@@ -27,12 +27,12 @@ const JoinConfig &hj_join_config();
 // each chunk (segment) is cut into `ranges_per_chunk` contiguous ranges of whole
 // tiles.  K4 counts per range, K5 turns the counts into per-range write bases,
 // and K6 pass 1 walks the same ranges with private cursors - no global atomics.
-constexpr uint32_t HJ_RANGES = 1024;            // total ranges (all chunks)
+constexpr uint32_t HJ_MAX_RANGE_ENTRIES = 1u << 24;   // ranges * F1 kept below this (64 MiB of counts)
 struct Pass1Geom {
     u64 b[9];                       // chunk boundaries b[0..chunks]
     uint32_t chunks;
     uint32_t align;                 // (address of the key column / 4) % 4
-    uint32_t ranges_per_chunk;      // HJ_RANGES / chunks
+    uint32_t ranges_per_chunk;      // ceil(tiles of the largest chunk / tiles per range)
     uint32_t tile;
 };
 #if defined(__HIPCC__)
@@ -56,6 +56,7 @@ struct ScatterArgs {
     uint32_t in_align;              // (address of kin / 4) % 4, same for vin
     // pass 1 only (ranged == 1): per-range bases instead of atomic cursors
     uint32_t ranged;
+    uint32_t strided;               // pass 2: tiles dealt round-robin instead of contiguous runs
     Pass1Geom geom;
     const u64 *range_base;          // [ranges][F] absolute output position of each (range, partition)
 };

@@ -104,7 +104,7 @@ struct MetaLayout {
     size_t total_bytes;
 };
 
-MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P)
+MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges)
 {
     MetaLayout m;
     u64 *p = reinterpret_cast<u64 *>(base);
@@ -124,7 +124,6 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P)
     }
     m.slice_prefix = take((size_t)P + 1);
     m.slices = take(P);
-    const size_t ranges = (size_t)(HJ_RANGES / C) * C;
     for (int r = 0; r < 2; ++r) {
         m.range_counts[r] = reinterpret_cast<uint32_t *>(take((ranges * F1 + 1) / 2));
         m.range_base[r] = take(ranges * F1);
@@ -186,10 +185,47 @@ int setup_output(hjgpu_ctx *ctx, const hjgpu_output *out, uint32_t workers, u64 
     return HJGPU_OK;
 }
 
+// Tiles per range (a range = the unit that owns private pass-1 write cursors).
+// Measured at |S| = 1G, F1 = 136: 1..32 tiles per range all land within run-to-run
+// noise for K6, while K4/K5b grow from 1.03+0.08 ms to 1.28+0.41 ms at 1 tile per
+// range.  HJGPU_RANGE_TILES overrides (tuning).
+uint32_t range_tiles_for(u64 max_tiles, uint32_t F1)
+{
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("HJGPU_RANGE_TILES"); forced = e ? atoi(e) : 0; }
+    // default: ~4096 ranges per relation - fine-grained enough that concurrently running
+    // workgroups write neighbouring regions, coarse enough that K4/K5b stay negligible
+    u64 k = forced > 0 ? (u64)forced : (max_tiles + 4095) / 4096;
+    if (k < 1) k = 1;
+    while ((max_tiles + k - 1) / k * F1 > HJ_MAX_RANGE_ENTRIES) k *= 2;
+    return (uint32_t)k;
+}
+
+Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1)
+{
+    // chunk ranges = thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
+    Pass1Geom g;
+    const size_t part = (n / C) & ~size_t(15);
+    for (uint32_t c = 0; c < C; ++c) g.b[c] = part * c;
+    for (uint32_t c = C; c < 9; ++c) g.b[c] = n;
+    g.chunks = C;
+    g.align = align_of(keys);
+    g.tile = (uint32_t)hj_scatter_tile();
+    u64 max_tiles = 1;
+    for (uint32_t c = 0; c < C; ++c) {
+        const u64 t = hj_tiles_of(g.b[c], g.b[c + 1], g.align, g.tile);
+        if (t > max_tiles) max_tiles = t;
+    }
+    const uint32_t k = range_tiles_for(max_tiles, F1);
+    g.ranges_per_chunk = (uint32_t)((max_tiles + k - 1) / k);
+    return g;
+}
+
 // ---------------------------------------------------------------------------
 // PHJ / CPRA: fused histogram -> plan -> scatter x2 -> LDS join
 // ---------------------------------------------------------------------------
 struct PhjPlan {
+    size_t ranges;
     uint32_t C, F1, F2, P;
     uint32_t f1, f2, tf0, tf1;
 };
@@ -217,24 +253,13 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
         CHK(ensure(ctx, ctx->tmp[4], rb)); CHK(ensure(ctx, ctx->tmp[5], rb));
         CHK(ensure(ctx, ctx->tmp[6], sb)); CHK(ensure(ctx, ctx->tmp[7], sb));
     }
-    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P);
+    // ranges of the larger relation bound the per-range tables of both
+    const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1), gs = make_geom(nullptr, outer, pl->C, pl->F1);
+    pl->ranges = (size_t)(gr.ranges_per_chunk > gs.ranges_per_chunk ? gr.ranges_per_chunk : gs.ranges_per_chunk) * pl->C;
+    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     return HJGPU_OK;
-}
-
-Pass1Geom make_geom(const void *keys, size_t n, uint32_t C)
-{
-    // chunk ranges = thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
-    Pass1Geom g;
-    const size_t part = (n / C) & ~size_t(15);
-    for (uint32_t c = 0; c < C; ++c) g.b[c] = part * c;
-    for (uint32_t c = C; c < 9; ++c) g.b[c] = n;
-    g.chunks = C;
-    g.align = align_of(keys);
-    g.ranges_per_chunk = HJ_RANGES / C;
-    g.tile = (uint32_t)hj_scatter_tile();
-    return g;
 }
 
 int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
@@ -242,7 +267,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
                 const hjgpu_output *out, hipStream_t stream)
 {
-    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P);
+    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
@@ -252,7 +277,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
 
     // K4: one read of each key column gives the histograms of both passes
-    const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C), make_geom(sk, outer, pl.C)};
+    const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C, pl.F1), make_geom(sk, outer, pl.C, pl.F1)};
     if (inner) CHK(hj_launch_hist2(rk, geom[0], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[0], m.range_counts[0], ctx->cus, stream));
     if (outer) CHK(hj_launch_hist2(sk, geom[1], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[1], m.range_counts[1], ctx->cus, stream));
     record(ctx, EV_HIST, stream);
@@ -588,10 +613,9 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
     HIPCHK(ctx, hipMemsetAsync(d_counts, 0, (size_t)fanout * sizeof(u64), stream));
     if (n) {
         // the per-range counts are a by-product here; they go to scratch
-        CHK(ensure(ctx, ctx->moves, (size_t)HJ_RANGES * sizeof(uint32_t)));
-        // (F1 = 1, F2 = fanout): the fused LDS histogram carries the counts, the
-        // per-range pass-1 rows degenerate to one counter each
-        CHK(hj_launch_hist2(d_keys, make_geom(d_keys, n, 1), 1u, 1u, factor, fanout, (u64 *)d_counts,
+        const Pass1Geom g = make_geom(d_keys, n, 1, 1);
+        CHK(ensure(ctx, ctx->moves, (size_t)g.ranges_per_chunk * sizeof(uint32_t)));
+        CHK(hj_launch_hist2(d_keys, g, 1u, 1u, factor, fanout, (u64 *)d_counts,
                             (uint32_t *)ctx->moves.p, ctx->cus, stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(stream));
@@ -609,11 +633,11 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     CHK(check_columns(ctx, d_keys, d_vals, n));
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    MetaLayout sz = carve(nullptr, 1, fanout, fanout);
+    const Pass1Geom geom = make_geom(d_keys, n, 1, fanout);
+    MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
-    MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout);
+    MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
-    const Pass1Geom geom = make_geom(d_keys, n, 1);
     if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], ctx->cus, stream));
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
@@ -665,10 +689,10 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     pl.tf1 = passes->table_factor[1] ? passes->table_factor[1] : DEFAULT_TF1;
     if (!(pl.f1 & 1) || !(pl.f2 & 1) || !(pl.tf0 & 1) || !(pl.tf1 & 1))
         return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
-    MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P);
+    MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P, 1);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
-    MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P);
+    MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P, 1);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
