@@ -38,7 +38,10 @@ def parse():
     ap.add_argument("--cpu-outer", type=int, default=256_000_000,
                     help="probe tuples of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
-    ap.add_argument("--materialize", action="store_true", help="also time the materialising join once")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even at --gpus 1 (exercises the multi-GPU code path)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="multi-GPU: broadcast the build side on the join's own stream (no overlap)")
     return ap.parse_args()
 
 
@@ -97,10 +100,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if n_gpus > 1:
+    if n_gpus > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=max(world, 1), device_id=dev)   # nccl == RCCL on ROCm
 
     hj = H.HjGpu(local_rank)
     info = hj.device_info()
@@ -132,16 +136,32 @@ def main():
     nprm = H.NpjParams(load=0.5)
     d_result = torch.zeros(4, dtype=torch.int64, device=dev)
 
+    side = torch.cuda.Stream(device=dev) if dist is not None else None
+    overlap = dist is not None and args.algo == "phj" and not args.no_overlap
+
     def step():
+        main = torch.cuda.current_stream()
+        ready = None
         if dist is not None:
-            # exchange step of the multi-GPU path: replicate the build side over xGMI
-            if rank == 0:
-                rk.copy_(r_src_k); rv.copy_(r_src_v)
-            dist.broadcast(rk, 0)
-            dist.broadcast(rv, 0)
-        s = torch.cuda.current_stream().cuda_stream
+            # exchange step of the multi-GPU path: replicate the build side over xGMI.
+            # With overlap the broadcast runs on a side stream while the probe shard is
+            # histogrammed and partitioned; the library waits for `ready` before it reads R.
+            bs = side if overlap else main
+            if overlap:
+                side.wait_stream(main)              # the previous step's join is done reading R
+            with torch.cuda.stream(bs):
+                if rank == 0:
+                    rk.copy_(r_src_k); rv.copy_(r_src_v)
+                dist.broadcast(rk, 0)
+                dist.broadcast(rv, 0)
+                if overlap:
+                    ready = torch.cuda.Event()
+                    ready.record(bs)
+        s = main.cuda_stream
         a = (rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer)
-        if args.algo == "phj":
+        if args.algo == "phj" and ready is not None:
+            hj.phj_overlapped_async(*a, prm, d_result.data_ptr(), s, ready.cuda_event)
+        elif args.algo == "phj":
             hj.phj_async(*a, prm, d_result.data_ptr(), s)
         elif args.algo == "cpra":
             hj.cpra_async(*a, prm, d_result.data_ptr(), s)
@@ -156,7 +176,7 @@ def main():
         torch.cuda.synchronize()
 
     phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join",
-              "ms_build", "ms_close_gaps"]
+              "ms_build", "ms_close_gaps", "ms_inner_wait"]
     acc = {p: 0.0 for p in phases}
     per_step = {p: [] for p in phases}
     for _ in range(args.warmup):
@@ -225,7 +245,8 @@ def main():
                    "outer_tuples_total": outer_total,
                    "fanout": [st["fanout1"], st["fanout2"]],
                    "parallelism": "probe side sharded over %d GPU(s), build side %s"
-                                  % (n_gpus, "RCCL-broadcast each step" if n_gpus > 1 else "local")},
+                                  % (n_gpus, ("RCCL-broadcast each step" + (", overlapped with probe-side partitioning" if overlap else ""))
+                                     if dist is not None else "local")},
         "roofline": roofline,
         "roofline_kernels": kernels,
         "join_phase": {"gtuples_per_s_per_gpu": round(outer / (join_ms * 1e-3) / 1e9, 2) if join_ms > 0 else None,

@@ -24,7 +24,7 @@ EXPORTS = [
     "hjgpu_histogram", "hjgpu_partition", "hjgpu_join_partitions",
     "hjgpu_npj_build", "hjgpu_npj_probe",
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
-    "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async",
+    "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
     "hjgpu_join_host", "hjgpu_generate", "hjgpu_column_sums",
 ]
 
@@ -57,6 +57,7 @@ class Stats(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_histogram", C.c_float), ("ms_plan", C.c_float),
                 ("ms_scatter1", C.c_float), ("ms_scatter2", C.c_float), ("ms_join", C.c_float),
                 ("ms_build", C.c_float), ("ms_close_gaps", C.c_float),
+                ("ms_inner_wait", C.c_float), ("reserved", C.c_float),
                 ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("buckets", C.c_uint64)]
 
     def as_dict(self):
@@ -117,6 +118,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_npj_async.argtypes = join + [C.POINTER(NpjParams), vp, vp]
     L.hjgpu_phj_async.argtypes = join + [C.POINTER(PhjParams), vp, vp]
     L.hjgpu_cpra_async.argtypes = join + [C.POINTER(PhjParams), vp, vp]
+    L.hjgpu_phj_overlapped_async.argtypes = join + [C.POINTER(PhjParams), vp, vp, vp]
     L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
                                   C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Stats)]
     L.hjgpu_generate.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
@@ -280,6 +282,11 @@ class HjGpu:
 
     def phj_async(self, rk, rv, inner, sk, sv, outer, params, d_result, stream=None):
         self._join_async(self.lib.hjgpu_phj_async, params, rk, rv, inner, sk, sv, outer, d_result, stream)
+
+    def phj_overlapped_async(self, rk, rv, inner, sk, sv, outer, params, d_result, stream, inner_ready_event):
+        self._check(self.lib.hjgpu_phj_overlapped_async(
+            self.handle, self._ptr(rk), self._ptr(rv), inner, self._ptr(sk), self._ptr(sv), outer,
+            C.byref(params) if params is not None else None, self._ptr(d_result), stream, inner_ready_event))
 
     def cpra_async(self, rk, rv, inner, sk, sv, outer, params, d_result, stream=None):
         self._join_async(self.lib.hjgpu_cpra_async, params, rk, rv, inner, sk, sv, outer, d_result, stream)

@@ -95,6 +95,7 @@ struct PlanArgs {
     uint32_t chunks, F1, F2;
     uint32_t in_align[2];     // alignment of the caller's input columns
     uint32_t tile, slice;
+    uint32_t mask;            // bit 0: plan R, bit 1: plan S, bit 2: join work items
 };
 
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,

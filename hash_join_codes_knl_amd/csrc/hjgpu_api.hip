@@ -29,7 +29,10 @@ struct DevState {
     uint32_t pad;
 };
 
-enum { EV_BEGIN = 0, EV_HIST, EV_PLAN, EV_SCAT1, EV_SCAT2, EV_JOIN, EV_GAPS, EV_COUNT };
+// probe side (S) is partitioned first, then the build side (R): a caller can overlap the
+// arrival of R (e.g. an RCCL broadcast) with the S passes through `inner_ready`
+enum { EV_BEGIN = 0, EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2, EV_WAITED,
+       EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2, EV_JOIN, EV_GAPS, EV_COUNT };
 
 }  // namespace
 
@@ -265,7 +268,7 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
 int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *rk, const uint32_t *rv, size_t inner,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
-                const hjgpu_output *out, hipStream_t stream)
+                const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr)
 {
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
@@ -276,13 +279,13 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
 
-    // K4: one read of each key column gives the histograms of both passes
     const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C, pl.F1), make_geom(sk, outer, pl.C, pl.F1)};
-    if (inner) CHK(hj_launch_hist2(rk, geom[0], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[0], m.range_counts[0], ctx->cus, stream));
-    if (outer) CHK(hj_launch_hist2(sk, geom[1], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[1], m.range_counts[1], ctx->cus, stream));
-    record(ctx, EV_HIST, stream);
-
-    // K5
+    const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
+    const size_t nn[2] = {inner, outer};
+    uint32_t *t1[4] = {(uint32_t *)ctx->tmp[0].p, (uint32_t *)ctx->tmp[1].p,
+                       (uint32_t *)ctx->tmp[2].p, (uint32_t *)ctx->tmp[3].p};
+    uint32_t *t2[4] = {(uint32_t *)ctx->tmp[4].p, (uint32_t *)ctx->tmp[5].p,
+                       (uint32_t *)ctx->tmp[6].p, (uint32_t *)ctx->tmp[7].p};
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
         pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
@@ -294,47 +297,49 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
     pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
-    CHK(hj_launch_plan(pa, stream));
-    // K5b: per-range write bases of pass 1
-    const size_t nn0[2] = {inner, outer};
-    for (int r = 0; r < 2; ++r)
-        if (nn0[r]) CHK(hj_launch_range_base(m.range_counts[r], m.off1[r], m.range_base[r], pl.C,
-                                             geom[r].ranges_per_chunk, pl.F1, stream));
-    record(ctx, EV_PLAN, stream);
 
-    // K6 pass 1: caller's columns -> tmp[0..3]
-    uint32_t *t1[4] = {(uint32_t *)ctx->tmp[0].p, (uint32_t *)ctx->tmp[1].p,
-                       (uint32_t *)ctx->tmp[2].p, (uint32_t *)ctx->tmp[3].p};
-    const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
-    const size_t nn[2] = {inner, outer};
-    for (int r = 0; r < 2; ++r) {
-        if (!nn[r]) continue;
-        ScatterArgs sa;
-        sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
-        sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
-        sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
-        sa.ranged = 1; sa.geom = geom[r]; sa.range_base = m.range_base[r];
-        CHK(hj_launch_scatter(sa, ctx->cus, stream));
-    }
-    record(ctx, EV_SCAT1, stream);
-
-    // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
-    const uint32_t *fin[4] = {t1[0], t1[1], t1[2], t1[3]};
-    if (pl.F2 > 1) {
-        uint32_t *t2[4] = {(uint32_t *)ctx->tmp[4].p, (uint32_t *)ctx->tmp[5].p,
-                           (uint32_t *)ctx->tmp[6].p, (uint32_t *)ctx->tmp[7].p};
-        for (int r = 0; r < 2; ++r) {
-            if (!nn[r]) continue;
+    // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
+    auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
+        // K4: one read of the key column gives the histograms of both passes
+        if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
+                                       m.range_counts[r], ctx->cus, stream));
+        record(ctx, ev[0], stream);
+        // K5 (+ the join's work items once both histograms exist), K5b
+        pa.mask = plan_mask;
+        CHK(hj_launch_plan(pa, stream));
+        if (nn[r]) CHK(hj_launch_range_base(m.range_counts[r], m.off1[r], m.range_base[r], pl.C,
+                                            geom[r].ranges_per_chunk, pl.F1, stream));
+        record(ctx, ev[1], stream);
+        // K6 pass 1: caller's columns -> tmp[0..3]
+        if (nn[r]) {
+            ScatterArgs sa;
+            sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
+            sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
+            sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
+            sa.ranged = 1; sa.strided = 0; sa.geom = geom[r]; sa.range_base = m.range_base[r];
+            CHK(hj_launch_scatter(sa, ctx->cus, stream));
+        }
+        record(ctx, ev[2], stream);
+        // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
+        if (nn[r] && pl.F2 > 1) {
             ScatterArgs sa;
             sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
             sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r];
             sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
-            sa.ranged = 0; sa.geom = geom[r]; sa.range_base = nullptr;
+            sa.ranged = 0; sa.strided = 1; sa.geom = geom[r]; sa.range_base = nullptr;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
-        for (int i = 0; i < 4; ++i) fin[i] = t2[i];
-    }
-    record(ctx, EV_SCAT2, stream);
+        record(ctx, ev[3], stream);
+        return HJGPU_OK;
+    };
+    const int ev_s[4] = {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2};
+    const int ev_r[4] = {EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2};
+    CHK(partition_relation(1, 2u, ev_s));                       // probe side first
+    if (inner_ready) HIPCHK(ctx, hipStreamWaitEvent(stream, inner_ready, 0));
+    record(ctx, EV_WAITED, stream);
+    CHK(partition_relation(0, 1u | 4u, ev_r));                  // build side + join work items
+    const uint32_t *fin[4] = {t1[0], t1[1], t1[2], t1[3]};
+    if (pl.F2 > 1) for (int i = 0; i < 4; ++i) fin[i] = t2[i];
 
     // K7+K8
     if (inner && outer) {
@@ -444,8 +449,7 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
     // K1 set() npj.cpp:865-868 ; K2 build() 871-877
     HIPCHK(ctx, hipMemsetAsync(table, 0, buckets * sizeof(u64), stream));
     if (inner) CHK(hj_launch_npj_build(rk, rv, inner, table, buckets, factor, &st->zero_key, ctx->cus, stream));
-    record(ctx, EV_HIST, stream);       // reused as "end of build"
-    ctx->ev_valid[EV_PLAN] = ctx->ev_valid[EV_SCAT1] = ctx->ev_valid[EV_SCAT2] = false;
+    record(ctx, EV_R_HIST, stream);     // reused as "end of build"
     CHK(npj_probe_enqueue(ctx, sk, sv, outer, table, buckets, factor, out, stream));
     ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets;
     ctx->last_algo = 0;
@@ -550,16 +554,18 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
     };
     hjgpu_stats r = ctx->stats;
     r.ms_total = span(EV_BEGIN, EV_GAPS);
+    r.ms_inner_wait = 0;
     if (ctx->last_algo == 0) {
-        r.ms_build = span(EV_BEGIN, EV_HIST);
-        r.ms_join = span(EV_HIST, EV_JOIN);
+        r.ms_build = span(EV_BEGIN, EV_R_HIST);
+        r.ms_join = span(EV_R_HIST, EV_JOIN);
         r.ms_histogram = r.ms_plan = r.ms_scatter1 = r.ms_scatter2 = 0;
     } else {
-        r.ms_histogram = span(EV_BEGIN, EV_HIST);
-        r.ms_plan = span(EV_HIST, EV_PLAN);
-        r.ms_scatter1 = span(EV_PLAN, EV_SCAT1);
-        r.ms_scatter2 = span(EV_SCAT1, EV_SCAT2);
-        r.ms_join = span(EV_SCAT2, EV_JOIN);
+        r.ms_histogram = span(EV_BEGIN, EV_S_HIST) + span(EV_WAITED, EV_R_HIST);
+        r.ms_plan = span(EV_S_HIST, EV_S_PLAN) + span(EV_R_HIST, EV_R_PLAN);
+        r.ms_scatter1 = span(EV_S_PLAN, EV_S_SC1) + span(EV_R_PLAN, EV_R_SC1);
+        r.ms_scatter2 = span(EV_S_SC1, EV_S_SC2) + span(EV_R_SC1, EV_R_SC2);
+        r.ms_inner_wait = span(EV_S_SC2, EV_WAITED);
+        r.ms_join = span(EV_R_SC2, EV_JOIN);
         r.ms_build = 0;
     }
     r.ms_close_gaps = span(EV_JOIN, EV_GAPS);
@@ -648,7 +654,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
-    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
+    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
     if (n) {
         CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
@@ -710,9 +716,9 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     }
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
-    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
+    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
-    for (int e : {EV_HIST, EV_PLAN, EV_SCAT1, EV_SCAT2}) record(ctx, e, stream);
+    for (int e : {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2, EV_WAITED, EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2}) record(ctx, e, stream);
     JoinArgs ja;
     memset(&ja, 0, sizeof(ja));
     ja.rk = rk; ja.rv = rv; ja.sk = sk; ja.sv = sv;
@@ -764,7 +770,7 @@ int hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     HIPCHK(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(DevState), stream));
-    record(ctx, EV_BEGIN, stream); record(ctx, EV_HIST, stream);
+    record(ctx, EV_BEGIN, stream); record(ctx, EV_R_HIST, stream);
     CHK(npj_probe_enqueue(ctx, d_keys, d_vals, n, (const u64 *)d_table, buckets, factor, out, stream));
     ctx->last_algo = 0;
     return finish_blocking(ctx, result, out, stream);
@@ -807,7 +813,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
                     const uint32_t *rk, const uint32_t *rv, size_t inner,
                     const uint32_t *sk, const uint32_t *sv, size_t outer,
                     const hjgpu_phj_params *prm, hjgpu_result *result, hjgpu_result *d_result,
-                    const hjgpu_output *out, void *stream_, bool blocking)
+                    const hjgpu_output *out, void *stream_, bool blocking, void *inner_ready = nullptr)
 {
     if (!ctx) return HJGPU_EINVAL;
     CHK(check_columns(ctx, rk, rv, inner));
@@ -817,7 +823,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PhjPlan pl;
     CHK(phj_prepare(ctx, inner, outer, prm, chunks, &pl));
-    CHK(phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, out, stream));
+    CHK(phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, out, stream, (hipEvent_t)inner_ready));
     if (d_result)
         HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
     if (blocking) return finish_blocking(ctx, result, out, stream);
@@ -836,6 +842,15 @@ int hjgpu_phj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size
                     const hjgpu_phj_params *prm, hjgpu_result *d_result, void *stream)
 {
     return phj_like(ctx, 1, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false);
+}
+
+int hjgpu_phj_overlapped_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
+                               const uint32_t *sk, const uint32_t *sv, size_t outer,
+                               const hjgpu_phj_params *prm, hjgpu_result *d_result, void *stream,
+                               void *inner_ready_event)
+{
+    return phj_like(ctx, 1, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false,
+                    inner_ready_event);
 }
 
 int hjgpu_cpra(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,

@@ -39,14 +39,19 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
     extern __shared__ uint32_t lds_hist[];          // [P] fused, then [F1] per-range
     const uint32_t P = F1 * F2;
     uint32_t *range_hist = lds_hist + P;
-    const uint32_t Rc = geom.ranges_per_chunk;         // launched once per chunk: geom.chunks == 1
+    const uint32_t Rc = geom.ranges_per_chunk;
+    const uint32_t chunk = blockIdx.y;                  // one grid row per chunk: a workgroup never mixes chunks
+    counts += (u64)chunk * P;
+    range_counts += (u64)chunk * Rc * F1;
+    u64 cb = 0, ce = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q == (int)chunk) { cb = geom.b[q]; ce = geom.b[q + 1]; }
     const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(keys - geom.align);
 
     for (uint32_t i = threadIdx.x; i < P; i += BLOCK) lds_hist[i] = 0;
 
     for (uint32_t r = blockIdx.x; r < Rc; r += gridDim.x) {
         const uint32_t j = r;
-        const u64 cb = geom.b[0], ce = geom.b[1];
         const u64 gb = geom.align + cb, ge = geom.align + ce;
         const u64 tiles = hj_tiles_of(cb, ce, geom.align, geom.tile);
         const u64 t_beg = tiles * j / Rc, t_end = tiles * (j + 1) / Rc;
@@ -86,7 +91,6 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
     }
 }
 
-// chunks > 1 (CPRA): one launch per chunk keeps the fused LDS histogram per chunk.
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
                     u64 *counts, uint32_t *range_counts, int cus, hipStream_t stream)
@@ -103,20 +107,11 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
         attr_set = true;
     }
     const uint32_t per_cu = (lds > 72 * 1024) ? 1 : 2;
-    for (uint32_t c = 0; c < geom.chunks; ++c) {
-        // present chunk c as a single-chunk geometry so that its fused histogram
-        // lands in its own row of `counts` and its ranges in their own rows
-        Pass1Geom g1 = geom;
-        g1.chunks = 1;
-        g1.b[0] = geom.b[c]; g1.b[1] = geom.b[c + 1];
-        for (int q = 2; q < 9; ++q) g1.b[q] = geom.b[c + 1];
-        uint32_t grid = (uint32_t)cus * per_cu;
-        if (geom.chunks > 1) grid = (grid + geom.chunks - 1) / geom.chunks;
-        if (grid > geom.ranges_per_chunk) grid = geom.ranges_per_chunk;
-        hipLaunchKernelGGL(hist2_kernel<BLOCK>, dim3(grid), dim3(BLOCK), lds, stream, keys, g1,
-                           f1, F1, f2, F2, counts + (u64)c * P,
-                           range_counts + (u64)c * geom.ranges_per_chunk * F1);
-    }
+    uint32_t gx = ((uint32_t)cus * per_cu + geom.chunks - 1) / geom.chunks;
+    if (gx > geom.ranges_per_chunk) gx = geom.ranges_per_chunk;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(hist2_kernel<BLOCK>, dim3(gx, geom.chunks), dim3(BLOCK), lds, stream, keys, geom,
+                       f1, F1, f2, F2, counts, range_counts);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
@@ -177,6 +172,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(PlanArgs a)
     __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
     const uint32_t P = a.F1 * a.F2;
     const uint32_t C = a.chunks;
+    if (!((a.mask >> blockIdx.x) & 1u)) return;
     if (blockIdx.x < 2) {
         const int r = blockIdx.x;
         const u64 *__restrict__ cnt = a.counts[r];

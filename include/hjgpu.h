@@ -91,6 +91,9 @@ typedef struct {
     float    ms_join;          /* K7+K8 (PHJ/CPRA) or K3 probe (NPJ)                         */
     float    ms_build;         /* NPJ: K1 clear + K2 build                                   */
     float    ms_close_gaps;    /* K9                                                         */
+    float    ms_inner_wait;    /* stream time spent waiting for the build side to arrive
+                                  (hjgpu_phj_overlapped_async), 0 otherwise                  */
+    float    reserved;
     uint32_t fanout1, fanout2; /* what was used                                              */
     uint64_t buckets;          /* NPJ table size                                             */
 } hjgpu_stats;
@@ -187,6 +190,16 @@ int  hjgpu_phj_async(hjgpu_ctx *ctx,
                      const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
                      const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
                      const hjgpu_phj_params *params, hjgpu_result *d_result, void *stream);
+/* As hjgpu_phj_async, but the build columns only become valid once
+ * `inner_ready_event` (a hipEvent_t passed as void*, recorded by the caller on the
+ * stream that produces them, e.g. an RCCL broadcast) has fired: the probe side is
+ * histogrammed and partitioned first, the wait sits right before the first kernel
+ * that reads R.  This is how the multi-GPU PHJ hides the build-side broadcast. */
+int  hjgpu_phj_overlapped_async(hjgpu_ctx *ctx,
+                     const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+                     const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+                     const hjgpu_phj_params *params, hjgpu_result *d_result, void *stream,
+                     void *inner_ready_event);
 int  hjgpu_cpra_async(hjgpu_ctx *ctx,
                       const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
                       const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,

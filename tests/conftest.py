@@ -24,6 +24,13 @@ def oracle():
 def hj():
     """One hjgpu context for the whole session.  No fallback: if the HIP library
     or the GPU is missing this raises and every gpu test errors out loudly."""
+    # torch bundles its own HIP runtime: when both live in one process torch has to
+    # initialise first (bench.py does the same), otherwise it finds no device
+    try:
+        import torch
+        torch.cuda.init()
+    except ImportError:
+        pass
     import hash_join_codes_knl_amd as H
     ctx = H.HjGpu()
     info = ctx.device_info()

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(H.PhjParams) == 32
     assert C.sizeof(H.NpjParams) == 16
     assert C.sizeof(H.Output) == 40
-    assert C.sizeof(H.Stats) == 48
+    assert C.sizeof(H.Stats) == 56
 
 
 def test_product_package_never_uses_the_oracle():

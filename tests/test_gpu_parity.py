@@ -302,3 +302,33 @@ def test_device_generator_duplicate_build_side(hj):
     assert hj.phj(ik, iv, inner, ok, ov, outer) == want
     assert hj.cpra(ik, iv, inner, ok, ov, outer) == want
     _free(ik, iv, ok, ov)
+
+
+# ---------------------------------------------------------------- overlapped build-side arrival
+def test_phj_overlapped_waits_for_build_side(hj, oracle):
+    """hjgpu_phj_overlapped_async: R is produced on a side stream AFTER the join was
+    enqueued; the library must not read it before the event fires."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    ik, iv, ok, ov = oracle.generate(1_000_000, 200_000, seed=31)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    t = lambda a: torch.from_numpy(np.concatenate([a, np.zeros(4, np.uint32)]).view(np.int32)).to(dev)
+    src_k, src_v, sk, sv = t(ik), t(iv), t(ok), t(ov)
+    rk, rv = torch.zeros_like(src_k), torch.zeros_like(src_v)        # garbage until the side stream ran
+    d_res = torch.zeros(4, dtype=torch.int64, device=dev)
+    hj.reserve(len(ik), len(ok))
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+    big = torch.empty(256 * 1024 * 1024, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big.add_(1)                                              # ~ms of delay before R exists
+        rk.copy_(src_k); rv.copy_(src_v)
+        ready = torch.cuda.Event()
+        ready.record(side)
+    hj.phj_overlapped_async(rk.data_ptr(), rv.data_ptr(), len(ik), sk.data_ptr(), sv.data_ptr(), len(ok),
+                            None, d_res.data_ptr(), main.cuda_stream, ready.cuda_event)
+    torch.cuda.synchronize()
+    got = tuple(int(x) & ((1 << 64) - 1) for x in d_res.tolist())
+    assert got == want
+    assert hj.stats()["ms_inner_wait"] > 0.0
