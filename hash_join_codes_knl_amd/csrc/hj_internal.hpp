@@ -47,8 +47,9 @@ inline u64 hj_tiles_of(u64 b, u64 e, uint32_t align, uint32_t tile)
 
 // One partitioning pass over `nseg` independent input segments.
 struct ScatterArgs {
-    const uint32_t *kin, *vin;      // input columns
-    uint32_t *kout, *vout;          // output columns (same length)
+    const uint32_t *kin, *vin;      // input columns (in_packed: kin = packed tuples, vin unused)
+    uint32_t *kout, *vout;          // output columns (out_packed: kout = packed tuples, vout unused)
+    uint32_t in_packed, out_packed; // packed tuple = payload << 32 | key (8 bytes)
     const u64 *seg_off;             // [nseg+1] element offsets of the segments in kin/vin
     const u64 *tile_prefix;         // [nseg+1] exclusive prefix of tiles per segment
     u64 *cursors;                   // [nseg*F] absolute output positions, advanced atomically
@@ -62,7 +63,8 @@ struct ScatterArgs {
 };
 
 struct JoinArgs {
-    const uint32_t *rk, *rv, *sk, *sv;   // co-partitioned columns
+    const uint32_t *rk, *rv, *sk, *sv;   // co-partitioned columns (packed: rk / sk = packed tuples)
+    uint32_t packed;                     // 1: payload << 32 | key tuples (the library's own passes)
     const u64 *roff, *soff;              // [chunks*P + 1] absolute offsets, chunk-major
     const u64 *slice_prefix;             // [P+1] exclusive prefix of work items per partition
     const u64 *slices;                   // [P]   work items of partition q

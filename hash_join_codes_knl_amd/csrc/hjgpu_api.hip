@@ -249,12 +249,14 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     if (!(pl->f1 & 1) || !(pl->f2 & 1) || !(pl->tf0 & 1) || !(pl->tf1 & 1))
         return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
     // workspace: pass-1 twins always, pass-2 twins when there is a second pass
-    const size_t rb = (inner + 4) * sizeof(uint32_t), sb = (outer + 4) * sizeof(uint32_t);
-    CHK(ensure(ctx, ctx->tmp[0], rb)); CHK(ensure(ctx, ctx->tmp[1], rb));
-    CHK(ensure(ctx, ctx->tmp[2], sb)); CHK(ensure(ctx, ctx->tmp[3], sb));
+    // packed (payload << 32 | key) twins: tmp[0] / tmp[2] = pass-1 output of R / S,
+    // tmp[4] / tmp[6] = pass-2 output
+    const size_t rb = (inner + 4) * sizeof(u64), sb = (outer + 4) * sizeof(u64);
+    CHK(ensure(ctx, ctx->tmp[0], rb));
+    CHK(ensure(ctx, ctx->tmp[2], sb));
     if (pl->F2 > 1) {
-        CHK(ensure(ctx, ctx->tmp[4], rb)); CHK(ensure(ctx, ctx->tmp[5], rb));
-        CHK(ensure(ctx, ctx->tmp[6], sb)); CHK(ensure(ctx, ctx->tmp[7], sb));
+        CHK(ensure(ctx, ctx->tmp[4], rb));
+        CHK(ensure(ctx, ctx->tmp[6], sb));
     }
     // ranges of the larger relation bound the per-range tables of both
     const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1), gs = make_geom(nullptr, outer, pl->C, pl->F1);
@@ -282,10 +284,8 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C, pl.F1), make_geom(sk, outer, pl.C, pl.F1)};
     const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
     const size_t nn[2] = {inner, outer};
-    uint32_t *t1[4] = {(uint32_t *)ctx->tmp[0].p, (uint32_t *)ctx->tmp[1].p,
-                       (uint32_t *)ctx->tmp[2].p, (uint32_t *)ctx->tmp[3].p};
-    uint32_t *t2[4] = {(uint32_t *)ctx->tmp[4].p, (uint32_t *)ctx->tmp[5].p,
-                       (uint32_t *)ctx->tmp[6].p, (uint32_t *)ctx->tmp[7].p};
+    uint32_t *t1[4] = {(uint32_t *)ctx->tmp[0].p, nullptr, (uint32_t *)ctx->tmp[2].p, nullptr};
+    uint32_t *t2[4] = {(uint32_t *)ctx->tmp[4].p, nullptr, (uint32_t *)ctx->tmp[6].p, nullptr};
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
         pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
@@ -317,6 +317,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
             sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
             sa.ranged = 1; sa.strided = 0; sa.geom = geom[r]; sa.range_base = m.range_base[r];
+            sa.in_packed = 0; sa.out_packed = 1;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
         record(ctx, ev[2], stream);
@@ -327,6 +328,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r];
             sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
             sa.ranged = 0; sa.strided = 1; sa.geom = geom[r]; sa.range_base = nullptr;
+            sa.in_packed = 1; sa.out_packed = 1;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
         record(ctx, ev[3], stream);
@@ -352,6 +354,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2;
         ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
         ja.s_align = 0;
+        ja.packed = 1;
         ja.result = &st->result;
         if (bs) {
             ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
@@ -663,7 +666,8 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
         sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
-        sa.ranged = 1; sa.geom = geom; sa.range_base = m.range_base[0];
+        sa.ranged = 1; sa.strided = 0; sa.geom = geom; sa.range_base = m.range_base[0];
+        sa.in_packed = 0; sa.out_packed = 0;
         CHK(hj_launch_scatter(sa, ctx->cus, stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),

@@ -35,7 +35,9 @@
 #include "hj_internal.hpp"
 #include "hj_emit.hpp"
 
-template <int BLOCK, int LOG2SLOTS, int BATCH>
+// PACKED: the relations arrive as payload << 32 | key tuples (the library's own
+// partition passes); !PACKED: separate key / payload columns (hjgpu_join_partitions).
+template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED>
 __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 {
     constexpr uint32_t SLOTS = 1u << LOG2SLOTS;
@@ -55,8 +57,9 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     const int wave = tid >> 6;
     const uint32_t P = a.P, C = a.chunks;
     const u64 total_items = a.slice_prefix[P];
-    const uint4 *__restrict__ sk4 = reinterpret_cast<const uint4 *>(a.sk - a.s_align);
-    const uint4 *__restrict__ sv4 = reinterpret_cast<const uint4 *>(a.sv - a.s_align);
+    const uint4 *__restrict__ sk4 = reinterpret_cast<const uint4 *>(PACKED ? a.sk : a.sk - a.s_align);
+    const uint4 *__restrict__ sv4 = reinterpret_cast<const uint4 *>(PACKED ? a.sk : a.sv - a.s_align);
+    const u64 *__restrict__ r64 = reinterpret_cast<const u64 *>(a.rk);
     const uint32_t tf0 = a.tf0, tf1 = a.tf1;
 
     Emitter em;
@@ -82,7 +85,10 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                 for (int j = 0; j < RB; ++j) {
                     const u64 i = base + (u64)j * BLOCK + tid;
                     k[j] = 0; v[j] = 0;
-                    if (i < hi) { k[j] = a.rk[b + (i - seen)]; v[j] = a.rv[b + (i - seen)]; }
+                    if (i < hi) {
+                        if (PACKED) { const u64 t = r64[b + (i - seen)]; k[j] = (uint32_t)t; v[j] = (uint32_t)(t >> 32); }
+                        else { k[j] = a.rk[b + (i - seen)]; v[j] = a.rv[b + (i - seen)]; }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < RB; ++j) {
@@ -102,14 +108,17 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             for (int u = 0; u < BATCH; ++u) {
                 const u64 g = g0 + (u64)u * BLOCK * 4;
                 kk[u] = make_uint4(0, 0, 0, 0); vv[u] = kk[u];
-                if (g < ge) { kk[u] = sk4[g >> 2]; vv[u] = sv4[g >> 2]; }
+                if (g < ge) {
+                    if (PACKED) { kk[u] = sk4[g >> 1]; vv[u] = sk4[(g >> 1) + 1]; }     // 4 tuples = 2 x 16 bytes
+                    else { kk[u] = sk4[g >> 2]; vv[u] = sv4[g >> 2]; }
+                }
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const u64 g = g0 + (u64)u * BLOCK * 4;
                 if (g >= ge) break;
-                const uint32_t key[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w};
-                const uint32_t val[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+                const uint32_t key[4] = {kk[u].x, PACKED ? kk[u].z : kk[u].y, PACKED ? vv[u].x : kk[u].z, PACKED ? vv[u].z : kk[u].w};
+                const uint32_t val[4] = {PACKED ? kk[u].y : vv[u].x, PACKED ? kk[u].w : vv[u].y, PACKED ? vv[u].y : vv[u].z, vv[u].w};
                 bool valid[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) valid[j] = (g + j >= gb) && (g + j < ge);
@@ -299,7 +308,8 @@ int hj_join_workers(int cus) { return hj_join_grid(cus) * (hj_join_config().bloc
 
 #define JOIN_CASE(B, L, U)                                                                        \
     if (c.block == B && c.log2slots == L && c.batch == U) {                                       \
-        hipLaunchKernelGGL((join_kernel<B, L, U>), dim3(hj_join_grid(cus)), dim3(B), 0, stream, a); \
+        if (a.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true>), dim3(hj_join_grid(cus)), dim3(B), 0, stream, a);  \
+        else hipLaunchKernelGGL((join_kernel<B, L, U, false>), dim3(hj_join_grid(cus)), dim3(B), 0, stream, a);          \
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
     }
 
@@ -311,16 +321,11 @@ int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream)
     JoinArgs b = a;
     b.force_chained = (ex && atoi(ex)) ? 1u : 0u;
 #define a b
-    JOIN_CASE(512, 13, 4)
     JOIN_CASE(512, 13, 2)
     JOIN_CASE(512, 13, 1)
-    JOIN_CASE(1024, 14, 4)
+    JOIN_CASE(512, 13, 4)
     JOIN_CASE(1024, 14, 2)
-    JOIN_CASE(1024, 13, 2)
-    JOIN_CASE(256, 12, 4)
-    JOIN_CASE(256, 12, 8)
-    JOIN_CASE(256, 13, 4)
-    JOIN_CASE(512, 12, 4)
+    JOIN_CASE(256, 12, 2)
 #undef a
     return HJGPU_EINVAL;
 }

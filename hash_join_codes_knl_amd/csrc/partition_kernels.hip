@@ -261,7 +261,12 @@ int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStre
 //     the same pass-1 partition for a while, so each partition's F2 cursors are
 //     shared by only a few workgroups; one returning atomic per (tile, partition).
 // --------------------------------------------------------------------------
-template <int BLOCK, int VPT, bool RANGED>
+// Column formats: the caller's relations are separate key / payload columns
+// (hj.h:1-72).  Between the passes and into the join the tuples travel PACKED
+// (payload << 32 | key, 8 bytes): a run of L tuples is then one 8L-byte burst
+// instead of two 4L-byte bursts in two arrays, which is what the DRAM sees.
+// IN_PACKED / OUT_PACKED select the format on either side.
+template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED>
 __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 {
     constexpr int TILE = BLOCK * VPT * 4;
@@ -271,14 +276,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     const uint32_t F = a.F;
     const uint32_t Fpad = (F + 3) & ~3u;
     u64 *delta = reinterpret_cast<u64 *>(smem);                     // [Fpad]  output - local position
-    uint32_t *hist = reinterpret_cast<uint32_t *>(delta + Fpad);    // [Fpad]  counts, then local bases
-    uint32_t *skeys = hist + Fpad;                                  // [TILE]
-    uint32_t *svals = skeys + TILE;                                 // [TILE]
-    uint32_t *wsum = svals + TILE;                                  // [NW + 1]
+    u64 *stage = delta + Fpad;                                      // [TILE]  payload << 32 | key, sorted by partition
+    uint32_t *hist = reinterpret_cast<uint32_t *>(stage + TILE);    // [Fpad]  counts, then local bases
+    uint32_t *wsum = hist + Fpad;                                   // [NW + 1]
 
     const int tid = threadIdx.x;
-    const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(a.kin - a.in_align);
-    const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(a.vin - a.in_align);
+    // IN_PACKED inputs are workspace arrays (in_align == 0): tuple g lives in uint4 g/2
+    const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.kin - a.in_align);
+    const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.vin - a.in_align);
     const uint32_t factor = a.factor;
     const uint32_t bpt = (F + BLOCK - 1) / BLOCK;                   // bins per thread in the scan
     u64 mycur[BPT];                                                 // RANGED: cursors of my bins
@@ -344,9 +349,17 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         for (int j = 0; j < VPT; ++j) {
             const u64 g = t.g0 + (u64)(j * BLOCK + tid) * 4;
             uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if ((g < t.ge) && (g + 4 > t.gb)) { kk = k4[g >> 2]; vv = v4[g >> 2]; }
-            key[j * 4 + 0] = kk.x; key[j * 4 + 1] = kk.y; key[j * 4 + 2] = kk.z; key[j * 4 + 3] = kk.w;
-            val[j * 4 + 0] = vv.x; val[j * 4 + 1] = vv.y; val[j * 4 + 2] = vv.z; val[j * 4 + 3] = vv.w;
+            if ((g < t.ge) && (g + 4 > t.gb)) {
+                if (IN_PACKED) { kk = k4[g >> 1]; vv = k4[(g >> 1) + 1]; }    // 4 tuples = 2 x 16 bytes
+                else { kk = k4[g >> 2]; vv = v4[g >> 2]; }
+            }
+            if (IN_PACKED) {
+                key[j * 4 + 0] = kk.x; val[j * 4 + 0] = kk.y; key[j * 4 + 1] = kk.z; val[j * 4 + 1] = kk.w;
+                key[j * 4 + 2] = vv.x; val[j * 4 + 2] = vv.y; key[j * 4 + 3] = vv.z; val[j * 4 + 3] = vv.w;
+            } else {
+                key[j * 4 + 0] = kk.x; key[j * 4 + 1] = kk.y; key[j * 4 + 2] = kk.z; key[j * 4 + 3] = kk.w;
+                val[j * 4 + 0] = vv.x; val[j * 4 + 1] = vv.y; val[j * 4 + 2] = vv.z; val[j * 4 + 3] = vv.w;
+            }
         }
     };
 
@@ -415,8 +428,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         for (int e = 0; e < VPT * 4; ++e) {
             if (pr[e] != 0xFFFFFFFFu) {
                 const uint32_t pos = hist[pr[e] >> 16] + (pr[e] & 0xFFFFu);
-                skeys[pos] = key[e];
-                svals[pos] = val[e];
+                stage[pos] = (u64)key[e] | ((u64)val[e] << 32);
             }
         }
         // The input registers are dead now: start the next tile's loads so that they
@@ -427,10 +439,11 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 
         // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
         for (uint32_t i = tid; i < tile_count; i += BLOCK) {
-            const uint32_t k = skeys[i];
+            const u64 kv = stage[i];
+            const uint32_t k = (uint32_t)kv;
             const u64 d = delta[hj_hash(k, factor, F)] + i;
-            a.kout[d] = k;
-            a.vout[d] = svals[i];
+            if (OUT_PACKED) reinterpret_cast<u64 *>(a.kout)[d] = kv;
+            else { a.kout[d] = k; a.vout[d] = (uint32_t)(kv >> 32); }
         }
         __syncthreads();
         if (!nxt.valid) break;
@@ -454,7 +467,7 @@ static const ScatterConfig &scatter_config()
 
 int hj_scatter_tile() { return scatter_config().block * scatter_config().vpt * 4; }
 
-template <int BLOCK, int VPT, bool RANGED>
+template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED>
 static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
 {
     constexpr int TILE = BLOCK * VPT * 4;
@@ -462,7 +475,7 @@ static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
     const size_t lds = (size_t)Fpad * 12 + (size_t)TILE * 8 + (BLOCK / 64 + 1) * 4 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return HJGPU_EHIP;
         attr_set = true;
@@ -478,14 +491,19 @@ static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
     // Infinity Cache: 3.9-4.0 ms vs 4.45-4.65 ms for contiguous runs.  HJGPU_PASS2_STRIDED=0 flips.
     const char *e = getenv("HJGPU_PASS2_STRIDED");
     b.strided = (e && !atoi(e)) ? 0u : 1u;
-    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED>), dim3(grid), dim3(BLOCK), lds, stream, b);
+    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED>), dim3(grid), dim3(BLOCK), lds, stream, b);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
+// pass 1: separate columns in, ranged; out packed (join pipeline) or separate (hjgpu_partition)
+// pass 2: packed in, packed out, atomic cursors
 #define SCATTER_CASE(B, V)                                                                   \
-    if (c.block == B && c.vpt == V)                                                          \
-        return a.ranged ? launch_scatter_t<B, V, true>(a, cus, stream)                       \
-                        : launch_scatter_t<B, V, false>(a, cus, stream);
+    if (c.block == B && c.vpt == V) {                                                        \
+        if (a.ranged && !a.in_packed && a.out_packed) return launch_scatter_t<B, V, true, false, true>(a, cus, stream);   \
+        if (a.ranged && !a.in_packed && !a.out_packed) return launch_scatter_t<B, V, true, false, false>(a, cus, stream); \
+        if (!a.ranged && a.in_packed && a.out_packed) return launch_scatter_t<B, V, false, true, true>(a, cus, stream);   \
+        return HJGPU_EINVAL;                                                                 \
+    }
 
 int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream)
 {
