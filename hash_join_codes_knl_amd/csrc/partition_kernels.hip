@@ -61,16 +61,28 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
         for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) range_hist[i] = 0;
         __syncthreads();
         if (t_end > t_beg) {
-            for (u64 g = g_lo + (u64)threadIdx.x * 4; g < g_hi; g += (u64)BLOCK * 4) {
-                const uint4 k = k4[g >> 2];
-                const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
-                const bool full = (g >= gb) && (g + 4 <= ge);
+            constexpr int U = 4;                       // key vectors in flight per lane
+            for (u64 g0 = g_lo + (u64)threadIdx.x * 4; g0 < g_hi; g0 += (u64)BLOCK * 4 * U) {
+                uint4 kv[U];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (full || (g + e >= gb && g + e < ge)) {
-                        const uint32_t p1 = hj_hash(kk[e], f1, F1);
-                        atomicAdd(&range_hist[p1], 1u);
-                        if (F2 > 1) atomicAdd(&lds_hist[p1 * F2 + hj_hash(kk[e], f2, F2)], 1u);
+                for (int u = 0; u < U; ++u) {
+                    const u64 g = g0 + (u64)u * BLOCK * 4;
+                    kv[u] = make_uint4(0, 0, 0, 0);
+                    if (g < g_hi) kv[u] = k4[g >> 2];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const u64 g = g0 + (u64)u * BLOCK * 4;
+                    if (g >= g_hi) break;
+                    const uint32_t kk[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
+                    const bool full = (g >= gb) && (g + 4 <= ge);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (full || (g + e >= gb && g + e < ge)) {
+                            const uint32_t p1 = hj_hash(kk[e], f1, F1);
+                            atomicAdd(&range_hist[p1], 1u);
+                            if (F2 > 1) atomicAdd(&lds_hist[p1 * F2 + hj_hash(kk[e], f2, F2)], 1u);
+                        }
                     }
                 }
             }
