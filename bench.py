@@ -227,6 +227,20 @@ def main():
         kernels["npj_probe_kernel"] = roof(16 * outer, avg["ms_join"], 1)
         join_ms = avg["ms_join"]
     kernels = {k: v for k, v in kernels.items() if v}
+    # HBM bytes per launch from the PMC passes of tools/collect_traffic.py (same workload only)
+    traffic_src = None
+    if (args.inner, args.outer, args.algo, n_gpus) == (64_000_000, 1_000_000_000, "phj", 1):
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if files:
+            traffic_src = os.path.basename(files[-1])
+            tk = json.load(open(files[-1]))["kernels"]
+            for name, entry in kernels.items():
+                hit = [v for k, v in tk.items() if k.startswith(name)]
+                if hit:
+                    # several template instances (pass 1 / pass 2) share a launch name prefix
+                    entry["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["launches_seen"] for h in hit)
+                                           / max(1, sum(h["launches_seen"] for h in hit)))
     dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches_per_step"])
     roofline = dict(kernels[dominant])
     roofline["kernel"] = dominant
@@ -249,6 +263,7 @@ def main():
                                      if dist is not None else "local")},
         "roofline": roofline,
         "roofline_kernels": kernels,
+        "traffic_source": traffic_src,
         "join_phase": {"gtuples_per_s_per_gpu": round(outer / (join_ms * 1e-3) / 1e9, 2) if join_ms > 0 else None,
                        "ms": round(join_ms, 4),
                        "hbm_read_frac": round(8 * n_tuples / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if join_ms > 0 else None},

@@ -194,8 +194,8 @@ int setup_output(hjgpu_ctx *ctx, const hjgpu_output *out, uint32_t workers, u64 
 // range.  HJGPU_RANGE_TILES overrides (tuning).
 uint32_t range_tiles_for(u64 max_tiles, uint32_t F1)
 {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("HJGPU_RANGE_TILES"); forced = e ? atoi(e) : 0; }
+    const char *e = getenv("HJGPU_RANGE_TILES");
+    const int forced = e ? atoi(e) : 0;
     // default: ~4096 ranges per relation - fine-grained enough that concurrently running
     // workgroups write neighbouring regions, coarse enough that K4/K5b stay negligible
     u64 k = forced > 0 ? (u64)forced : (max_tiles + 4095) / 4096;

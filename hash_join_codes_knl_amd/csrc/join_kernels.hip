@@ -283,14 +283,11 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 
 const JoinConfig &hj_join_config()
 {
-    static JoinConfig cfg = {512, 13, 2};
-    static bool init = false;
-    if (!init) {
-        init = true;
-        const char *e = getenv("HJGPU_JOIN_CFG");
-        int b, l, u;
-        if (e && sscanf(e, "%d,%d,%d", &b, &l, &u) == 3) { cfg.block = b; cfg.log2slots = l; cfg.batch = u; }
-    }
+    static JoinConfig cfg;
+    cfg.block = 512; cfg.log2slots = 13; cfg.batch = 2;
+    const char *e = getenv("HJGPU_JOIN_CFG");
+    int b, l, u;
+    if (e && sscanf(e, "%d,%d,%d", &b, &l, &u) == 3) { cfg.block = b; cfg.log2slots = l; cfg.batch = u; }
     return cfg;
 }
 

@@ -466,14 +466,11 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 struct ScatterConfig { int block, vpt; };
 static const ScatterConfig &scatter_config()
 {
-    static ScatterConfig cfg = {1024, 4};
-    static bool init = false;
-    if (!init) {
-        init = true;
-        const char *e = getenv("HJGPU_SCATTER_CFG");       // "block,vectors_per_thread" (tuning)
-        int b, v;
-        if (e && sscanf(e, "%d,%d", &b, &v) == 2) { cfg.block = b; cfg.vpt = v; }
-    }
+    static ScatterConfig cfg;
+    cfg.block = 1024; cfg.vpt = 4;
+    const char *e = getenv("HJGPU_SCATTER_CFG");           // "block,vectors_per_thread" (tuning)
+    int b, v;
+    if (e && sscanf(e, "%d,%d", &b, &v) == 2) { cfg.block = b; cfg.vpt = v; }
     return cfg;
 }
 

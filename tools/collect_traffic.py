@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel launch from rocprofv3 PMC counters, as MI355X_MICROARCH.md
+prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), values in
+KiB, and on gfx950 FETCH_SIZE reports exactly half of a wide coalesced read stream, so
+    bytes_read    = 2 * FETCH_SIZE * 1024
+    bytes_written =     WRITE_SIZE * 1024
+Run on the GPU box (rocprofv3 gets the program itself after `--`):
+    python tools/collect_traffic.py [bench.py args...]
+Writes gpurun_out/traffic.json; copy it to profiles/rNN_traffic.json (bench.py reads
+profiles/*_traffic.json for its `roofline.traffic` field)."""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_pass(counter, extra):
+    out = os.path.join(ROOT, "gpurun_out", "traffic_" + counter)
+    os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-outer", "0"] + extra
+    subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            per[name][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items()}
+
+
+def main():
+    extra = sys.argv[1:]
+    fetch = run_pass("FETCH_SIZE", extra)
+    write = run_pass("WRITE_SIZE", extra)
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, (0.0, 0))
+        w, _ = write.get(k, (0.0, 0))
+        res[k] = {"launches_seen": nf, "read_bytes_per_launch": 2.0 * f * 1024.0,
+                  "written_bytes_per_launch": w * 1024.0,
+                  "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0}
+    out = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
+                     "`bench.py --steps 2 --warmup 1`, averaged over all launches of a kernel; "
+                     "read = 2*FETCH_SIZE KiB (gfx950 correction), written = WRITE_SIZE KiB",
+           "bench_args": extra, "kernels": res}
+    path = os.path.join(ROOT, "gpurun_out", "traffic.json")
+    json.dump(out, open(path, "w"), indent=1)
+    for k, v in res.items():
+        if any(s in k for s in ("scatter", "join", "hist2", "npj")):
+            print("%-40s read %.3f GB  written %.3f GB per launch (%d launches)"
+                  % (k[:40], v["read_bytes_per_launch"] / 1e9, v["written_bytes_per_launch"] / 1e9, v["launches_seen"]))
+
+
+if __name__ == "__main__":
+    main()
