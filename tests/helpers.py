@@ -16,7 +16,7 @@ def numpy_join(ik, iv, ok, ov):
     """Independent definition of the result: (count, sum_keys, sum_outer, sum_inner)."""
     order = np.argsort(ik, kind="stable")
     sk, sv = ik[order], iv[order].astype(np.uint64)
-    csum = np.concatenate([[0], np.cumsum(sv, dtype=np.uint64)])
+    csum = np.concatenate([np.zeros(1, np.uint64), np.cumsum(sv, dtype=np.uint64)])   # stays uint64
     lo = np.searchsorted(sk, ok, side="left")
     hi = np.searchsorted(sk, ok, side="right")
     mult = (hi - lo).astype(np.uint64)
