@@ -228,23 +228,20 @@ __global__ __launch_bounds__(CG_BLOCK) void close_gaps_plan_kernel(
     }
 }
 
-// All workgroups copy the planned moves (sources lie above every remaining
-// hole, so a move never overlaps its destination or another move).
+// The whole chip copies the planned moves: one move per workgroup at a time
+// (sources lie above every remaining hole, so a move never overlaps its
+// destination or another move; a move is at most one block long).
 __global__ __launch_bounds__(256) void close_gaps_copy_kernel(
     uint32_t *k, uint32_t *ov, uint32_t *iv, const Move *__restrict__ moves,
     const uint32_t *__restrict__ nmoves)
 {
-    constexpr u64 CH = 2048;
     const uint32_t nm = *nmoves;
-    for (uint32_t m = 0; m < nm; ++m) {
+    for (uint32_t m = blockIdx.x; m < nm; m += gridDim.x) {
         const u64 dst = moves[m].dst, src = moves[m].src, cnt = moves[m].cnt;
-        for (u64 c = (u64)blockIdx.x * CH; c < cnt; c += (u64)gridDim.x * CH) {
-            const u64 e = min(cnt, c + CH);
-            for (u64 i = c + threadIdx.x; i < e; i += 256) {
-                k[dst + i] = k[src + i];
-                ov[dst + i] = ov[src + i];
-                iv[dst + i] = iv[src + i];
-            }
+        for (u64 i = threadIdx.x; i < cnt; i += 256) {
+            k[dst + i] = k[src + i];
+            ov[dst + i] = ov[src + i];
+            iv[dst + i] = iv[src + i];
         }
     }
 }
