@@ -114,3 +114,25 @@ def test_partition_sample_is_in_partition(hj):
     assert np.array_equal(pv.download(), ko)
     for c in (dk, dv, pk, pv, off):
         c.free()
+
+
+def test_probe_side_beyond_2_32_tuples(hj):
+    """the reference's uint32 offsets cannot address >= 2^32 tuples per
+    relation; this library uses 64-bit offsets everywhere.  |S| = 4.4 G (> 2^32) probe
+    tuples against |R| = 16 M: count and the three sums must equal the column checksums."""
+    inner, outer = 16_000_000, 4_400_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(9, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    # the tail beyond element 2^32 really took part: joining only the first 2^32 tuples differs
+    head = hj.phj(ik, iv, inner, ok, ov, 1 << 32)
+    assert head[0] == 1 << 32 and head != want
+    tail_n = outer - (1 << 32)
+    tail = hj.phj(ik, iv, inner, ok.ptr + 4 * (1 << 32), ov.ptr + 4 * (1 << 32), tail_n)
+    assert tail[0] == tail_n
+    assert tuple((a + b) & ((1 << 64) - 1) for a, b in zip(head, tail)) == want
+    for c in (ik, iv, ok, ov):
+        c.free()
