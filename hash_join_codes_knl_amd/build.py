@@ -36,7 +36,8 @@ def _newer(target, deps):
 
 
 def lib_path():
-    return os.path.join(LIB, "libhjgpu.so")
+    # HJGPU_LIBRARY: load another build of the same ABI (A/B timing of kernel variants)
+    return os.environ.get("HJGPU_LIBRARY") or os.path.join(LIB, "libhjgpu.so")
 
 
 def build_library(force=False, verbose=True):
