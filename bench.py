@@ -118,9 +118,18 @@ def main():
         return torch.empty(n + 4, dtype=torch.int32, device=dev)
     rk, rv, sk, sv = col(inner), col(inner), col(outer), col(outer)
     stream = torch.cuda.current_stream().cuda_stream
-    # every rank generates R (identical) and its own shard of S
-    hj.generate(1, inner, outer_total, rank * outer, outer, INNER_FACTOR, OUTER_FACTOR,
-                rk.data_ptr(), rv.data_ptr(), sk.data_ptr(), sv.data_ptr(), stream)
+    # CPRA across GPUs (BASELINE configs[4]): every rank owns a chunk of BOTH relations and the
+    # tuples are co-partitioned with one all-to-all; PHJ / NPJ: R replicated, S sharded.
+    copart = dist is not None and args.algo == "cpra"
+    inner_total = inner * n_gpus if copart else inner
+    if copart:
+        hj.generate_range(1, inner_total, outer_total, rank * inner, inner, rank * outer, outer,
+                          INNER_FACTOR, OUTER_FACTOR, rk.data_ptr(), rv.data_ptr(), sk.data_ptr(),
+                          sv.data_ptr(), stream)
+    else:
+        # every rank generates R (identical) and its own shard of S
+        hj.generate(1, inner, outer_total, rank * outer, outer, INNER_FACTOR, OUTER_FACTOR,
+                    rk.data_ptr(), rv.data_ptr(), sk.data_ptr(), sv.data_ptr(), stream)
     sums = hj.column_sums(sk.data_ptr(), outer, OUTER_FACTOR, INNER_FACTOR, stream)
     # uint64 aggregates as int64 bit patterns (sums stay far below 2^63 at these sizes)
     expect_local = [outer, sums[0], sums[1], sums[2]]
@@ -140,8 +149,18 @@ def main():
 
     side = torch.cuda.Stream(device=dev) if dist is not None else None
     overlap = dist is not None and args.algo == "phj" and not args.no_overlap
+    if copart:
+        from hash_join_codes_knl_amd import distributed as D
+        gpu_ops = D.GpuOps(hj, torch, "phj", prm)
+        views = (rk[:inner], rv[:inner], sk[:outer], sv[:outer])
 
     def step():
+        if copart:
+            # local top-level partition -> all-to-all-v over xGMI -> local PHJ -> all-reduce
+            res = D.cpra_copartitioned(dist, torch, gpu_ops, *views)
+            d_result.copy_(torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in res],
+                                        dtype=torch.int64, device=dev))
+            return
         main = torch.cuda.current_stream()
         ready = None
         if dist is not None:
@@ -192,6 +211,8 @@ def main():
         for p in phases:
             acc[p] += st[p]
             per_step[p].append(st[p])
+        if copart:
+            continue
     barrier()
     elapsed = time.perf_counter() - t0
     got = [int(x) for x in d_result.tolist()]
@@ -247,6 +268,13 @@ def main():
     roofline = dict(kernels[dominant])
     roofline["kernel"] = dominant
 
+    if copart:
+        parallelism = "both sides chunked over %d GPU(s), RCCL all-to-all-v co-partitioning, local PHJ" % n_gpus
+    elif dist is not None:
+        parallelism = "probe side sharded over %d GPU(s), build side RCCL-broadcast each step%s" % (
+            n_gpus, ", overlapped with probe-side partitioning" if overlap else "")
+    else:
+        parallelism = "probe side sharded over 1 GPU(s), build side local"
     out = {
         "metric": "probe Gtuples/s + % HBM roofline, PHJ |R|=64M join |S|=1G, 1/2/4/8 GPU",
         "value": round(value, 3), "unit": "Gtuples/s", "n_gpus": n_gpus,
@@ -254,15 +282,13 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s end-to-end (histogram + %s + LDS build/probe, aggregate output), "
-                               "uniform unique 32-bit keys, |R|=%d replicated, |S|=%d per GPU, selectivity 1"
+                               "uniform unique 32-bit keys, |R|=%d %s, |S|=%d per GPU, selectivity 1"
                                % (args.algo.upper(), "2 scatter passes" if st["fanout2"] > 1 else "1 scatter pass",
-                                  inner, outer),
+                                  inner, "per GPU (co-partitioned)" if copart else "replicated", outer),
                    "algorithm": args.algo, "inner_tuples": inner, "outer_tuples_per_gpu": outer,
                    "outer_tuples_total": outer_total,
                    "fanout": [st["fanout1"], st["fanout2"]],
-                   "parallelism": "probe side sharded over %d GPU(s), build side %s"
-                                  % (n_gpus, ("RCCL-broadcast each step" + (", overlapped with probe-side partitioning" if overlap else ""))
-                                     if dist is not None else "local")},
+                   "parallelism": parallelism},
         "roofline": roofline,
         "roofline_kernels": kernels,
         "traffic_source": traffic_src,

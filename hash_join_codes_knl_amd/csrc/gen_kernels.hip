@@ -33,7 +33,7 @@ __device__ __forceinline__ u64 splitmix64(u64 z)
 
 struct GenArgs {
     u64 seed;
-    u64 inner, outer_total, outer_begin, outer_count;
+    u64 inner, inner_begin, inner_count, outer_total, outer_begin, outer_count;
     u64 distinct;               // min(inner, outer_total)  (write.cpp:1687-1689)
     u64 mul, add;               // position permutation j' = (j*mul + add) mod outer_total
     u64 mul_r, add_r;           // same for the build side, mod inner
@@ -47,14 +47,15 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.ik) {
-        for (u64 i = tid; i < a.inner; i += stride) {
+        for (u64 j = tid; j < a.inner_count; j += stride) {
+            const u64 i = a.inner_begin + j;
             const u64 ip = (i * a.mul_r + a.add_r) % a.inner;
             u64 r;
             if (ip < a.distinct) r = ip;                               // every distinct key once
             else r = __umul64hi(splitmix64(ip ^ ~a.seed), a.distinct); // then repeats (outer < inner)
             const uint32_t k = mix32(a.key_base + (uint32_t)r);
-            a.ik[i] = k;
-            a.iv[i] = k * a.inner_factor;
+            a.ik[j] = k;
+            a.iv[j] = k * a.inner_factor;
         }
     }
     if (a.ok) {
@@ -73,16 +74,19 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
 
 static u64 gcd_u64(u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } return x; }
 
-int hj_launch_generate(u64 seed, size_t inner, size_t outer_total, size_t outer_begin,
+int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_count,
+                       size_t outer_total, size_t outer_begin,
                        size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
                        uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream)
 {
     if (inner == 0 || inner >= 0xFFFFFFFFull) return HJGPU_EINVAL;
+    if (ik && inner_begin + inner_count > inner) return HJGPU_EINVAL;
     if (ok && (outer_total == 0 || outer_begin + outer_count > outer_total)) return HJGPU_EINVAL;
     if (outer_total >= (1ull << 35)) return HJGPU_EINVAL;      // pos*mul must stay below 2^64
     GenArgs a;
     a.seed = seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;
-    a.inner = inner; a.outer_total = outer_total ? outer_total : 1;
+    a.inner = inner; a.inner_begin = inner_begin; a.inner_count = inner_count;
+    a.outer_total = outer_total ? outer_total : 1;
     a.outer_begin = outer_begin; a.outer_count = outer_count;
     u64 mul = 402653189ull;                                    // prime < 2^29
     while (gcd_u64(mul, a.outer_total) != 1) mul += 2;

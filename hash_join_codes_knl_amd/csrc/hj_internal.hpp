@@ -142,7 +142,8 @@ int hj_join_workers(int cus);
 int hj_npj_probe_grid(int cus, size_t n);
 
 // generator / checksums
-int hj_launch_generate(u64 seed, size_t inner, size_t outer_total, size_t outer_begin,
+int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_count,
+                       size_t outer_total, size_t outer_begin,
                        size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
                        uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream);
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,

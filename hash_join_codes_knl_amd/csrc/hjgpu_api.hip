@@ -909,19 +909,28 @@ int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
 }
 
 // ---- generator ------------------------------------------------------------------
-int hjgpu_generate(hjgpu_ctx *ctx, uint64_t seed, size_t inner, size_t outer_total,
-                   size_t outer_begin, size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
-                   uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
+int hjgpu_generate_range(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
+                         size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
+                         uint32_t inner_factor, uint32_t outer_factor,
+                         uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
 {
     if (!ctx) return HJGPU_EINVAL;
     if ((ik && !iv) || (ok && !ov)) return fail(ctx, HJGPU_EINVAL, "key column without payload column");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = hj_launch_generate(seed, inner, outer_total, outer_begin, outer_count, inner_factor,
-                                outer_factor, ik, iv, ok, ov, stream);
+    int rc = hj_launch_generate(seed, inner_total, inner_begin, inner_count, outer_total, outer_begin,
+                                outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream);
     if (rc != HJGPU_OK) return fail(ctx, rc, "generate: bad sizes or launch failure");
     HIPCHK(ctx, hipStreamSynchronize(stream));
     return HJGPU_OK;
+}
+
+int hjgpu_generate(hjgpu_ctx *ctx, uint64_t seed, size_t inner, size_t outer_total,
+                   size_t outer_begin, size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
+                   uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
+{
+    return hjgpu_generate_range(ctx, seed, inner, outer_total, 0, inner, outer_begin, outer_count,
+                                inner_factor, outer_factor, ik, iv, ok, ov, stream_);
 }
 
 int hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t fa, uint32_t fb,

@@ -62,7 +62,35 @@ def phj_replicated_build(dist, torch, ops, r_keys, r_vals, s_keys_local, s_vals_
     return all_reduce_result(dist, torch, local, r_keys.device)
 
 
-def cpra_exchange(dist, torch, ops, keys, vals, world, rank):
+MAX_MESSAGE_ELEMS = 1 << 28      # 1 GiB of uint32 per peer and collective call
+
+
+def _all_to_all_v(dist, torch, out, inp, recv_counts, send_counts, max_elems):
+    """all-to-all-v of one column.  A single all_to_all_single moved only half of a 4 GB
+    self-message on RCCL 2.26 (observed at |S| = 1 G on one rank), so per-peer messages are
+    capped at `max_elems` and larger exchanges run in rounds through staging buffers."""
+    world = len(send_counts)
+    biggest = torch.tensor([max(send_counts + recv_counts)], dtype=torch.int64, device=inp.device)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX)            # every rank runs the same number of rounds
+    rounds = max(1, -(-int(biggest.item()) // max_elems))
+    if rounds == 1:
+        dist.all_to_all_single(out, inp, recv_counts, send_counts)
+        return
+    s_off = [sum(send_counts[:g]) for g in range(world)]
+    r_off = [sum(recv_counts[:g]) for g in range(world)]
+    for r in range(rounds):
+        sc = [min(max(c - r * max_elems, 0), max_elems) for c in send_counts]
+        rc = [min(max(c - r * max_elems, 0), max_elems) for c in recv_counts]
+        stage_in = torch.cat([inp[s_off[g] + r * max_elems: s_off[g] + r * max_elems + sc[g]] for g in range(world)])
+        stage_out = torch.empty(sum(rc), dtype=out.dtype, device=out.device)
+        dist.all_to_all_single(stage_out, stage_in, rc, sc)
+        at = 0
+        for g in range(world):
+            out[r_off[g] + r * max_elems: r_off[g] + r * max_elems + rc[g]].copy_(stage_out[at: at + rc[g]])
+            at += rc[g]
+
+
+def cpra_exchange(dist, torch, ops, keys, vals, world, rank, max_elems=MAX_MESSAGE_ELEMS):
     """Co-partition one relation: local top-level partition + all-to-all-v.
     Returns (keys, vals) tensors holding every tuple whose top-level partition this rank owns."""
     pk, pv, offsets = ops.partition(keys, vals, TOP_LEVEL_FACTOR, world)   # offsets: world+1 ints
@@ -71,18 +99,19 @@ def cpra_exchange(dist, torch, ops, keys, vals, world, rank):
     rc = torch.empty(world, dtype=torch.int64, device=keys.device)
     dist.all_to_all_single(rc, sc)                       # counts first, payload second
     recv_counts = [int(x) for x in rc.tolist()]
-    out_k = torch.empty(sum(recv_counts), dtype=keys.dtype, device=keys.device)
-    out_v = torch.empty(sum(recv_counts), dtype=vals.dtype, device=vals.device)
-    dist.all_to_all_single(out_k, pk, recv_counts, send_counts)
-    dist.all_to_all_single(out_v, pv, recv_counts, send_counts)
+    out_k = torch.empty(sum(recv_counts) + 4, dtype=keys.dtype, device=keys.device)[:sum(recv_counts)]
+    out_v = torch.empty(sum(recv_counts) + 4, dtype=vals.dtype, device=vals.device)[:sum(recv_counts)]
+    _all_to_all_v(dist, torch, out_k, pk, recv_counts, send_counts, max_elems)
+    _all_to_all_v(dist, torch, out_v, pv, recv_counts, send_counts, max_elems)
     return out_k, out_v
 
 
-def cpra_copartitioned(dist, torch, ops, r_keys_local, r_vals_local, s_keys_local, s_vals_local):
+def cpra_copartitioned(dist, torch, ops, r_keys_local, r_vals_local, s_keys_local, s_vals_local,
+                       max_elems=MAX_MESSAGE_ELEMS):
     """Both relations chunked over the ranks; one exchange step, then a local join."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    rk, rv = cpra_exchange(dist, torch, ops, r_keys_local, r_vals_local, world, rank)
-    sk, sv = cpra_exchange(dist, torch, ops, s_keys_local, s_vals_local, world, rank)
+    rk, rv = cpra_exchange(dist, torch, ops, r_keys_local, r_vals_local, world, rank, max_elems)
+    sk, sv = cpra_exchange(dist, torch, ops, s_keys_local, s_vals_local, world, rank, max_elems)
     local = ops.join(rk, rv, sk, sv)
     return all_reduce_result(dist, torch, local, r_keys_local.device)
 

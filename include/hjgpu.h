@@ -225,6 +225,14 @@ int  hjgpu_generate(hjgpu_ctx *ctx, uint64_t seed, size_t inner, size_t outer_to
                     uint32_t *d_inner_keys, uint32_t *d_inner_vals,   /* may be NULL */
                     uint32_t *d_outer_keys, uint32_t *d_outer_vals,   /* may be NULL */
                     void *stream);
+/* Same relations, but also the build side in ranges: rows [inner_begin, +inner_count)
+ * of the inner_total-tuple build relation (CPRA across GPUs: every GPU owns a chunk of
+ * BOTH relations, cpra2.cpp:1737-1742). */
+int  hjgpu_generate_range(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
+                          size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
+                          uint32_t inner_factor, uint32_t outer_factor,
+                          uint32_t *d_inner_keys, uint32_t *d_inner_vals,
+                          uint32_t *d_outer_keys, uint32_t *d_outer_vals, void *stream);
 /* sum over a column of key, key*f_a, key*f_b (mod 2^32 per term, uint64 sums):
  * the analytic join aggregates of a selectivity-1 workload. */
 int  hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n,
