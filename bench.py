@@ -144,7 +144,7 @@ def main():
 
     hj.reserve(inner, outer)
     prm = H.PhjParams(fanout1=args.fanout1, fanout2=args.fanout2)
-    nprm = H.NpjParams(load=0.5)
+    nprm = H.NpjParams()                       # library default load factor (0.25)
     d_result = torch.zeros(4, dtype=torch.int64, device=dev)
 
     side = torch.cuda.Stream(device=dev) if dist is not None else None

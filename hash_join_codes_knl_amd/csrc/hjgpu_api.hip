@@ -397,11 +397,12 @@ int finish_blocking(hjgpu_ctx *ctx, hjgpu_result *result, const hjgpu_output *ou
 int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_t *buckets,
                 uint32_t *factor)
 {
-    double load = (prm && prm->load > 0) ? prm->load : 0.5;
+    double load = (prm && prm->load > 0) ? prm->load : 0.25;
     if (load > 0.99) return fail(ctx, HJGPU_EINVAL, "load factor must be <= 0.99");
     size_t b = (size_t)((double)inner / load);             // npj.cpp:947
     if (b <= inner) b = inner + 1;
     if (b < 16) b = 16;
+    b = (b + 3) & ~size_t(3);                               // whole 4-bucket groups: grouped probe walk
     *buckets = b;
     *factor = (prm && prm->factor) ? prm->factor : DEFAULT_NPJ_FACTOR;
     if (!(*factor & 1)) return fail(ctx, HJGPU_EINVAL, "hash factor must be odd");

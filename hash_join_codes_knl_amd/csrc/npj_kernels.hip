@@ -60,6 +60,13 @@ int hj_launch_npj_build(const uint32_t *keys, const uint32_t *vals, size_t n, u6
 
 constexpr int NPJ_PROBE_BLOCK = 256;
 
+// GROUPED: the walk fetches aligned groups of 4 buckets (32 bytes, two 16-byte loads
+// issued together) instead of one bucket per dependent load.  The walk has to reach
+// the first EMPTY bucket (every match counts, npj.cpp:426-442), i.e. 2.5 buckets on
+// average at load 0.5: with one bucket per load that is 2.5 dependent memory round
+// trips per probe; a group resolves most walks in one.  Needs buckets % 4 == 0
+// (the library's own tables; any other table takes the bucket-at-a-time path).
+template <bool GROUPED>
 __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs a)
 {
     constexpr int NW = NPJ_PROBE_BLOCK / 64;
@@ -87,28 +94,62 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs
         const u64 g = v << 2;
         const uint32_t key[4] = {kk.x, kk.y, kk.z, kk.w};
         const uint32_t val[4] = {vv.x, vv.y, vv.z, vv.w};
-        u64 h[4], t[4];
+        u64 h[4];
         bool act[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             act[j] = (g + j >= gb) && (g + j < ge);
             h[j] = npj_bucket(key[j], factor, buckets);
-            t[j] = act[j] ? table[h[j]] : 0ull;
         }
-        while (act[0] | act[1] | act[2] | act[3]) {
+        if (GROUPED) {
+            const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(table);
+            while (act[0] | act[1] | act[2] | act[3]) {
+                uint4 lo[4], hi[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (act[j]) {
-                    if ((uint32_t)t[j] == 0u) {
-                        act[j] = false;
-                    } else {
-                        if ((uint32_t)t[j] == key[j]) {
-                            const uint32_t iv = (uint32_t)(t[j] >> 32);
-                            acc_n += 1; acc_k += key[j]; acc_o += val[j]; acc_i += iv;
-                            em.emit(key[j], val[j], iv);
+                for (int j = 0; j < 4; ++j) {           // all group loads of the 4 chains in flight together
+                    lo[j] = make_uint4(0, 0, 0, 0); hi[j] = lo[j];
+                    if (act[j]) { const u64 grp = h[j] >> 2; lo[j] = t4[2 * grp]; hi[j] = t4[2 * grp + 1]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (act[j]) {
+                        const uint32_t bk[4] = {lo[j].x, lo[j].z, hi[j].x, hi[j].z};   // keys of the group
+                        const uint32_t bv[4] = {lo[j].y, lo[j].w, hi[j].y, hi[j].w};   // payloads
+                        const uint32_t first = (uint32_t)h[j] & 3u;
+                        bool open = true;                                              // no empty bucket seen yet
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const bool in = open && ((uint32_t)b >= first);
+                            if (in && bk[b] == 0u) open = false;
+                            else if (in && bk[b] == key[j]) {
+                                acc_n += 1; acc_k += key[j]; acc_o += val[j]; acc_i += bv[b];
+                                em.emit(key[j], val[j], bv[b]);
+                            }
                         }
-                        if (++h[j] == buckets) h[j] = 0;
-                        t[j] = table[h[j]];
+                        if (!open) act[j] = false;
+                        else { h[j] = (h[j] & ~3ull) + 4; if (h[j] >= buckets) h[j] = 0; }
+                    }
+                }
+            }
+        } else {
+            u64 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = act[j] ? table[h[j]] : 0ull;
+            while (act[0] | act[1] | act[2] | act[3]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (act[j]) {
+                        if ((uint32_t)t[j] == 0u) {
+                            act[j] = false;
+                        } else {
+                            if ((uint32_t)t[j] == key[j]) {
+                                const uint32_t iv = (uint32_t)(t[j] >> 32);
+                                acc_n += 1; acc_k += key[j]; acc_o += val[j]; acc_i += iv;
+                                em.emit(key[j], val[j], iv);
+                            }
+                            if (++h[j] == buckets) h[j] = 0;
+                            t[j] = table[h[j]];
+                        }
                     }
                 }
             }
@@ -139,7 +180,9 @@ int hj_launch_npj_probe(const NpjProbeArgs &a, int cus, hipStream_t stream, int 
 {
     const int grid = hj_npj_probe_grid(cus, a.n);
     if (grid_out) *grid_out = grid;
-    hipLaunchKernelGGL(npj_probe_kernel, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+    const bool grouped = (a.buckets % 4 == 0) && (((uintptr_t)a.table & 31) == 0);
+    if (grouped) hipLaunchKernelGGL(npj_probe_kernel<true>, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL(npj_probe_kernel<false>, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 

@@ -76,7 +76,7 @@ typedef struct {
 } hjgpu_phj_params;
 
 typedef struct {
-    double   load;             /* buckets = inner/load (npj.cpp:944-947); 0 = 0.5            */
+    double   load;             /* buckets = inner/load (npj.cpp:944-947); 0 = 0.25           */
     uint32_t factor;           /* odd multiplier; 0 = default                                */
     uint32_t reserved;
 } hjgpu_npj_params;
