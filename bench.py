@@ -42,6 +42,8 @@ def parse():
                     help="additionally run the materialising PHJ (3 result columns + close_gaps) and report it")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even at --gpus 1 (exercises the multi-GPU code path)")
+    ap.add_argument("--ring-broadcast", action="store_true",
+                    help="multi-GPU: replicate the build side with dist.broadcast instead of scatter + all-gather")
     ap.add_argument("--no-overlap", action="store_true",
                     help="multi-GPU: broadcast the build side on the join's own stream (no overlap)")
     return ap.parse_args()
@@ -147,6 +149,8 @@ def main():
     nprm = H.NpjParams()                       # library default load factor (0.25)
     d_result = torch.zeros(4, dtype=torch.int64, device=dev)
 
+    from hash_join_codes_knl_amd import distributed as DD
+    state = {"ring": bool(args.ring_broadcast)}
     side = torch.cuda.Stream(device=dev) if dist is not None else None
     overlap = dist is not None and args.algo == "phj" and not args.no_overlap
     if copart:
@@ -173,8 +177,18 @@ def main():
             with torch.cuda.stream(bs):
                 if rank == 0:
                     rk.copy_(r_src_k); rv.copy_(r_src_v)
-                dist.broadcast(rk, 0)
-                dist.broadcast(rv, 0)
+                if state["ring"]:
+                    dist.broadcast(rk, 0)
+                    dist.broadcast(rv, 0)
+                else:                       # scatter + all-gather: all 7 xGMI links of every GPU
+                    try:
+                        DD.replicate(dist, torch, rk, 0)
+                        DD.replicate(dist, torch, rv, 0)
+                    except Exception as ex:                    # argument/backend errors are raised on every rank
+                        print("replicate() failed (%r): falling back to dist.broadcast" % (ex,), file=sys.stderr)
+                        state["ring"] = True
+                        dist.broadcast(rk, 0)
+                        dist.broadcast(rv, 0)
                 if overlap:
                     ready = torch.cuda.Event()
                     ready.record(bs)
@@ -271,8 +285,9 @@ def main():
     if copart:
         parallelism = "both sides chunked over %d GPU(s), RCCL all-to-all-v co-partitioning, local PHJ" % n_gpus
     elif dist is not None:
-        parallelism = "probe side sharded over %d GPU(s), build side RCCL-broadcast each step%s" % (
-            n_gpus, ", overlapped with probe-side partitioning" if overlap else "")
+        parallelism = "probe side sharded over %d GPU(s), build side replicated each step by RCCL %s%s" % (
+            n_gpus, "broadcast" if state["ring"] else "scatter + all-gather",
+            ", overlapped with probe-side partitioning" if overlap else "")
     else:
         parallelism = "probe side sharded over 1 GPU(s), build side local"
     out = {

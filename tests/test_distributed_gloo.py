@@ -68,6 +68,39 @@ def test_multi_process_join(world, mode):
         assert ok, (rank, got, want)
 
 
+def _replicate_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from hash_join_codes_knl_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        want = torch.arange(n, dtype=torch.int32) * 7 - 3
+        t = want.clone() if rank == 1 % world else torch.zeros(n, dtype=torch.int32)
+        D.replicate(dist, torch, t, src=1 % world)
+        q.put((rank, bool(torch.equal(t, want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 100_003), (3, 50_000), (3, 17)])
+def test_replicate_scatter_allgather(world, n):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replicate_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results
+
+
 def test_shard_bounds_and_ownership():
     sys.path.insert(0, ROOT)
     from hash_join_codes_knl_amd import distributed as D
