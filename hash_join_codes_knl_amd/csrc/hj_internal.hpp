@@ -73,6 +73,7 @@ struct JoinArgs {
     uint32_t tf0, tf1;                   // table hash / step multipliers
     uint32_t s_align;                    // (address of sk / 4) % 4
     hjgpu_result *result;                // device, accumulated atomically
+    u64 *work_counter;                   // device, zeroed per launch: next unclaimed work item
     // materialised output (NULL keys = aggregate only)
     uint32_t *ok, *oov, *oiv;
     u64 block_size, block_limit;

@@ -23,6 +23,7 @@ struct DevState {
     hjgpu_result result;
     u64 block_counter;
     u64 dense;
+    u64 work_counter;
     uint32_t overflow;
     uint32_t zero_key;
     uint32_t nmoves;
@@ -356,6 +357,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.s_align = 0;
         ja.packed = 1;
         ja.result = &st->result;
+        ja.work_counter = &st->work_counter;
         if (bs) {
             ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
             ja.block_size = bs; ja.block_limit = bl;
@@ -731,7 +733,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     ja.slice_prefix = m.slice_prefix; ja.slices = m.slices;
     ja.P = pl.P; ja.chunks = 1;
     ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2; ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
-    ja.s_align = 0; ja.result = &st->result;
+    ja.s_align = 0; ja.result = &st->result; ja.work_counter = &st->work_counter;
     if (bs) {
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;

@@ -201,7 +201,15 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
         }
     };
 
-    for (u64 w = blockIdx.x; w < total_items; w += gridDim.x) {
+    // work items are claimed dynamically (one atomic per item): partitions differ in size
+    // and so does the memory system's service, a static round-robin leaves a tail
+    __shared__ u64 next_item;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) next_item = atomicAdd(a.work_counter, 1ull);
+        __syncthreads();
+        const u64 w = next_item;
+        if (w >= total_items) break;
         q = hj_find_segment(a.slice_prefix, P, w);
         const u64 slice = w - a.slice_prefix[q];
         const u64 nslices = a.slices[q];
