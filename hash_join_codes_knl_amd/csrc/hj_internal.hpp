@@ -86,6 +86,7 @@ struct JoinArgs {
 struct PlanArgs {
     const u64 *counts[2];     // [chunks*P] fused two-level histograms of R (0) and S (1)
     u64 n[2];                 // relation sizes
+    u64 chunk_beg[2][9];      // first row of every chunk (host-known: sizes only)
     u64 *off2[2];             // [chunks*P + 1] absolute final offsets
     u64 *cur2[2];             // [chunks*P]
     u64 *off1[2];             // [chunks*F1 + 1]

@@ -294,6 +294,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
     pa.n[0] = inner; pa.n[1] = outer;
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
     pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
@@ -658,6 +659,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
     pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
@@ -722,6 +724,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
     pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));

@@ -179,7 +179,35 @@ __device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 
 }
 
 
-__global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(PlanArgs a)
+// K5, step 1: one workgroup per (chunk, relation).  A chunk's final offsets are its
+// own exclusive scan plus the chunk's first row (known on the host), so the chunks
+// scan in parallel.
+__global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
+{
+    __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
+    const uint32_t P = a.F1 * a.F2, C = a.chunks;
+    const uint32_t c = blockIdx.x;
+    const int r = blockIdx.y;
+    if (!((a.mask >> r) & 1u)) return;
+    const u64 *__restrict__ cnt = a.counts[r] + (u64)c * P;
+    u64 *off2 = a.off2[r] + (u64)c * P;
+    const u64 base = a.chunk_beg[r][c];
+    plan_scan(P, [&](uint32_t i) { return cnt[i]; }, off2, base, scratch);
+    // off2[P] of this chunk is the next chunk's first row (same value: chunks are contiguous)
+    for (uint32_t i = threadIdx.x; i < P; i += PLAN_BLOCK) a.cur2[r][(u64)c * P + i] = off2[i];
+    for (uint32_t p1 = threadIdx.x; p1 < a.F1; p1 += PLAN_BLOCK) {
+        const u64 o = off2[(u64)p1 * a.F2];
+        a.off1[r][(u64)c * a.F1 + p1] = o;
+        a.cur1[r][(u64)c * a.F1 + p1] = o;
+    }
+    if (threadIdx.x == 0) {
+        a.seg1[r][c] = base;
+        if (c == C - 1) { a.seg1[r][C] = a.n[r]; a.off1[r][(u64)C * a.F1] = a.n[r]; }
+    }
+}
+
+// K5, step 2: tile prefixes of both passes (blocks 0, 1) and the join's work items (block 2).
+__global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
 {
     __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
     const uint32_t P = a.F1 * a.F2;
@@ -187,22 +215,6 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(PlanArgs a)
     if (!((a.mask >> blockIdx.x) & 1u)) return;
     if (blockIdx.x < 2) {
         const int r = blockIdx.x;
-        const u64 *__restrict__ cnt = a.counts[r];
-        // final offsets: chunk-major flat scan == absolute positions, because the
-        // chunks are contiguous, ordered, and each chunk's counts sum to its size
-        plan_scan(C * P, [&](uint32_t i) { return cnt[i]; }, a.off2[r], 0, scratch);
-        __threadfence_block();
-        const u64 *off2 = a.off2[r];          // written above by this workgroup: no __restrict__
-        for (uint32_t i = threadIdx.x; i < C * P; i += PLAN_BLOCK) a.cur2[r][i] = off2[i];
-        for (uint32_t i = threadIdx.x; i <= C * a.F1; i += PLAN_BLOCK) {
-            const uint32_t c = i / a.F1, p1 = i - c * a.F1;
-            const u64 o = (i == C * a.F1) ? off2[C * P] : off2[(u64)c * P + (u64)p1 * a.F2];
-            a.off1[r][i] = o;
-            if (i < C * a.F1) a.cur1[r][i] = o;
-        }
-        for (uint32_t i = threadIdx.x; i <= C; i += PLAN_BLOCK)
-            a.seg1[r][i] = (i == C) ? off2[C * P] : off2[(u64)i * P];
-        __syncthreads();
         // pass-1 tiles: segments are the chunks of the caller's (possibly unaligned) input
         const uint32_t al = a.in_align[r];
         const uint32_t tile = a.tile;
@@ -230,7 +242,9 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_kernel(PlanArgs a)
 
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(plan_kernel, dim3(3), dim3(PLAN_BLOCK), 0, stream, a);
+    if (a.mask & 3u)
+        hipLaunchKernelGGL(plan_offsets_kernel, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(plan_tiles_kernel, dim3(3), dim3(PLAN_BLOCK), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
