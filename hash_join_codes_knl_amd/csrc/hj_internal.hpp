@@ -68,6 +68,7 @@ struct JoinArgs {
     const u64 *roff, *soff;              // [chunks*P + 1] absolute offsets, chunk-major
     const u64 *slice_prefix;             // [P+1] exclusive prefix of work items per partition
     const u64 *slices;                   // [P]   work items of partition q
+    const uint32_t *item_part;           // [items] partition of work item w
     uint32_t P, chunks;
     uint32_t f1, F1, f2, F2;             // the passes that produced the partitions
     uint32_t tf0, tf1;                   // table hash / step multipliers
@@ -96,6 +97,7 @@ struct PlanArgs {
     u64 *tp2[2];              // [chunks*F1 + 1] pass-2 tile prefix
     u64 *slice_prefix;        // [P + 1]
     u64 *slices;              // [P]
+    uint32_t *item_part;      // [P + outer/slice + 1] partition of every join work item
     uint32_t chunks, F1, F2;
     uint32_t in_align[2];     // alignment of the caller's input columns
     uint32_t tile, slice;

@@ -102,13 +102,14 @@ inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) 
 struct MetaLayout {
     u64 *counts[2], *off2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
     u64 *slice_prefix, *slices;
+    uint32_t *item_part;         // [P + items_extra] partition of every join work item
     uint32_t *range_counts[2];   // [ranges][F1] pass-1 counts per range (K4 -> K5b)
     u64 *range_base[2];          // [ranges][F1] pass-1 write bases per range (K5b -> K6)
     size_t counts_bytes;    // both relations, contiguous (zeroed per join)
     size_t total_bytes;
 };
 
-MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges)
+MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges, size_t items_extra = 0)
 {
     MetaLayout m;
     u64 *p = reinterpret_cast<u64 *>(base);
@@ -128,6 +129,7 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges)
     }
     m.slice_prefix = take((size_t)P + 1);
     m.slices = take(P);
+    m.item_part = reinterpret_cast<uint32_t *>(take(((size_t)P + items_extra + 2) / 2 + 1));
     for (int r = 0; r < 2; ++r) {
         m.range_counts[r] = reinterpret_cast<uint32_t *>(take((ranges * F1 + 1) / 2));
         m.range_base[r] = take(ranges * F1);
@@ -229,7 +231,7 @@ Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1)
 // PHJ / CPRA: fused histogram -> plan -> scatter x2 -> LDS join
 // ---------------------------------------------------------------------------
 struct PhjPlan {
-    size_t ranges;
+    size_t ranges, items_extra;
     uint32_t C, F1, F2, P;
     uint32_t f1, f2, tf0, tf1;
 };
@@ -262,7 +264,8 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     // ranges of the larger relation bound the per-range tables of both
     const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1), gs = make_geom(nullptr, outer, pl->C, pl->F1);
     pl->ranges = (size_t)(gr.ranges_per_chunk > gs.ranges_per_chunk ? gr.ranges_per_chunk : gs.ranges_per_chunk) * pl->C;
-    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges);
+    pl->items_extra = outer / HJ_JOIN_SLICE + 1;
+    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges, pl->items_extra);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     return HJGPU_OK;
@@ -273,7 +276,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
                 const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr)
 {
-    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges);
+    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
@@ -295,7 +298,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     }
     pa.n[0] = inner; pa.n[1] = outer;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
-    pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
     pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
@@ -351,7 +354,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         memset(&ja, 0, sizeof(ja));
         ja.rk = fin[0]; ja.rv = fin[1]; ja.sk = fin[2]; ja.sv = fin[3];
         ja.roff = m.off2[0]; ja.soff = m.off2[1];
-        ja.slice_prefix = m.slice_prefix; ja.slices = m.slices;
+        ja.slice_prefix = m.slice_prefix; ja.slices = m.slices; ja.item_part = m.item_part;
         ja.P = pl.P; ja.chunks = pl.C;
         ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2;
         ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
@@ -658,7 +661,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
-    pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
@@ -704,10 +707,16 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     pl.tf1 = passes->table_factor[1] ? passes->table_factor[1] : DEFAULT_TF1;
     if (!(pl.f1 & 1) || !(pl.f2 & 1) || !(pl.tf0 & 1) || !(pl.tf1 & 1))
         return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
-    MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P, 1);
+    // the work-item directory is sized from the probe rows, which only the device knows here
+    u64 s_ends[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(&s_ends[0], soff, sizeof(u64), hipMemcpyDeviceToHost, stream));
+    HIPCHK(ctx, hipMemcpyAsync(&s_ends[1], soff + pl.P, sizeof(u64), hipMemcpyDeviceToHost, stream));
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    const size_t items_extra = (size_t)((s_ends[1] - s_ends[0]) / HJ_JOIN_SLICE + 1);
+    MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P, 1, items_extra);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
-    MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P, 1);
+    MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P, 1, items_extra);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
@@ -723,7 +732,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
-    pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices;
+    pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
     pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
@@ -733,7 +742,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     memset(&ja, 0, sizeof(ja));
     ja.rk = rk; ja.rv = rv; ja.sk = sk; ja.sv = sv;
     ja.roff = (const u64 *)roff; ja.soff = (const u64 *)soff;    // caller's offsets (may start at non-zero)
-    ja.slice_prefix = m.slice_prefix; ja.slices = m.slices;
+    ja.slice_prefix = m.slice_prefix; ja.slices = m.slices; ja.item_part = m.item_part;
     ja.P = pl.P; ja.chunks = 1;
     ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2; ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
     ja.s_align = 0; ja.result = &st->result; ja.work_counter = &st->work_counter;

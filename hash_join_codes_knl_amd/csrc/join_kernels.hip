@@ -210,7 +210,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
         __syncthreads();
         const u64 w = next_item;
         if (w >= total_items) break;
-        q = hj_find_segment(a.slice_prefix, P, w);
+        q = a.item_part[w];
         const u64 slice = w - a.slice_prefix[q];
         const u64 nslices = a.slices[q];
 

@@ -236,7 +236,13 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
             return (nr && ns) ? (ns + slice - 1) / slice : 0;
         };
         plan_scan(P, items, a.slice_prefix, 0, scratch);
-        for (uint32_t q = threadIdx.x; q < P; q += PLAN_BLOCK) a.slices[q] = items(q);
+        const u64 *sp = a.slice_prefix;                 // written above by this workgroup
+        for (uint32_t q = threadIdx.x; q < P; q += PLAN_BLOCK) {
+            const u64 n = items(q);
+            a.slices[q] = n;
+            // item -> partition directory: the join reads one word instead of a binary search
+            for (u64 s = 0; s < n; ++s) a.item_part[sp[q] + s] = q;
+        }
     }
 }
 
