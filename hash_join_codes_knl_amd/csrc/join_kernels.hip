@@ -203,16 +203,28 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 
     // work items are claimed dynamically (one atomic per item): partitions differ in size
     // and so does the memory system's service, a static round-robin leaves a tail
-    __shared__ u64 next_item;
+    // The claim for item n+1 and its descriptor are fetched while item n is being probed.
+    __shared__ u64 next_item, next_slice, next_nslices;
+    __shared__ uint32_t next_q;
+    auto claim = [&]() {                                  // thread 0 only
+        const u64 w = atomicAdd(a.work_counter, 1ull);
+        next_item = w;
+        if (w < total_items) {
+            const uint32_t nq = a.item_part[w];
+            next_q = nq;
+            next_slice = w - a.slice_prefix[nq];
+            next_nslices = a.slices[nq];
+        }
+    };
+    if (tid == 0) claim();
+    __syncthreads();
     for (;;) {
-        __syncthreads();
-        if (tid == 0) next_item = atomicAdd(a.work_counter, 1ull);
-        __syncthreads();
         const u64 w = next_item;
         if (w >= total_items) break;
-        q = a.item_part[w];
-        const u64 slice = w - a.slice_prefix[q];
-        const u64 nslices = a.slices[q];
+        q = next_q;
+        const u64 slice = next_slice;
+        const u64 nslices = next_nslices;
+        bool claimed_next = false;
 
         // empty sentinel: smallest value whose partition is not q (P >= 2)
         empty = 0;
@@ -246,6 +258,10 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                 if (it == CUCKOO_MAX_EVICTIONS) cuckoo_failed = 1;           // a tuple is left in hand
             });
             __syncthreads();
+            // every thread has copied this item's descriptor into registers long ago:
+            // thread 0 may overwrite the shared copy with the next item's now
+            if (tid == 0 && !claimed_next) claim();
+            claimed_next = true;
             if (!cuckoo_failed) {
                 probe_item(slice, nslices, probe4_cuckoo);
             } else {
@@ -266,6 +282,10 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                 probe_item(slice, nslices, probe4_chained);
             }
             __syncthreads();   // table is reused by the next fill / work item
+        }
+        if (nr == 0) {         // (cannot happen for planned items; keeps the claim protocol total)
+            if (tid == 0) claim();
+            __syncthreads();
         }
     }
 
