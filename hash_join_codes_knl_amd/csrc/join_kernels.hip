@@ -72,12 +72,13 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     uint32_t q = 0;
 
     // ---- visit rows [fill_beg, fill_end) of the chunk-concatenated build partition q ----
-    auto for_each_build_row = [&](u64 fill_beg, u64 fill_end, auto insert) {
+    // rows below `from_row` were already inserted (from the prefetch registers)
+    auto for_each_build_row = [&](u64 fill_beg, u64 fill_end, u64 from_row, auto insert) {
         u64 seen = 0;
         for (uint32_t c = 0; c < C; ++c) {
             const u64 b = a.roff[(u64)c * P + q], e = a.roff[(u64)c * P + q + 1];
             const u64 len = e - b;
-            const u64 lo = max(seen, fill_beg), hi = min(seen + len, fill_end);
+            const u64 lo = max(max(seen, fill_beg), from_row), hi = min(seen + len, fill_end);
             for (u64 base = lo; base < hi; base += (u64)BLOCK * RB) {
                 uint32_t k[RB], v[RB];
                 // all loads of the batch are issued before the first insert
@@ -203,28 +204,40 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 
     // work items are claimed dynamically (one atomic per item): partitions differ in size
     // and so does the memory system's service, a static round-robin leaves a tail
-    // The claim for item n+1 and its descriptor are fetched while item n is being probed.
-    __shared__ u64 next_item, next_slice, next_nslices;
-    __shared__ uint32_t next_q;
-    auto claim = [&]() {                                  // thread 0 only
+    // Work-item descriptors are double-buffered: while item n runs out of slot `par`, thread 0
+    // claims item n+1 into the other slot at the top of the loop; the clear barrier publishes it,
+    // and (single-chunk joins) every lane then loads its share of item n+1's build rows into
+    // registers right after item n's build, so that they arrive during the probe of item n.
+    __shared__ u64 d_item[2], d_slice[2], d_nslices[2], d_rb[2], d_rn[2];
+    __shared__ uint32_t d_q[2];
+    auto claim = [&](int slot) {                          // thread 0 only
         const u64 w = atomicAdd(a.work_counter, 1ull);
-        next_item = w;
+        d_item[slot] = w;
         if (w < total_items) {
             const uint32_t nq = a.item_part[w];
-            next_q = nq;
-            next_slice = w - a.slice_prefix[nq];
-            next_nslices = a.slices[nq];
+            d_q[slot] = nq;
+            d_slice[slot] = w - a.slice_prefix[nq];
+            d_nslices[slot] = a.slices[nq];
+            d_rb[slot] = a.roff[nq];
+            d_rn[slot] = a.roff[nq + 1] - a.roff[nq];
         }
     };
-    if (tid == 0) claim();
+    uint32_t pk[RB], pv[RB];                              // prefetched build rows j*BLOCK + tid
+#pragma unroll
+    for (int j = 0; j < RB; ++j) { pk[j] = 0; pv[j] = 0; }
+    u64 pre_rows = 0;                                     // rows [0, pre_rows) of the coming item are in pk/pv
+    int par = 0;
+    if (tid == 0) claim(0);
     __syncthreads();
     for (;;) {
-        const u64 w = next_item;
+        const u64 w = d_item[par];
         if (w >= total_items) break;
-        q = next_q;
-        const u64 slice = next_slice;
-        const u64 nslices = next_nslices;
-        bool claimed_next = false;
+        q = d_q[par];
+        const u64 slice = d_slice[par];
+        const u64 nslices = d_nslices[par];
+        if (tid == 0) claim(par ^ 1);                     // published by the clear barrier below
+        u64 have_rows = pre_rows;
+        pre_rows = 0;
 
         // empty sentinel: smallest value whose partition is not q (P >= 2)
         empty = 0;
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             for (uint32_t i = tid; i < SLOTS; i += BLOCK) tab64[i] = EMPTY64;
             if (tid == 0) cuckoo_failed = a.force_chained;
             __syncthreads();
-            for_each_build_row(fill_beg, fill_end, [&](uint32_t k, uint32_t v) {
+            auto cuckoo_insert = [&](uint32_t k, uint32_t v) {
                 u64 cur = (u64)k | ((u64)v << 32);
                 uint32_t loc = (k * tf0) >> SHIFT;
                 int it = 0;
@@ -256,12 +269,23 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                     cur = old;
                 }
                 if (it == CUCKOO_MAX_EVICTIONS) cuckoo_failed = 1;           // a tuple is left in hand
-            });
+            };
+            const u64 from_regs = (fill_beg == 0) ? have_rows : 0;
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                if ((u64)j * BLOCK + tid < from_regs) cuckoo_insert(pk[j], pv[j]);
+            for_each_build_row(fill_beg, fill_end, from_regs, cuckoo_insert);
             __syncthreads();
-            // every thread has copied this item's descriptor into registers long ago:
-            // thread 0 may overwrite the shared copy with the next item's now
-            if (tid == 0 && !claimed_next) claim();
-            claimed_next = true;
+            // build rows of the NEXT item: issue the loads now, they land during this probe
+            if (fill_beg == 0 && C == 1 && PACKED && d_item[par ^ 1] < total_items) {
+                const u64 nb = d_rb[par ^ 1];
+                pre_rows = min(min(d_rn[par ^ 1], (u64)BLOCK * RB), (u64)CAP);
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const u64 i = (u64)j * BLOCK + tid;
+                    if (i < pre_rows) { const u64 t = r64[nb + i]; pk[j] = (uint32_t)t; pv[j] = (uint32_t)(t >> 32); }
+                }
+            }
             if (!cuckoo_failed) {
                 probe_item(slice, nslices, probe4_cuckoo);
             } else {
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                 __syncthreads();
                 for (uint32_t i = tid; i < SLOTS; i += BLOCK) tab64[i] = EMPTY64;
                 __syncthreads();
-                for_each_build_row(fill_beg, fill_end, [&](uint32_t k, uint32_t v) {
+                for_each_build_row(fill_beg, fill_end, 0, [&](uint32_t k, uint32_t v) {
                     uint32_t slot = (k * tf0) >> SHIFT;
                     const uint32_t step = ((k * tf1) >> SHIFT) | 1u;
                     for (;;) {
@@ -283,10 +307,8 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             }
             __syncthreads();   // table is reused by the next fill / work item
         }
-        if (nr == 0) {         // (cannot happen for planned items; keeps the claim protocol total)
-            if (tid == 0) claim();
-            __syncthreads();
-        }
+        if (nr == 0) __syncthreads();      // (cannot happen for planned items) publish the next claim
+        par ^= 1;
     }
 
     // ---- per-wave cursors -> final offsets (close_gaps input) ---------------------
