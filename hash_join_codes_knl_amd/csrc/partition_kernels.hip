@@ -429,28 +429,30 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         __syncthreads();
 
         // ---- local bases + one output run per non-empty partition --------------
-        uint32_t cnt[BPT];
+        // Pass 2 claims its runs with returning global atomics; they are ISSUED here, as soon
+        // as the counts exist, and CONSUMED only after the LDS sort, so their round trip
+        // (1-2 us under load) overlaps the scan and the staging instead of stalling the tile.
+        uint32_t cnt[BPT], lb[BPT];
+        u64 dst[BPT];
         uint32_t sum = 0;
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
             cnt[i] = ((uint32_t)i < bpt && bin < F) ? hist[bin] : 0;
             sum += cnt[i];
+            dst[i] = 0;
+            if (cnt[i]) {
+                if (RANGED) { dst[i] = mycur[i]; mycur[i] = dst[i] + cnt[i]; }
+                else dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
+            }
         }
         uint32_t run = block_exclusive_scan<BLOCK, uint32_t>(sum, wsum);
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
-            if ((uint32_t)i < bpt && bin < F) {
-                hist[bin] = run;
-                if (cnt[i]) {
-                    u64 dst;
-                    if (RANGED) { dst = mycur[i]; mycur[i] = dst + cnt[i]; }
-                    else dst = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
-                    delta[bin] = dst - run;
-                }
-                run += cnt[i];
-            }
+            lb[i] = run;
+            if ((uint32_t)i < bpt && bin < F) hist[bin] = run;
+            run += cnt[i];
         }
         __syncthreads();
         const uint32_t tile_count = wsum[NW];
@@ -467,6 +469,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         // are in flight during the stream-out below (no extra registers needed).
         const Tile nxt = next_tile();
         if (nxt.valid) load_tile(nxt);
+#pragma unroll
+        for (int i = 0; i < BPT; ++i)
+            if (cnt[i]) delta[tid * bpt + i] = dst[i] - lb[i];
         __syncthreads();
 
         // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
