@@ -21,6 +21,17 @@ __device__ __forceinline__ uint32_t hj_part2(uint32_t key, uint32_t f1, uint32_t
 
 __device__ __forceinline__ int hj_lane() { return threadIdx.x & 63; }
 
+// Workgroup barrier that orders LDS traffic only.  HIP's __syncthreads() also drains
+// the vector-memory counter (s_waitcnt vmcnt(0)), which turns every global load issued
+// before it into an exposed round trip; kernels that keep loads (or stores) in flight
+// across a barrier use this one: wait for this wave's LDS operations, then s_barrier.
+__device__ __forceinline__ void hj_barrier_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // Inclusive scan across the 64 lanes of a wave.
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T x)
@@ -45,7 +56,8 @@ __device__ __forceinline__ T wave_reduce_sum(T x)
 // Block-wide exclusive scan of one value per thread. `scratch` needs
 // BLOCK/64 + 1 entries of T in LDS; scratch[BLOCK/64] receives the block total.
 // Contains two __syncthreads(); every thread of the block must call it.
-template <int BLOCK, typename T>
+// LDS_ONLY: use hj_barrier_lds() (global loads / stores / atomics stay in flight across it).
+template <int BLOCK, typename T, bool LDS_ONLY = false>
 __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch)
 {
     constexpr int NW = BLOCK / 64;
@@ -53,14 +65,14 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch)
     const int wave = threadIdx.x >> 6;
     T inc = wave_inclusive_scan(v);
     if (lane == 63) scratch[wave] = inc;
-    __syncthreads();
+    if (LDS_ONLY) hj_barrier_lds(); else __syncthreads();
     if (wave == 0) {
         T w = (lane < NW) ? scratch[lane] : T(0);
         T winc = wave_inclusive_scan(w);
         if (lane < NW) scratch[lane] = winc - w;      // exclusive prefix of the wave sums
         if (lane == NW - 1) scratch[NW] = winc;       // block total
     }
-    __syncthreads();
+    if (LDS_ONLY) hj_barrier_lds(); else __syncthreads();
     return inc - v + scratch[wave];
 }
 

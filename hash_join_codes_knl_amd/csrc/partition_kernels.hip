@@ -375,24 +375,29 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         return t;
     };
 
-    uint32_t key[VPT * 4], val[VPT * 4];
+    // The loaded vectors themselves are the loop-carried state (no per-element copies,
+    // no zero-initialised phi): the loads of tile t+1 are issued unconditionally - the
+    // vector index is clamped into the segment, validity is decided later from the
+    // coordinates - so the compiler has no reason to wait for them before the back edge.
+    uint4 kq[VPT], vq[VPT];
     auto load_tile = [&](const Tile &t) {
+        const u64 g_last = (t.ge - 1) & ~3ull;            // last vector that overlaps the segment
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
-            const u64 g = t.g0 + (u64)(j * BLOCK + tid) * 4;
-            uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if ((g < t.ge) && (g + 4 > t.gb)) {
-                if (IN_PACKED) { kk = k4[g >> 1]; vv = k4[(g >> 1) + 1]; }    // 4 tuples = 2 x 16 bytes
-                else { kk = k4[g >> 2]; vv = v4[g >> 2]; }
-            }
-            if (IN_PACKED) {
-                key[j * 4 + 0] = kk.x; val[j * 4 + 0] = kk.y; key[j * 4 + 1] = kk.z; val[j * 4 + 1] = kk.w;
-                key[j * 4 + 2] = vv.x; val[j * 4 + 2] = vv.y; key[j * 4 + 3] = vv.z; val[j * 4 + 3] = vv.w;
-            } else {
-                key[j * 4 + 0] = kk.x; key[j * 4 + 1] = kk.y; key[j * 4 + 2] = kk.z; key[j * 4 + 3] = kk.w;
-                val[j * 4 + 0] = vv.x; val[j * 4 + 1] = vv.y; val[j * 4 + 2] = vv.z; val[j * 4 + 3] = vv.w;
-            }
+            u64 g = t.g0 + (u64)(j * BLOCK + tid) * 4;
+            g = g < g_last ? g : g_last;
+            if (IN_PACKED) { kq[j] = k4[g >> 1]; vq[j] = k4[(g >> 1) + 1]; }    // 4 tuples = 2 x 16 bytes
+            else { kq[j] = k4[g >> 2]; vq[j] = v4[g >> 2]; }
         }
+    };
+    // tuple c (0..3) of vector j
+    auto key_of = [&](int j, int c) -> uint32_t {
+        if (IN_PACKED) return c == 0 ? kq[j].x : c == 1 ? kq[j].z : c == 2 ? vq[j].x : vq[j].z;
+        return c == 0 ? kq[j].x : c == 1 ? kq[j].y : c == 2 ? kq[j].z : kq[j].w;
+    };
+    auto val_of = [&](int j, int c) -> uint32_t {
+        if (IN_PACKED) return c == 0 ? kq[j].y : c == 1 ? kq[j].w : c == 2 ? vq[j].y : vq[j].w;
+        return c == 0 ? vq[j].x : c == 1 ? vq[j].y : c == 2 ? vq[j].z : vq[j].w;
     };
 
     Tile cur = next_tile();
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             }
         }
         for (uint32_t i = tid; i < F; i += BLOCK) hist[i] = 0;
-        __syncthreads();
+        hj_barrier_lds();
 
         // ---- rank every tuple inside its partition (ds_add_rtn_u32) --------------
         uint32_t pr[VPT * 4];
@@ -419,14 +424,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 const bool valid = (g + c >= cur.gb) && (g + c < cur.ge);
                 uint32_t code = 0xFFFFFFFFu;
                 if (valid) {
-                    const uint32_t p = hj_hash(key[j * 4 + c], factor, F);
+                    const uint32_t p = hj_hash(key_of(j, c), factor, F);
                     const uint32_t r = atomicAdd(&hist[p], 1u);
                     code = (p << 16) | r;
                 }
                 pr[j * 4 + c] = code;
             }
         }
-        __syncthreads();
+        hj_barrier_lds();
 
         // ---- local bases + one output run per non-empty partition --------------
         // Pass 2 claims its runs with returning global atomics; they are ISSUED here, as soon
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 else dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
             }
         }
-        uint32_t run = block_exclusive_scan<BLOCK, uint32_t>(sum, wsum);
+        uint32_t run = block_exclusive_scan<BLOCK, uint32_t, true>(sum, wsum);
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
@@ -454,25 +459,32 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             if ((uint32_t)i < bpt && bin < F) hist[bin] = run;
             run += cnt[i];
         }
-        __syncthreads();
+        hj_barrier_lds();
         const uint32_t tile_count = wsum[NW];
 
         // ---- counting sort inside LDS --------------------------------------------
 #pragma unroll
-        for (int e = 0; e < VPT * 4; ++e) {
-            if (pr[e] != 0xFFFFFFFFu) {
-                const uint32_t pos = hist[pr[e] >> 16] + (pr[e] & 0xFFFFu);
-                stage[pos] = (u64)key[e] | ((u64)val[e] << 32);
+        for (int j = 0; j < VPT; ++j) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t code = pr[j * 4 + c];
+                if (code != 0xFFFFFFFFu) {
+                    const uint32_t pos = hist[code >> 16] + (code & 0xFFFFu);
+                    stage[pos] = (u64)key_of(j, c) | ((u64)val_of(j, c) << 32);
+                }
             }
         }
-        // The input registers are dead now: start the next tile's loads so that they
-        // are in flight during the stream-out below (no extra registers needed).
-        const Tile nxt = next_tile();
-        if (nxt.valid) load_tile(nxt);
+        // consume the claims (pass 2: the atomics have had the scan and the sort to return) ...
 #pragma unroll
         for (int i = 0; i < BPT; ++i)
             if (cnt[i]) delta[tid * bpt + i] = dst[i] - lb[i];
-        __syncthreads();
+        // ... and only then start the next tile's loads: the vector-memory counter is in
+        // order, so any wait on an older result placed after these loads would also wait for
+        // them.  Nothing below touches them until the next tile is ranked, and the barriers are
+        // LDS-only, so they stay in flight during the whole stream-out.
+        const Tile nxt = next_tile();
+        if (nxt.valid) load_tile(nxt);
+        hj_barrier_lds();
 
         // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
         for (uint32_t i = tid; i < tile_count; i += BLOCK) {
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             if (OUT_PACKED) reinterpret_cast<u64 *>(a.kout)[d] = kv;
             else { a.kout[d] = k; a.vout[d] = (uint32_t)(kv >> 32); }
         }
-        __syncthreads();
+        hj_barrier_lds();
         if (!nxt.valid) break;
         cur = nxt;
     }
