@@ -332,3 +332,82 @@ def test_phj_overlapped_waits_for_build_side(hj, oracle):
     got = tuple(int(x) & ((1 << 64) - 1) for x in d_res.tolist())
     assert got == want
     assert hj.stats()["ms_inner_wait"] > 0.0
+
+
+# ---------------------------------------------------------------- operator-level K7+K8, host path, async forms
+def test_join_partitions_on_oracle_partitioned_columns(hj, oracle):
+    """hjgpu_join_partitions consumes co-partitioned columns + offsets produced elsewhere
+    (here: by the CPU oracle's partition()) - the reference's operator-level seam
+    (phj.cpp:1869-1924): partition(...) then build/probe per partition."""
+    ik, iv, ok, ov = oracle.generate(300_000, 60_000, seed=41)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    f, F = 0x9E3779B1, 97
+    rc, rk, rv = oracle.partition(ik, iv, f, F)
+    sc, sk, sv = oracle.partition(ok, ov, f, F)
+    roff = np.concatenate([np.zeros(1, np.uint64), np.cumsum(rc, dtype=np.uint64)])
+    soff = np.concatenate([np.zeros(1, np.uint64), np.cumsum(sc, dtype=np.uint64)])
+    cols = [hj.column(x) for x in (rk, rv, sk, sv)]
+    d_roff, d_soff = hj.column(roff, np.uint64), hj.column(soff, np.uint64)
+    prm = H.PhjParams(fanout1=F, fanout2=1, factor1=f)
+    assert hj.join_partitions(cols[0], cols[1], d_roff, cols[2], cols[3], d_soff, prm) == want
+    # GPU-partitioned columns (hjgpu_partition x2) feed the same operator
+    pk, pv, poff = hj.column(len(ik)), hj.column(len(ik)), hj.column(F + 1, np.uint64)
+    qk, qv, qoff = hj.column(len(ok)), hj.column(len(ok)), hj.column(F + 1, np.uint64)
+    raw = [hj.column(x) for x in (ik, iv, ok, ov)]
+    hj.partition(raw[0], raw[1], len(ik), f, F, pk, pv, poff)
+    hj.partition(raw[2], raw[3], len(ok), f, F, qk, qv, qoff)
+    assert hj.join_partitions(pk, pv, poff, qk, qv, qoff, prm) == want
+    # two-level layout (p1 * F2 + p2) built on the host
+    f2, F1, F2 = 0x85EBCA6B, 13, 11
+    def two_level(k, v):
+        pid = mulhi_hash(k, f, F1) * F2 + mulhi_hash(k, f2, F2)
+        order = np.argsort(pid, kind="stable")
+        off = np.concatenate([np.zeros(1, np.uint64), np.cumsum(np.bincount(pid, minlength=F1 * F2), dtype=np.uint64)])
+        return k[order], v[order], off
+    rk2, rv2, roff2 = two_level(ik, iv)
+    sk2, sv2, soff2 = two_level(ok, ov)
+    c2 = [hj.column(x) for x in (rk2, rv2, sk2, sv2)]
+    o2 = [hj.column(roff2, np.uint64), hj.column(soff2, np.uint64)]
+    prm2 = H.PhjParams(fanout1=F1, fanout2=F2, factor1=f, factor2=f2)
+    assert hj.join_partitions(c2[0], c2[1], o2[0], c2[2], c2[3], o2[1], prm2) == want
+    _free(*cols, d_roff, d_soff, pk, pv, poff, qk, qv, qoff, *raw, *c2, *o2)
+
+
+@pytest.mark.parametrize("algorithm", [0, 1, 2])
+def test_join_host_path(hj, oracle, algorithm):
+    """hjgpu_join_host: what the npj/phj/cpra mains call after their fread()s."""
+    ik, iv, ok, ov = oracle.generate(150_000, 40_000, seed=42)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    got, stats = hj.join_host(algorithm, ik, iv, ok, ov)
+    assert got == want
+    assert stats["ms_total"] > 0 and stats["ms_join"] > 0
+    if algorithm:
+        assert stats["fanout1"] * stats["fanout2"] >= 2
+    else:
+        assert stats["buckets"] > len(ik)
+
+
+def test_async_entry_points_write_device_result(hj, oracle):
+    ik, iv, ok, ov = oracle.generate(400_000, 90_000, seed=43)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    rk, rv, sk, sv = _cols(hj, ik, iv, ok, ov)
+    hj.reserve(len(ik), len(ok))
+    for fn, prm in ((hj.phj_async, None), (hj.cpra_async, H.PhjParams(chunks=4)), (hj.npj_async, None)):
+        d_res = hj.column(np.zeros(4, np.uint64), np.uint64)
+        fn(rk, rv, len(ik), sk, sv, len(ok), prm, d_res)
+        hj.synchronize()
+        assert tuple(int(x) for x in d_res.download()) == want
+        d_res.free()
+    _free(rk, rv, sk, sv)
+
+
+def test_generate_range_is_position_pure(hj):
+    inner, outer = 50_000, 300_000
+    full = [hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)]
+    hj.generate(5, inner, outer, 0, outer, 7, 9, *full)
+    hik, hiv = full[0].download(), full[1].download()
+    part_k, part_v = hj.column(1000), hj.column(1000)
+    hj.generate_range(5, inner, outer, 12_345, 1000, 0, 0, 7, 9, part_k, part_v, None, None)
+    assert np.array_equal(part_k.download(), hik[12_345:13_345])
+    assert np.array_equal(part_v.download(), hiv[12_345:13_345])
+    _free(*full, part_k, part_v)
