@@ -105,16 +105,30 @@ int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_
 }
 
 // sums[0] += key, sums[1] += key*fa, sums[2] += key*fb  (products mod 2^32)
+// Also the "simple dwordx4 read kernel" of SURVEY 8d: 16-byte loads, 4 per lane in flight,
+// nothing written - bench.py times it for the empirical streaming-read ceiling of the box.
 __global__ __launch_bounds__(256) void column_sums_kernel(const uint32_t *__restrict__ keys, u64 n,
                                                           uint32_t fa, uint32_t fb, u64 *sums)
 {
     __shared__ u64 red[3][4];
     u64 s0 = 0, s1 = 0, s2 = 0;
+    auto add = [&](uint32_t k) { s0 += k; s1 += (uint32_t)(k * fa); s2 += (uint32_t)(k * fb); };
+    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t k = keys[i];
-        s0 += k; s1 += (uint32_t)(k * fa); s2 += (uint32_t)(k * fb);
+    // scalar head up to the first 16-byte boundary, vector body, scalar tail
+    const u64 head = min(n, (u64)((16 - ((uintptr_t)keys & 15)) & 15) / 4);
+    const uint4 *v = (const uint4 *)(keys + head);
+    const u64 nv = (n - head) / 4;
+    u64 i = tid;
+    for (; i + 3 * stride < nv; i += 4 * stride) {
+        const uint4 a = v[i], b = v[i + stride], c = v[i + 2 * stride], d = v[i + 3 * stride];
+        add(a.x); add(a.y); add(a.z); add(a.w); add(b.x); add(b.y); add(b.z); add(b.w);
+        add(c.x); add(c.y); add(c.z); add(c.w); add(d.x); add(d.y); add(d.z); add(d.w);
     }
+    for (; i < nv; i += stride) { const uint4 a = v[i]; add(a.x); add(a.y); add(a.z); add(a.w); }
+    if (tid < head) add(keys[tid]);
+    const u64 done = head + nv * 4;
+    if (tid < n - done) add(keys[done + tid]);
     s0 = wave_reduce_sum(s0); s1 = wave_reduce_sum(s1); s2 = wave_reduce_sum(s2);
     const int wave = threadIdx.x >> 6;
     if (hj_lane() == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }

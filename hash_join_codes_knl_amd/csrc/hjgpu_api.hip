@@ -565,6 +565,12 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
     hjgpu_stats r = ctx->stats;
     r.ms_total = span(EV_BEGIN, EV_GAPS);
     r.ms_inner_wait = 0;
+    if (ctx->last_algo == 2) {                 // hjgpu_column_sums: one kernel
+        memset(&r, 0, sizeof(r));
+        r.ms_total = span(EV_BEGIN, EV_GAPS);
+        *s = r;
+        return HJGPU_OK;
+    }
     if (ctx->last_algo == 0) {
         r.ms_build = span(EV_BEGIN, EV_R_HIST);
         r.ms_join = span(EV_R_HIST, EV_JOIN);
@@ -956,7 +962,12 @@ int hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->moves, 64));
     u64 *d = (u64 *)ctx->moves.p;
+    // hjgpu_get_stats().ms_total afterwards = duration of this one streaming read
+    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
+    ctx->last_algo = 2;
+    record(ctx, EV_BEGIN, stream);
     CHK(hj_launch_column_sums(d_keys, n, fa, fb, d, stream));
+    record(ctx, EV_GAPS, stream);
     HIPCHK(ctx, hipMemcpyAsync(sums, d, 3 * sizeof(u64), hipMemcpyDeviceToHost, stream));
     HIPCHK(ctx, hipStreamSynchronize(stream));
     return HJGPU_OK;

@@ -234,7 +234,9 @@ int  hjgpu_generate_range(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, siz
                           uint32_t *d_inner_keys, uint32_t *d_inner_vals,
                           uint32_t *d_outer_keys, uint32_t *d_outer_vals, void *stream);
 /* sum over a column of key, key*f_a, key*f_b (mod 2^32 per term, uint64 sums):
- * the analytic join aggregates of a selectivity-1 workload. */
+ * the analytic join aggregates of a selectivity-1 workload.
+ * The kernel is a plain 16-byte-load streaming read; hjgpu_get_stats().ms_total after
+ * the call is its duration (bench.py's empirical streaming-read ceiling). */
 int  hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n,
                        uint32_t f_a, uint32_t f_b, uint64_t sums[3], void *stream);
 

@@ -411,3 +411,15 @@ def test_generate_range_is_position_pure(hj):
     assert np.array_equal(part_k.download(), hik[12_345:13_345])
     assert np.array_equal(part_v.download(), hiv[12_345:13_345])
     _free(*full, part_k, part_v)
+
+
+@pytest.mark.parametrize("n,skew", [(0, 0), (1, 0), (3, 1), (5, 3), (1027, 2), (1_000_003, 1), (4_000_000, 0)])
+def test_column_sums_any_alignment(hj, n, skew):
+    rng = np.random.default_rng(n + skew)
+    host = rng.integers(0, 2**32, n + skew + 4, dtype=np.uint64).astype(np.uint32)
+    col = hj.column(host)
+    k = host[skew:skew + n].astype(np.uint64)
+    fa, fb = 0x9E3779B1, 0x85EBCA6B
+    want = (int(k.sum()), int(((k * fa) & 0xFFFFFFFF).sum()), int(((k * fb) & 0xFFFFFFFF).sum()))
+    assert hj.column_sums(col.ptr + 4 * skew, n, fa, fb) == want
+    col.free()
