@@ -53,6 +53,13 @@ __device__ __forceinline__ T wave_reduce_sum(T x)
     return x;   // valid in lane 0
 }
 
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t x)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = max(x, (uint32_t)__shfl_down(x, d, 64));
+    return x;   // valid in lane 0
+}
+
 // Block-wide exclusive scan of one value per thread. `scratch` needs
 // BLOCK/64 + 1 entries of T in LDS; scratch[BLOCK/64] receives the block total.
 // Contains two __syncthreads(); every thread of the block must call it.

@@ -8,9 +8,13 @@
 typedef unsigned long long u64;
 
 // Geometry constants (also read by the planner on the host side).
-// Scatter tile = block * vectors_per_thread * 4 tuples (default 512 * 4 * 4 = 8192);
-// HJGPU_SCATTER_CFG="block,vpt" selects another built variant (tuning).
-int hj_scatter_tile();
+// Scatter tile = block * vectors_per_thread * 4 tuples.  Pass 1 of the join pipeline
+// (packed output) runs in whole-line mode when its carry buffers fit the LDS beside the
+// tile, which decides the tile size from the fan-out; see hj_scatter_config().
+constexpr uint32_t HJ_LINE_TUPLES = 16;          // packed (8-byte) tuples per 128-byte line
+struct ScatterConfig { int block, vpt; bool carry; };
+ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed);
+int hj_scatter_tile(int pass, uint32_t F, bool out_packed);
 constexpr int HJ_JOIN_SLICE    = 1 << 16;       // probe tuples per work item (target)
 
 // Join-kernel geometry: threads per workgroup, log2 of the LDS table slots, and
@@ -52,6 +56,7 @@ struct ScatterArgs {
     uint32_t in_packed, out_packed; // packed tuple = payload << 32 | key (8 bytes)
     const u64 *seg_off;             // [nseg+1] element offsets of the segments in kin/vin
     const u64 *tile_prefix;         // [nseg+1] exclusive prefix of tiles per segment
+    const uint4 *tile_desc;         // pass 2: [tiles][2] {first row, end row of the segment | first slot of the tile, cursor row}
     u64 *cursors;                   // [nseg*F] absolute output positions, advanced atomically
     uint32_t nseg, F, factor;
     uint32_t in_align;              // (address of kin / 4) % 4, same for vin
@@ -60,6 +65,7 @@ struct ScatterArgs {
     uint32_t strided;               // pass 2: tiles dealt round-robin instead of contiguous runs
     Pass1Geom geom;
     const u64 *range_base;          // [ranges][F] absolute output position of each (range, partition)
+    u64 *prof;                      // diagnostics (HJGPU_SCATTER_PROF=1): s_memtime ticks per phase, else NULL
 };
 
 struct JoinArgs {
@@ -95,12 +101,15 @@ struct PlanArgs {
     u64 *tp1[2];              // [chunks + 1] pass-1 tile prefix
     u64 *seg1[2];             // [chunks + 1] chunk boundaries
     u64 *tp2[2];              // [chunks*F1 + 1] pass-2 tile prefix
+    uint4 *tdesc[2];          // [pass-2 tiles][2] per-tile descriptors (one independent load per tile in K6)
+    uint32_t tdesc_cap;       // tiles the descriptor table holds
     u64 *slice_prefix;        // [P + 1]
     u64 *slices;              // [P]
     uint32_t *item_part;      // [P + outer/slice + 1] partition of every join work item
     uint32_t chunks, F1, F2;
     uint32_t in_align[2];     // alignment of the caller's input columns
-    uint32_t tile, slice;
+    uint32_t tile1, tile2;    // tuples per tile in pass 1 / pass 2
+    uint32_t slice;
     uint32_t mask;            // bit 0: plan R, bit 1: plan S, bit 2: join work items
 };
 

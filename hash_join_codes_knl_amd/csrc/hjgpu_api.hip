@@ -103,13 +103,16 @@ struct MetaLayout {
     u64 *counts[2], *off2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
     u64 *slice_prefix, *slices;
     uint32_t *item_part;         // [P + items_extra] partition of every join work item
+    uint4 *tdesc[2];             // [tdesc_cap][2] pass-2 tile descriptors (K5 -> K6 pass 2)
+    size_t tdesc_cap;
     uint32_t *range_counts[2];   // [ranges][F1] pass-1 counts per range (K4 -> K5b)
     u64 *range_base[2];          // [ranges][F1] pass-1 write bases per range (K5b -> K6)
     size_t counts_bytes;    // both relations, contiguous (zeroed per join)
     size_t total_bytes;
 };
 
-MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges, size_t items_extra = 0)
+MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges, size_t items_extra = 0,
+                 size_t tiles2 = 0)
 {
     MetaLayout m;
     u64 *p = reinterpret_cast<u64 *>(base);
@@ -134,6 +137,8 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
         m.range_counts[r] = reinterpret_cast<uint32_t *>(take((ranges * F1 + 1) / 2));
         m.range_base[r] = take(ranges * F1);
     }
+    m.tdesc_cap = tiles2;
+    for (int r = 0; r < 2; ++r) m.tdesc[r] = reinterpret_cast<uint4 *>(take(tiles2 * 4));
     m.total_bytes = at * sizeof(u64);
     return m;
 }
@@ -202,12 +207,15 @@ uint32_t range_tiles_for(u64 max_tiles, uint32_t F1)
     // default: ~4096 ranges per relation - fine-grained enough that concurrently running
     // workgroups write neighbouring regions, coarse enough that K4/K5b stay negligible
     u64 k = forced > 0 ? (u64)forced : (max_tiles + 4095) / 4096;
+    // whole-line mode (K6 CARRY) completes a line with the NEXT tile of the same range: give a
+    // range up to 8 tiles once there are enough tiles to keep >= 512 ranges
+    if (forced <= 0) { const u64 want = max_tiles / 512 < 8 ? max_tiles / 512 : 8; if (k < want) k = want; }
     if (k < 1) k = 1;
     while ((max_tiles + k - 1) / k * F1 > HJ_MAX_RANGE_ENTRIES) k *= 2;
     return (uint32_t)k;
 }
 
-Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1)
+Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1, bool out_packed)
 {
     // chunk ranges = thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
     Pass1Geom g;
@@ -216,7 +224,7 @@ Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1)
     for (uint32_t c = C; c < 9; ++c) g.b[c] = n;
     g.chunks = C;
     g.align = align_of(keys);
-    g.tile = (uint32_t)hj_scatter_tile();
+    g.tile = (uint32_t)hj_scatter_tile(1, F1, out_packed);
     u64 max_tiles = 1;
     for (uint32_t c = 0; c < C; ++c) {
         const u64 t = hj_tiles_of(g.b[c], g.b[c + 1], g.align, g.tile);
@@ -231,7 +239,7 @@ Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1)
 // PHJ / CPRA: fused histogram -> plan -> scatter x2 -> LDS join
 // ---------------------------------------------------------------------------
 struct PhjPlan {
-    size_t ranges, items_extra;
+    size_t ranges, items_extra, tiles2;
     uint32_t C, F1, F2, P;
     uint32_t f1, f2, tf0, tf1;
 };
@@ -262,10 +270,13 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
         CHK(ensure(ctx, ctx->tmp[6], sb));
     }
     // ranges of the larger relation bound the per-range tables of both
-    const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1), gs = make_geom(nullptr, outer, pl->C, pl->F1);
+    const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1, true), gs = make_geom(nullptr, outer, pl->C, pl->F1, true);
     pl->ranges = (size_t)(gr.ranges_per_chunk > gs.ranges_per_chunk ? gr.ranges_per_chunk : gs.ranges_per_chunk) * pl->C;
     pl->items_extra = outer / HJ_JOIN_SLICE + 1;
-    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges, pl->items_extra);
+    // pass-2 tiles: whole tiles of the relation plus up to two ragged tiles per segment
+    const size_t larger = inner > outer ? inner : outer;
+    pl->tiles2 = pl->F2 > 1 ? larger / (size_t)hj_scatter_tile(2, pl->F2, true) + 2 * (size_t)pl->C * pl->F1 + 8 : 0;
+    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges, pl->items_extra, pl->tiles2);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     return HJGPU_OK;
@@ -276,7 +287,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
                 const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr)
 {
-    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra);
+    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
@@ -285,7 +296,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
 
-    const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C, pl.F1), make_geom(sk, outer, pl.C, pl.F1)};
+    const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C, pl.F1, true), make_geom(sk, outer, pl.C, pl.F1, true)};
     const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
     const size_t nn[2] = {inner, outer};
     uint32_t *t1[4] = {(uint32_t *)ctx->tmp[0].p, nullptr, (uint32_t *)ctx->tmp[2].p, nullptr};
@@ -294,14 +305,16 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     for (int r = 0; r < 2; ++r) {
         pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
-        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
+        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r]; pa.tdesc[r] = m.tdesc[r];
     }
+    pa.tdesc_cap = (uint32_t)m.tdesc_cap;
     pa.n[0] = inner; pa.n[1] = outer;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
     pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
-    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE;
+    pa.tile1 = (uint32_t)hj_scatter_tile(1, pl.F1, true); pa.tile2 = (uint32_t)hj_scatter_tile(2, pl.F2, true);
+    pa.slice = HJ_JOIN_SLICE;
 
     // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
     auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
@@ -330,7 +343,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         if (nn[r] && pl.F2 > 1) {
             ScatterArgs sa;
             sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
-            sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r];
+            sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
             sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
             sa.ranged = 0; sa.strided = 1; sa.geom = geom[r]; sa.range_base = nullptr;
             sa.in_packed = 1; sa.out_packed = 1;
@@ -635,7 +648,7 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
     HIPCHK(ctx, hipMemsetAsync(d_counts, 0, (size_t)fanout * sizeof(u64), stream));
     if (n) {
         // the per-range counts are a by-product here; they go to scratch
-        const Pass1Geom g = make_geom(d_keys, n, 1, 1);
+        const Pass1Geom g = make_geom(d_keys, n, 1, 1, false);
         CHK(ensure(ctx, ctx->moves, (size_t)g.ranges_per_chunk * sizeof(uint32_t)));
         CHK(hj_launch_hist2(d_keys, g, 1u, 1u, factor, fanout, (u64 *)d_counts,
                             (uint32_t *)ctx->moves.p, ctx->cus, stream));
@@ -655,7 +668,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     CHK(check_columns(ctx, d_keys, d_vals, n));
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const Pass1Geom geom = make_geom(d_keys, n, 1, fanout);
+    const Pass1Geom geom = make_geom(d_keys, n, 1, fanout, false);
     MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
@@ -667,11 +680,12 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
+    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0;
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
-    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
+    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
     if (n) {
         CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
@@ -738,10 +752,11 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
+    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0;
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
-    pa.tile = (uint32_t)hj_scatter_tile(); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
+    pa.tile1 = pa.tile2 = (uint32_t)hj_scatter_tile(2, 1, true); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
     for (int e : {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2, EV_WAITED, EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2}) record(ctx, e, stream);
     JoinArgs ja;

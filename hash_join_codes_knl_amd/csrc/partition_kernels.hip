@@ -217,14 +217,30 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
         const int r = blockIdx.x;
         // pass-1 tiles: segments are the chunks of the caller's (possibly unaligned) input
         const uint32_t al = a.in_align[r];
-        const uint32_t tile = a.tile;
+        const uint32_t tile1 = a.tile1, tile2 = a.tile2;
         const u64 *seg1 = a.seg1[r];
-        plan_scan(C, [&](uint32_t i) { return hj_tiles_of(seg1[i], seg1[i + 1], al, tile); },
+        plan_scan(C, [&](uint32_t i) { return hj_tiles_of(seg1[i], seg1[i + 1], al, tile1); },
                   a.tp1[r], 0, scratch);
         // pass-2 tiles: segments are the pass-1 partitions inside the (aligned) workspace
         const u64 *off1 = a.off1[r];
-        plan_scan(C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile); },
+        plan_scan(C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile2); },
                   a.tp2[r], 0, scratch);
+        // per-tile descriptors of pass 2: K6 then needs ONE independent 32-byte load per tile instead
+        // of a search in tp2 followed by dependent reads of off1 (exposed latency on every tile)
+        if (a.tdesc[r]) {
+            const u64 *tp2 = a.tp2[r];
+            uint4 *td = a.tdesc[r];
+            // one wave per segment, one lane per tile (a segment of the probe side has hundreds of tiles)
+            for (uint32_t sgm = threadIdx.x >> 6; sgm < C * a.F1; sgm += PLAN_BLOCK / 64) {
+                const u64 gb = off1[sgm], ge = off1[sgm + 1];
+                const u64 t0 = tp2[sgm], t1 = min(tp2[sgm + 1], (u64)a.tdesc_cap);
+                for (u64 t = t0 + (threadIdx.x & 63); t < t1; t += 64) {
+                    const u64 g0 = (gb & ~3ull) + (t - t0) * tile2;
+                    td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
+                    td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), sgm * a.F2, sgm);
+                }
+            }
+        }
     } else {
         // join work items: partition q gets ceil(|S_q| / slice) items when both sides are non-empty
         const u64 *__restrict__ cr = a.counts[0];
@@ -298,19 +314,38 @@ int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStre
 // (payload << 32 | key, 8 bytes): a run of L tuples is then one 8L-byte burst
 // instead of two 4L-byte bursts in two arrays, which is what the DRAM sees.
 // IN_PACKED / OUT_PACKED select the format on either side.
-template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED>
+//
+// CARRY (pass 1 of the join pipeline: private cursors + packed output): every 128-byte
+// line of the output leaves the CU in one piece.  A run that ends in the middle of a line
+// is cut at the line boundary and its tail (< 16 tuples) waits in an LDS carry buffer for the
+// next tile of the range; the lanes that write the head of that tile's run also write the
+// carried tuples in front of it, in the same loop iteration.
+// Measured with tools/ubench_scatter_align.hip (same traffic, no sort), ms per 1G tuples:
+//   runs that start and end on 128-byte lines      3.3-3.4 at fan-out 16, 128 and 512
+//                                                  (even ONE line per partition and tile)
+//   the same runs shifted by 40 bytes              3.5 / 4.0 / 5.1
+//   a line completed one barrier later (split)     3.7 (128) / 5.8 (512)
+//   a line written by two waves in the same sweep  3.3 (no cost)
+// i.e. a partial line is not kept in the XCD's L2 until somebody completes it: it becomes a
+// read-modify-write at the memory side unless the rest arrives at about the same time.
+template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY>
 __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 {
+    static_assert(!CARRY || (RANGED && OUT_PACKED), "carry needs private cursors and packed output");
     constexpr int TILE = BLOCK * VPT * 4;
     constexpr int NW = BLOCK / 64;
     constexpr int BPT = (1024 + BLOCK - 1) / BLOCK;                 // max bins per thread (F <= 1024)
+    constexpr uint32_t LINE = HJ_LINE_TUPLES;                       // packed tuples per 128-byte line
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t F = a.F;
     const uint32_t Fpad = (F + 3) & ~3u;
-    u64 *delta = reinterpret_cast<u64 *>(smem);                     // [Fpad]  output - local position
+    u64 *delta = reinterpret_cast<u64 *>(smem);                     // [Fpad]  packed out: output position of the run; else output - local position
     u64 *stage = delta + Fpad;                                      // [TILE]  payload << 32 | key, sorted by partition
-    uint32_t *hist = reinterpret_cast<uint32_t *>(stage + TILE);    // [Fpad]  counts, then local bases
-    uint32_t *wsum = hist + Fpad;                                   // [NW + 1]
+    u64 *carry = stage + TILE;                                      // CARRY: [Fpad][LINE] tails waiting for their line
+    uint32_t *hist = reinterpret_cast<uint32_t *>(carry + (CARRY ? Fpad * LINE : 0));   // [Fpad]  counts, then local bases
+    uint32_t *meta = hist + Fpad;                                   // [Fpad] tuples leaving this tile | carried ones among them << 16
+    uint32_t *left = meta + Fpad;                                   // CARRY: [Fpad] first staying index | carry offset << 16 | count << 20
+    uint32_t *wsum = left + (CARRY ? Fpad : 0);                     // [NW + 2]; [NW + 1] = longest run (+ its offset inside a line)
 
     const int tid = threadIdx.x;
     // IN_PACKED inputs are workspace arrays (in_align == 0): tuple g lives in uint4 g/2
@@ -318,19 +353,20 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.vin - a.in_align);
     const uint32_t factor = a.factor;
     const uint32_t bpt = (F + BLOCK - 1) / BLOCK;                   // bins per thread in the scan
+    const u64 inv_F = 0x100000000ull / F + 1;                       // (u * inv_F) >> 32 == u / F for u * F < 2^32
     u64 mycur[BPT];                                                 // RANGED: cursors of my bins
+    uint32_t mycc[BPT];                                             // CARRY: tuples of my bins waiting in `carry`
 #pragma unroll
-    for (int i = 0; i < BPT; ++i) mycur[i] = 0;
+    for (int i = 0; i < BPT; ++i) { mycur[i] = 0; mycc[i] = 0; }
 
     // ---- the sequence of tiles this workgroup owns -------------------------------
-    struct Tile { u64 gb, ge, g0, cursor_row; uint32_t range; bool new_range, valid; };
+    struct Tile { u64 gb, ge, g0, cursor_row; uint32_t range; bool new_range, last_in_range, valid; };
     // RANGED state
     uint32_t r_cur = blockIdx.x;
     u64 rt = 0, rt_end = 0, r_gb = 0, r_ge = 0;
     bool r_open = false;
     // !RANGED state
     u64 t_cur = 0, t_end = 0;
-    uint32_t seg = 0;
     if (!RANGED) {
         const u64 total_tiles = a.tile_prefix[a.nseg];
         if (a.strided) { t_cur = blockIdx.x; t_end = total_tiles; }
@@ -338,11 +374,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             t_cur = total_tiles * blockIdx.x / gridDim.x;
             t_end = total_tiles * (blockIdx.x + 1) / gridDim.x;
         }
-        if (t_cur < t_end) seg = hj_find_segment(a.tile_prefix, a.nseg, t_cur);
     }
     auto next_tile = [&]() -> Tile {
         Tile t;
-        t.valid = false; t.new_range = false; t.range = 0; t.gb = t.ge = t.g0 = t.cursor_row = 0;
+        t.valid = false; t.new_range = false; t.last_in_range = false; t.range = 0; t.gb = t.ge = t.g0 = t.cursor_row = 0;
         if (RANGED) {
             const uint32_t Rc = a.geom.ranges_per_chunk;
             const uint32_t nranges = Rc * a.geom.chunks;
@@ -362,13 +397,15 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             t.gb = r_gb; t.ge = r_ge; t.g0 = (r_gb & ~3ull) + rt * (u64)TILE;
             t.range = r_cur; t.valid = true;
             ++rt;
+            t.last_in_range = rt >= rt_end;                         // CARRY: everything still waiting goes out
         } else {
             if (t_cur >= t_end) return t;
-            while (t_cur >= a.tile_prefix[seg + 1]) ++seg;          // skips empty segments too
-            t.gb = a.in_align + a.seg_off[seg];
-            t.ge = a.in_align + a.seg_off[seg + 1];
-            t.g0 = (t.gb & ~3ull) + (t_cur - a.tile_prefix[seg]) * (u64)TILE;
-            t.cursor_row = (u64)seg * F;
+            // one independent 32-byte read of the descriptor K5 wrote for this tile (in_align == 0)
+            const uint4 d0 = a.tile_desc[2 * t_cur], d1 = a.tile_desc[2 * t_cur + 1];
+            t.gb = (u64)d0.x | ((u64)d0.y << 32);
+            t.ge = (u64)d0.z | ((u64)d0.w << 32);
+            t.g0 = (u64)d1.x | ((u64)d1.y << 32);
+            t.cursor_row = d1.z;
             t.valid = true;
             t_cur += a.strided ? gridDim.x : 1;
         }
@@ -403,16 +440,41 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     Tile cur = next_tile();
     if (!cur.valid) return;
     load_tile(cur);
+    bool have_left = false;                                         // CARRY: the previous tile may have left tails in `stage`
+    // diagnostics: thread 0 adds the s_memtime ticks between consecutive barriers to prof[phase]
+    u64 t_prev = (a.prof && tid == 0) ? __builtin_amdgcn_s_memtime() : 0;
+    auto stamp = [&](int phase) {
+        if (a.prof && tid == 0) {
+            const u64 now = __builtin_amdgcn_s_memtime();
+            atomicAdd(&a.prof[phase], now - t_prev);
+            t_prev = now;
+        }
+    };
     for (;;) {
         if (RANGED && cur.new_range) {
 #pragma unroll
             for (int i = 0; i < BPT; ++i) {
                 const uint32_t bin = tid * bpt + i;
                 if ((uint32_t)i < bpt && bin < F) mycur[i] = a.range_base[(u64)cur.range * F + bin];
+                mycc[i] = 0;                                        // the previous range flushed its carry
+            }
+        }
+        if (CARRY && have_left) {
+            // tails of the previous tile's runs (still in `stage`, described by `left`) move
+            // behind whatever already waits in the carry; nobody touches either until the sort
+            for (uint32_t idx = tid; idx < F * LINE; idx += BLOCK) {
+                const uint32_t p = idx / LINE, j = idx % LINE;
+                const uint32_t m = left[p];
+                if (j < (m >> 20)) carry[p * LINE + ((m >> 16) & 0xFu) + j] = stage[(m & 0xFFFFu) + j];
             }
         }
         for (uint32_t i = tid; i < F; i += BLOCK) hist[i] = 0;
+        if (tid == 0) wsum[NW + 1] = 0;
         hj_barrier_lds();
+        stamp(0);
+        // the next tile's descriptor (pass 2: one read of K5's table; a scalar load, which the next
+        // barrier's lgkmcnt(0) would expose) is requested here so that it lands during the ranking
+        const Tile nxt = next_tile();
 
         // ---- rank every tuple inside its partition (ds_add_rtn_u32) --------------
         uint32_t pr[VPT * 4];
@@ -432,6 +494,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             }
         }
         hj_barrier_lds();
+        stamp(1);
 
         // ---- local bases + one output run per non-empty partition --------------
         // Pass 2 claims its runs with returning global atomics; they are ISSUED here, as soon
@@ -439,27 +502,61 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         // (1-2 us under load) overlaps the scan and the staging instead of stalling the tile.
         uint32_t cnt[BPT], lb[BPT];
         u64 dst[BPT];
+        uint32_t carried[BPT], emitted[BPT], coff[BPT];                // CARRY only
         uint32_t sum = 0;
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
-            cnt[i] = ((uint32_t)i < bpt && bin < F) ? hist[bin] : 0;
+            const bool mine = (uint32_t)i < bpt && bin < F;
+            cnt[i] = mine ? hist[bin] : 0;
             sum += cnt[i];
-            dst[i] = 0;
-            if (cnt[i]) {
+            dst[i] = 0; carried[i] = emitted[i] = coff[i] = 0;
+            if (CARRY) {
+                if (mine) {
+                    // c tuples wait in the carry, cnt[i] are new: emit up to the last line boundary
+                    // that [cur0, cur0 + c + cnt) reaches (everything on the range's last tile)
+                    const uint32_t c = mycc[i], avail = c + cnt[i];
+                    const u64 cur0 = mycur[i];
+                    uint32_t e = avail;
+                    if (!cur.last_in_range) {
+                        const u64 end = (cur0 + avail) & ~(u64)(LINE - 1);
+                        e = end > cur0 ? (uint32_t)(end - cur0) : 0u;
+                    }
+                    if (e) carried[i] = c;                              // e >= c: cur0 + c lies before the boundary
+                    else coff[i] = c;                                   // nothing leaves: the new tuples join the carry
+                    emitted[i] = e;
+                    dst[i] = cur0;
+                    mycur[i] = cur0 + e; mycc[i] = avail - e;           // < LINE, and 0 after the range's last tile
+                }
+            } else if (cnt[i]) {
                 if (RANGED) { dst[i] = mycur[i]; mycur[i] = dst[i] + cnt[i]; }
                 else dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
             }
         }
         uint32_t run = block_exclusive_scan<BLOCK, uint32_t, true>(sum, wsum);
+        uint32_t longest = 0;                                           // longest run of my bins, in output slots
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
             lb[i] = run;
-            if ((uint32_t)i < bpt && bin < F) hist[bin] = run;
+            if ((uint32_t)i < bpt && bin < F) {
+                hist[bin] = run;
+                if (CARRY) {
+                    const uint32_t fresh = emitted[i] - carried[i];     // new tuples that leave with this tile
+                    meta[bin] = emitted[i] | (carried[i] << 16);
+                    left[bin] = (run + fresh) | (coff[i] << 16) | ((cnt[i] - fresh) << 20);
+                    delta[bin] = dst[i];
+                    if (emitted[i]) longest = max(longest, emitted[i] + ((uint32_t)dst[i] & (LINE - 1)));
+                } else if (OUT_PACKED) meta[bin] = cnt[i];
+            }
             run += cnt[i];
         }
+        if (CARRY) {
+            longest = wave_reduce_max(longest);
+            if (hj_lane() == 0 && longest) atomicMax(&wsum[NW + 1], longest);
+        }
         hj_barrier_lds();
+        stamp(2);
         const uint32_t tile_count = wsum[NW];
 
         // ---- counting sort inside LDS --------------------------------------------
@@ -475,92 +572,182 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             }
         }
         // consume the claims (pass 2: the atomics have had the scan and the sort to return) ...
+        if (!CARRY) {
+            uint32_t longest = 0;
 #pragma unroll
-        for (int i = 0; i < BPT; ++i)
-            if (cnt[i]) delta[tid * bpt + i] = dst[i] - lb[i];
+            for (int i = 0; i < BPT; ++i)
+                if (cnt[i]) {
+                    if (OUT_PACKED) {
+                        delta[tid * bpt + i] = dst[i];
+                        longest = max(longest, cnt[i] + ((uint32_t)dst[i] & (LINE - 1)));
+                    } else delta[tid * bpt + i] = dst[i] - lb[i];
+                }
+            if (OUT_PACKED) {
+                longest = wave_reduce_max(longest);
+                if (hj_lane() == 0 && longest) atomicMax(&wsum[NW + 1], longest);
+            }
+        }
         // ... and only then start the next tile's loads: the vector-memory counter is in
         // order, so any wait on an older result placed after these loads would also wait for
         // them.  Nothing below touches them until the next tile is ranked, and the barriers are
         // LDS-only, so they stay in flight during the whole stream-out.
-        const Tile nxt = next_tile();
         if (nxt.valid) load_tile(nxt);
         hj_barrier_lds();
+        stamp(3);
 
-        // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
-        for (uint32_t i = tid; i < tile_count; i += BLOCK) {
-            const u64 kv = stage[i];
-            const uint32_t k = (uint32_t)kv;
-            const u64 d = delta[hj_hash(k, factor, F)] + i;
-            if (OUT_PACKED) reinterpret_cast<u64 *>(a.kout)[d] = kv;
-            else { a.kout[d] = k; a.vout[d] = (uint32_t)(kv >> 32); }
+        if (OUT_PACKED) {
+            // ---- stream out, one 16-lane group per run --------------------------------
+            // A group walks a partition's run in 128-byte lines of the OUTPUT: lane `sub` moves the two
+            // tuples of its 16-byte slot, so a line leaves the CU as one piece of one instruction,
+            // no hash and no per-tuple lookups are needed, and a store carries 16 bytes per lane.
+            // A unit is (partition, UNIT consecutive output slots); units are dealt round-robin.
+            constexpr uint32_t NG = BLOCK / 16, UNIT = 256;
+            const uint32_t gid = tid >> 4, sub = tid & 15;
+            const uint32_t units_per_part = (wsum[NW + 1] + UNIT - 1) / UNIT;
+            u64 *__restrict__ out64 = reinterpret_cast<u64 *>(a.kout);
+            for (uint32_t u = gid; u < units_per_part * F; u += NG) {
+                const uint32_t c = (uint32_t)(((u64)u * inv_F) >> 32), p = u - c * F;     // u / F, u % F
+                const uint32_t m = meta[p], e = m & 0xFFFFu, fc = m >> 16;
+                if (e == 0) continue;
+                const u64 d0 = delta[p];
+                const uint32_t off = (uint32_t)d0 & (LINE - 1);     // slot of the run's first tuple inside its line
+                const uint32_t lim = off + e, s_end = min(lim, (c + 1) * UNIT);
+                const u64 base = d0 - off;
+                const uint32_t src0 = hist[p];                      // sorted index of the first fresh tuple
+                auto fetch = [&](uint32_t k) -> u64 { return k < fc ? carry[p * LINE + k] : stage[src0 + (k - fc)]; };
+                for (uint32_t s = c * UNIT + sub * 2; s < s_end; s += 32) {
+                    const bool v0 = s >= off, v1 = s + 1 >= off && s + 1 < lim;
+                    if (v0 && v1) {
+                        const u64 t0 = fetch(s - off), t1 = fetch(s + 1 - off);
+                        *reinterpret_cast<uint4 *>(out64 + base + s) =
+                            make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
+                    } else if (v0) out64[base + s] = fetch(s - off);
+                    else if (v1) out64[base + s + 1] = fetch(s + 1 - off);
+                }
+            }
+        } else {
+            // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
+            for (uint32_t i = tid; i < tile_count; i += BLOCK) {
+                const u64 kv = stage[i];
+                const uint32_t k = (uint32_t)kv;
+                const u64 d = delta[hj_hash(k, factor, F)] + i;
+                a.kout[d] = k; a.vout[d] = (uint32_t)(kv >> 32);
+            }
         }
         hj_barrier_lds();
+        stamp(4);
         if (!nxt.valid) break;
         cur = nxt;
+        have_left = true;
     }
 }
 
-struct ScatterConfig { int block, vpt; };
-static const ScatterConfig &scatter_config()
+// ---- geometry of a pass: workgroup size, vectors per thread, whole-line mode -------
+static size_t scatter_lds(int block, int vpt, uint32_t F, bool carry)
 {
-    static ScatterConfig cfg;
-    cfg.block = 1024; cfg.vpt = 4;
-    const char *e = getenv("HJGPU_SCATTER_CFG");           // "block,vectors_per_thread" (tuning)
-    int b, v;
-    if (e && sscanf(e, "%d,%d", &b, &v) == 2) { cfg.block = b; cfg.vpt = v; }
+    const size_t Fpad = (F + 3) & ~3u;
+    return Fpad * 16 + (size_t)block * vpt * 4 * 8 + (carry ? Fpad * (HJ_LINE_TUPLES * 8 + 4) : 0) +
+           (block / 64 + 2) * 4 + 16;
+}
+constexpr size_t HJ_LDS_LIMIT = 160 * 1024;          // gfx950: 160 KiB per CU, all of it usable by one workgroup
+
+// pass 1: the largest tile whose stage + carry buffers fit the LDS (F <= 209: 16384 tuples,
+// <= 421: 12288, <= 640: 8192); beyond that, and for separate output columns, no carry.
+// pass 2: 16384-tuple tiles, shared atomic cursors (a workgroup visits a segment about once,
+// so there is no "next tile" to complete a line).
+// HJGPU_SCATTER_CFG / HJGPU_SCATTER2_CFG = "block,vpt[,carry]" override (tuning).
+ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed)
+{
+    ScatterConfig cfg = {1024, 4, false};
+    const char *e = getenv(pass == 1 ? "HJGPU_SCATTER_CFG" : "HJGPU_SCATTER2_CFG");
+    int b, v, c = -1;
+    if (e && sscanf(e, "%d,%d,%d", &b, &v, &c) >= 2) {
+        cfg.block = b; cfg.vpt = v;
+        cfg.carry = pass == 1 && out_packed && c != 0 && scatter_lds(b, v, F, true) <= HJ_LDS_LIMIT;
+        return cfg;
+    }
+    if (pass == 1 && out_packed) {
+        for (int vpt = 4; vpt >= 2; --vpt)
+            if (scatter_lds(1024, vpt, F, true) <= HJ_LDS_LIMIT) { cfg.vpt = vpt; cfg.carry = true; break; }
+    }
     return cfg;
 }
 
-int hj_scatter_tile() { return scatter_config().block * scatter_config().vpt * 4; }
+int hj_scatter_tile(int pass, uint32_t F, bool out_packed)
+{
+    const ScatterConfig c = hj_scatter_config(pass, F, out_packed);
+    return c.block * c.vpt * 4;
+}
 
-template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED>
+template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY>
 static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
 {
-    constexpr int TILE = BLOCK * VPT * 4;
-    const uint32_t Fpad = (a.F + 3) & ~3u;
-    const size_t lds = (size_t)Fpad * 12 + (size_t)TILE * 8 + (BLOCK / 64 + 1) * 4 + 16;
+    const size_t lds = scatter_lds(BLOCK, VPT, a.F, CARRY);
+    if (lds > HJ_LDS_LIMIT) return HJGPU_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HJ_LDS_LIMIT) != hipSuccess)
             return HJGPU_EHIP;
         attr_set = true;
     }
     // persistent grid: as many workgroups per CU as LDS (160 KiB) and threads (2048) allow
-    int per_cu = (int)((160 * 1024) / (lds + 512));
+    int per_cu = (int)(HJ_LDS_LIMIT / (lds + 512));
     if (per_cu > 2048 / BLOCK) per_cu = 2048 / BLOCK;
     if (per_cu < 1) per_cu = 1;
     const int grid = cus * per_cu;
     ScatterArgs b = a;
     // pass-2 tile ownership: round-robin (default) keeps all workgroups inside the same
-    // one or two pass-1 partitions, whose output region (~60 MB at |S| = 1G) stays in the
-    // Infinity Cache: 3.9-4.0 ms vs 4.45-4.65 ms for contiguous runs.  HJGPU_PASS2_STRIDED=0 flips.
+    // one or two pass-1 partitions, whose output region stays in the Infinity Cache:
+    // 3.9-4.0 ms vs 4.45-4.65 ms for contiguous runs at 136 x 136.  HJGPU_PASS2_STRIDED=0 flips.
     const char *e = getenv("HJGPU_PASS2_STRIDED");
     b.strided = (e && !atoi(e)) ? 0u : 1u;
-    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED>), dim3(grid), dim3(BLOCK), lds, stream, b);
+    // diagnostics only: HJGPU_SCATTER_PROF=1 prints where a workgroup's time goes (synchronises!)
+    static u64 *prof = nullptr;
+    const char *pe = getenv("HJGPU_SCATTER_PROF");
+    b.prof = nullptr;
+    if (pe && atoi(pe)) {
+        if (!prof && hipMalloc(&prof, 8 * sizeof(u64)) != hipSuccess) return HJGPU_ENOMEM;
+        (void)hipMemsetAsync(prof, 0, 8 * sizeof(u64), stream);
+        b.prof = prof;
+    }
+    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY>), dim3(grid), dim3(BLOCK), lds, stream, b);
+    if (b.prof) {
+        u64 h[8];
+        (void)hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, stream);
+        (void)hipStreamSynchronize(stream);
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        fprintf(stderr, "scatter<%d,%d,%s%s> F=%u grid=%d: zero %.1f%% rank(+load wait) %.1f%% scan %.1f%% sort %.1f%% stream-out %.1f%%  (%.0f ticks/wg)\n",
+                BLOCK, VPT, RANGED ? "ranged" : "atomic", CARRY ? ",carry" : "", a.F, grid, 100 * h[0] / tot, 100 * h[1] / tot,
+                100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, tot / grid);
+    }
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
-// pass 1: separate columns in, ranged; out packed (join pipeline) or separate (hjgpu_partition)
+// pass 1: separate columns in, ranged; out packed (join pipeline, whole-line mode when it
+//         fits) or separate (hjgpu_partition)
 // pass 2: packed in, packed out, atomic cursors
 #define SCATTER_CASE(B, V)                                                                   \
     if (c.block == B && c.vpt == V) {                                                        \
-        if (a.ranged && !a.in_packed && a.out_packed) return launch_scatter_t<B, V, true, false, true>(a, cus, stream);   \
-        if (a.ranged && !a.in_packed && !a.out_packed) return launch_scatter_t<B, V, true, false, false>(a, cus, stream); \
-        if (!a.ranged && a.in_packed && a.out_packed) return launch_scatter_t<B, V, false, true, true>(a, cus, stream);   \
+        if (a.ranged && !a.in_packed && a.out_packed && c.carry) return launch_scatter_t<B, V, true, false, true, true>(a, cus, stream);   \
+        if (a.ranged && !a.in_packed && a.out_packed) return launch_scatter_t<B, V, true, false, true, false>(a, cus, stream);  \
+        if (a.ranged && !a.in_packed && !a.out_packed) return launch_scatter_t<B, V, true, false, false, false>(a, cus, stream); \
+        if (!a.ranged && a.in_packed && a.out_packed) return launch_scatter_t<B, V, false, true, true, false>(a, cus, stream);   \
         return HJGPU_EINVAL;                                                                 \
     }
 
 int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream)
 {
     if (a.F == 0 || a.F > HJGPU_MAX_FANOUT) return HJGPU_EINVAL;
-    if (a.ranged && a.geom.tile != (uint32_t)hj_scatter_tile()) return HJGPU_EINVAL;
-    const ScatterConfig &c = scatter_config();
-    SCATTER_CASE(512, 4)
-    SCATTER_CASE(256, 4)
-    SCATTER_CASE(256, 8)
-    SCATTER_CASE(1024, 2)
+    const ScatterConfig c = hj_scatter_config(a.ranged ? 1 : 2, a.F, a.out_packed != 0);
+    if (a.ranged && a.geom.tile != (uint32_t)(c.block * c.vpt * 4)) return HJGPU_EINVAL;
     SCATTER_CASE(1024, 4)
+    SCATTER_CASE(1024, 3)
+    SCATTER_CASE(1024, 2)
+    SCATTER_CASE(512, 4)
+    SCATTER_CASE(512, 3)
     SCATTER_CASE(512, 2)
+    SCATTER_CASE(256, 4)
+    SCATTER_CASE(256, 2)
     return HJGPU_EINVAL;
 }
