@@ -127,13 +127,14 @@ int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStre
 // NPJ
 int hj_launch_npj_build(const uint32_t *keys, const uint32_t *vals, size_t n, u64 *table,
                         size_t buckets, uint32_t factor, uint32_t *zero_key_flag,
-                        int cus, hipStream_t stream);
+                        int cus, hipStream_t stream, bool line_hash = false);
 struct NpjProbeArgs {
     const uint32_t *keys, *vals;
     size_t n;
     const u64 *table;
     size_t buckets;
     uint32_t factor;
+    uint32_t line_hash;                  // 1: walks start on 64-byte lines (the library's own tables)
     hjgpu_result *result;
     uint32_t *ok, *oov, *oiv;
     u64 block_size, block_limit;

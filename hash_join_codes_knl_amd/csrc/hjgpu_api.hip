@@ -421,7 +421,7 @@ int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_
     size_t b = (size_t)((double)inner / load);             // npj.cpp:947
     if (b <= inner) b = inner + 1;
     if (b < 16) b = 16;
-    b = (b + 3) & ~size_t(3);                               // whole 4-bucket groups: grouped probe walk
+    b = (b + 7) & ~size_t(7);                               // whole 64-byte lines of 8 buckets (line-hashed walk)
     *buckets = b;
     *factor = (prm && prm->factor) ? prm->factor : DEFAULT_NPJ_FACTOR;
     if (!(*factor & 1)) return fail(ctx, HJGPU_EINVAL, "hash factor must be odd");
@@ -432,7 +432,7 @@ int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_
 
 int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, size_t outer,
                       const u64 *table, size_t buckets, uint32_t factor, const hjgpu_output *out,
-                      hipStream_t stream)
+                      hipStream_t stream, bool line_hash = false)
 {
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
@@ -442,7 +442,7 @@ int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, si
         NpjProbeArgs pa;
         memset(&pa, 0, sizeof(pa));
         pa.keys = sk; pa.vals = sv; pa.n = outer; pa.table = table; pa.buckets = buckets;
-        pa.factor = factor; pa.result = &st->result;
+        pa.factor = factor; pa.line_hash = line_hash ? 1u : 0u; pa.result = &st->result;
         if (bs) {
             pa.ok = out->d_keys; pa.oov = out->d_outer_vals; pa.oiv = out->d_inner_vals;
             pa.block_size = bs; pa.block_limit = bl; pa.block_counter = &st->block_counter;
@@ -471,9 +471,12 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
     // K1 set() npj.cpp:865-868 ; K2 build() 871-877
     HIPCHK(ctx, hipMemsetAsync(table, 0, buckets * sizeof(u64), stream));
-    if (inner) CHK(hj_launch_npj_build(rk, rv, inner, table, buckets, factor, &st->zero_key, ctx->cus, stream));
+    // whole joins own their table: line-hashed layout (operator-level hjgpu_npj_build / _probe keep
+    // the reference's hash so that their tables stay interchangeable with the reference's)
+    const bool line = getenv("HJGPU_NPJ_REFHASH") == nullptr;
+    if (inner) CHK(hj_launch_npj_build(rk, rv, inner, table, buckets, factor, &st->zero_key, ctx->cus, stream, line));
     record(ctx, EV_R_HIST, stream);     // reused as "end of build"
-    CHK(npj_probe_enqueue(ctx, sk, sv, outer, table, buckets, factor, out, stream));
+    CHK(npj_probe_enqueue(ctx, sk, sv, outer, table, buckets, factor, out, stream, line));
     ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets;
     ctx->last_algo = 0;
     return HJGPU_OK;
