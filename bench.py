@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--algo", choices=["phj", "npj", "cpra"], default="phj")
     ap.add_argument("--inner", type=int, default=64_000_000, help="|R| build tuples (replicated)")
     ap.add_argument("--outer", type=int, default=1_000_000_000, help="|S| probe tuples PER GPU")
+    ap.add_argument("--zipf", type=float, default=0.0,
+                    help="Zipf exponent of the probe side's repeat picks (0 = uniform, the headline workload)")
     ap.add_argument("--fanout1", type=int, default=0)
     ap.add_argument("--fanout2", type=int, default=0)
     ap.add_argument("--cpu-outer", type=int, default=256_000_000,
@@ -130,8 +132,8 @@ def main():
                           sv.data_ptr(), stream)
     else:
         # every rank generates R (identical) and its own shard of S
-        hj.generate(1, inner, outer_total, rank * outer, outer, INNER_FACTOR, OUTER_FACTOR,
-                    rk.data_ptr(), rv.data_ptr(), sk.data_ptr(), sv.data_ptr(), stream)
+        hj.generate_zipf(1, inner, outer_total, 0, inner, rank * outer, outer, INNER_FACTOR, OUTER_FACTOR,
+                         args.zipf, rk.data_ptr(), rv.data_ptr(), sk.data_ptr(), sv.data_ptr(), stream)
     sums = hj.column_sums(sk.data_ptr(), outer, OUTER_FACTOR, INNER_FACTOR, stream)
     # uint64 aggregates as int64 bit patterns (sums stay far below 2^63 at these sizes)
     expect_local = [outer, sums[0], sums[1], sums[2]]
@@ -314,9 +316,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s end-to-end (histogram + %s + LDS build/probe, aggregate output), "
-                               "uniform unique 32-bit keys, |R|=%d %s, |S|=%d per GPU, selectivity 1"
+                               "%s unique 32-bit keys, |R|=%d %s, |S|=%d per GPU, selectivity 1"
                                % (args.algo.upper(), "2 scatter passes" if st["fanout2"] > 1 else "1 scatter pass",
-                                  inner, "per GPU (co-partitioned)" if copart else "replicated", outer),
+                                  "uniform" if args.zipf <= 0 else "Zipf(%g) probe side," % args.zipf, inner, "per GPU (co-partitioned)" if copart else "replicated", outer),
                    "algorithm": args.algo, "inner_tuples": inner, "outer_tuples_per_gpu": outer,
                    "outer_tuples_total": outer_total,
                    "fanout": [st["fanout1"], st["fanout2"]],

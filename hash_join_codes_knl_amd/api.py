@@ -25,7 +25,7 @@ EXPORTS = [
     "hjgpu_npj_build", "hjgpu_npj_probe",
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
-    "hjgpu_join_host", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_column_sums",
+    "hjgpu_join_host", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums",
 ]
 
 
@@ -123,6 +123,7 @@ def load_library(build_if_missing=True):
                                   C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Stats)]
     L.hjgpu_generate.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
     L.hjgpu_generate_range.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
+    L.hjgpu_generate_zipf.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, C.c_double, vp, vp, vp, vp, vp]
     L.hjgpu_column_sums.argtypes = [vp, vp, sz, u32, u32, u64p, vp]
     for name in EXPORTS:
         if name not in ("hjgpu_last_error", "hjgpu_status_string"):
@@ -318,6 +319,13 @@ class HjGpu:
                                                   inner_count, outer_begin, outer_count, inner_factor,
                                                   outer_factor, self._ptr(ik), self._ptr(iv),
                                                   self._ptr(ok), self._ptr(ov), stream))
+
+    def generate_zipf(self, seed, inner_total, outer_total, inner_begin, inner_count, outer_begin,
+                      outer_count, inner_factor, outer_factor, zipf, ik, iv, ok, ov, stream=None):
+        self._check(self.lib.hjgpu_generate_zipf(self.handle, seed, inner_total, outer_total, inner_begin,
+                                                 inner_count, outer_begin, outer_count, inner_factor,
+                                                 outer_factor, float(zipf), self._ptr(ik), self._ptr(iv),
+                                                 self._ptr(ok), self._ptr(ov), stream))
 
     def column_sums(self, d_keys, n, fa, fb, stream=None):
         sums = (C.c_uint64 * 3)()

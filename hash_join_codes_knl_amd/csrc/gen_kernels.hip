@@ -12,6 +12,7 @@
 // goal (the host-side oracle generator covers that, oracle/hj_oracle.c).
 #include "hj_device.hpp"
 #include "hj_internal.hpp"
+#include <math.h>
 
 // lowbias32: a bijection on 32-bit integers with mix32(0) == 0, hence
 // mix32(x) != 0 for x != 0 and distinct x give distinct keys.
@@ -39,6 +40,8 @@ struct GenArgs {
     u64 mul_r, add_r;           // same for the build side, mod inner
     uint32_t key_base;          // build key i = mix32(key_base + i), key_base + i in [1, 2^32)
     uint32_t inner_factor, outer_factor;
+    double zipf;                // > 0: repeat picks of the probe side follow a Zipf law over the distinct keys
+    double zipf_a, zipf_b;      // rank = (a*x + 1)^b for x uniform in (0,1)   (s != 1);  distinct^x  (s == 1)
     uint32_t *ik, *iv, *ok, *ov;
 };
 
@@ -64,7 +67,15 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
             const u64 jp = (pos * a.mul + a.add) % a.outer_total;     // "shuffle": a bijection of positions
             u64 r;
             if (jp < a.distinct) r = jp;                               // every distinct key once
-            else r = __umul64hi(splitmix64(jp ^ a.seed), a.distinct);  // then uniform picks
+            else if (a.zipf > 0.0) {
+                // continuous inverse-CDF approximation of a Zipf(s) law over ranks 1..distinct
+                // (the same formula as the host generator, host/write_main.cpp; write.cpp:1477-1480
+                // is the reference's unfinished attempt): rank 1 is the hottest key
+                const double x = ((double)(splitmix64(jp ^ a.seed) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+                const double rank = a.zipf_b == 0.0 ? pow((double)a.distinct, x) : pow(a.zipf_a * x + 1.0, a.zipf_b);
+                r = rank >= 1.0 ? (u64)rank - 1 : 0;
+                if (r >= a.distinct) r = a.distinct - 1;
+            } else r = __umul64hi(splitmix64(jp ^ a.seed), a.distinct);  // then uniform picks
             const uint32_t k = mix32(a.key_base + (uint32_t)r);
             a.ok[j] = k;
             a.ov[j] = k * a.outer_factor;
@@ -77,7 +88,7 @@ static u64 gcd_u64(u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } re
 int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_count,
                        size_t outer_total, size_t outer_begin,
                        size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
-                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream)
+                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream, double zipf)
 {
     if (inner == 0 || inner >= 0xFFFFFFFFull) return HJGPU_EINVAL;
     if (ik && inner_begin + inner_count > inner) return HJGPU_EINVAL;
@@ -99,6 +110,11 @@ int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_
     a.add = (a.seed >> 7) % a.outer_total;
     a.key_base = 1u + (uint32_t)((a.seed >> 11) % (0xFFFFFFFFull - a.distinct));
     a.inner_factor = inner_factor | 1u; a.outer_factor = outer_factor | 1u;
+    a.zipf = zipf > 0.0 ? zipf : 0.0; a.zipf_a = a.zipf_b = 0.0;
+    if (a.zipf > 0.0 && fabs(a.zipf - 1.0) >= 1e-9) {
+        a.zipf_a = pow((double)a.distinct, 1.0 - a.zipf) - 1.0;
+        a.zipf_b = 1.0 / (1.0 - a.zipf);
+    }
     a.ik = ik; a.iv = iv; a.ok = ok; a.ov = ov;
     hipLaunchKernelGGL(generate_kernel, dim3(4096), dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;

@@ -12,6 +12,8 @@ typedef unsigned long long u64;
 // (packed output) runs in whole-line mode when its carry buffers fit the LDS beside the
 // tile, which decides the tile size from the fan-out; see hj_scatter_config().
 constexpr uint32_t HJ_LINE_TUPLES = 16;          // packed (8-byte) tuples per 128-byte line
+constexpr uint32_t HJ_STREAM_UNIT = 256;         // output slots one 16-lane group streams out at a time
+constexpr uint32_t HJ_MAX_HEAVY = 16384 / HJ_STREAM_UNIT + 8;   // runs longer than a unit in one tile (tile <= 16384)
 struct ScatterConfig { int block, vpt; bool carry; };
 ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed);
 int hj_scatter_tile(int pass, uint32_t F, bool out_packed);
@@ -159,6 +161,7 @@ int hj_npj_probe_grid(int cus, size_t n);
 int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_count,
                        size_t outer_total, size_t outer_begin,
                        size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
-                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream);
+                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream,
+                       double zipf = 0.0);
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
                           hipStream_t stream);

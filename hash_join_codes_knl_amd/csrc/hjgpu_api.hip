@@ -953,12 +953,22 @@ int hjgpu_generate_range(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size
                          uint32_t inner_factor, uint32_t outer_factor,
                          uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
 {
+    return hjgpu_generate_zipf(ctx, seed, inner_total, outer_total, inner_begin, inner_count, outer_begin,
+                               outer_count, inner_factor, outer_factor, 0.0, ik, iv, ok, ov, stream_);
+}
+
+int hjgpu_generate_zipf(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
+                        size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
+                        uint32_t inner_factor, uint32_t outer_factor, double zipf,
+                        uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
+{
     if (!ctx) return HJGPU_EINVAL;
+    if (!(zipf >= 0.0) || zipf > 8.0) return fail(ctx, HJGPU_EINVAL, "zipf exponent must be in [0, 8]");
     if ((ik && !iv) || (ok && !ov)) return fail(ctx, HJGPU_EINVAL, "key column without payload column");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = hj_launch_generate(seed, inner_total, inner_begin, inner_count, outer_total, outer_begin,
-                                outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream);
+                                outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream, zipf);
     if (rc != HJGPU_OK) return fail(ctx, rc, "generate: bad sizes or launch failure");
     HIPCHK(ctx, hipStreamSynchronize(stream));
     return HJGPU_OK;

@@ -336,6 +336,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     constexpr int NW = BLOCK / 64;
     constexpr int BPT = (1024 + BLOCK - 1) / BLOCK;                 // max bins per thread (F <= 1024)
     constexpr uint32_t LINE = HJ_LINE_TUPLES;                       // packed tuples per 128-byte line
+    constexpr uint32_t UNIT = HJ_STREAM_UNIT;                       // output slots a 16-lane group moves at a time
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t F = a.F;
     const uint32_t Fpad = (F + 3) & ~3u;
@@ -345,7 +346,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     uint32_t *hist = reinterpret_cast<uint32_t *>(carry + (CARRY ? Fpad * LINE : 0));   // [Fpad]  counts, then local bases
     uint32_t *meta = hist + Fpad;                                   // [Fpad] tuples leaving this tile | carried ones among them << 16
     uint32_t *left = meta + Fpad;                                   // CARRY: [Fpad] first staying index | carry offset << 16 | count << 20
-    uint32_t *wsum = left + (CARRY ? Fpad : 0);                     // [NW + 2]; [NW + 1] = longest run (+ its offset inside a line)
+    uint32_t *wsum = left + (CARRY ? Fpad : 0);                     // [NW + 6]; [NW + 1] = number of runs longer than one unit,
+                                                                    // [NW + 2] = this tile's heavy partition (count << 10 | bin, 0 = none),
+                                                                    // [NW + 3] = the same for the next tile
+    uint32_t *heavy = wsum + NW + 6;                                // [HJ_MAX_HEAVY] partitions whose run is longer than one unit
 
     const int tid = threadIdx.x;
     // IN_PACKED inputs are workspace arrays (in_align == 0): tuple g lives in uint4 g/2
@@ -353,7 +357,6 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.vin - a.in_align);
     const uint32_t factor = a.factor;
     const uint32_t bpt = (F + BLOCK - 1) / BLOCK;                   // bins per thread in the scan
-    const u64 inv_F = 0x100000000ull / F + 1;                       // (u * inv_F) >> 32 == u / F for u * F < 2^32
     u64 mycur[BPT];                                                 // RANGED: cursors of my bins
     uint32_t mycc[BPT];                                             // CARRY: tuples of my bins waiting in `carry`
 #pragma unroll
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     if (!cur.valid) return;
     load_tile(cur);
     bool have_left = false;                                         // CARRY: the previous tile may have left tails in `stage`
+    bool have_left_or_prev = false;                                 // a previous tile exists (its skew verdict is in wsum[NW + 3])
     // diagnostics: thread 0 adds the s_memtime ticks between consecutive barriers to prof[phase]
     u64 t_prev = (a.prof && tid == 0) ? __builtin_amdgcn_s_memtime() : 0;
     auto stamp = [&](int phase) {
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             }
         }
         for (uint32_t i = tid; i < F; i += BLOCK) hist[i] = 0;
-        if (tid == 0) wsum[NW + 1] = 0;
+        if (tid == 0) { wsum[NW + 1] = 0; wsum[NW + 2] = have_left_or_prev ? wsum[NW + 3] : 0; wsum[NW + 3] = 0; }
         hj_barrier_lds();
         stamp(0);
         // the next tile's descriptor (pass 2: one read of K5's table; a scalar load, which the next
@@ -477,21 +481,44 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         const Tile nxt = next_tile();
 
         // ---- rank every tuple inside its partition (ds_add_rtn_u32) --------------
+        // Skew: when one partition takes a large share of the tile (a heavy-hitter key, e.g. a Zipf
+        // probe side) many lanes of an instruction add to the SAME LDS word and the adds serialise.
+        // The previous tile names its largest partition when that held > 1/16 of the tile; its lanes
+        // are then served by ONE add of the group's size, with ranks from mbcnt.
+        const uint32_t hot_word = wsum[NW + 2];
+        const bool hot = hot_word != 0;
+        const uint32_t hot_p = hot_word & 1023u;
         uint32_t pr[VPT * 4];
+        uint32_t hot_n = 0;                                             // heavy-partition tuples of this wave
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             const u64 g = cur.g0 + (u64)(j * BLOCK + tid) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const bool valid = (g + c >= cur.gb) && (g + c < cur.ge);
-                uint32_t code = 0xFFFFFFFFu;
-                if (valid) {
-                    const uint32_t p = hj_hash(key_of(j, c), factor, F);
-                    const uint32_t r = atomicAdd(&hist[p], 1u);
-                    code = (p << 16) | r;
-                }
-                pr[j * 4 + c] = code;
+                const uint32_t p = valid ? hj_hash(key_of(j, c), factor, F) : 0xFFFFFFFFu;
+                pr[j * 4 + c] = p;
+                if (hot) hot_n += (uint32_t)__popcll(__ballot(p == hot_p));
             }
+        }
+        uint32_t hot_base = 0;
+        if (hot && hot_n) {                                             // ONE add per wave for all its heavy tuples
+            if (hj_lane() == 0) hot_base = atomicAdd(&hist[hot_p], hot_n);
+            hot_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)hot_base);
+        }
+#pragma unroll
+        for (int k = 0; k < VPT * 4; ++k) {
+            const uint32_t p = pr[k];
+            uint32_t code = 0xFFFFFFFFu;
+            if (hot) {
+                const u64 grp = __ballot(p == hot_p);
+                if (p == hot_p)
+                    code = (p << 16) | (hot_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u)));
+                hot_base += (uint32_t)__popcll(grp);
+            }
+            if (p != 0xFFFFFFFFu && !(hot && p == hot_p)) code = (p << 16) | atomicAdd(&hist[p], 1u);
+            pr[k] = code;
         }
         hj_barrier_lds();
         stamp(1);
@@ -533,8 +560,12 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 else dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
             }
         }
+        uint32_t biggest = 0;                                           // largest of my bins: count << 10 | bin
+#pragma unroll
+        for (int i = 0; i < BPT; ++i)
+            if (cnt[i] > (uint32_t)TILE / 16) biggest = max(biggest, (cnt[i] << 10) | (tid * bpt + i));
         uint32_t run = block_exclusive_scan<BLOCK, uint32_t, true>(sum, wsum);
-        uint32_t longest = 0;                                           // longest run of my bins, in output slots
+        if (biggest) atomicMax(&wsum[NW + 3], biggest);                 // rare; nobody reads it before the next tile
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             const uint32_t bin = tid * bpt + i;
@@ -546,14 +577,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     meta[bin] = emitted[i] | (carried[i] << 16);
                     left[bin] = (run + fresh) | (coff[i] << 16) | ((cnt[i] - fresh) << 20);
                     delta[bin] = dst[i];
-                    if (emitted[i]) longest = max(longest, emitted[i] + ((uint32_t)dst[i] & (LINE - 1)));
+                    if (emitted[i] + ((uint32_t)dst[i] & (LINE - 1)) > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = bin;
                 } else if (OUT_PACKED) meta[bin] = cnt[i];
             }
             run += cnt[i];
-        }
-        if (CARRY) {
-            longest = wave_reduce_max(longest);
-            if (hj_lane() == 0 && longest) atomicMax(&wsum[NW + 1], longest);
         }
         hj_barrier_lds();
         stamp(2);
@@ -573,19 +600,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         }
         // consume the claims (pass 2: the atomics have had the scan and the sort to return) ...
         if (!CARRY) {
-            uint32_t longest = 0;
 #pragma unroll
             for (int i = 0; i < BPT; ++i)
                 if (cnt[i]) {
                     if (OUT_PACKED) {
                         delta[tid * bpt + i] = dst[i];
-                        longest = max(longest, cnt[i] + ((uint32_t)dst[i] & (LINE - 1)));
+                        if (cnt[i] + ((uint32_t)dst[i] & (LINE - 1)) > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = tid * bpt + i;
                     } else delta[tid * bpt + i] = dst[i] - lb[i];
                 }
-            if (OUT_PACKED) {
-                longest = wave_reduce_max(longest);
-                if (hj_lane() == 0 && longest) atomicMax(&wsum[NW + 1], longest);
-            }
         }
         // ... and only then start the next tile's loads: the vector-memory counter is in
         // order, so any wait on an older result placed after these loads would also wait for
@@ -601,14 +623,15 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             // tuples of its 16-byte slot, so a line leaves the CU as one piece of one instruction,
             // no hash and no per-tuple lookups are needed, and a store carries 16 bytes per lane.
             // A unit is (partition, UNIT consecutive output slots); units are dealt round-robin.
-            constexpr uint32_t NG = BLOCK / 16, UNIT = 256;
+            // A unit is (partition, UNIT consecutive output slots).  Every partition's first unit is dealt
+            // round-robin; the few runs longer than one unit (a heavy-hitter key under skew: up to the whole
+            // tile in one partition) are listed in `heavy` and their further units are shared by all groups.
+            constexpr uint32_t NG = BLOCK / 16;
             const uint32_t gid = tid >> 4, sub = tid & 15;
-            const uint32_t units_per_part = (wsum[NW + 1] + UNIT - 1) / UNIT;
             u64 *__restrict__ out64 = reinterpret_cast<u64 *>(a.kout);
-            for (uint32_t u = gid; u < units_per_part * F; u += NG) {
-                const uint32_t c = (uint32_t)(((u64)u * inv_F) >> 32), p = u - c * F;     // u / F, u % F
+            auto move_unit = [&](uint32_t p, uint32_t c) {
                 const uint32_t m = meta[p], e = m & 0xFFFFu, fc = m >> 16;
-                if (e == 0) continue;
+                if (e == 0) return;
                 const u64 d0 = delta[p];
                 const uint32_t off = (uint32_t)d0 & (LINE - 1);     // slot of the run's first tuple inside its line
                 const uint32_t lim = off + e, s_end = min(lim, (c + 1) * UNIT);
@@ -624,6 +647,13 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     } else if (v0) out64[base + s] = fetch(s - off);
                     else if (v1) out64[base + s + 1] = fetch(s + 1 - off);
                 }
+            };
+            for (uint32_t p = gid; p < F; p += NG) move_unit(p, 0);
+            const uint32_t nheavy = wsum[NW + 1];
+            for (uint32_t h = 0; h < nheavy; ++h) {
+                const uint32_t p = heavy[h];
+                const uint32_t units = (((uint32_t)delta[p] & (LINE - 1)) + (meta[p] & 0xFFFFu) + UNIT - 1) / UNIT;
+                for (uint32_t c = 1 + gid; c < units; c += NG) move_unit(p, c);
             }
         } else {
             // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
@@ -639,6 +669,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         if (!nxt.valid) break;
         cur = nxt;
         have_left = true;
+        have_left_or_prev = true;
     }
 }
 
@@ -647,7 +678,7 @@ static size_t scatter_lds(int block, int vpt, uint32_t F, bool carry)
 {
     const size_t Fpad = (F + 3) & ~3u;
     return Fpad * 16 + (size_t)block * vpt * 4 * 8 + (carry ? Fpad * (HJ_LINE_TUPLES * 8 + 4) : 0) +
-           (block / 64 + 2) * 4 + 16;
+           (block / 64 + 6) * 4 + HJ_MAX_HEAVY * 4 + 16;
 }
 constexpr size_t HJ_LDS_LIMIT = 160 * 1024;          // gfx950: 160 KiB per CU, all of it usable by one workgroup
 

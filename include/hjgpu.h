@@ -233,6 +233,16 @@ int  hjgpu_generate_range(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, siz
                           uint32_t inner_factor, uint32_t outer_factor,
                           uint32_t *d_inner_keys, uint32_t *d_inner_vals,
                           uint32_t *d_outer_keys, uint32_t *d_outer_vals, void *stream);
+/* As hjgpu_generate_range, but the repeat picks of the probe side follow a Zipf law of exponent
+ * `zipf` over the build keys (0 = uniform): the `zipf` argument of ./write (write.cpp:1685-1686,
+ * whose own Zipf walk is unfinished).  Every build key still appears at least once
+ * when outer_total >= inner_total, so with unique build keys the join aggregates remain
+ * count = |S| and the column sums of S. */
+int  hjgpu_generate_zipf(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
+                         size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
+                         uint32_t inner_factor, uint32_t outer_factor, double zipf,
+                         uint32_t *d_inner_keys, uint32_t *d_inner_vals,
+                         uint32_t *d_outer_keys, uint32_t *d_outer_vals, void *stream);
 /* sum over a column of key, key*f_a, key*f_b (mod 2^32 per term, uint64 sums):
  * the analytic join aggregates of a selectivity-1 workload.
  * The kernel is a plain 16-byte-load streaming read; hjgpu_get_stats().ms_total after

@@ -103,3 +103,48 @@ def test_materialised_heavy_output(hj):
         assert np.array_equal(ik[i], k) and np.array_equal(ok[(o.astype(np.uint64) * pow(3, -1, 2**32) % 2**32).astype(np.int64)], k)
     for c in (rk, rv, sk, sv, jk, jo, ji):
         c.free()
+
+
+def test_device_generator_zipf_skews_and_keeps_the_contract(hj):
+    """hjgpu_generate_zipf: same statistical contract as the uniform generator (unique non-zero
+    build keys, every build key at least once on the probe side, payload = key * factor), but
+    the repeat picks follow a Zipf law: the hottest key must carry far more than the mean."""
+    inner, outer = 50_000, 2_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate_zipf(7, inner, outer, 0, inner, 0, outer, fi, fo, 1.0, ik, iv, ok, ov)
+    hik, hiv, hok, hov = ik.download(), iv.download(), ok.download(), ov.download()
+    assert len(np.unique(hik)) == inner and (hik != 0).all()
+    assert np.array_equal(hiv, hik * np.uint32(fi)) and np.array_equal(hov, hok * np.uint32(fo))
+    keys, counts = np.unique(hok, return_counts=True)
+    assert np.array_equal(keys, np.sort(hik))                 # every build key at least once
+    assert counts.max() > 50 * outer / inner                  # Zipf(1): top key ~ 1/ln(N) of the picks
+    # shards are independent: two halves generated separately equal the whole
+    h1, h2 = hj.column(outer // 2), hj.column(outer - outer // 2)
+    v1, v2 = hj.column(outer // 2), hj.column(outer - outer // 2)
+    hj.generate_zipf(7, inner, outer, 0, 0, 0, outer // 2, fi, fo, 1.0, None, None, h1, v1)
+    hj.generate_zipf(7, inner, outer, 0, 0, outer // 2, outer - outer // 2, fi, fo, 1.0, None, None, h2, v2)
+    assert np.array_equal(np.concatenate([h1.download(), h2.download()]), hok)
+    want = numpy_join(hik, hiv, hok, hov)
+    assert want[0] == outer
+    for a in ("npj", "phj", "cpra"):
+        assert getattr(hj, a)(ik, iv, inner, ok, ov, outer) == want, a
+    for c in (ik, iv, ok, ov, h1, h2, v1, v2):
+        c.free()
+
+
+@pytest.mark.parametrize("zipf", [0.75, 1.25])
+def test_full_size_zipf_probe_side(hj, zipf):
+    """|R| = 64 M, |S| = 512 M with a Zipf probe side: one partition receives tens of millions of
+    probe tuples (its work items are slices), the aggregates stay the column sums of S."""
+    inner, outer = 64_000_000, 512_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate_zipf(3, inner, outer, 0, inner, 0, outer, fi, fo, zipf, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=4)) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    for c in (ik, iv, ok, ov):
+        c.free()
