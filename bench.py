@@ -75,6 +75,7 @@ def cpu_baseline(hj, H, args, algo):
     sums = hj.column_sums(ok, outer, OUTER_FACTOR, INNER_FACTOR)
     for c in (ik, iv, ok, ov):
         c.free()
+    simd = O.set_simd(True)             # AVX-512 histogram / partition / probe where the host has it
     tm = O.Timing()
     if algo == "npj":
         res = O.npj(hik, hiv, hok, hov, threads=threads, load=0.90, timing=tm)     # npj.cpp:944
@@ -82,12 +83,14 @@ def cpu_baseline(hj, H, args, algo):
         res = O.cpra(hik, hiv, hok, hov, threads=threads, timing=tm)
     else:
         res = O.phj(hik, hiv, hok, hov, threads=threads, timing=tm)
+    O.set_simd(False)
     ok_ = res == (outer, sums[0], sums[1], sums[2])
     return {"value": outer / tm.seconds / 1e9, "unit": "Gtuples/s", "cores": threads,
             "kind": "port",
             "sample": "%s |R|=%d join |S|=%d (same generator, 1/%g of the per-GPU workload), "
-                      "oracle/hj_oracle.c pthreads, %.3f s, checksum %s"
-                      % (algo, inner, outer, args.outer / outer, tm.seconds,
+                      "oracle/hj_oracle.c pthreads restatement of run_hj with %s operators, %.3f s, checksum %s"
+                      % (algo, inner, outer, args.outer / outer,
+                         "AVX-512 (oracle/hj_oracle_avx512.c)" if simd else "scalar", tm.seconds,
                          "ok" if ok_ else "MISMATCH"),
             "seconds": tm.seconds}
 

@@ -202,11 +202,42 @@ int hjo_generate(size_t outer, size_t inner, double selectivity, uint32_t seed,
 /* partitioning                                                             */
 /* ------------------------------------------------------------------------ */
 
+/* AVX-512 forms of the three hot operators (hj_oracle_avx512.c), off unless hjo_set_simd(1):
+ * the scalar definitions below stay the oracle; the vector forms are the timed CPU baseline. */
+int hjo_avx512_compiled(void);
+void hjo_histogram_avx512(const uint32_t *, size_t, uint32_t *, uint32_t, size_t);
+void hjo_partition_avx512(const uint32_t *, const uint32_t *, size_t, const uint32_t *, uint32_t *,
+                          uint32_t *, uint32_t, size_t);
+void hjo_partition_shared_avx512(const uint32_t *, const uint32_t *, size_t, uint32_t *, uint32_t *,
+                                 uint32_t *, uint32_t, size_t);
+void hjo_phj_probe_avx512(const uint32_t *, const uint32_t *, size_t, const uint64_t *, size_t,
+                          const uint32_t[2], uint32_t, hjo_result *);
+static int g_simd = 0;
+
+int hjo_simd_available(void)
+{
+#if defined(__x86_64__)
+    return hjo_avx512_compiled() && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") &&
+           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
+#else
+    return 0;
+#endif
+}
+
+int hjo_set_simd(int on)
+{
+    g_simd = (on && hjo_simd_available()) ? 1 : 0;
+    return g_simd;
+}
+
 /* phj.cpp:1295-1306 (scalar), vector form 693-772 */
 void hjo_histogram(const uint32_t *keys, size_t size, uint32_t *counts,
                    uint32_t factor, size_t partitions)
 {
     memset(counts, 0, partitions * sizeof(uint32_t));
+#if defined(__x86_64__)
+    if (g_simd && partitions < (1u << 27)) { hjo_histogram_avx512(keys, size, counts, factor, partitions); return; }
+#endif
     for (size_t i = 0; i != size; ++i)
         counts[hash_wide(keys[i] * factor, partitions)]++;
 }
@@ -217,6 +248,12 @@ void hjo_partition(const uint32_t *keys, const uint32_t *vals, size_t size,
                    const uint32_t *counts, uint32_t *keys_out, uint32_t *vals_out,
                    uint32_t factor, size_t partitions)
 {
+#if defined(__x86_64__)
+    if (g_simd && partitions < (1u << 27)) {
+        hjo_partition_avx512(keys, vals, size, counts, keys_out, vals_out, factor, partitions);
+        return;
+    }
+#endif
     size_t *offsets = (size_t *)malloc((partitions ? partitions : 1) * sizeof(size_t));
     size_t acc = 0;
     for (size_t p = 0; p != partitions; ++p) { offsets[p] = acc; acc += counts[p]; }
@@ -253,6 +290,12 @@ void hjo_partition_shared(const uint32_t *keys, const uint32_t *vals, size_t siz
                           uint32_t *offsets, uint32_t *keys_out, uint32_t *vals_out,
                           uint32_t factor, size_t partitions)
 {
+#if defined(__x86_64__)
+    if (g_simd && partitions < (1u << 27)) {
+        hjo_partition_shared_avx512(keys, vals, size, offsets, keys_out, vals_out, factor, partitions);
+        return;
+    }
+#endif
     for (size_t i = 0; i != size; ++i) {
         uint32_t key = keys[i];
         size_t o = offsets[hash_wide(key * factor, partitions)]++;
@@ -418,6 +461,12 @@ void hjo_phj_probe(const uint32_t *keys, const uint32_t *vals, size_t size,
                    uint32_t empty, hjo_result *agg, const hjo_output *out,
                    size_t *o_inout)
 {
+#if defined(__x86_64__)
+    if (g_simd && !out && !o_inout && agg && buckets >= 3 && buckets < (1u << 31)) {
+        hjo_phj_probe_avx512(keys, vals, size, table, buckets, factor, empty, agg);
+        return;
+    }
+#endif
     size_t o = o_inout ? *o_inout : 0;
     for (size_t i = 0; i != size; ++i) {
         uint32_t k = keys[i];

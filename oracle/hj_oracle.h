@@ -45,6 +45,12 @@ typedef struct {
     volatile size_t *block_counter;
 } hjo_output;
 
+/* AVX-512 forms of histogram / partition / probe (hj_oracle_avx512.c) for the timed CPU
+ * baseline: off by default; hjo_set_simd(1) turns them on where the CPU has AVX-512 and
+ * returns what is in effect.  Results are identical to the scalar definitions. */
+int hjo_simd_available(void);
+int hjo_set_simd(int on);
+
 /* ---- primitives ------------------------------------------------------- */
 /* mulhi32: ((uint64)x * n) >> 32   (npj.cpp:200-201, phj.cpp:83-100, 721-722) */
 uint32_t hjo_hash(uint32_t x, uint32_t n);

@@ -35,9 +35,9 @@ class Output(C.Structure):
 
 def build(force=False):
     so = os.path.join(HERE, "libhjoracle.so")
-    src = os.path.join(HERE, "hj_oracle.c")
-    if force or not os.path.exists(so) or (
-            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+    srcs = [os.path.join(HERE, f) for f in ("hj_oracle.c", "hj_oracle_avx512.c", "hj_oracle.h")]
+    if force or not os.path.exists(so) or any(
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so) for src in srcs):
         subprocess.check_call(["make", "-C", HERE, "-s"])
     return so
 
@@ -51,6 +51,9 @@ def lib():
         L = C.CDLL(build())
         L.hjo_hash.restype = C.c_uint32
         L.hjo_hash.argtypes = [C.c_uint32, C.c_uint32]
+        L.hjo_simd_available.restype = C.c_int
+        L.hjo_set_simd.restype = C.c_int
+        L.hjo_set_simd.argtypes = [C.c_int]
         for f in (L.hjo_thread_beg, L.hjo_thread_end):
             f.restype = C.c_size_t
             f.argtypes = [C.c_size_t] * 4
@@ -106,6 +109,17 @@ def _c(a):
 
 
 # ---- convenience wrappers --------------------------------------------------
+
+def simd_available():
+    """True where the AVX-512 forms of histogram / partition / probe can run on this CPU."""
+    return bool(lib().hjo_simd_available())
+
+
+def set_simd(on):
+    """Selects the AVX-512 operator forms (the timed CPU baseline) or the scalar definitions
+    (default); returns what is in effect.  Results are identical either way."""
+    return bool(lib().hjo_set_simd(1 if on else 0))
+
 
 def generate(outer, inner, selectivity=1.0, seed=1, unique_factor=0x9E3779B1,
              inner_factor=0x85EBCA6B, outer_factor=0xC2B2AE35):

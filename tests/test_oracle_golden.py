@@ -19,6 +19,19 @@ FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDE
                   if not os.path.basename(p).startswith("rand32"))
 
 
+@pytest.fixture(params=["scalar", "avx512"], autouse=True)
+def operator_forms(request, oracle):
+    """Every test of this module runs twice: with the scalar definitions (the oracle proper) and
+    with the AVX-512 forms of histogram / partition / probe that bench.py times as the CPU
+    baseline.  Both must reproduce the reference's outputs bit for bit."""
+    if request.param == "avx512":
+        if not oracle.simd_available():
+            pytest.skip("no AVX-512 on this CPU")
+        assert oracle.set_simd(True)
+    yield request.param
+    oracle.set_simd(False)
+
+
 def load(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
@@ -134,3 +147,16 @@ def test_oracle_matches_reference_build_when_present(oracle, seed):
         for t in range(T):
             assert R.hjref_thread_beg(n, 16, t, T) == oracle.lib().hjo_thread_beg(n, 16, t, T)
             assert R.hjref_thread_end(n, 16, t, T) == oracle.lib().hjo_thread_end(n, 16, t, T)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_whole_joins_agree_with_the_join_definition(oracle, threads):
+    """run / run_hj restatements (thread-level pass with ragged thread ranges, local passes,
+    per-partition build + probe) against the sort-merge definition of the join, in both
+    operator forms (the AVX-512 partition must cope with output ranges that start and end in
+    the middle of a 64-byte line and are shared with other threads)."""
+    ik, iv, ok, ov = oracle.generate(300_007, 61_003, seed=threads)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    assert oracle.phj(ik, iv, ok, ov, threads=threads, hash_table_limit=700) == want
+    assert oracle.cpra(ik, iv, ok, ov, threads=threads) == want
+    assert oracle.npj(ik, iv, ok, ov, threads=threads) == want
