@@ -21,6 +21,7 @@ EXPORTS = [
     "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
     "hjgpu_get_device_info", "hjgpu_reserve", "hjgpu_get_stats",
     "hjgpu_malloc", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
+    "hjgpu_host_alloc", "hjgpu_host_free",
     "hjgpu_histogram", "hjgpu_partition", "hjgpu_join_partitions",
     "hjgpu_npj_build", "hjgpu_npj_probe",
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
@@ -57,7 +58,7 @@ class Stats(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_histogram", C.c_float), ("ms_plan", C.c_float),
                 ("ms_scatter1", C.c_float), ("ms_scatter2", C.c_float), ("ms_join", C.c_float),
                 ("ms_build", C.c_float), ("ms_close_gaps", C.c_float),
-                ("ms_inner_wait", C.c_float), ("reserved", C.c_float),
+                ("ms_inner_wait", C.c_float), ("ms_upload", C.c_float),
                 ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("buckets", C.c_uint64)]
 
     def as_dict(self):
@@ -67,6 +68,19 @@ class Stats(C.Structure):
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int),
                 ("lds_bytes_per_block", C.c_int), ("hbm_bytes", C.c_uint64)]
+
+
+class PinnedColumn:
+    """numpy view of page-locked host memory owned by the library (hjgpu_host_alloc)."""
+
+    def __init__(self, hj, ptr, array):
+        self.hj, self.ptr, self.array = hj, ptr, array
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.hj._check(self.hj.lib.hjgpu_host_free(self.hj.handle, self.ptr))
+            self.ptr = None
 
 
 class HjGpuError(RuntimeError):
@@ -104,6 +118,8 @@ def load_library(build_if_missing=True):
     L.hjgpu_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.hjgpu_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     L.hjgpu_synchronize.argtypes = [vp, vp]
+    L.hjgpu_host_alloc.argtypes = [vp, C.POINTER(vp), sz]
+    L.hjgpu_host_free.argtypes = [vp, vp]
     L.hjgpu_histogram.argtypes = [vp, vp, sz, u32, u32, vp, vp]
     L.hjgpu_partition.argtypes = [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]
     L.hjgpu_join_partitions.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(PhjParams),
@@ -293,10 +309,19 @@ class HjGpu:
     def cpra_async(self, rk, rv, inner, sk, sv, outer, params, d_result, stream=None):
         self._join_async(self.lib.hjgpu_cpra_async, params, rk, rv, inner, sk, sv, outer, d_result, stream)
 
+    def host_column(self, n, dtype=np.uint32):
+        """Page-locked host column (hjgpu_host_alloc) as a numpy array; `arr.base_free()` releases it."""
+        p = C.c_void_p()
+        nbytes = int(n) * np.dtype(dtype).itemsize
+        self._check(self.lib.hjgpu_host_alloc(self.handle, C.byref(p), nbytes))
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(n))
+        return PinnedColumn(self, p.value, arr)
+
     def join_host(self, algorithm, ik, iv, ok, ov, phj_params=None, npj_params=None):
         """algorithm: 0 npj, 1 phj, 2 cpra; host numpy columns in, (result, stats) out."""
-        ik, iv = np.ascontiguousarray(ik, np.uint32), np.ascontiguousarray(iv, np.uint32)
-        ok, ov = np.ascontiguousarray(ok, np.uint32), np.ascontiguousarray(ov, np.uint32)
+        ik, iv, ok, ov = (c.array if isinstance(c, PinnedColumn) else np.ascontiguousarray(c, np.uint32)
+                          for c in (ik, iv, ok, ov))
         r, s = Result(), Stats()
         self._check(self.lib.hjgpu_join_host(
             self.handle, algorithm, ik.ctypes.data, iv.ctypes.data, ik.size,

@@ -4,6 +4,7 @@
 // cpra2.cpp:1697-1986): phase order, pass planning, factor choice.  Barriers
 // between phases become stream order; there is no host round trip inside a join.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -632,6 +633,20 @@ int hjgpu_memcpy_d2h(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes)
     if (bytes) HIPCHK(ctx, hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
     return HJGPU_OK;
 }
+int hjgpu_host_alloc(hjgpu_ctx *ctx, void **p, size_t bytes)
+{
+    if (!ctx || !p) return HJGPU_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { *p = nullptr; return fail(ctx, HJGPU_ENOMEM, "hipHostMalloc", e); }
+    return HJGPU_OK;
+}
+int hjgpu_host_free(hjgpu_ctx *ctx, void *p)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (p) HIPCHK(ctx, hipHostFree(p));
+    return HJGPU_OK;
+}
 int hjgpu_synchronize(hjgpu_ctx *ctx, void *stream)
 {
     if (!ctx) return HJGPU_EINVAL;
@@ -912,6 +927,31 @@ int hjgpu_cpra_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, siz
     return phj_like(ctx, chunks, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false);
 }
 
+// Host column -> HBM on `copy`.  Page-locked memory (hjgpu_host_alloc, hipHostRegister'ed, ...) is
+// DMA'd directly; pageable memory goes through two pinned staging buffers so that the CPU's copy
+// of chunk i+1 overlaps the DMA of chunk i.
+static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, hipStream_t copy,
+                         void *stage[2], hipEvent_t stage_free[2], size_t stage_bytes, int *next)
+{
+    if (!bytes) return HJGPU_OK;
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, h) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();                            // a pageable pointer reports an error: expected
+    if (pinned) {
+        HIPCHK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, copy));
+        return HJGPU_OK;
+    }
+    for (size_t at_ = 0; at_ < bytes; at_ += stage_bytes) {
+        const size_t n = bytes - at_ < stage_bytes ? bytes - at_ : stage_bytes;
+        const int b = *next; *next ^= 1;
+        HIPCHK(ctx, hipEventSynchronize(stage_free[b]));           // the DMA that last used this buffer is done
+        memcpy(stage[b], (const char *)h + at_, n);
+        HIPCHK(ctx, hipMemcpyAsync((char *)d + at_, stage[b], n, hipMemcpyHostToDevice, copy));
+        HIPCHK(ctx, hipEventRecord(stage_free[b], copy));
+    }
+    return HJGPU_OK;
+}
+
 int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
                     const uint32_t *ik, const uint32_t *iv, size_t inner,
                     const uint32_t *ok, const uint32_t *ov, size_t outer,
@@ -924,26 +964,67 @@ int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
     void *d[4] = {nullptr, nullptr, nullptr, nullptr};
     const void *h[4] = {ik, iv, ok, ov};
     const size_t n[4] = {inner, inner, outer, outer};
+    constexpr size_t STAGE = 32u << 20;
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_free[2] = {nullptr, nullptr}, r_ready = nullptr, s_ready = nullptr;
+    hipStream_t copy = nullptr, run = nullptr;
     int rc = HJGPU_OK;
-    for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) {
-        rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
-        if (rc == HJGPU_OK) rc = hjgpu_memcpy_h2d(ctx, d[i], h[i], n[i] * sizeof(uint32_t));
+    auto hip_ok = [&](hipError_t e, const char *what) { if (rc == HJGPU_OK && e != hipSuccess) rc = fail(ctx, HJGPU_EHIP, what, e); };
+    for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
+    hip_ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking), "hipStreamCreate(copy)");
+    hip_ok(hipStreamCreateWithFlags(&run, hipStreamNonBlocking), "hipStreamCreate(run)");
+    hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
+    hip_ok(hipEventCreateWithFlags(&s_ready, hipEventDisableTiming), "hipEventCreate");
+    for (int b = 0; b < 2; ++b) {
+        hip_ok(hipHostMalloc(&stage[b], STAGE, hipHostMallocDefault), "hipHostMalloc(stage)");
+        hip_ok(hipEventCreateWithFlags(&stage_free[b], hipEventDisableTiming), "hipEventCreate");
     }
+    PhjPlan pl;
+    size_t buckets = 0; uint32_t factor = 0;
     if (rc == HJGPU_OK) {
-        // allocate the workspace before the timed region, like the reference's
-        // mamalloc()s before its clock starts (npj.cpp:982-1000 vs 861-863)
-        if (algorithm == 0) { size_t b; uint32_t f; rc = npj_prepare(ctx, inner, np, &b, &f); }
-        else { PhjPlan pl; rc = phj_prepare(ctx, inner, outer, pp, algorithm == 2 ? ((pp && pp->chunks) ? pp->chunks : 8) : 1, &pl); }
+        // allocate the workspace before the clocks start, like the reference's mamalloc()s before
+        // its timed region (npj.cpp:982-1000 vs 861-863)
+        if (algorithm == 0) rc = npj_prepare(ctx, inner, np, &buckets, &factor);
+        else rc = phj_prepare(ctx, inner, outer, pp, algorithm == 2 ? ((pp && pp->chunks) ? pp->chunks : 8) : 1, &pl);
     }
+    float ms_upload = 0;
     if (rc == HJGPU_OK) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int next = 0;
+        // probe side first, build side behind it: PHJ / CPRA partition S while R is still arriving
+        const int order[4] = {2, 3, 0, 1};
+        for (int k = 0; k < 4 && rc == HJGPU_OK; ++k) {
+            const int i = order[k];
+            rc = upload_column(ctx, d[i], h[i], n[i] * sizeof(uint32_t), copy, stage, stage_free, STAGE, &next);
+            if (rc == HJGPU_OK && i == 3) hip_ok(hipEventRecord(s_ready, copy), "hipEventRecord");
+        }
+        hip_ok(hipEventRecord(r_ready, copy), "hipEventRecord");
         const uint32_t *rk = (const uint32_t *)d[0], *rv = (const uint32_t *)d[1];
         const uint32_t *sk = (const uint32_t *)d[2], *sv = (const uint32_t *)d[3];
-        if (algorithm == 0) rc = hjgpu_npj(ctx, rk, rv, inner, sk, sv, outer, np, result, nullptr, nullptr);
-        else if (algorithm == 1) rc = hjgpu_phj(ctx, rk, rv, inner, sk, sv, outer, pp, result, nullptr, nullptr);
-        else rc = hjgpu_cpra(ctx, rk, rv, inner, sk, sv, outer, pp, result, nullptr, nullptr);
+        if (rc == HJGPU_OK) {
+            if (algorithm == 0) {
+                // NPJ builds first: it needs R, which arrives last
+                hip_ok(hipStreamWaitEvent(run, r_ready, 0), "hipStreamWaitEvent");
+                if (rc == HJGPU_OK) rc = npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, nullptr, run);
+            } else {
+                hip_ok(hipStreamWaitEvent(run, s_ready, 0), "hipStreamWaitEvent");
+                if (rc == HJGPU_OK) rc = phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, nullptr, run, r_ready);
+            }
+        }
+        if (rc == HJGPU_OK) {
+            hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
+            ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            rc = finish_blocking(ctx, result, nullptr, run);
+        }
     }
-    if (rc == HJGPU_OK && stats) rc = hjgpu_get_stats(ctx, stats);
+    if (rc == HJGPU_OK && stats) { rc = hjgpu_get_stats(ctx, stats); stats->ms_upload = ms_upload; }
+    (void)hipDeviceSynchronize();
     for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
+    for (int b = 0; b < 2; ++b) { if (stage[b]) (void)hipHostFree(stage[b]); if (stage_free[b]) (void)hipEventDestroy(stage_free[b]); }
+    if (r_ready) (void)hipEventDestroy(r_ready);
+    if (s_ready) (void)hipEventDestroy(s_ready);
+    if (copy) (void)hipStreamDestroy(copy);
+    if (run) (void)hipStreamDestroy(run);
     return rc;
 }
 

@@ -71,6 +71,25 @@ struct Relations {
     std::vector<uint32_t> ik, iv, ok, ov;
 };
 
+// Columns of the join programs live in page-locked memory (hjgpu_host_alloc): the fread()s land
+// where the GPU can DMA from at the PCIe rate (the reference's mamalloc'd columns, npj.cpp:982-1000).
+struct PinnedRelations {
+    hjgpu_ctx *ctx = nullptr;
+    uint32_t *col[4] = {nullptr, nullptr, nullptr, nullptr};     // ik, iv, ok, ov
+    size_t inner = 0, outer = 0;
+    ~PinnedRelations() { for (uint32_t *c : col) if (c) hjgpu_host_free(ctx, c); }
+};
+
+inline bool read_into(const std::string &path, size_t tuples, uint32_t *out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot open %s (generate it with ./write)\n", path.c_str()); return false; }
+    const size_t got = tuples ? fread(out, sizeof(uint32_t), tuples, f) : 0;
+    fclose(f);
+    if (got != tuples) { fprintf(stderr, "%s: expected %zu tuples, read %zu\n", path.c_str(), tuples, got); return false; }
+    return true;
+}
+
 inline bool load_relations(const Args &a, Relations &r)
 {
     return read_column(column_path("ik", a.inner), a.inner, r.ik) &&
@@ -79,34 +98,55 @@ inline bool load_relations(const Args &a, Relations &r)
            read_column(column_path("ov", a.outer), a.outer, r.ov);
 }
 
-// Runs one join on the GPU and prints the extended report on stderr; the
-// reference's own stdout line is printed by each main in its own format.
-inline int run_join(int algorithm, const Args &a, const Relations &r, hjgpu_result *res,
-                    hjgpu_stats *st)
+// Loads the four column files, runs one join on the GPU and prints the extended report on stderr;
+// the reference's own stdout line is printed by each main in its own format.
+// Exit codes of the mains: 2 = input files, 1 = no GPU / join failed.
+inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats *st)
 {
+    // the files are checked before the device is touched: a missing input is reported as such
+    const char *prefix[4] = {"ik", "iv", "ok", "ov"};
+    const size_t tuples[4] = {a.inner, a.inner, a.outer, a.outer};
+    for (int i = 0; i < 4; ++i) {
+        FILE *f = fopen(column_path(prefix[i], tuples[i]).c_str(), "rb");
+        if (!f) { fprintf(stderr, "cannot open %s (generate it with ./write)\n", column_path(prefix[i], tuples[i]).c_str()); return -2; }
+        fclose(f);
+    }
     hjgpu_ctx *ctx = nullptr;
     int rc = hjgpu_create(-1, &ctx);
     if (rc != HJGPU_OK) { fprintf(stderr, "hjgpu_create: %s\n", hjgpu_status_string(rc)); return rc; }
-    hjgpu_phj_params pp;
-    memset(&pp, 0, sizeof(pp));
-    if (algorithm == 2) pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 8 ? a.threads : 8);
-    hjgpu_npj_params np;
-    memset(&np, 0, sizeof(np));
-    rc = hjgpu_join_host(ctx, algorithm, r.ik.data(), r.iv.data(), r.ik.size(),
-                         r.ok.data(), r.ov.data(), r.ok.size(), &pp, &np, res, st);
-    if (rc != HJGPU_OK)
-        fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_last_error(ctx));
-    hjgpu_device_info info;
-    if (rc == HJGPU_OK && hjgpu_get_device_info(ctx, &info) == HJGPU_OK) {
-        const double sec = st->ms_total * 1e-3;
-        const double n = (double)r.ik.size() + (double)r.ok.size();
-        fprintf(stderr, "device: %s (%s, %d CUs)\n", info.name, info.arch, info.compute_units);
-        fprintf(stderr, "join_tuples=%llu sum_keys=%llu sum_outer_vals=%llu sum_inner_vals=%llu\n",
-                (unsigned long long)res->count, (unsigned long long)res->sum_keys,
-                (unsigned long long)res->sum_outer_vals, (unsigned long long)res->sum_inner_vals);
-        fprintf(stderr, "device time %.4f s: %.2f Gtuples/s probe-side, %.1f GB/s of input columns\n",
-                sec, sec > 0 ? r.ok.size() / sec / 1e9 : 0.0, sec > 0 ? 8.0 * n / sec / 1e9 : 0.0);
-    }
+    {
+        PinnedRelations r;
+        r.ctx = ctx; r.inner = a.inner; r.outer = a.outer;
+        for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) {
+            rc = hjgpu_host_alloc(ctx, (void **)&r.col[i], tuples[i] * sizeof(uint32_t));
+            if (rc != HJGPU_OK) fprintf(stderr, "host allocation failed: %s\n", hjgpu_last_error(ctx));
+            else if (!read_into(column_path(prefix[i], tuples[i]), tuples[i], r.col[i])) rc = -2;
+        }
+        hjgpu_phj_params pp;
+        memset(&pp, 0, sizeof(pp));
+        if (algorithm == 2) pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 8 ? a.threads : 8);
+        hjgpu_npj_params np;
+        memset(&np, 0, sizeof(np));
+        if (rc == HJGPU_OK) {
+            rc = hjgpu_join_host(ctx, algorithm, r.col[0], r.col[1], a.inner, r.col[2], r.col[3], a.outer,
+                                 &pp, &np, res, st);
+            if (rc != HJGPU_OK)
+                fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_last_error(ctx));
+        }
+        hjgpu_device_info info;
+        if (rc == HJGPU_OK && hjgpu_get_device_info(ctx, &info) == HJGPU_OK) {
+            const double sec = st->ms_total * 1e-3, up = st->ms_upload * 1e-3;
+            const double n = (double)a.inner + (double)a.outer;
+            fprintf(stderr, "device: %s (%s, %d CUs)\n", info.name, info.arch, info.compute_units);
+            fprintf(stderr, "join_tuples=%llu sum_keys=%llu sum_outer_vals=%llu sum_inner_vals=%llu\n",
+                    (unsigned long long)res->count, (unsigned long long)res->sum_keys,
+                    (unsigned long long)res->sum_outer_vals, (unsigned long long)res->sum_inner_vals);
+            fprintf(stderr, "device time %.4f s: %.2f Gtuples/s probe-side, %.1f GB/s of input columns\n",
+                    sec, sec > 0 ? a.outer / sec / 1e9 : 0.0, sec > 0 ? 8.0 * n / sec / 1e9 : 0.0);
+            fprintf(stderr, "upload of the four columns %.4f s (%.1f GB/s over PCIe, pipelined with the join)\n",
+                    up, up > 0 ? 8.0 * n / up / 1e9 : 0.0);
+        }
+    }   // pinned columns are released before the context
     hjgpu_destroy(ctx);
     return rc;
 }

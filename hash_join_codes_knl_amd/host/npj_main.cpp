@@ -6,11 +6,10 @@
 int main(int argc, char **argv)
 {
     const hjhost::Args a = hjhost::parse(argc, argv, 1.0);
-    hjhost::Relations r;
-    if (!hjhost::load_relations(a, r)) return 2;
     hjgpu_result res;
     hjgpu_stats st;
-    if (hjhost::run_join(0, a, r, &res, &st) != HJGPU_OK) return 1;
+    const int rc = hjhost::run_join(0, a, &res, &st);     // loads the column files into pinned memory
+    if (rc != HJGPU_OK) return rc == -2 ? 2 : 1;
     // Phase 1 = table init + build, Phase 2 = probe, Phase 3 = close_gaps (npj.cpp:878-915)
     const double ph[3] = {st.ms_build * 1e-3, st.ms_join * 1e-3, st.ms_close_gaps * 1e-3};
     const double total = st.ms_total * 1e-3;

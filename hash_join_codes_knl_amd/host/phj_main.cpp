@@ -6,11 +6,10 @@
 int main(int argc, char **argv)
 {
     const hjhost::Args a = hjhost::parse(argc, argv, 1.0);
-    hjhost::Relations r;
-    if (!hjhost::load_relations(a, r)) return 2;
     hjgpu_result res;
     hjgpu_stats st;
-    if (hjhost::run_join(1, a, r, &res, &st) != HJGPU_OK) return 1;
+    const int rc = hjhost::run_join(1, a, &res, &st);     // loads the column files into pinned memory
+    if (rc != HJGPU_OK) return rc == -2 ? 2 : 1;
     fprintf(stderr, "fan-out %u x %u; histogram %.4f s, scatter %.4f + %.4f s, join %.4f s\n",
             st.fanout1, st.fanout2, st.ms_histogram * 1e-3, st.ms_scatter1 * 1e-3,
             st.ms_scatter2 * 1e-3, st.ms_join * 1e-3);

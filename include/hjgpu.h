@@ -93,7 +93,8 @@ typedef struct {
     float    ms_close_gaps;    /* K9                                                         */
     float    ms_inner_wait;    /* stream time spent waiting for the build side to arrive
                                   (hjgpu_phj_overlapped_async), 0 otherwise                  */
-    float    reserved;
+    float    ms_upload;        /* hjgpu_join_host: host columns -> HBM (wall clock, pipelined
+                                  with the probe side's partitioning for PHJ / CPRA)         */
     uint32_t fanout1, fanout2; /* what was used                                              */
     uint64_t buckets;          /* NPJ table size                                             */
 } hjgpu_stats;
@@ -124,6 +125,11 @@ int  hjgpu_free(hjgpu_ctx *ctx, void *d_ptr);
 int  hjgpu_memcpy_h2d(hjgpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int  hjgpu_memcpy_d2h(hjgpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int  hjgpu_synchronize(hjgpu_ctx *ctx, void *stream);
+/* Page-locked host memory for the fread() targets of the host programs (the reference's
+ * mamalloc'd columns, npj.cpp:982-1000): hjgpu_join_host DMAs such columns straight to HBM at
+ * the PCIe rate; pageable columns are staged through two pinned buffers instead. */
+int  hjgpu_host_alloc(hjgpu_ctx *ctx, void **h_ptr, size_t bytes);
+int  hjgpu_host_free(hjgpu_ctx *ctx, void *h_ptr);
 
 /* ---- partition operators ------------------------------------------------------ */
 /* histogram(), phj.cpp:693 (shared form 773): d_counts[p] = |{i: H(key_i,f,F)=p}|. */
@@ -206,7 +212,10 @@ int  hjgpu_cpra_async(hjgpu_ctx *ctx,
                       const hjgpu_phj_params *params, hjgpu_result *d_result, void *stream);
 
 /* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
- * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates. ---------- */
+ * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates.
+ * The upload runs on its own stream: probe side first, build side behind it; PHJ / CPRA
+ * partition the probe side while the build side is still arriving.
+ * stats->ms_upload is the wall-clock time of the upload, ms_total the device time of the join. */
 int  hjgpu_join_host(hjgpu_ctx *ctx, int algorithm /* 0 npj, 1 phj, 2 cpra */,
                      const uint32_t *inner_keys, const uint32_t *inner_vals, size_t inner,
                      const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,

@@ -1,6 +1,8 @@
 """GPU parity tests: every HIP operator / whole join, called through the C-ABI
 (include/hjgpu.h via ctypes), against the CPU oracle on the same seeded inputs.
 Integer work: the bar is bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -423,3 +425,48 @@ def test_column_sums_any_alignment(hj, n, skew):
     want = (int(k.sum()), int(((k * fa) & 0xFFFFFFFF).sum()), int(((k * fb) & 0xFFFFFFFF).sum()))
     assert hj.column_sums(col.ptr + 4 * skew, n, fa, fb) == want
     col.free()
+
+
+@pytest.mark.parametrize("algorithm", [0, 1, 2])
+def test_join_host_from_pinned_columns(hj, oracle, algorithm):
+    """hjgpu_host_alloc + hjgpu_join_host: page-locked columns are DMA'd directly (the host
+    programs' fread targets); same result as from pageable memory, upload time reported.
+    3 M probe tuples: more than one 32 MiB staging buffer's worth on the pageable path."""
+    ik, iv, ok, ov = oracle.generate(9_000_000, 300_000, seed=44)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    pinned = [hj.host_column(len(c)) for c in (ik, iv, ok, ov)]
+    for dst, src in zip(pinned, (ik, iv, ok, ov)):
+        dst.array[:] = src
+    got_pinned, st = hj.join_host(algorithm, *pinned)
+    got_pageable, st2 = hj.join_host(algorithm, ik, iv, ok, ov)
+    for c in pinned:
+        c.free()
+    assert got_pinned == want and got_pageable == want
+    assert st["ms_upload"] > 0 and st2["ms_upload"] > 0
+
+
+def test_host_programs_end_to_end(hj, oracle, tmp_path):
+    """./write -> ./npj ./phj ./cpra on the GPU box: same CLI, files and stdout formats as the
+    reference's programs (npj.cpp:1114, phj.cpp:2197, cpra2.cpp:1984/2208); the aggregates on
+    stderr equal the oracle's join of the generated files."""
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.abspath(H.__file__)), "lib")
+    env = dict(os.environ, HJ_SEED="11")
+    subprocess.check_call([os.path.join(lib, "write"), "4", "400000", "90000"], cwd=tmp_path, env=env,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    cols = [np.fromfile(tmp_path / ("%s_%d.txt" % (p, n)), dtype="<u4")
+            for p, n in (("ik", 90000), ("iv", 90000), ("ok", 400000), ("ov", 400000))]
+    want = oracle.join_definition(*cols)
+    for prog in ("npj", "phj", "cpra"):
+        p = subprocess.run([os.path.join(lib, prog), "8", "400000", "90000"], cwd=tmp_path,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert ("join_tuples=%d sum_keys=%d sum_outer_vals=%d sum_inner_vals=%d" % want) in p.stderr
+        assert "upload of the four columns" in p.stderr
+        lines = p.stdout.strip().splitlines()
+        if prog == "npj":
+            assert len(lines) == 1 and float(lines[0]) > 0
+        elif prog == "phj":
+            assert len(lines[0].split("\t")) >= 3
+        else:
+            assert lines[0].startswith("copy:\t") and float(lines[1]) > 0
