@@ -64,7 +64,7 @@ struct ScatterArgs {
     uint32_t in_align;              // (address of kin / 4) % 4, same for vin
     // pass 1 only (ranged == 1): per-range bases instead of atomic cursors
     uint32_t ranged;
-    uint32_t strided;               // pass 2: tiles dealt round-robin instead of contiguous runs
+    uint32_t *work_counter;         // device, zeroed per launch: ticket of the next unclaimed range (pass 1) / tile (pass 2)
     Pass1Geom geom;
     const u64 *range_base;          // [ranges][F] absolute output position of each (range, partition)
     u64 *prof;                      // diagnostics (HJGPU_SCATTER_PROF=1): s_memtime ticks per phase, else NULL
@@ -117,7 +117,8 @@ struct PlanArgs {
 
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-                    u64 *counts, uint32_t *range_counts, int cus, hipStream_t stream);
+                    u64 *counts, uint32_t *range_counts, uint32_t *work_counter /* [chunks], zeroed */,
+                    int cus, hipStream_t stream);
 int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
                          uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream);
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream);

@@ -103,6 +103,7 @@ inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) 
 struct MetaLayout {
     u64 *counts[2], *off2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
     u64 *slice_prefix, *slices;
+    uint32_t *tickets;           // [64] work-claim counters of K4 / K6 (inside the block zeroed per join)
     uint32_t *item_part;         // [P + items_extra] partition of every join work item
     uint4 *tdesc[2];             // [tdesc_cap][2] pass-2 tile descriptors (K5 -> K6 pass 2)
     size_t tdesc_cap;
@@ -121,6 +122,7 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
     auto take = [&](size_t n) { u64 *r = p ? p + at : nullptr; at += (n + 1) & ~size_t(1); return r; };
     m.counts[0] = take((size_t)C * P);
     m.counts[1] = take((size_t)C * P);
+    m.tickets = reinterpret_cast<uint32_t *>(take(32));      // K4: [r * 8 + chunk]; K6: [16 + 2 * r + pass - 1]
     m.counts_bytes = at * sizeof(u64);
     for (int r = 0; r < 2; ++r) {
         m.off2[r] = take((size_t)C * P + 1);
@@ -321,7 +323,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
         // K4: one read of the key column gives the histograms of both passes
         if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
-                                       m.range_counts[r], ctx->cus, stream));
+                                       m.range_counts[r], m.tickets + 8 * r, ctx->cus, stream));
         record(ctx, ev[0], stream);
         // K5 (+ the join's work items once both histograms exist), K5b
         pa.mask = plan_mask;
@@ -335,7 +337,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
             sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
             sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
-            sa.ranged = 1; sa.strided = 0; sa.geom = geom[r]; sa.range_base = m.range_base[r];
+            sa.ranged = 1; sa.work_counter = m.tickets + 16 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
             sa.in_packed = 0; sa.out_packed = 1;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
@@ -346,7 +348,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
             sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
             sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
-            sa.ranged = 0; sa.strided = 1; sa.geom = geom[r]; sa.range_base = nullptr;
+            sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
             sa.in_packed = 1; sa.out_packed = 1;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
@@ -667,9 +669,11 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
     if (n) {
         // the per-range counts are a by-product here; they go to scratch
         const Pass1Geom g = make_geom(d_keys, n, 1, 1, false);
-        CHK(ensure(ctx, ctx->moves, (size_t)g.ranges_per_chunk * sizeof(uint32_t)));
+        CHK(ensure(ctx, ctx->moves, ((size_t)g.ranges_per_chunk + 16) * sizeof(uint32_t)));
+        uint32_t *ticket = (uint32_t *)ctx->moves.p + g.ranges_per_chunk;
+        HIPCHK(ctx, hipMemsetAsync(ticket, 0, 8 * sizeof(uint32_t), stream));
         CHK(hj_launch_hist2(d_keys, g, 1u, 1u, factor, fanout, (u64 *)d_counts,
-                            (uint32_t *)ctx->moves.p, ctx->cus, stream));
+                            (uint32_t *)ctx->moves.p, ticket, ctx->cus, stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(stream));
     return HJGPU_OK;
@@ -691,7 +695,8 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
-    if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], ctx->cus, stream));
+    if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets,
+                               ctx->cus, stream));
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
         pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
@@ -712,7 +717,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
         sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
-        sa.ranged = 1; sa.strided = 0; sa.geom = geom; sa.range_base = m.range_base[0];
+        sa.ranged = 1; sa.work_counter = m.tickets + 16; sa.geom = geom; sa.range_base = m.range_base[0];
         sa.in_packed = 0; sa.out_packed = 0;
         CHK(hj_launch_scatter(sa, ctx->cus, stream));
     }

@@ -34,7 +34,7 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void hist2_kernel(
     const uint32_t *__restrict__ keys, Pass1Geom geom,
     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-    u64 *__restrict__ counts, uint32_t *__restrict__ range_counts)
+    u64 *__restrict__ counts, uint32_t *__restrict__ range_counts, uint32_t *work_counter)
 {
     extern __shared__ uint32_t lds_hist[];          // [P] fused, then [F1] per-range
     const uint32_t P = F1 * F2;
@@ -50,7 +50,17 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
 
     for (uint32_t i = threadIdx.x; i < P; i += BLOCK) lds_hist[i] = 0;
 
-    for (uint32_t r = blockIdx.x; r < Rc; r += gridDim.x) {
+    // ranges are claimed from a per-chunk ticket counter (see K6: whoever runs, works); the next
+    // ticket is requested while the current range is counted
+    __shared__ uint32_t next_range;
+    uint32_t *ticket = work_counter + chunk;
+    if (threadIdx.x == 0) next_range = atomicAdd(ticket, 1u);
+    __syncthreads();
+    for (;;) {
+        const uint32_t r = next_range;
+        if (r >= Rc) break;
+        uint32_t upcoming = 0;
+        if (threadIdx.x == 0) upcoming = atomicAdd(ticket, 1u);
         const uint32_t j = r;
         const u64 gb = geom.align + cb, ge = geom.align + ce;
         const u64 tiles = hj_tiles_of(cb, ce, geom.align, geom.tile);
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
             rc[i] = v;
             if (F2 == 1 && v) atomicAdd(&lds_hist[i], v);       // single pass: fused == pass-1 histogram
         }
+        if (threadIdx.x == 0) next_range = upcoming;            // everybody read the old value before the first barrier above
         __syncthreads();
     }
     __syncthreads();
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
 
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-                    u64 *counts, uint32_t *range_counts, int cus, hipStream_t stream)
+                    u64 *counts, uint32_t *range_counts, uint32_t *work_counter, int cus, hipStream_t stream)
 {
     constexpr int BLOCK = 1024;
     const uint32_t P = F1 * F2;
@@ -123,7 +134,7 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
     if (gx > geom.ranges_per_chunk) gx = geom.ranges_per_chunk;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(hist2_kernel<BLOCK>, dim3(gx, geom.chunks), dim3(BLOCK), lds, stream, keys, geom,
-                       f1, F1, f2, F2, counts, range_counts);
+                       f1, F1, f2, F2, counts, range_counts, work_counter);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     uint32_t *hist = reinterpret_cast<uint32_t *>(carry + (CARRY ? Fpad * LINE : 0));   // [Fpad]  counts, then local bases
     uint32_t *meta = hist + Fpad;                                   // [Fpad] tuples leaving this tile | carried ones among them << 16
     uint32_t *left = meta + Fpad;                                   // CARRY: [Fpad] first staying index | carry offset << 16 | count << 20
-    uint32_t *wsum = left + (CARRY ? Fpad : 0);                     // [NW + 6]; [NW + 1] = number of runs longer than one unit,
+    uint32_t *wsum = left + (CARRY ? Fpad : 0);                     // [NW + 6]; [NW + 1] = number of runs longer than one unit, [NW + 4..5] = tickets,
                                                                     // [NW + 2] = this tile's heavy partition (count << 10 | bin, 0 = none),
                                                                     // [NW + 3] = the same for the next tile
     uint32_t *heavy = wsum + NW + 6;                                // [HJ_MAX_HEAVY] partitions whose run is longer than one unit
@@ -362,31 +373,49 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 #pragma unroll
     for (int i = 0; i < BPT; ++i) { mycur[i] = 0; mycc[i] = 0; }
 
-    // ---- the sequence of tiles this workgroup owns -------------------------------
-    struct Tile { u64 gb, ge, g0, cursor_row; uint32_t range; bool new_range, last_in_range, valid; };
-    // RANGED state
-    uint32_t r_cur = blockIdx.x;
-    u64 rt = 0, rt_end = 0, r_gb = 0, r_ge = 0;
-    bool r_open = false;
-    // !RANGED state
-    u64 t_cur = 0, t_end = 0;
-    if (!RANGED) {
-        const u64 total_tiles = a.tile_prefix[a.nseg];
-        if (a.strided) { t_cur = blockIdx.x; t_end = total_tiles; }
-        else {
-            t_cur = total_tiles * blockIdx.x / gridDim.x;
-            t_end = total_tiles * (blockIdx.x + 1) / gridDim.x;
-        }
+    // ---- the sequence of tiles this workgroup processes ------------------------------
+    // Work is CLAIMED, not owned: pass 1 takes whole ranges, pass 2 single tiles, in order, from a
+    // global ticket counter (zeroed per launch).  A static split (range r = blockIdx + k * grid)
+    // makes the kernel as slow as its unluckiest workgroup: when other kernels hold some CUs - the
+    // RCCL transfer of the build side on the multi-GPU path - the workgroups that found no CU
+    // start only after the others have finished their share.  With tickets whoever runs, works.
+    // Tickets are prefetched: thread 0 issues the atomic for ticket n+2 when ticket n+1 is taken
+    // and deposits it in LDS a few barriers later, so nobody ever waits for an atomic.
+    struct Tile { u64 gb, ge, g0, cursor_row; uint32_t range; bool new_range, last_in_range, empty, valid; };
+    uint32_t *claim = wsum + NW + 4;                                 // [2] prefetched tickets
+    int claim_parity = 0;
+    uint32_t pending_ticket = 0;                                    // thread 0: ticket on its way
+    int pending_slot = -1;                                          // thread 0: where it goes (-1: none)
+    if (tid == 0) {
+        const uint32_t t0 = atomicAdd(a.work_counter, 2u);
+        claim[0] = t0; claim[1] = t0 + 1;
     }
+    __syncthreads();
+    auto take_ticket = [&]() -> uint32_t {                          // uniform; at most once between two deposits
+        const uint32_t t = claim[claim_parity];
+        if (tid == 0) { pending_ticket = atomicAdd(a.work_counter, 1u); pending_slot = claim_parity; }
+        claim_parity ^= 1;
+        return t;
+    };
+    auto deposit_ticket = [&]() {                                   // >= 1 barrier after the take, >= 1 before the slot's next take
+        if (tid == 0 && pending_slot >= 0) { claim[pending_slot] = pending_ticket; pending_slot = -1; }
+    };
+    // RANGED state
+    uint32_t r_cur = 0;
+    u64 rt = 0, rt_end = 0, r_gb = 0, r_ge = 0;
+    bool r_open = false, exhausted = false;
+    const u64 total_tiles = RANGED ? 0 : a.tile_prefix[a.nseg];
     auto next_tile = [&]() -> Tile {
         Tile t;
-        t.valid = false; t.new_range = false; t.last_in_range = false; t.range = 0; t.gb = t.ge = t.g0 = t.cursor_row = 0;
+        t.valid = false; t.new_range = false; t.last_in_range = false; t.empty = false; t.range = 0;
+        t.gb = t.ge = t.g0 = t.cursor_row = 0;
+        if (exhausted) return t;
         if (RANGED) {
             const uint32_t Rc = a.geom.ranges_per_chunk;
             const uint32_t nranges = Rc * a.geom.chunks;
-            while (!r_open || rt >= rt_end) {
-                if (r_open) { r_cur += gridDim.x; r_open = false; }
-                if (r_cur >= nranges) return t;
+            if (!r_open || rt >= rt_end) {
+                r_cur = take_ticket();
+                if (r_cur >= nranges) { exhausted = true; return t; }
                 const uint32_t c = r_cur / Rc, j = r_cur - c * Rc;
                 u64 cb = 0, ce = 0;
 #pragma unroll
@@ -396,13 +425,18 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 rt = tiles * j / Rc; rt_end = tiles * (j + 1) / Rc;
                 r_open = true;
                 t.new_range = true;
+                if (rt >= rt_end) {                                 // a range without tiles (small inputs): a tile without tuples
+                    t.range = r_cur; t.valid = true; t.empty = true; t.last_in_range = true;
+                    return t;
+                }
             }
             t.gb = r_gb; t.ge = r_ge; t.g0 = (r_gb & ~3ull) + rt * (u64)TILE;
             t.range = r_cur; t.valid = true;
             ++rt;
             t.last_in_range = rt >= rt_end;                         // CARRY: everything still waiting goes out
         } else {
-            if (t_cur >= t_end) return t;
+            const u64 t_cur = take_ticket();
+            if (t_cur >= total_tiles) { exhausted = true; return t; }
             // one independent 32-byte read of the descriptor K5 wrote for this tile (in_align == 0)
             const uint4 d0 = a.tile_desc[2 * t_cur], d1 = a.tile_desc[2 * t_cur + 1];
             t.gb = (u64)d0.x | ((u64)d0.y << 32);
@@ -410,7 +444,6 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             t.g0 = (u64)d1.x | ((u64)d1.y << 32);
             t.cursor_row = d1.z;
             t.valid = true;
-            t_cur += a.strided ? gridDim.x : 1;
         }
         return t;
     };
@@ -421,6 +454,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     // coordinates - so the compiler has no reason to wait for them before the back edge.
     uint4 kq[VPT], vq[VPT];
     auto load_tile = [&](const Tile &t) {
+        if (t.empty) return;                              // no tuples: the registers keep whatever they hold
         const u64 g_last = (t.ge - 1) & ~3ull;            // last vector that overlaps the segment
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
@@ -441,6 +475,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     };
 
     Tile cur = next_tile();
+    deposit_ticket();                                               // the loop's first take needs its slot refilled
+    __syncthreads();
     if (!cur.valid) return;
     load_tile(cur);
     bool have_left = false;                                         // CARRY: the previous tile may have left tails in `stage`
@@ -613,6 +649,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         // order, so any wait on an older result placed after these loads would also wait for
         // them.  Nothing below touches them until the next tile is ranked, and the barriers are
         // LDS-only, so they stay in flight during the whole stream-out.
+        deposit_ticket();
         if (nxt.valid) load_tile(nxt);
         hj_barrier_lds();
         stamp(3);
@@ -728,11 +765,9 @@ static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
     if (per_cu < 1) per_cu = 1;
     const int grid = cus * per_cu;
     ScatterArgs b = a;
-    // pass-2 tile ownership: round-robin (default) keeps all workgroups inside the same
-    // one or two pass-1 partitions, whose output region stays in the Infinity Cache:
-    // 3.9-4.0 ms vs 4.45-4.65 ms for contiguous runs at 136 x 136.  HJGPU_PASS2_STRIDED=0 flips.
-    const char *e = getenv("HJGPU_PASS2_STRIDED");
-    b.strided = (e && !atoi(e)) ? 0u : 1u;
+    // pass-2 tiles are claimed in order, so all workgroups sit inside the same one or two pass-1
+    // partitions, whose output region stays in the Infinity Cache (contiguous ownership instead:
+    // 4.45-4.65 vs 3.9-4.0 ms in the first version)
     // diagnostics only: HJGPU_SCATTER_PROF=1 prints where a workgroup's time goes (synchronises!)
     static u64 *prof = nullptr;
     const char *pe = getenv("HJGPU_SCATTER_PROF");
