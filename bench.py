@@ -123,7 +123,13 @@ def main():
     # ---- relations resident in HBM (torch owns the memory; the library borrows pointers)
     def col(n):
         return torch.empty(n + 4, dtype=torch.int32, device=dev)
-    rk, rv, sk, sv = col(inner), col(inner), col(outer), col(outer)
+    # the two build columns are halves of ONE buffer: the multi-GPU path replicates it with one
+    # scatter + one all-gather (each RCCL kernel has to find free CUs next to the persistent
+    # partitioning kernels: two get in during the first millisecond of a step, four would not)
+    stride_r = (inner + 4 + 3) // 4 * 4                 # keeps the payload column 16-byte aligned
+    r_both = torch.empty(2 * stride_r, dtype=torch.int32, device=dev)
+    rk, rv = r_both[:stride_r], r_both[stride_r:]
+    sk, sv = col(outer), col(outer)
     stream = torch.cuda.current_stream().cuda_stream
     # CPRA across GPUs (BASELINE configs[4]): every rank owns a chunk of BOTH relations and the
     # tuples are co-partitioned with one all-to-all; PHJ / NPJ: R replicated, S sharded.
@@ -145,7 +151,7 @@ def main():
         dist.all_reduce(e)
         expect_global = [int(x) for x in e.tolist()]
         # the build side lives on rank 0 and is broadcast each step (measured, not assumed)
-        r_src_k, r_src_v = rk.clone(), rv.clone()
+        r_src = r_both.clone()
     else:
         expect_global = expect_local
 
@@ -185,20 +191,17 @@ def main():
                 x0 = torch.cuda.Event(enable_timing=True)
                 x1 = torch.cuda.Event(enable_timing=True)
                 if rank == 0:
-                    rk.copy_(r_src_k); rv.copy_(r_src_v)
+                    r_both.copy_(r_src)
                 x0.record(bs)
                 if state["ring"]:
-                    dist.broadcast(rk, 0)
-                    dist.broadcast(rv, 0)
+                    dist.broadcast(r_both, 0)
                 else:                       # scatter + all-gather: all 7 xGMI links of every GPU
                     try:
-                        DD.replicate(dist, torch, rk, 0)
-                        DD.replicate(dist, torch, rv, 0)
+                        DD.replicate(dist, torch, r_both, 0)
                     except Exception as ex:                    # argument/backend errors are raised on every rank
                         print("replicate() failed (%r): falling back to dist.broadcast" % (ex,), file=sys.stderr)
                         state["ring"] = True
-                        dist.broadcast(rk, 0)
-                        dist.broadcast(rv, 0)
+                        dist.broadcast(r_both, 0)
                 x1.record(bs)
                 exchange_events.append((x0, x1))
                 if overlap:
