@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""NPJ on small relations (duplicate-heavy build sides, so every walk leaves its first line) at
+several load factors, against the oracle's join definition: the quick check used while the
+line-hashed cooperative probe was brought up.  Run under `timeout`: a wrong walk may not end."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
