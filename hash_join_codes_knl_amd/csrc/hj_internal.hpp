@@ -148,7 +148,7 @@ struct NpjProbeArgs {
 int hj_launch_npj_probe(const NpjProbeArgs &a, int cus, hipStream_t stream, int *grid_out);
 
 // K9: compact the per-wave partially filled tail blocks (npj.cpp:475-514).
-// moves: scratch of 2*HJ_MAX_WORKERS entries of 24 bytes.
+// moves: scratch of 2*HJ_MAX_WORKERS entries of 24 bytes + HJ_MAX_WORKERS entries of 8 bytes.
 constexpr uint32_t HJ_MAX_WORKERS = 8192;
 int hj_launch_close_gaps_ex(uint32_t *k, uint32_t *ov, uint32_t *iv, const u64 *final_offsets,
                             uint32_t nworkers, u64 block_size, const u64 *block_counter,

@@ -194,7 +194,7 @@ int setup_output(hjgpu_ctx *ctx, const hjgpu_output *out, uint32_t workers, u64 
     if (bl == 0) return fail(ctx, HJGPU_EINVAL, "output capacity below one block");
     if (workers > HJ_MAX_WORKERS) return fail(ctx, HJGPU_EINVAL, "too many workers for close_gaps");
     CHK(ensure(ctx, ctx->final_offsets, (size_t)workers * sizeof(u64)));
-    CHK(ensure(ctx, ctx->moves, (size_t)2 * HJ_MAX_WORKERS * 24));
+    CHK(ensure(ctx, ctx->moves, (size_t)2 * HJ_MAX_WORKERS * 24 + (size_t)HJ_MAX_WORKERS * 8));   // move list + stretch starts
     *block_size = bs; *block_limit = bl;
     return HJGPU_OK;
 }
