@@ -151,8 +151,10 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             si_ += (h1 ? (uint32_t)(t1[j] >> 32) : 0u);
             si_ += (h2 ? (uint32_t)(t2[j] >> 32) : 0u);
             if (a.ok) {
-                if (h1) em.emit(key[j], val[j], (uint32_t)(t1[j] >> 32));
-                if (h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
+                // one emit for "this key matched" (with unique build keys that is every lane of the wave:
+                // 64 rows, the cursor moves in whole lines), a second one only for a key found in BOTH slots
+                if (h1 | h2) em.emit(key[j], val[j], (uint32_t)((h1 ? t1[j] : t2[j]) >> 32));
+                if (h1 & h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
             }
         }
         acc_n += n; acc_k += sk_; acc_o += so_; acc_i += si_;
