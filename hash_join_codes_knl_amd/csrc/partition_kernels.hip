@@ -175,17 +175,34 @@ int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *ran
 // --------------------------------------------------------------------------
 constexpr int PLAN_BLOCK = 1024;
 
-// Exclusive scan of f(i), i in [0, n), written to out[0..n] (out[n] = total).
-template <typename F>
-__device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 *scratch)
+// Exclusive scan of f(i), i in [0, n), written to out[0..n] (out[n] = total); then(i, f(i), out[i]) is
+// called for every i.  A thread's values (<= 32 for n <= 32768) are fetched together and kept in
+// registers: the loads of f are global reads, and one dependent read per element and pass was most
+// of these latency-bound kernels' time.
+struct PlanNoop { __device__ void operator()(uint32_t, u64, u64) const {} };
+template <int MAXPER = 32, typename F, typename G = PlanNoop>
+__device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 *scratch, G then = G())
 {
     const uint32_t per = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     u64 sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += f(i);
-    u64 run = base + block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
-    for (uint32_t i = lo; i < hi; ++i) { out[i] = run; run += f(i); }
-    if (threadIdx.x == PLAN_BLOCK - 1) out[n] = run;   // last thread's run == base + total
+    if (per <= MAXPER) {
+        u64 v[MAXPER];
+#pragma unroll
+        for (int j = 0; j < MAXPER; ++j) { v[j] = 0; if (lo + j < hi) v[j] = f(lo + j); }
+#pragma unroll
+        for (int j = 0; j < MAXPER; ++j) sum += v[j];
+        u64 run = base + block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
+#pragma unroll
+        for (int j = 0; j < MAXPER; ++j)
+            if (lo + j < hi) { out[lo + j] = run; then(lo + j, v[j], run); run += v[j]; }
+        if (threadIdx.x == PLAN_BLOCK - 1) out[n] = run;   // last thread's run == base + total
+    } else {
+        for (uint32_t i = lo; i < hi; ++i) sum += f(i);
+        u64 run = base + block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
+        for (uint32_t i = lo; i < hi; ++i) { const u64 x = f(i); out[i] = run; then(i, x, run); run += x; }
+        if (threadIdx.x == PLAN_BLOCK - 1) out[n] = run;
+    }
     __syncthreads();
 }
 
@@ -217,25 +234,24 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
     }
 }
 
-// K5, step 2: tile prefixes of both passes (blocks 0, 1) and the join's work items (block 2).
+// K5, step 2: tile prefixes of both passes (block r = relation r).
 __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
 {
     __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
-    const uint32_t P = a.F1 * a.F2;
     const uint32_t C = a.chunks;
     if (!((a.mask >> blockIdx.x) & 1u)) return;
-    if (blockIdx.x < 2) {
+    {
         const int r = blockIdx.x;
         // pass-1 tiles: segments are the chunks of the caller's (possibly unaligned) input
         const uint32_t al = a.in_align[r];
         const uint32_t tile1 = a.tile1, tile2 = a.tile2;
         const u64 *seg1 = a.seg1[r];
-        plan_scan(C, [&](uint32_t i) { return hj_tiles_of(seg1[i], seg1[i + 1], al, tile1); },
-                  a.tp1[r], 0, scratch);
+        plan_scan<8>(C, [&](uint32_t i) { return hj_tiles_of(seg1[i], seg1[i + 1], al, tile1); },
+                     a.tp1[r], 0, scratch);
         // pass-2 tiles: segments are the pass-1 partitions inside the (aligned) workspace
         const u64 *off1 = a.off1[r];
-        plan_scan(C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile2); },
-                  a.tp2[r], 0, scratch);
+        plan_scan<8>(C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile2); },
+                     a.tp2[r], 0, scratch);
         // per-tile descriptors of pass 2: K6 then needs ONE independent 32-byte load per tile instead
         // of a search in tp2 followed by dependent reads of off1 (exposed latency on every tile)
         if (a.tdesc[r]) {
@@ -252,8 +268,16 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
                 }
             }
         }
-    } else {
-        // join work items: partition q gets ceil(|S_q| / slice) items when both sides are non-empty
+    }
+}
+
+// K5, step 3: the join's work items: partition q gets ceil(|S_q| / slice) items when both sides are non-empty.
+__global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
+{
+    __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
+    const uint32_t P = a.F1 * a.F2;
+    const uint32_t C = a.chunks;
+    {
         const u64 *__restrict__ cr = a.counts[0];
         const u64 *__restrict__ cs = a.counts[1];
         const uint32_t slice = a.slice;
@@ -262,14 +286,26 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
             for (uint32_t c = 0; c < C; ++c) { nr += cr[(u64)c * P + q]; ns += cs[(u64)c * P + q]; }
             return (nr && ns) ? (ns + slice - 1) / slice : 0;
         };
-        plan_scan(P, items, a.slice_prefix, 0, scratch);
-        const u64 *sp = a.slice_prefix;                 // written above by this workgroup
-        for (uint32_t q = threadIdx.x; q < P; q += PLAN_BLOCK) {
-            const u64 n = items(q);
+        // a thread's item counts (<= 32 partitions, 32-bit each) are fetched together and kept in registers
+        constexpr int MAXPER = HJGPU_MAX_PARTS / PLAN_BLOCK;
+        const uint32_t per = (P + PLAN_BLOCK - 1) / PLAN_BLOCK;
+        const uint32_t lo = min(P, threadIdx.x * per), hi = min(P, lo + per);
+        uint32_t v[MAXPER];
+        u64 sum = 0;
+#pragma unroll
+        for (int j = 0; j < MAXPER; ++j) { v[j] = 0; if (lo + j < hi) v[j] = (uint32_t)items(lo + j); }
+#pragma unroll
+        for (int j = 0; j < MAXPER; ++j) sum += v[j];
+        u64 run = block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
+        for (uint32_t q = lo; q < hi; ++q) {
+            const uint32_t n = (uint32_t)items(q);      // second read: L2 hit, and keeps v[] out of a dynamic index
+            a.slice_prefix[q] = run;
             a.slices[q] = n;
             // item -> partition directory: the join reads one word instead of a binary search
-            for (u64 s = 0; s < n; ++s) a.item_part[sp[q] + s] = q;
+            for (uint32_t s = 0; s < n; ++s) a.item_part[run + s] = q;
+            run += n;
         }
+        if (threadIdx.x == PLAN_BLOCK - 1) a.slice_prefix[P] = run;
     }
 }
 
@@ -277,7 +313,8 @@ int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
 {
     if (a.mask & 3u)
         hipLaunchKernelGGL(plan_offsets_kernel, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
-    hipLaunchKernelGGL(plan_tiles_kernel, dim3(3), dim3(PLAN_BLOCK), 0, stream, a);
+    if (a.mask & 3u) hipLaunchKernelGGL(plan_tiles_kernel, dim3(2), dim3(PLAN_BLOCK), 0, stream, a);
+    if (a.mask & 4u) hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
