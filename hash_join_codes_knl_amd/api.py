@@ -26,7 +26,7 @@ EXPORTS = [
     "hjgpu_npj_build", "hjgpu_npj_probe",
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
-    "hjgpu_join_host", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums",
+    "hjgpu_join_host", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums", "hjgpu_stream_read_ms",
 ]
 
 
@@ -118,6 +118,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.hjgpu_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     L.hjgpu_synchronize.argtypes = [vp, vp]
+    L.hjgpu_stream_read_ms.argtypes = [vp, vp, sz, C.POINTER(C.c_float), vp]
     L.hjgpu_host_alloc.argtypes = [vp, C.POINTER(vp), sz]
     L.hjgpu_host_free.argtypes = [vp, vp]
     L.hjgpu_histogram.argtypes = [vp, vp, sz, u32, u32, vp, vp]
@@ -351,6 +352,11 @@ class HjGpu:
                                                  inner_count, outer_begin, outer_count, inner_factor,
                                                  outer_factor, float(zipf), self._ptr(ik), self._ptr(iv),
                                                  self._ptr(ok), self._ptr(ov), stream))
+
+    def stream_read_ms(self, d_ptr, nbytes, stream=None):
+        ms = C.c_float()
+        self._check(self.lib.hjgpu_stream_read_ms(self.handle, self._ptr(d_ptr), nbytes, C.byref(ms), stream))
+        return ms.value
 
     def column_sums(self, d_keys, n, fa, fb, stream=None):
         sums = (C.c_uint64 * 3)()

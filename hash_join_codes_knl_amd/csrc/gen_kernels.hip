@@ -162,3 +162,25 @@ int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t 
     hipLaunchKernelGGL(column_sums_kernel, dim3(2048), dim3(256), 0, stream, keys, (u64)n, fa, fb, sums3);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
+
+// The "simple dwordx4 read kernel" of SURVEY 8d: 1024-thread workgroups sweep 64 KiB pieces, four
+// 16-byte loads per lane in flight, the data only XORed together (column_sums_kernel's two 32-bit
+// multiplies per key make IT instruction-bound at ~5.2 TB/s; this one reads at 6.6-6.7 TB/s).
+__global__ __launch_bounds__(1024) void stream_read_kernel(const uint4 *__restrict__ in, u64 pieces, uint4 *sink)
+{
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (u64 t = blockIdx.x; t < pieces; t += gridDim.x) {
+        const uint4 *p = in + t * 4096 + threadIdx.x;
+        const uint4 a = p[0], b = p[1024], c = p[2048], d = p[3072];
+        acc.x ^= a.x ^ b.y; acc.y ^= c.z ^ d.w; acc.z ^= a.z ^ c.x; acc.w ^= b.w ^ d.y;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = acc;      // keeps the loads alive
+}
+
+int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hipStream_t stream)
+{
+    const u64 pieces = bytes / 65536;
+    if (pieces == 0 || ((uintptr_t)p & 15)) return HJGPU_EINVAL;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(cus * 2), dim3(1024), 0, stream, (const uint4 *)p, pieces, (uint4 *)sink16);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
     for (int q = 0; q < 8; ++q) if (q == (int)chunk) { cb = geom.b[q]; ce = geom.b[q + 1]; }
     const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(keys - geom.align);
 
-    for (uint32_t i = threadIdx.x; i < P; i += BLOCK) lds_hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < P + F1; i += BLOCK) lds_hist[i] = 0;     // fused histogram + range_hist
 
     // ranges are claimed from a per-chunk ticket counter (see K6: whoever runs, works); the next
     // ticket is requested while the current range is counted
@@ -68,9 +68,15 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
         const u64 g_lo = (gb & ~3ull) + t_beg * geom.tile;
         const u64 g_hi = min(ge, (gb & ~3ull) + t_end * geom.tile);
 
-        for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) range_hist[i] = 0;
-        __syncthreads();
-        if (t_end > t_beg) {
+        // F2 > 1: ONE LDS add per key, into the fused histogram; the range's pass-1 counts are the growth of
+        // the fused rows' sums over the range (range_hist keeps the sums seen so far).  The second add per
+        // key (a private pass-1 histogram per range) made K4 LDS-atomic-bound: 0.80 ms for a sweep that the
+        // memory system delivers in 0.64 ms.  F2 == 1: the pass-1 histogram is the only one.
+        if (F2 == 1) {
+            for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) range_hist[i] = 0;
+            __syncthreads();
+        }
+        auto count_range = [&](auto part1) {
             constexpr int U = 4;                       // key vectors in flight per lane
             for (u64 g0 = g_lo + (u64)threadIdx.x * 4; g0 < g_hi; g0 += (u64)BLOCK * 4 * U) {
                 uint4 kv[U];
@@ -89,20 +95,37 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (full || (g + e >= gb && g + e < ge)) {
-                            const uint32_t p1 = hj_hash(kk[e], f1, F1);
-                            atomicAdd(&range_hist[p1], 1u);
+                            const uint32_t p1 = part1(kk[e]);
                             if (F2 > 1) atomicAdd(&lds_hist[p1 * F2 + hj_hash(kk[e], f2, F2)], 1u);
+                            else atomicAdd(&range_hist[p1], 1u);
                         }
                     }
                 }
             }
+        };
+        if (t_end > t_beg) {
+            // H(key, f, 2^k) = (key * f) >> (32 - k): same function, one multiply less
+            if (F1 > 1 && (F1 & (F1 - 1)) == 0) {
+                const uint32_t sh = 32 - (uint32_t)__builtin_ctz(F1);
+                count_range([&](uint32_t k) { return (k * f1) >> sh; });
+            } else count_range([&](uint32_t k) { return hj_hash(k, f1, F1); });
         }
         __syncthreads();
         uint32_t *__restrict__ rc = range_counts + (u64)r * F1;
-        for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) {
-            const uint32_t v = range_hist[i];
-            rc[i] = v;
-            if (F2 == 1 && v) atomicAdd(&lds_hist[i], v);       // single pass: fused == pass-1 histogram
+        if (F2 > 1) {
+            // one wave per fused row: sum of the row now minus the sum after the previous range
+            for (uint32_t p1 = threadIdx.x >> 6; p1 < F1; p1 += BLOCK / 64) {
+                uint32_t sum = 0;
+                for (uint32_t p2 = hj_lane(); p2 < F2; p2 += 64) sum += lds_hist[p1 * F2 + p2];
+                sum = (uint32_t)wave_reduce_sum((u64)sum);
+                if (hj_lane() == 0) { rc[p1] = sum - range_hist[p1]; range_hist[p1] = sum; }
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) {
+                const uint32_t v = range_hist[i];
+                rc[i] = v;
+                if (v) atomicAdd(&lds_hist[i], v);              // single pass: fused == pass-1 histogram
+            }
         }
         if (threadIdx.x == 0) next_range = upcoming;            // everybody read the old value before the first barrier above
         __syncthreads();

@@ -259,6 +259,11 @@ int  hjgpu_generate_zipf(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size
 int  hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n,
                        uint32_t f_a, uint32_t f_b, uint64_t sums[3], void *stream);
 
+/* Measurement helper: duration of a plain streaming read (16-byte loads, nothing computed)
+ * of `bytes` (a multiple of 64 KiB is read) at d_ptr: the empirical HBM-read ceiling of this
+ * device that bench.py reports next to the kernels' rates. */
+int  hjgpu_stream_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, float *ms, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
