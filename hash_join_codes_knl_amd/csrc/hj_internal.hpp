@@ -59,7 +59,10 @@ struct ScatterArgs {
     const u64 *seg_off;             // [nseg+1] element offsets of the segments in kin/vin
     const u64 *tile_prefix;         // [nseg+1] exclusive prefix of tiles per segment
     const uint4 *tile_desc;         // pass 2: [tiles][2] {first row, end row of the segment | first slot of the tile, cursor row}
-    u64 *cursors;                   // [nseg*F] absolute output positions, advanced atomically
+    u64 *cursors;                   // [nseg*F] pass 2: absolute output positions, advanced atomically;
+                                    //          aligned_claims: lines claimed | tail tuples << 32
+    const u64 *part_start, *part_end; // pass 2, aligned_claims: [nseg*F] first row / one past the last row of every partition
+    uint32_t aligned_claims;
     uint32_t nseg, F, factor;
     uint32_t in_align;              // (address of kin / 4) % 4, same for vin
     // pass 1 only (ranged == 1): per-range bases instead of atomic cursors
@@ -73,7 +76,8 @@ struct ScatterArgs {
 struct JoinArgs {
     const uint32_t *rk, *rv, *sk, *sv;   // co-partitioned columns (packed: rk / sk = packed tuples)
     uint32_t packed;                     // 1: payload << 32 | key tuples (the library's own passes)
-    const u64 *roff, *soff;              // [chunks*P + 1] absolute offsets, chunk-major
+    const u64 *roff, *soff;              // [chunks*P] first row of every partition, chunk-major
+    const u64 *rend, *send;              // [chunks*P] one past its last row (dense layouts: roff + 1, soff + 1)
     const u64 *slice_prefix;             // [P+1] exclusive prefix of work items per partition
     const u64 *slices;                   // [P]   work items of partition q
     const uint32_t *item_part;           // [items] partition of work item w
@@ -96,7 +100,9 @@ struct PlanArgs {
     const u64 *counts[2];     // [chunks*P] fused two-level histograms of R (0) and S (1)
     u64 n[2];                 // relation sizes
     u64 chunk_beg[2][9];      // first row of every chunk (host-known: sizes only)
-    u64 *off2[2];             // [chunks*P + 1] absolute final offsets
+    u64 *off2[2];             // [chunks*P + 1] first row of every final partition
+    u64 *end2[2];             // [chunks*P] one past its last row
+    uint32_t pad2;            // 1: final partitions start on 128-byte lines (two-pass plans)
     u64 *cur2[2];             // [chunks*P]
     u64 *off1[2];             // [chunks*F1 + 1]
     u64 *cur1[2];             // [chunks*F1]

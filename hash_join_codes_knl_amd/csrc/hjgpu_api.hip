@@ -101,7 +101,7 @@ inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) 
 
 // Carves the meta buffer; must match between sizing and use.
 struct MetaLayout {
-    u64 *counts[2], *off2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
+    u64 *counts[2], *off2[2], *end2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
     u64 *slice_prefix, *slices;
     uint32_t *tickets;           // [64] work-claim counters of K4 / K6 (inside the block zeroed per join)
     uint32_t *item_part;         // [P + items_extra] partition of every join work item
@@ -126,6 +126,7 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
     m.counts_bytes = at * sizeof(u64);
     for (int r = 0; r < 2; ++r) {
         m.off2[r] = take((size_t)C * P + 1);
+        m.end2[r] = take((size_t)C * P);
         m.cur2[r] = take((size_t)C * P);
         m.off1[r] = take((size_t)C * F1 + 1);
         m.cur1[r] = take((size_t)C * F1);
@@ -269,8 +270,10 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     CHK(ensure(ctx, ctx->tmp[0], rb));
     CHK(ensure(ctx, ctx->tmp[2], sb));
     if (pl->F2 > 1) {
-        CHK(ensure(ctx, ctx->tmp[4], rb));
-        CHK(ensure(ctx, ctx->tmp[6], sb));
+        // the final layout starts every partition on a 128-byte line: < 16 tuples of padding each
+        const size_t pad = (size_t)pl->C * pl->P * HJ_LINE_TUPLES * sizeof(u64);
+        CHK(ensure(ctx, ctx->tmp[4], rb + pad));
+        CHK(ensure(ctx, ctx->tmp[6], sb + pad));
     }
     // ranges of the larger relation bound the per-range tables of both
     const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1, true), gs = make_geom(nullptr, outer, pl->C, pl->F1, true);
@@ -306,11 +309,15 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     uint32_t *t2[4] = {(uint32_t *)ctx->tmp[4].p, nullptr, (uint32_t *)ctx->tmp[6].p, nullptr};
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
-        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
+        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r]; pa.tdesc[r] = m.tdesc[r];
     }
     pa.tdesc_cap = (uint32_t)m.tdesc_cap;
+    // two-pass plans: final partitions start on 128-byte lines (pass 2 claims whole lines); HJGPU_DENSE2=1: dense
+    const char *dense2 = getenv("HJGPU_DENSE2");
+    const bool pad2 = pl.F2 > 1 && !(dense2 && atoi(dense2));
+    pa.pad2 = pad2 ? 1u : 0u;
     pa.n[0] = inner; pa.n[1] = outer;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
     pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
@@ -334,6 +341,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         // K6 pass 1: caller's columns -> tmp[0..3]
         if (nn[r]) {
             ScatterArgs sa;
+            memset(&sa, 0, sizeof(sa));
             sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
             sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
             sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
@@ -345,10 +353,12 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
         if (nn[r] && pl.F2 > 1) {
             ScatterArgs sa;
+            memset(&sa, 0, sizeof(sa));
             sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
             sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
             sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
             sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
+            sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
             sa.in_packed = 1; sa.out_packed = 1;
             CHK(hj_launch_scatter(sa, ctx->cus, stream));
         }
@@ -370,6 +380,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         memset(&ja, 0, sizeof(ja));
         ja.rk = fin[0]; ja.rv = fin[1]; ja.sk = fin[2]; ja.sv = fin[3];
         ja.roff = m.off2[0]; ja.soff = m.off2[1];
+        ja.rend = m.end2[0]; ja.send = m.end2[1];
         ja.slice_prefix = m.slice_prefix; ja.slices = m.slices; ja.item_part = m.item_part;
         ja.P = pl.P; ja.chunks = pl.C;
         ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2;
@@ -699,11 +710,11 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
                                ctx->cus, stream));
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
-        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
+        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
-    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0;
+    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0;
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
@@ -714,6 +725,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
                                  geom.ranges_per_chunk, fanout, stream));
         ScatterArgs sa;
+        memset(&sa, 0, sizeof(sa));
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
         sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
@@ -771,11 +783,11 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     CHK(hj_launch_offsets_to_counts((const u64 *)soff, m.counts[1], pl.P, stream));
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
-        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.cur2[r] = m.cur2[r];
+        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
-    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0;
+    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0;
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
@@ -786,6 +798,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     memset(&ja, 0, sizeof(ja));
     ja.rk = rk; ja.rv = rv; ja.sk = sk; ja.sv = sv;
     ja.roff = (const u64 *)roff; ja.soff = (const u64 *)soff;    // caller's offsets (may start at non-zero)
+    ja.rend = ja.roff + 1; ja.send = ja.soff + 1;
     ja.slice_prefix = m.slice_prefix; ja.slices = m.slices; ja.item_part = m.item_part;
     ja.P = pl.P; ja.chunks = 1;
     ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2; ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;

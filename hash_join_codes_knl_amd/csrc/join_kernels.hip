@@ -76,7 +76,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     auto for_each_build_row = [&](u64 fill_beg, u64 fill_end, u64 from_row, auto insert) {
         u64 seen = 0;
         for (uint32_t c = 0; c < C; ++c) {
-            const u64 b = a.roff[(u64)c * P + q], e = a.roff[(u64)c * P + q + 1];
+            const u64 b = a.roff[(u64)c * P + q], e = a.rend[(u64)c * P + q];
             const u64 len = e - b;
             const u64 lo = max(max(seen, fill_beg), from_row), hi = min(seen + len, fill_end);
             for (u64 base = lo; base < hi; base += (u64)BLOCK * RB) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 
     auto probe_item = [&](u64 slice, u64 nslices, auto probe4) {
         for (uint32_t c = 0; c < C; ++c) {
-            const u64 b = a.soff[(u64)c * P + q], e = a.soff[(u64)c * P + q + 1];
+            const u64 b = a.soff[(u64)c * P + q], e = a.send[(u64)c * P + q];
             const u64 len = e - b;
             if (len == 0) continue;
             // sub-range `slice` of `nslices` equal parts (len < 2^40, slices < 2^24)
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             d_slice[slot] = w - a.slice_prefix[nq];
             d_nslices[slot] = a.slices[nq];
             d_rb[slot] = a.roff[nq];
-            d_rn[slot] = a.roff[nq + 1] - a.roff[nq];
+            d_rn[slot] = a.rend[nq] - a.roff[nq];
         }
     };
     uint32_t pk[RB], pv[RB];                              // prefetched build rows j*BLOCK + tid
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 
         // total build rows of q over all chunks
         u64 nr = 0;
-        for (uint32_t c = 0; c < C; ++c) nr += a.roff[(u64)c * P + q + 1] - a.roff[(u64)c * P + q];
+        for (uint32_t c = 0; c < C; ++c) nr += a.rend[(u64)c * P + q] - a.roff[(u64)c * P + q];
 
         for (u64 fill_beg = 0; fill_beg < nr; fill_beg += CAP) {
             const u64 fill_end = min(nr, fill_beg + CAP);

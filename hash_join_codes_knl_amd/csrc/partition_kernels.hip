@@ -204,7 +204,8 @@ constexpr int PLAN_BLOCK = 1024;
 // of these latency-bound kernels' time.
 struct PlanNoop { __device__ void operator()(uint32_t, u64, u64) const {} };
 template <int MAXPER = 32, typename F, typename G = PlanNoop>
-__device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 *scratch, G then = G())
+__device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 *scratch, G then = G(),
+                          bool write_total = true)
 {
     const uint32_t per = (n + PLAN_BLOCK - 1) / PLAN_BLOCK;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
@@ -219,12 +220,12 @@ __device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 
 #pragma unroll
         for (int j = 0; j < MAXPER; ++j)
             if (lo + j < hi) { out[lo + j] = run; then(lo + j, v[j], run); run += v[j]; }
-        if (threadIdx.x == PLAN_BLOCK - 1) out[n] = run;   // last thread's run == base + total
+        if (write_total && threadIdx.x == PLAN_BLOCK - 1) out[n] = run;   // last thread's run == base + total
     } else {
         for (uint32_t i = lo; i < hi; ++i) sum += f(i);
         u64 run = base + block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
         for (uint32_t i = lo; i < hi; ++i) { const u64 x = f(i); out[i] = run; then(i, x, run); run += x; }
-        if (threadIdx.x == PLAN_BLOCK - 1) out[n] = run;
+        if (write_total && threadIdx.x == PLAN_BLOCK - 1) out[n] = run;
     }
     __syncthreads();
 }
@@ -233,6 +234,7 @@ __device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 
 // K5, step 1: one workgroup per (chunk, relation).  A chunk's final offsets are its
 // own exclusive scan plus the chunk's first row (known on the host), so the chunks
 // scan in parallel.
+template <bool PAD>
 __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
 {
     __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
@@ -242,14 +244,48 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
     if (!((a.mask >> r) & 1u)) return;
     const u64 *__restrict__ cnt = a.counts[r] + (u64)c * P;
     u64 *off2 = a.off2[r] + (u64)c * P;
+    u64 *end2 = a.end2[r] + (u64)c * P;
     const u64 base = a.chunk_beg[r][c];
-    plan_scan(P, [&](uint32_t i) { return cnt[i]; }, off2, base, scratch);
-    // off2[P] of this chunk is the next chunk's first row (same value: chunks are contiguous)
-    for (uint32_t i = threadIdx.x; i < P; i += PLAN_BLOCK) a.cur2[r][(u64)c * P + i] = off2[i];
-    for (uint32_t p1 = threadIdx.x; p1 < a.F1; p1 += PLAN_BLOCK) {
-        const u64 o = off2[(u64)p1 * a.F2];
-        a.off1[r][(u64)c * a.F1 + p1] = o;
-        a.cur1[r][(u64)c * a.F1 + p1] = o;
+    if (!PAD) {
+        // dense final layout: partition q occupies [off2[q], off2[q + 1])
+        plan_scan(P, [&](uint32_t i) { return cnt[i]; }, off2, base, scratch,
+                  [&](uint32_t i, u64 n, u64 first) { end2[i] = first + n; });
+        // off2[P] of this chunk is the next chunk's first row (same value: chunks are contiguous)
+        for (uint32_t i = threadIdx.x; i < P; i += PLAN_BLOCK) a.cur2[r][(u64)c * P + i] = off2[i];
+        for (uint32_t p1 = threadIdx.x; p1 < a.F1; p1 += PLAN_BLOCK) {
+            const u64 o = off2[(u64)p1 * a.F2];
+            a.off1[r][(u64)c * a.F1 + p1] = o;
+            a.cur1[r][(u64)c * a.F1 + p1] = o;
+        }
+    } else {
+        // Two passes: the pass-1 output (= pass-2 input) stays dense, the FINAL layout starts every
+        // partition on a 128-byte line (K6 pass 2 then claims whole lines from the front of a partition
+        // and the few leftover tuples of a tile from its back).
+        const uint32_t per = (P + PLAN_BLOCK - 1) / PLAN_BLOCK;
+        const uint32_t lo = min(P, threadIdx.x * per), hi = min(P, lo + per);
+        auto padded = [](u64 n) { return (n + HJ_LINE_TUPLES - 1) & ~(u64)(HJ_LINE_TUPLES - 1); };
+        u64 dsum = 0, psum = 0;
+#pragma unroll 8
+        for (uint32_t q = lo; q < hi; ++q) { const u64 n = cnt[q]; dsum += n; psum += padded(n); }
+        u64 drun = base + block_exclusive_scan<PLAN_BLOCK, u64>(dsum, scratch);
+        __syncthreads();
+        const u64 base2 = base + (u64)c * HJ_LINE_TUPLES * P;        // room for every partition's padding
+        u64 prun = base2 + block_exclusive_scan<PLAN_BLOCK, u64>(psum, scratch);
+        uint32_t p1 = (lo + a.F2 - 1) / a.F2;                         // next pass-1 partition that starts at or after lo
+        uint32_t p1_first = p1 * a.F2;                                // ... and its first final partition
+#pragma unroll 8
+        for (uint32_t q = lo; q < hi; ++q) {
+            const u64 n = cnt[q];                                    // second read: L2
+            if (q == p1_first) {                                     // first partition of a pass-1 partition: dense offset
+                a.off1[r][(u64)c * a.F1 + p1] = drun;
+                a.cur1[r][(u64)c * a.F1 + p1] = drun;
+                ++p1; p1_first += a.F2;
+            }
+            off2[q] = prun; end2[q] = prun + n;
+            a.cur2[r][(u64)c * P + q] = 0;                           // lines claimed | tail tuples << 32
+            drun += n;
+            prun += padded(n);
+        }
     }
     if (threadIdx.x == 0) {
         a.seg1[r][c] = base;
@@ -334,8 +370,10 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
 
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
 {
-    if (a.mask & 3u)
-        hipLaunchKernelGGL(plan_offsets_kernel, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
+    if (a.mask & 3u) {
+        if (a.pad2) hipLaunchKernelGGL(plan_offsets_kernel<true>, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL(plan_offsets_kernel<false>, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
+    }
     if (a.mask & 3u) hipLaunchKernelGGL(plan_tiles_kernel, dim3(2), dim3(PLAN_BLOCK), 0, stream, a);
     if (a.mask & 4u) hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
@@ -414,7 +452,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     u64 *delta = reinterpret_cast<u64 *>(smem);                     // [Fpad]  packed out: output position of the run; else output - local position
     u64 *stage = delta + Fpad;                                      // [TILE]  payload << 32 | key, sorted by partition
     u64 *carry = stage + TILE;                                      // CARRY: [Fpad][LINE] tails waiting for their line
-    uint32_t *hist = reinterpret_cast<uint32_t *>(carry + (CARRY ? Fpad * LINE : 0));   // [Fpad]  counts, then local bases
+    u64 *tinfo = carry;                                             // pass 2: [Fpad] (position of the run's tail << 4) | tail tuples
+    uint32_t *hist = reinterpret_cast<uint32_t *>(carry + (CARRY ? Fpad * LINE : (RANGED ? 0 : Fpad)));   // [Fpad]  counts, then local bases
     uint32_t *meta = hist + Fpad;                                   // [Fpad] tuples leaving this tile | carried ones among them << 16
     uint32_t *left = meta + Fpad;                                   // CARRY: [Fpad] first staying index | carry offset << 16 | count << 20
     uint32_t *wsum = left + (CARRY ? Fpad : 0);                     // [NW + 6]; [NW + 1] = number of runs longer than one unit, [NW + 4..5] = tickets,
@@ -626,6 +665,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         uint32_t cnt[BPT], lb[BPT];
         u64 dst[BPT];
         uint32_t carried[BPT], emitted[BPT], coff[BPT];                // CARRY only
+        u64 pstart[BPT], pend[BPT];                                    // pass 2, aligned claims: my partitions' bounds
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) { pstart[i] = 0; pend[i] = 0; }
         uint32_t sum = 0;
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
@@ -653,7 +695,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 }
             } else if (cnt[i]) {
                 if (RANGED) { dst[i] = mycur[i]; mycur[i] = dst[i] + cnt[i]; }
-                else dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
+                else if (a.aligned_claims) {
+                    // whole lines from the front of the partition, the last (< 16) tuples from its back:
+                    // one returning atomic carries both claims (lines | tail tuples << 32)
+                    const uint32_t front = cnt[i] & ~(LINE - 1), tail = cnt[i] & (LINE - 1);
+                    dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], ((u64)tail << 32) | (u64)(front / LINE));
+                    pstart[i] = a.part_start[cur.cursor_row + bin];
+                    pend[i] = a.part_end[cur.cursor_row + bin];
+                } else dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
             }
         }
         uint32_t biggest = 0;                                           // largest of my bins: count << 10 | bin
@@ -674,7 +723,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     left[bin] = (run + fresh) | (coff[i] << 16) | ((cnt[i] - fresh) << 20);
                     delta[bin] = dst[i];
                     if (emitted[i] + ((uint32_t)dst[i] & (LINE - 1)) > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = bin;
-                } else if (OUT_PACKED) meta[bin] = cnt[i];
+                } else if (OUT_PACKED) meta[bin] = (!RANGED && a.aligned_claims) ? (cnt[i] & ~(LINE - 1)) : cnt[i];
             }
             run += cnt[i];
         }
@@ -698,7 +747,15 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         if (!CARRY) {
 #pragma unroll
             for (int i = 0; i < BPT; ++i)
-                if (cnt[i]) {
+                if (!RANGED && OUT_PACKED && a.aligned_claims) {
+                    const uint32_t bin = tid * bpt + i;
+                    if ((uint32_t)i < bpt && bin < F) {
+                        const uint32_t front = cnt[i] & ~(LINE - 1), tail = cnt[i] & (LINE - 1);
+                        delta[bin] = pstart[i] + (u64)LINE * (uint32_t)dst[i];               // lines claimed before mine
+                        tinfo[bin] = ((pend[i] - (dst[i] >> 32) - tail) << 4) | tail;        // tails fill the back, downwards
+                        if (front > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = bin;
+                    }
+                } else if (cnt[i]) {
                     if (OUT_PACKED) {
                         delta[tid * bpt + i] = dst[i];
                         if (cnt[i] + ((uint32_t)dst[i] & (LINE - 1)) > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = tid * bpt + i;
@@ -752,6 +809,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 const uint32_t units = (((uint32_t)delta[p] & (LINE - 1)) + (meta[p] & 0xFFFFu) + UNIT - 1) / UNIT;
                 for (uint32_t c = 1 + gid; c < units; c += NG) move_unit(p, c);
             }
+            if (!RANGED && a.aligned_claims) {
+                // the runs' tails (< 16 tuples each): 16 lanes per partition, 8-byte stores
+                for (uint32_t idx = tid; idx < F * LINE; idx += BLOCK) {
+                    const uint32_t p = idx / LINE, j = idx % LINE;
+                    const u64 ti = tinfo[p];
+                    if (j < ((uint32_t)ti & (LINE - 1))) out64[(ti >> 4) + j] = stage[hist[p] + (meta[p] & 0xFFFFu) + j];
+                }
+            }
         } else {
             // ---- stream out: lane i writes tuple i, runs are contiguous ---------------
             for (uint32_t i = tid; i < tile_count; i += BLOCK) {
@@ -771,10 +836,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 }
 
 // ---- geometry of a pass: workgroup size, vectors per thread, whole-line mode -------
-static size_t scatter_lds(int block, int vpt, uint32_t F, bool carry)
+static size_t scatter_lds(int block, int vpt, uint32_t F, bool carry, bool pass2 = false)
 {
     const size_t Fpad = (F + 3) & ~3u;
-    return Fpad * 16 + (size_t)block * vpt * 4 * 8 + (carry ? Fpad * (HJ_LINE_TUPLES * 8 + 4) : 0) +
+    return Fpad * 16 + (size_t)block * vpt * 4 * 8 + (carry ? Fpad * (HJ_LINE_TUPLES * 8 + 4) : 0) + (pass2 ? Fpad * 8 : 0) +
            (block / 64 + 6) * 4 + HJ_MAX_HEAVY * 4 + 16;
 }
 constexpr size_t HJ_LDS_LIMIT = 160 * 1024;          // gfx950: 160 KiB per CU, all of it usable by one workgroup
@@ -810,7 +875,7 @@ int hj_scatter_tile(int pass, uint32_t F, bool out_packed)
 template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY>
 static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
 {
-    const size_t lds = scatter_lds(BLOCK, VPT, a.F, CARRY);
+    const size_t lds = scatter_lds(BLOCK, VPT, a.F, CARRY, !RANGED);
     if (lds > HJ_LDS_LIMIT) return HJGPU_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
