@@ -161,8 +161,13 @@ void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint
         if (parts > HJGPU_MAX_PARTS) parts = HJGPU_MAX_PARTS;
         if (parts <= 256) { f1 = (uint32_t)parts; f2 = 1; }
         else {
-            f1 = (uint32_t)ceil(sqrt(parts));
+            // pass 1: the power of two nearest to sqrt(parts) (H(key, f, 2^k) is a shift: one multiply
+            // less per key in K4 and K6); measured flat between 96 x 192 and 192 x 97 at 64M x 1G
+            f1 = 2;
+            while ((double)f1 * f1 * 2.0 < parts) f1 <<= 1;          // f1 ~ sqrt(parts) within a factor sqrt(2)
+            if (f1 > 256) f1 = 256;
             f2 = (uint32_t)ceil(parts / f1);
+            while (f2 > HJGPU_MAX_FANOUT) { f1 <<= 1; f2 = (uint32_t)ceil(parts / f1); }
             while ((u64)f1 * f2 > HJGPU_MAX_PARTS) --f2;
         }
     } else if (f2 == 0) f2 = 1;
