@@ -13,7 +13,7 @@ typedef unsigned long long u64;
 // tile, which decides the tile size from the fan-out; see hj_scatter_config().
 constexpr uint32_t HJ_LINE_TUPLES = 16;          // packed (8-byte) tuples per 128-byte line
 constexpr uint32_t HJ_STREAM_UNIT = 256;         // output slots one 16-lane group streams out at a time
-constexpr uint32_t HJ_MAX_HEAVY = 16384 / HJ_STREAM_UNIT + 8;   // runs longer than a unit in one tile (tile <= 16384)
+constexpr uint32_t HJ_MAX_HEAVY = 128;           // listed units per tile: <= (16384 + 30 * 209) / HJ_STREAM_UNIT (carry + line offsets)
 struct ScatterConfig { int block, vpt; bool carry; };
 ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed);
 int hj_scatter_tile(int pass, uint32_t F, bool out_packed);

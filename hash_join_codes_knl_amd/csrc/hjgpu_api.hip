@@ -159,7 +159,9 @@ void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint
         double parts = ceil((double)inner / target);
         if (parts < 2) parts = 2;
         if (parts > HJGPU_MAX_PARTS) parts = HJGPU_MAX_PARTS;
-        if (parts <= 256) { f1 = (uint32_t)parts; f2 = 1; }
+        // one pass while whole-line mode fits the LDS (fan-out <= 640): 3.7-3.9 ms per 1G tuples at
+        // fan-out 288-403 (12 K-tuple tiles), ~5.4 ms at 512-640 (8 K), against 2 x 3.3 ms for two passes
+        if (parts <= 640) { f1 = (uint32_t)parts; f2 = 1; }
         else {
             // pass 1: the power of two nearest to sqrt(parts) (H(key, f, 2^k) is a shift: one multiply
             // less per key in K4 and K6); measured flat between 96 x 192 and 192 x 97 at 64M x 1G

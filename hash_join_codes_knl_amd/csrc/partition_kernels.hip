@@ -589,6 +589,15 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             t_prev = now;
         }
     };
+    // A run longer than one stream-out unit gets its further units listed (partition | unit << 16): the
+    // stream-out deals the partitions' first units and these round-robin to the 16-lane groups.
+    auto add_units = [&](uint32_t bin, uint32_t slots) {
+        if (slots > UNIT) {
+            const uint32_t extra = (slots - 1) / UNIT;
+            const uint32_t at = atomicAdd(&wsum[NW + 1], extra);
+            for (uint32_t u = 0; u < extra; ++u) heavy[at + u] = bin | ((u + 1) << 16);
+        }
+    };
     for (;;) {
         if (RANGED && cur.new_range) {
 #pragma unroll
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     meta[bin] = emitted[i] | (carried[i] << 16);
                     left[bin] = (run + fresh) | (coff[i] << 16) | ((cnt[i] - fresh) << 20);
                     delta[bin] = dst[i];
-                    if (emitted[i] + ((uint32_t)dst[i] & (LINE - 1)) > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = bin;
+                    add_units(bin, emitted[i] + ((uint32_t)dst[i] & (LINE - 1)));
                 } else if (OUT_PACKED) meta[bin] = (!RANGED && a.aligned_claims) ? (cnt[i] & ~(LINE - 1)) : cnt[i];
             }
             run += cnt[i];
@@ -753,12 +762,12 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                         const uint32_t front = cnt[i] & ~(LINE - 1), tail = cnt[i] & (LINE - 1);
                         delta[bin] = pstart[i] + (u64)LINE * (uint32_t)dst[i];               // lines claimed before mine
                         tinfo[bin] = ((pend[i] - (dst[i] >> 32) - tail) << 4) | tail;        // tails fill the back, downwards
-                        if (front > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = bin;
+                        add_units(bin, front);
                     }
                 } else if (cnt[i]) {
                     if (OUT_PACKED) {
                         delta[tid * bpt + i] = dst[i];
-                        if (cnt[i] + ((uint32_t)dst[i] & (LINE - 1)) > UNIT) heavy[atomicAdd(&wsum[NW + 1], 1u)] = tid * bpt + i;
+                        add_units(tid * bpt + i, cnt[i] + ((uint32_t)dst[i] & (LINE - 1)));
                     } else delta[tid * bpt + i] = dst[i] - lb[i];
                 }
         }
@@ -777,9 +786,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             // tuples of its 16-byte slot, so a line leaves the CU as one piece of one instruction,
             // no hash and no per-tuple lookups are needed, and a store carries 16 bytes per lane.
             // A unit is (partition, UNIT consecutive output slots); units are dealt round-robin.
-            // A unit is (partition, UNIT consecutive output slots).  Every partition's first unit is dealt
-            // round-robin; the few runs longer than one unit (a heavy-hitter key under skew: up to the whole
-            // tile in one partition) are listed in `heavy` and their further units are shared by all groups.
+            // A unit is (partition, UNIT consecutive output slots): every partition's first unit plus the
+            // listed further units of the runs longer than that (small fan-outs; a heavy-hitter key under
+            // skew: up to the whole tile in one partition), dealt round-robin to the groups.
             constexpr uint32_t NG = BLOCK / 16;
             const uint32_t gid = tid >> 4, sub = tid & 15;
             u64 *__restrict__ out64 = reinterpret_cast<u64 *>(a.kout);
@@ -802,12 +811,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     else if (v1) out64[base + s + 1] = fetch(s + 1 - off);
                 }
             };
-            for (uint32_t p = gid; p < F; p += NG) move_unit(p, 0);
-            const uint32_t nheavy = wsum[NW + 1];
-            for (uint32_t h = 0; h < nheavy; ++h) {
-                const uint32_t p = heavy[h];
-                const uint32_t units = (((uint32_t)delta[p] & (LINE - 1)) + (meta[p] & 0xFFFFu) + UNIT - 1) / UNIT;
-                for (uint32_t c = 1 + gid; c < units; c += NG) move_unit(p, c);
+            const uint32_t nunits = F + wsum[NW + 1];
+            for (uint32_t u = gid; u < nunits; u += NG) {
+                if (u < F) move_unit(u, 0);
+                else { const uint32_t h = heavy[u - F]; move_unit(h & 0xFFFFu, h >> 16); }
             }
             if (!RANGED && a.aligned_claims) {
                 // the runs' tails (< 16 tuples each): 16 lanes per partition, 8-byte stores
