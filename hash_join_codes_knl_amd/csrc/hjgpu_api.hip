@@ -157,7 +157,9 @@ void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint
     if (f1 == 0) {
         const double target = hj_join_config().cap() * 0.85;   // mean fill; Poisson tail stays below CAP
         double parts = ceil((double)inner / target);
-        if (parts < 2) parts = 2;
+        // never fewer than 64 partitions: with a handful of bins every lane of K4 / K6 adds to the same
+        // few LDS words (|R| = 4000 x 1G: histogram 1.97 ms and scatter 4.26 ms at fan-out 2)
+        if (parts < 64) parts = 64;
         if (parts > HJGPU_MAX_PARTS) parts = HJGPU_MAX_PARTS;
         // one pass while whole-line mode fits the LDS (fan-out <= 640): 3.7-3.9 ms per 1G tuples at
         // fan-out 288-403 (12 K-tuple tiles), ~5.4 ms at 512-640 (8 K), against 2 x 3.3 ms for two passes
