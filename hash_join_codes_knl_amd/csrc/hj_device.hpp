@@ -63,7 +63,8 @@ __device__ __forceinline__ uint32_t wave_reduce_max(uint32_t x)
 // Block-wide exclusive scan of one value per thread. `scratch` needs
 // BLOCK/64 + 1 entries of T in LDS; scratch[BLOCK/64] receives the block total.
 // Contains two __syncthreads(); every thread of the block must call it.
-// LDS_ONLY: use hj_barrier_lds() (global loads / stores / atomics stay in flight across it).
+// LDS_ONLY: ONE hj_barrier_lds() (global loads / stores / atomics stay in flight across it); scratch[BLOCK/64]
+// is then only valid after the caller's next barrier, and scratch[0..NW) must not be rewritten before it.
 template <int BLOCK, typename T, bool LDS_ONLY = false>
 __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch)
 {
@@ -72,25 +73,23 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *scratch)
     const int wave = threadIdx.x >> 6;
     T inc = wave_inclusive_scan(v);
     if (lane == 63) scratch[wave] = inc;
-    if (LDS_ONLY) hj_barrier_lds(); else __syncthreads();
+    if (LDS_ONLY) {
+        // one barrier: every thread adds up the totals of the waves before its own (NW broadcast reads);
+        // thread 0 leaves the block total in scratch[NW] for whoever reads it after the caller's next barrier
+        hj_barrier_lds();
+        T before = T(0), total = T(0);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const T x = scratch[w]; total += x; if (w < wave) before += x; }
+        if (threadIdx.x == 0) scratch[NW] = total;
+        return inc - v + before;
+    }
+    __syncthreads();
     if (wave == 0) {
         T w = (lane < NW) ? scratch[lane] : T(0);
         T winc = wave_inclusive_scan(w);
         if (lane < NW) scratch[lane] = winc - w;      // exclusive prefix of the wave sums
         if (lane == NW - 1) scratch[NW] = winc;       // block total
     }
-    if (LDS_ONLY) hj_barrier_lds(); else __syncthreads();
+    __syncthreads();
     return inc - v + scratch[wave];
-}
-
-// Largest index s in [0, n) with prefix[s] <= t, given prefix[0] <= t < prefix[n].
-// Wave-uniform when t is (all lanes walk the same path).
-__device__ __forceinline__ uint32_t hj_find_segment(const u64 *__restrict__ prefix, uint32_t n, u64 t)
-{
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (prefix[mid] <= t) lo = mid; else hi = mid;
-    }
-    return lo;
 }
