@@ -490,9 +490,14 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         claim[0] = t0; claim[1] = t0 + 1;
     }
     __syncthreads();
+    // A lane-dependent zero the compiler cannot see through: with a provably uniform address LLVM's atomic
+    // optimizer aggregates the add over the wave and needs its result at once (s_waitcnt vmcnt(0) +
+    // readfirstlane right after the atomic), which stalls wave 0 for the round trip on every tile of pass 2.
+    uint32_t opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
     auto take_ticket = [&]() -> uint32_t {                          // uniform; at most once between two deposits
         const uint32_t t = claim[claim_parity];
-        if (tid == 0) { pending_ticket = atomicAdd(a.work_counter, 1u); pending_slot = claim_parity; }
+        if (tid == 0) { pending_ticket = atomicAdd(a.work_counter + opaque_zero, 1u); pending_slot = claim_parity; }
         claim_parity ^= 1;
         return t;
     };
