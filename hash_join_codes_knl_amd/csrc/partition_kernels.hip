@@ -22,6 +22,7 @@
 #include "hj_internal.hpp"
 #include <stdlib.h>
 #include <stdio.h>
+#include <type_traits>
 
 // --------------------------------------------------------------------------
 // K4: fused two-level histogram + per-range pass-1 counts.
@@ -490,6 +491,13 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         claim[0] = t0; claim[1] = t0 + 1;
     }
     __syncthreads();
+    // H(key, f, 2^k) = (key * f) >> (32 - k): the same function, one multiply less
+    const bool f_pow2 = F > 1 && (F & (F - 1)) == 0;
+    const uint32_t f_shift = f_pow2 ? 32u - (uint32_t)__builtin_ctz(F) : 0u;
+    auto part_of = [&](uint32_t key) -> uint32_t {
+        const uint32_t x = key * factor;
+        return f_pow2 ? x >> f_shift : __umulhi(x, F);
+    };
     // A lane-dependent zero the compiler cannot see through: with a provably uniform address LLVM's atomic
     // optimizer aggregates the add over the wave and needs its result at once (s_waitcnt vmcnt(0) +
     // readfirstlane right after the atomic), which stalls wave 0 for the round trip on every tile of pass 2.
@@ -639,17 +647,22 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         const uint32_t hot_p = hot_word & 1023u;
         uint32_t pr[VPT * 4];
         uint32_t hot_n = 0;                                             // heavy-partition tuples of this wave
+        // interior tiles (all but the first and last of a segment) need no per-tuple bounds checks
+        const bool interior = cur.g0 >= cur.gb && cur.g0 + (u64)TILE <= cur.ge;
+        auto partition_ids = [&](auto checked) {
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const u64 g = cur.g0 + (u64)(j * BLOCK + tid) * 4;
+            for (int j = 0; j < VPT; ++j) {
+                const u64 g = cur.g0 + (u64)(j * BLOCK + tid) * 4;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bool valid = (g + c >= cur.gb) && (g + c < cur.ge);
-                const uint32_t p = valid ? hj_hash(key_of(j, c), factor, F) : 0xFFFFFFFFu;
-                pr[j * 4 + c] = p;
-                if (hot) hot_n += (uint32_t)__popcll(__ballot(p == hot_p));
+                for (int c = 0; c < 4; ++c) {
+                    const bool valid = !decltype(checked)::value || ((g + c >= cur.gb) && (g + c < cur.ge));
+                    const uint32_t p = valid ? part_of(key_of(j, c)) : 0xFFFFFFFFu;
+                    pr[j * 4 + c] = p;
+                    if (hot) hot_n += (uint32_t)__popcll(__ballot(p == hot_p));
+                }
             }
-        }
+        };
+        if (interior) partition_ids(std::false_type()); else partition_ids(std::true_type());
         uint32_t hot_base = 0;
         if (hot && hot_n) {                                             // ONE add per wave for all its heavy tuples
             if (hj_lane() == 0) hot_base = atomicAdd(&hist[hot_p], hot_n);
