@@ -26,7 +26,7 @@ EXPORTS = [
     "hjgpu_npj_build", "hjgpu_npj_probe",
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
-    "hjgpu_join_host", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums", "hjgpu_stream_read_ms",
+    "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums", "hjgpu_stream_read_ms",
 ]
 
 
@@ -41,6 +41,11 @@ class Result(C.Structure):
 class Output(C.Structure):
     _fields_ = [("d_keys", C.c_void_p), ("d_outer_vals", C.c_void_p), ("d_inner_vals", C.c_void_p),
                 ("capacity", C.c_size_t), ("block_size", C.c_size_t)]
+
+
+class HostRows(C.Structure):
+    _fields_ = [("keys", C.c_void_p), ("outer_vals", C.c_void_p), ("inner_vals", C.c_void_p),
+                ("capacity", C.c_size_t)]
 
 
 class PhjParams(C.Structure):
@@ -58,7 +63,7 @@ class Stats(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_histogram", C.c_float), ("ms_plan", C.c_float),
                 ("ms_scatter1", C.c_float), ("ms_scatter2", C.c_float), ("ms_join", C.c_float),
                 ("ms_build", C.c_float), ("ms_close_gaps", C.c_float),
-                ("ms_inner_wait", C.c_float), ("ms_upload", C.c_float),
+                ("ms_inner_wait", C.c_float), ("ms_upload", C.c_float), ("ms_download", C.c_float),
                 ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("buckets", C.c_uint64)]
 
     def as_dict(self):
@@ -138,6 +143,8 @@ def load_library(build_if_missing=True):
     L.hjgpu_phj_overlapped_async.argtypes = join + [C.POINTER(PhjParams), vp, vp, vp]
     L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
                                   C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Stats)]
+    L.hjgpu_join_host_rows.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
+                                       C.POINTER(NpjParams), C.POINTER(HostRows), C.POINTER(Result), C.POINTER(Stats)]
     L.hjgpu_generate.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
     L.hjgpu_generate_range.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
     L.hjgpu_generate_zipf.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, C.c_double, vp, vp, vp, vp, vp]
@@ -330,6 +337,30 @@ class HjGpu:
             C.byref(phj_params) if phj_params is not None else None,
             C.byref(npj_params) if npj_params is not None else None, C.byref(r), C.byref(s)))
         return r.as_tuple(), s.as_dict()
+
+    def join_host_rows(self, algorithm, ik, iv, ok, ov, capacity, phj_params=None, npj_params=None, pinned=False):
+        """As join_host, with the join materialised into three host columns of `capacity` rows
+        (page-locked if `pinned`): returns (result, stats, (keys, outer_vals, inner_vals)) with the
+        columns cut to result.count rows.  Raises HjGpuError(HJGPU_EOVERFLOW) when the join has more
+        rows than `capacity`."""
+        ik, iv, ok, ov = (c.array if isinstance(c, PinnedColumn) else np.ascontiguousarray(c, np.uint32)
+                          for c in (ik, iv, ok, ov))
+        cols = [self.host_column(max(capacity, 1)) if pinned else np.empty(max(capacity, 1), np.uint32) for _ in range(3)]
+        arrs = [c.array if pinned else c for c in cols]
+        rows = HostRows(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, capacity)
+        r, s = Result(), Stats()
+        try:
+            self._check(self.lib.hjgpu_join_host_rows(
+                self.handle, algorithm, ik.ctypes.data, iv.ctypes.data, ik.size,
+                ok.ctypes.data, ov.ctypes.data, ok.size,
+                C.byref(phj_params) if phj_params is not None else None,
+                C.byref(npj_params) if npj_params is not None else None, C.byref(rows), C.byref(r), C.byref(s)))
+            out = tuple(a[:r.count].copy() for a in arrs)
+        finally:
+            if pinned:
+                for c in cols:
+                    c.free()
+        return r.as_tuple(), s.as_dict(), out
 
     # ---- generator --------------------------------------------------------------------
     def generate(self, seed, inner, outer_total, outer_begin, outer_count, inner_factor,

@@ -979,15 +979,79 @@ static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, h
     return HJGPU_OK;
 }
 
+// HBM column -> host column on `copy`: the mirror image of upload_column.  Pageable destinations are
+// filled from two pinned staging buffers, the CPU's copy of chunk i overlapping the DMA of chunk i+1.
+static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes, hipStream_t copy,
+                           void *stage[2], hipEvent_t stage_done[2], size_t stage_bytes)
+{
+    if (!bytes) return HJGPU_OK;
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, h) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (pinned) {
+        HIPCHK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, copy));
+        return HJGPU_OK;
+    }
+    const size_t chunks = (bytes + stage_bytes - 1) / stage_bytes;
+    auto len = [&](size_t c) { return c + 1 < chunks ? stage_bytes : bytes - c * stage_bytes; };
+    auto fetch = [&](size_t c) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(stage[c & 1], (const char *)d + c * stage_bytes, len(c), hipMemcpyDeviceToHost, copy);
+        return e != hipSuccess ? e : hipEventRecord(stage_done[c & 1], copy);
+    };
+    HIPCHK(ctx, fetch(0));
+    for (size_t c = 0; c < chunks; ++c) {
+        if (c + 1 < chunks) HIPCHK(ctx, fetch(c + 1));            // the other buffer: emptied one round ago
+        HIPCHK(ctx, hipEventSynchronize(stage_done[c & 1]));
+        memcpy((char *)h + c * stage_bytes, stage[c & 1], len(c));
+    }
+    return HJGPU_OK;
+}
+
+static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
+                          const uint32_t *ik, const uint32_t *iv, size_t inner,
+                          const uint32_t *ok, const uint32_t *ov, size_t outer,
+                          const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
+                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats);
+
 int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
                     const uint32_t *ik, const uint32_t *iv, size_t inner,
                     const uint32_t *ok, const uint32_t *ov, size_t outer,
                     const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
                     hjgpu_result *result, hjgpu_stats *stats)
 {
+    return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, nullptr, result, stats);
+}
+
+int hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm,
+                         const uint32_t *ik, const uint32_t *iv, size_t inner,
+                         const uint32_t *ok, const uint32_t *ov, size_t outer,
+                         const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
+                         const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (!rows || !result) return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows: rows and result are required");
+    if (rows->capacity && (!rows->keys || !rows->outer_vals || !rows->inner_vals))
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows: null result column");
+    return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result, stats);
+}
+
+static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
+                          const uint32_t *ik, const uint32_t *iv, size_t inner,
+                          const uint32_t *ok, const uint32_t *ov, size_t outer,
+                          const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
+                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats)
+{
     if (!ctx || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
     if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return fail(ctx, HJGPU_EINVAL, "null column");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // materialised result: device columns of the caller's capacity plus one open block per worker
+    // (the reference sizes its output the same way: 1.05 J + 2T blocks, npj.cpp:997-1000)
+    hjgpu_output dev_out;
+    memset(&dev_out, 0, sizeof(dev_out));
+    void *d_rows[3] = {nullptr, nullptr, nullptr};
+    const hjgpu_output *out = nullptr;
+    hjgpu_result local_result;
+    if (rows && !result) result = &local_result;
     void *d[4] = {nullptr, nullptr, nullptr, nullptr};
     const void *h[4] = {ik, iv, ok, ov};
     const size_t n[4] = {inner, inner, outer, outer};
@@ -998,6 +1062,16 @@ int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
     int rc = HJGPU_OK;
     auto hip_ok = [&](hipError_t e, const char *what) { if (rc == HJGPU_OK && e != hipSuccess) rc = fail(ctx, HJGPU_EHIP, what, e); };
     for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
+    if (rows && inner && outer) {
+        const size_t workers = algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, outer) * 4
+                                              : (size_t)hj_join_workers(ctx->cus);
+        dev_out.block_size = rows->capacity >= (64u << 20) ? 65536 : 1024;
+        dev_out.capacity = (rows->capacity / dev_out.block_size + 1 + workers) * dev_out.block_size;
+        for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_rows[i], dev_out.capacity * sizeof(uint32_t));
+        dev_out.d_keys = (uint32_t *)d_rows[0]; dev_out.d_outer_vals = (uint32_t *)d_rows[1];
+        dev_out.d_inner_vals = (uint32_t *)d_rows[2];
+        out = &dev_out;
+    }
     hip_ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking), "hipStreamCreate(copy)");
     hip_ok(hipStreamCreateWithFlags(&run, hipStreamNonBlocking), "hipStreamCreate(run)");
     hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
@@ -1032,21 +1106,40 @@ int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
             if (algorithm == 0) {
                 // NPJ builds first: it needs R, which arrives last
                 hip_ok(hipStreamWaitEvent(run, r_ready, 0), "hipStreamWaitEvent");
-                if (rc == HJGPU_OK) rc = npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, nullptr, run);
+                if (rc == HJGPU_OK) rc = npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, run);
             } else {
                 hip_ok(hipStreamWaitEvent(run, s_ready, 0), "hipStreamWaitEvent");
-                if (rc == HJGPU_OK) rc = phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, nullptr, run, r_ready);
+                if (rc == HJGPU_OK) rc = phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, out, run, r_ready);
             }
         }
         if (rc == HJGPU_OK) {
             hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
             ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            rc = finish_blocking(ctx, result, nullptr, run);
+            rc = finish_blocking(ctx, result, out, run);
         }
     }
-    if (rc == HJGPU_OK && stats) { rc = hjgpu_get_stats(ctx, stats); stats->ms_upload = ms_upload; }
+    // the dense prefix [0, J) of the three result columns -> the caller's host columns
+    float ms_download = 0;
+    if (rc == HJGPU_OK && rows) {
+        if (result->count > rows->capacity) {
+            rc = fail(ctx, HJGPU_EOVERFLOW, "hjgpu_join_host_rows: the result has more rows than rows->capacity (see result->count)");
+        } else if (result->count) {
+            const auto t0 = std::chrono::steady_clock::now();
+            void *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
+            for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
+                rc = download_column(ctx, hcol[i], d_rows[i], result->count * sizeof(uint32_t), copy, stage, stage_free, STAGE);
+            if (rc == HJGPU_OK) hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
+            ms_download = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+    if (stats && (rc == HJGPU_OK || rc == HJGPU_EOVERFLOW)) {
+        const int rs = hjgpu_get_stats(ctx, stats);
+        if (rc == HJGPU_OK) rc = rs;
+        stats->ms_upload = ms_upload; stats->ms_download = ms_download;
+    }
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
+    for (int i = 0; i < 3; ++i) if (d_rows[i]) (void)hipFree(d_rows[i]);
     for (int b = 0; b < 2; ++b) { if (stage[b]) (void)hipHostFree(stage[b]); if (stage_free[b]) (void)hipEventDestroy(stage_free[b]); }
     if (r_ready) (void)hipEventDestroy(r_ready);
     if (s_ready) (void)hipEventDestroy(s_ready);

@@ -127,12 +127,59 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
         if (algorithm == 2) pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 8 ? a.threads : 8);
         hjgpu_npj_params np;
         memset(&np, 0, sizeof(np));
-        if (rc == HJGPU_OK) {
+        // HJGPU_ROWS=1: materialise the join into three host columns, as the reference's mains do
+        // (join_keys / join_outer_vals / join_inner_vals, npj.cpp:997-1000); HJGPU_ROWS=<prefix> also
+        // writes them as raw uint32 files <prefix>jk_<J>.txt, <prefix>jo_<J>.txt, <prefix>ji_<J>.txt.
+        const char *rows_env = getenv("HJGPU_ROWS");
+        const bool want_rows = rows_env && *rows_env && strcmp(rows_env, "0") != 0;
+        uint32_t *rows_col[3] = {nullptr, nullptr, nullptr};
+        if (rc == HJGPU_OK && !want_rows) {
             rc = hjgpu_join_host(ctx, algorithm, r.col[0], r.col[1], a.inner, r.col[2], r.col[3], a.outer,
                                  &pp, &np, res, st);
             if (rc != HJGPU_OK)
                 fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_last_error(ctx));
+        } else if (rc == HJGPU_OK) {
+            // the reference sizes its result for 1.05 x the expected matches (npj.cpp:997); a join with
+            // more rows than that reports its size and is run again with columns of that size
+            size_t cap = (size_t)((double)(a.outer > a.inner ? a.outer : a.inner) * 1.05) + 1;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
+                    rc = hjgpu_host_alloc(ctx, (void **)&rows_col[i], cap * sizeof(uint32_t));
+                if (rc != HJGPU_OK) { fprintf(stderr, "host allocation failed: %s\n", hjgpu_last_error(ctx)); break; }
+                hjgpu_host_rows rows = {rows_col[0], rows_col[1], rows_col[2], cap};
+                rc = hjgpu_join_host_rows(ctx, algorithm, r.col[0], r.col[1], a.inner, r.col[2], r.col[3], a.outer,
+                                          &pp, &np, &rows, res, st);
+                if (rc != HJGPU_EOVERFLOW || attempt == 1) break;
+                for (int i = 0; i < 3; ++i) { hjgpu_host_free(ctx, rows_col[i]); rows_col[i] = nullptr; }
+                cap = res->count;
+                rc = HJGPU_OK;
+            }
+            if (rc != HJGPU_OK)
+                fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_last_error(ctx));
+            if (rc == HJGPU_OK) {
+                // the columns that arrived must add up to the aggregates the device computed
+                uint64_t sums[3] = {0, 0, 0};
+                for (int i = 0; i < 3; ++i)
+                    for (size_t j = 0; j < res->count; ++j) sums[i] += rows_col[i][j];
+                const bool same = sums[0] == res->sum_keys && sums[1] == res->sum_outer_vals && sums[2] == res->sum_inner_vals;
+                const double down = st->ms_download * 1e-3;
+                fprintf(stderr, "result rows on the host: %llu x 12 bytes in %.4f s (%.1f GB/s), column sums %s\n",
+                        (unsigned long long)res->count, down, down > 0 ? 12.0 * res->count / down / 1e9 : 0.0,
+                        same ? "match" : "DIFFER");
+                if (!same) rc = HJGPU_EHIP;
+                if (same && strcmp(rows_env, "1") != 0) {
+                    const char *name[3] = {"jk", "jo", "ji"};
+                    for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) {
+                        const std::string path = std::string(rows_env) + name[i] + "_" + std::to_string(res->count) + ".txt";
+                        FILE *f = fopen(path.c_str(), "wb");
+                        const size_t put = f && res->count ? fwrite(rows_col[i], sizeof(uint32_t), res->count, f) : 0;
+                        if (f) fclose(f);
+                        if (!f || put != res->count) { fprintf(stderr, "cannot write %s\n", path.c_str()); rc = -2; }
+                    }
+                }
+            }
         }
+        for (uint32_t *c : rows_col) if (c) hjgpu_host_free(ctx, c);
         hjgpu_device_info info;
         if (rc == HJGPU_OK && hjgpu_get_device_info(ctx, &info) == HJGPU_OK) {
             const double sec = st->ms_total * 1e-3, up = st->ms_upload * 1e-3;

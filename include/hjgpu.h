@@ -95,6 +95,7 @@ typedef struct {
                                   (hjgpu_phj_overlapped_async), 0 otherwise                  */
     float    ms_upload;        /* hjgpu_join_host: host columns -> HBM (wall clock, pipelined
                                   with the probe side's partitioning for PHJ / CPRA)         */
+    float    ms_download;      /* hjgpu_join_host_rows: result columns -> host (wall clock)  */
     uint32_t fanout1, fanout2; /* what was used                                              */
     uint64_t buckets;          /* NPJ table size                                             */
 } hjgpu_stats;
@@ -221,6 +222,23 @@ int  hjgpu_join_host(hjgpu_ctx *ctx, int algorithm /* 0 npj, 1 phj, 2 cpra */,
                      const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
                      const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
                      hjgpu_result *result, hjgpu_stats *stats);
+
+/* As hjgpu_join_host, but the join is materialised (the reference's join_keys / join_outer_vals /
+ * join_inner_vals columns, npj.cpp:997-1000, which its mains allocate on the host) and the dense
+ * result [0, result->count) is copied back into the caller's three host columns.
+ * Page-locked result columns (hjgpu_host_alloc) are filled by DMA, pageable ones through two pinned
+ * staging buffers.  Returns HJGPU_EOVERFLOW, with result->count set, when the join has more rows
+ * than rows->capacity: call again with columns of at least that many rows.  Row order is
+ * unspecified, as in the reference (block claiming, npj.cpp:244-246). */
+typedef struct {
+    uint32_t *keys, *outer_vals, *inner_vals;   /* host columns of `capacity` uint32 each */
+    size_t    capacity;                         /* in rows                                */
+} hjgpu_host_rows;
+int  hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm /* 0 npj, 1 phj, 2 cpra */,
+                          const uint32_t *inner_keys, const uint32_t *inner_vals, size_t inner,
+                          const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
+                          const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
+                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats);
 
 /* ---- data generator (write.cpp / generate_data_for_join, cpra2.cpp:1578-1696):
  * statistical contract only — unique non-zero build keys, probe keys drawn from

@@ -38,12 +38,30 @@ def test_status_strings_and_no_silent_fallback():
         assert st == H.api.ENODEVICE and not h.value
 
 
-def test_struct_layouts_match_header():
-    assert C.sizeof(H.Result) == 32
-    assert C.sizeof(H.PhjParams) == 32
-    assert C.sizeof(H.NpjParams) == 16
-    assert C.sizeof(H.Output) == 40
-    assert C.sizeof(H.Stats) == 56
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors have the sizes and field offsets gcc gives include/hjgpu.h's structs."""
+    import subprocess
+    from hash_join_codes_knl_amd import api
+    pairs = [("hjgpu_result", H.Result), ("hjgpu_phj_params", H.PhjParams), ("hjgpu_npj_params", H.NpjParams),
+             ("hjgpu_output", H.Output), ("hjgpu_stats", H.Stats), ("hjgpu_host_rows", api.HostRows),
+             ("hjgpu_device_info", api.DeviceInfo)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hjgpu.h"', 'int main(void){']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('printf("\\n");')
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    for (cname, cls), line in zip(pairs, out):
+        got = [int(x) for x in line.split()[1:]]
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert got == want, (cname, got, want)
+    assert C.sizeof(H.Stats) == 64 and C.sizeof(api.HostRows) == 32
 
 
 def test_product_package_never_uses_the_oracle():

@@ -470,3 +470,60 @@ def test_host_programs_end_to_end(hj, oracle, tmp_path):
             assert len(lines[0].split("\t")) >= 3
         else:
             assert lines[0].startswith("copy:\t") and float(lines[1]) > 0
+
+
+@pytest.mark.parametrize("algorithm", [0, 1, 2])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_join_host_rows_returns_the_materialised_join(hj, algorithm, pinned):
+    """hjgpu_join_host_rows: host columns in, the dense result rows in three host
+    columns out.  3.4 M result rows = more than one 32 MiB staging buffer per column on the pageable
+    path; duplicates on the build side so that J != |S|."""
+    rng = np.random.default_rng(77 + algorithm)
+    base = np.unique(rng.integers(1, 2**32, size=200_000, dtype=np.uint64).astype(np.uint32))
+    ik = np.concatenate([base, base[:50_000]])
+    iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+    ok = base[rng.integers(0, len(base), size=2_700_000)]
+    ov = rng.integers(0, 2**32, size=len(ok), dtype=np.uint64).astype(np.uint32)
+    want = numpy_join(ik, iv, ok, ov)
+    assert want[0] > 3_000_000
+    got, st, rows = hj.join_host_rows(algorithm, ik, iv, ok, ov, want[0] + 12345, pinned=pinned)
+    assert got == want and len(rows[0]) == want[0]
+    assert st["ms_download"] > 0 and st["ms_close_gaps"] >= 0
+    for a, b in zip(sort_rows(*rows), materialised_rows(ik, iv, ok, ov)):
+        assert np.array_equal(a, b)
+
+
+def test_join_host_rows_reports_overflow_with_the_row_count(hj, oracle):
+    """More result rows than rows->capacity: HJGPU_EOVERFLOW, and the caller can size a retry."""
+    ik, iv, ok, ov = oracle.generate(300_000, 60_000, seed=46)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    with pytest.raises(H.HjGpuError) as e:
+        hj.join_host_rows(1, ik, iv, ok, ov, want[0] // 2)
+    assert e.value.status == 6
+    got, _, rows = hj.join_host_rows(1, ik, iv, ok, ov, want[0])      # exactly enough
+    assert got == want and len(rows[0]) == want[0]
+    # an empty join fills nothing
+    got, _, rows = hj.join_host_rows(2, ik, iv, (ok ^ np.uint32(0x5a5a5a5a)) | np.uint32(1), ov, 16)
+    if got[0] == 0:
+        assert len(rows[0]) == 0
+
+
+def test_host_programs_materialise_to_host_columns(hj, oracle, tmp_path):
+    """HJGPU_ROWS=<prefix>: the host programs return the join as three columns in host memory (what
+    the reference's mains hold after run(), npj.cpp:997-1000) and write them as raw uint32 files."""
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.abspath(H.__file__)), "lib")
+    subprocess.check_call([os.path.join(lib, "write"), "4", "300000", "70000"], cwd=tmp_path,
+                          env=dict(os.environ, HJ_SEED="12"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    cols = [np.fromfile(tmp_path / ("%s_%d.txt" % (p, n)), dtype="<u4")
+            for p, n in (("ik", 70000), ("iv", 70000), ("ok", 300000), ("ov", 300000))]
+    want = numpy_join(*cols)
+    for prog in ("npj", "phj", "cpra"):
+        prefix = "./%s_" % prog
+        p = subprocess.run([os.path.join(lib, prog), "8", "300000", "70000"], cwd=tmp_path,
+                           env=dict(os.environ, HJGPU_ROWS=prefix), capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert "column sums match" in p.stderr
+        got = [np.fromfile(tmp_path / ("%s_%s_%d.txt" % (prog, c, want[0])), dtype="<u4") for c in ("jk", "jo", "ji")]
+        for a, b in zip(sort_rows(*got), materialised_rows(*cols)):
+            assert np.array_equal(a, b)
