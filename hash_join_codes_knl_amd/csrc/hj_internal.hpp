@@ -28,6 +28,9 @@ struct JoinConfig {
     int cap() const { return slots() / 2; }      // max build tuples per table fill (load <= 0.5)
 };
 const JoinConfig &hj_join_config();
+// 16 K-slot tables (128 KiB of LDS, one 1024-thread workgroup per CU): half the partitions for the same build
+// side.  Chosen when the 8 K-slot tables would need more than HJGPU_MAX_PARTS partitions (|R| > ~114 M).
+const JoinConfig &hj_join_config_big();
 
 // Geometry of partitioning pass 1, known on the host (sizes + alignment only):
 // each chunk (segment) is cut into `ranges_per_chunk` contiguous ranges of whole
@@ -93,6 +96,7 @@ struct JoinArgs {
     u64 *block_counter;                  // device
     u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
     uint32_t *overflow;                  // device flag
+    uint32_t big_tables;                 // hj_join_config_big() instead of hj_join_config()
     uint32_t force_chained;              // tests: skip the cuckoo fast path (HJGPU_FORCE_CHAINED=1)
 };
 
@@ -161,7 +165,7 @@ int hj_launch_close_gaps_ex(uint32_t *k, uint32_t *ov, uint32_t *iv, const u64 *
                             const uint32_t *overflow, void *moves, uint32_t *nmoves,
                             u64 *dense_count, int cus, hipStream_t stream);
 int hj_join_grid(int cus);
-int hj_join_workers(int cus);
+int hj_join_workers(int cus, bool big_tables = false);
 int hj_npj_probe_grid(int cus, size_t n);
 
 // generator / checksums

@@ -4,6 +4,7 @@
 // cpra2.cpp:1697-1986): phase order, pass planning, factor choice.  Barriers
 // between phases become stream order; there is no host round trip inside a join.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <math.h>
 #include <stdio.h>
@@ -151,12 +152,20 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
 // table and derives 1-4 passes of equal fan-out (phj.cpp:1791-1808); here the
 // partition size comes from the LDS table (HJ_JOIN_CAP tuples at load 0.5) and
 // two passes of ~sqrt(P) reach every |R| the 32768-partition cap allows.
-void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint32_t *F2)
+void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint32_t *F2, bool *big_tables)
 {
     uint32_t f1 = prm ? prm->fanout1 : 0, f2 = prm ? prm->fanout2 : 0;
+    *big_tables = false;
     if (f1 == 0) {
-        const double target = hj_join_config().cap() * 0.85;   // mean fill; Poisson tail stays below CAP
+        double target = hj_join_config().cap() * 0.85;   // mean fill; Poisson tail stays below CAP
         double parts = ceil((double)inner / target);
+        // more partitions than K4's LDS histogram holds: 16 K-slot tables, half as many partitions
+        // (|R| = 128 M x |S| = 2.2 G, join phase 5.2 -> 4.3 ms: no table is filled twice)
+        if (parts > HJGPU_MAX_PARTS) {
+            *big_tables = true;
+            target = hj_join_config_big().cap() * 0.85;
+            parts = ceil((double)inner / target);
+        }
         // never fewer than 64 partitions: with a handful of bins every lane of K4 / K6 adds to the same
         // few LDS words (|R| = 4000 x 1G: histogram 1.97 ms and scatter 4.26 ms at fan-out 2)
         if (parts < 64) parts = 64;
@@ -255,13 +264,14 @@ struct PhjPlan {
     size_t ranges, items_extra, tiles2;
     uint32_t C, F1, F2, P;
     uint32_t f1, f2, tf0, tf1;
+    bool big_tables;
 };
 
 int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm,
                 uint32_t chunks, PhjPlan *pl)
 {
     pl->C = chunks;
-    choose_fanout(inner, prm, &pl->F1, &pl->F2);
+    choose_fanout(inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
     pl->P = pl->F1 * pl->F2;
     if (pl->F1 < 1 || pl->F2 < 1 || pl->F1 > HJGPU_MAX_FANOUT || pl->F2 > HJGPU_MAX_FANOUT ||
         pl->P < 2 || pl->P > HJGPU_MAX_PARTS)
@@ -305,7 +315,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus, pl.big_tables), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
@@ -396,6 +406,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
         ja.s_align = 0;
         ja.packed = 1;
+        ja.big_tables = pl.big_tables ? 1u : 0u;
         ja.result = &st->result;
         ja.work_counter = &st->work_counter;
         if (bs) {
@@ -411,7 +422,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     if (bs && inner && outer) {
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
                                     (const u64 *)ctx->final_offsets.p,
-                                    (uint32_t)hj_join_workers(ctx->cus), bs, &st->block_counter,
+                                    (uint32_t)hj_join_workers(ctx->cus, pl.big_tables), bs, &st->block_counter,
                                     &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
     }
     record(ctx, EV_GAPS, stream);
@@ -1064,7 +1075,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
     if (rows && inner && outer) {
         const size_t workers = algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, outer) * 4
-                                              : (size_t)hj_join_workers(ctx->cus);
+                                              : (size_t)std::max(hj_join_workers(ctx->cus, false), hj_join_workers(ctx->cus, true));
         dev_out.block_size = rows->capacity >= (64u << 20) ? 65536 : 1024;
         dev_out.capacity = (rows->capacity / dev_out.block_size + 1 + workers) * dev_out.block_size;
         for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_rows[i], dev_out.capacity * sizeof(uint32_t));

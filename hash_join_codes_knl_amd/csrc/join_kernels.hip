@@ -343,6 +343,12 @@ const JoinConfig &hj_join_config()
     return cfg;
 }
 
+const JoinConfig &hj_join_config_big()
+{
+    static const JoinConfig cfg = {1024, 14, 2};
+    return cfg;
+}
+
 // workgroups per CU the LDS table allows (160 KiB per CU), capped by 2048 threads per CU
 static int join_wgs_per_cu(const JoinConfig &c)
 {
@@ -352,20 +358,25 @@ static int join_wgs_per_cu(const JoinConfig &c)
     return n < 1 ? 1 : n;
 }
 
-int hj_join_grid(int cus) { return cus * join_wgs_per_cu(hj_join_config()); }
-int hj_join_workers(int cus) { return hj_join_grid(cus) * (hj_join_config().block / 64); }
+static int join_grid(int cus, const JoinConfig &c) { return cus * join_wgs_per_cu(c); }
+int hj_join_grid(int cus) { return join_grid(cus, hj_join_config()); }
+int hj_join_workers(int cus, bool big_tables)
+{
+    const JoinConfig &c = big_tables ? hj_join_config_big() : hj_join_config();
+    return join_grid(cus, c) * (c.block / 64);
+}
 
 #define JOIN_CASE(B, L, U)                                                                        \
     if (c.block == B && c.log2slots == L && c.batch == U) {                                       \
-        if (a.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true>), dim3(hj_join_grid(cus)), dim3(B), 0, stream, a);  \
-        else hipLaunchKernelGGL((join_kernel<B, L, U, false>), dim3(hj_join_grid(cus)), dim3(B), 0, stream, a);          \
+        if (a.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, a);  \
+        else hipLaunchKernelGGL((join_kernel<B, L, U, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, a);          \
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
     }
 
 int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream)
 {
     if (a.P < 2 || a.chunks == 0) return HJGPU_EINVAL;
-    const JoinConfig &c = hj_join_config();
+    const JoinConfig &c = a.big_tables ? hj_join_config_big() : hj_join_config();
     const char *ex = getenv("HJGPU_FORCE_CHAINED");     // tests: exercise the fallback table everywhere
     JoinArgs b = a;
     b.force_chained = (ex && atoi(ex)) ? 1u : 0u;

@@ -136,3 +136,31 @@ def test_probe_side_beyond_2_32_tuples(hj):
     assert tuple((a + b) & ((1 << 64) - 1) for a, b in zip(head, tail)) == want
     for c in (ik, iv, ok, ov):
         c.free()
+
+
+def test_beyond_2_31_tuples_128m_2g2(hj):
+    """BASELINE.json configs[4]'s per-GPU shape (CPRA, |R| = 1 G / 8 GPUs, |S| = 16 G / 8 GPUs): a build
+    side of 128 M tuples, for which the library switches to 16 K-slot LDS tables (8 K-slot ones would need
+    more than HJGPU_MAX_PARTS partitions), and a probe side of more than 2^31 tuples, so every offset,
+    cursor and output slot index above 32 bits is exercised.  Properties as in the 64 M x 1 G test, plus
+    the materialised result: J = |S| rows, dense, whose column sums are the aggregates."""
+    inner, outer = 128_000_000, 2_200_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(3, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    st = hj.stats()
+    assert 16_000 <= st["fanout1"] * st["fanout2"] <= 32768
+    assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=8)) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    block = 65536
+    cap = (outer // block + hj.device_info()["compute_units"] * 16 + 8) * block
+    jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+    assert hj.phj(ik, iv, inner, ok, ov, outer, out=(jk, jo, ji, cap, block)) == want
+    assert hj.column_sums(jk, outer, 1, 1)[0] == want[1]
+    assert hj.column_sums(jo, outer, 1, 1)[0] == want[2]
+    assert hj.column_sums(ji, outer, 1, 1)[0] == want[3]
+    for c in (ik, iv, ok, ov, jk, jo, ji):
+        c.free()
