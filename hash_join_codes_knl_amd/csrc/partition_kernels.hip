@@ -78,15 +78,17 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
             __syncthreads();
         }
         auto count_range = [&](auto part1) {
-            constexpr int U = 4;                       // key vectors in flight per lane
-            for (u64 g0 = g_lo + (u64)threadIdx.x * 4; g0 < g_hi; g0 += (u64)BLOCK * 4 * U) {
-                uint4 kv[U];
+            constexpr int U = 4;                       // key vectors per lane and batch; two batches in flight
+            const u64 step = (u64)BLOCK * 4 * U;
+            auto fetch = [&](u64 g0, uint4 (&kv)[U]) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const u64 g = g0 + (u64)u * BLOCK * 4;
                     kv[u] = make_uint4(0, 0, 0, 0);
                     if (g < g_hi) kv[u] = k4[g >> 2];
                 }
+            };
+            auto count = [&](u64 g0, const uint4 (&kv)[U]) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const u64 g = g0 + (u64)u * BLOCK * 4;
@@ -102,6 +104,20 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
                         }
                     }
                 }
+            };
+            // the next batch's loads are issued before the current batch is counted: the lane always has
+            // 4-8 loads outstanding (one workgroup per CU at fan-outs whose histogram takes > 72 KiB of LDS)
+            uint4 ka[U], kb[U];
+            u64 g0 = g_lo + (u64)threadIdx.x * 4;
+            fetch(g0, ka);
+            while (g0 < g_hi) {
+                fetch(g0 + step, kb);
+                count(g0, ka);
+                g0 += step;
+                if (g0 >= g_hi) break;
+                fetch(g0 + step, ka);
+                count(g0, kb);
+                g0 += step;
             }
         };
         if (t_end > t_beg) {
