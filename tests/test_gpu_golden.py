@@ -164,3 +164,19 @@ def test_beyond_2_31_tuples_128m_2g2(hj):
     assert hj.column_sums(ji, outer, 1, 1)[0] == want[3]
     for c in (ik, iv, ok, ov, jk, jo, ji):
         c.free()
+
+
+def test_beyond_2_32_probe_tuples_64m_4g4(hj):
+    """A probe side of 4.4 G tuples (> 2^32; 35 GB of columns, 70 GB of scratch twins: what one 288 GB GPU
+    holds): every tuple index, tile count and offset beyond 32 bits.  count = |S| shows that every probe key
+    found its build key; the sums are the column checksums of S."""
+    inner, outer = 64_000_000, 4_400_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(5, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    for c in (ik, iv, ok, ov):
+        c.free()
