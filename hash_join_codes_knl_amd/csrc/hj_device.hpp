@@ -53,6 +53,14 @@ __device__ __forceinline__ T wave_reduce_sum(T x)
     return x;   // valid in lane 0
 }
 
+// A value every lane of the wave holds identically (read from LDS, say), moved to scalar registers: what is
+// computed from it - addresses of descriptor tables, loop bounds - becomes scalar work and scalar loads.
+__device__ __forceinline__ uint32_t hj_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ u64 hj_uniform(u64 x)
+{
+    return ((u64)hj_uniform((uint32_t)(x >> 32)) << 32) | hj_uniform((uint32_t)x);
+}
+
 __device__ __forceinline__ uint32_t wave_reduce_max(uint32_t x)
 {
 #pragma unroll

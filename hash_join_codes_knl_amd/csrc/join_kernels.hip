@@ -74,6 +74,39 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     // ---- visit rows [fill_beg, fill_end) of the chunk-concatenated build partition q ----
     // rows below `from_row` were already inserted (from the prefetch registers)
     auto for_each_build_row = [&](u64 fill_beg, u64 fill_end, u64 from_row, auto insert) {
+        if (C > 1) {
+            // chunked relation (CPRA): the partition's rows lie in C pieces.  Walking the pieces one after
+            // another costs one memory round trip per piece (C x ~2 us against ~40 us per work item); here a
+            // lane's RB rows are rows of the CONCATENATION, so that all loads of a fill are in flight together.
+            u64 pb[8], cum[9];                        // piece c = rows [cum[c], cum[c+1]) at pb[c]
+            cum[0] = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                pb[c] = 0; cum[c + 1] = cum[c];
+                if ((uint32_t)c < C) { pb[c] = a.roff[(u64)c * P + q]; cum[c + 1] = cum[c] + (a.rend[(u64)c * P + q] - pb[c]); }
+            }
+            for (u64 base = max(fill_beg, from_row); base < fill_end; base += (u64)BLOCK * RB) {
+                uint32_t k[RB], v[RB];
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const u64 i = base + (u64)j * BLOCK + tid;
+                    k[j] = 0; v[j] = 0;
+                    if (i < fill_end) {
+                        u64 at = pb[0] + i;
+#pragma unroll
+                        for (int c = 1; c < 8; ++c) if (i >= cum[c]) at = pb[c] + (i - cum[c]);   // cum is non-decreasing
+                        if (PACKED) { const u64 t = r64[at]; k[j] = (uint32_t)t; v[j] = (uint32_t)(t >> 32); }
+                        else { k[j] = a.rk[at]; v[j] = a.rv[at]; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const u64 i = base + (u64)j * BLOCK + tid;
+                    if (i < fill_end) insert(k[j], v[j]);
+                }
+            }
+            return;
+        }
         u64 seen = 0;
         for (uint32_t c = 0; c < C; ++c) {
             const u64 b = a.roff[(u64)c * P + q], e = a.rend[(u64)c * P + q];
@@ -232,11 +265,11 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     if (tid == 0) claim(0);
     __syncthreads();
     for (;;) {
-        const u64 w = d_item[par];
+        const u64 w = hj_uniform(d_item[par]);
         if (w >= total_items) break;
-        q = d_q[par];
-        const u64 slice = d_slice[par];
-        const u64 nslices = d_nslices[par];
+        q = hj_uniform(d_q[par]);
+        const u64 slice = hj_uniform(d_slice[par]);
+        const u64 nslices = hj_uniform(d_nslices[par]);
         if (tid == 0) claim(par ^ 1);                     // published by the clear barrier below
         u64 have_rows = pre_rows;
         pre_rows = 0;
