@@ -46,6 +46,8 @@ def parse():
                     help="initialise torch.distributed even at --gpus 1 (exercises the multi-GPU code path)")
     ap.add_argument("--ring-broadcast", action="store_true",
                     help="multi-GPU: replicate the build side with dist.broadcast instead of scatter + all-gather")
+    ap.add_argument("--exchange-slices", type=int, default=4,
+                    help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="multi-GPU: broadcast the build side on the join's own stream (no overlap)")
     return ap.parse_args()
@@ -174,7 +176,7 @@ def main():
     def step():
         if copart:
             # local top-level partition -> all-to-all-v over xGMI -> local PHJ -> all-reduce
-            res = D.cpra_copartitioned(dist, torch, gpu_ops, *views)
+            res = D.cpra_copartitioned(dist, torch, gpu_ops, *views, slices=args.exchange_slices)
             d_result.copy_(torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in res],
                                         dtype=torch.int64, device=dev))
             return
@@ -241,15 +243,24 @@ def main():
         best = min(best, hj.stream_read_ms(sk.data_ptr(), 4 * outer // 65536 * 65536, stream))
     stream_read_gbs = (4 * outer // 65536 * 65536) / (best * 1e-3) / 1e9
     barrier()
+    joins_done = 0
+    tuples_joined = 0                   # co-partitioned mode: tuples the local joins of the timed steps read
+    if copart:
+        gpu_ops.join_log = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        st = hj.stats()                 # hipEvent spans of this step's kernels (same stream)
+        if copart:
+            # several local joins per step (one per probe-side slice): their phase times add up
+            calls, gpu_ops.join_log = gpu_ops.join_log, []
+            st = {p: sum(c["stats"][p] for c in calls) for p in phases}
+            tuples_joined += sum(c["inner"] + c["outer"] for c in calls)
+            joins_done += len(calls)
+        else:
+            st = hj.stats()             # hipEvent spans of this step's kernels (same stream)
         for p in phases:
             acc[p] += st[p]
             per_step[p].append(st[p])
-        if copart:
-            continue
     barrier()
     elapsed = time.perf_counter() - t0
     got = [int(x) for x in d_result.tolist()]
@@ -263,7 +274,10 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = outer_total / (elapsed / args.steps) / 1e9
     avg = {p: acc[p] / args.steps for p in phases}
-    n_tuples = inner + outer                      # per GPU
+    # tuples the kernels of one step read, per GPU (co-partitioned: what this rank's local joins were handed,
+    # the received build side once per probe-side slice)
+    n_tuples = tuples_joined / args.steps if copart else inner + outer
+    jps = max(1, round(joins_done / args.steps)) if copart else 1          # local joins per step
     st = hj.stats()
 
     # ---- roofline of each kernel: algorithmic bytes / measured time ----
@@ -279,10 +293,10 @@ def main():
     kernels = {}
     if args.algo in ("phj", "cpra"):
         two = st["fanout2"] > 1
-        kernels["hist2_kernel"] = roof(4 * n_tuples, avg["ms_histogram"], 2)
+        kernels["hist2_kernel"] = roof(4 * n_tuples, avg["ms_histogram"], 2 * jps)
         kernels["scatter_kernel"] = roof((2 if two else 1) * 16 * n_tuples,
-                                         avg["ms_scatter1"] + avg["ms_scatter2"], 4 if two else 2)
-        kernels["join_kernel"] = roof(8 * n_tuples, avg["ms_join"], 1)
+                                         avg["ms_scatter1"] + avg["ms_scatter2"], (4 if two else 2) * jps)
+        kernels["join_kernel"] = roof(8 * n_tuples, avg["ms_join"], jps)
         join_ms = avg["ms_join"]
     else:
         kernels["npj_build_kernel"] = roof(8 * inner + 8 * st["buckets"] + 8 * inner, avg["ms_build"], 1)
@@ -308,7 +322,8 @@ def main():
     roofline["kernel"] = dominant
 
     if copart:
-        parallelism = "both sides chunked over %d GPU(s), RCCL all-to-all-v co-partitioning, local PHJ" % n_gpus
+        parallelism = ("both sides chunked over %d GPU(s), RCCL all-to-all-v co-partitioning (probe side in %d slices, "
+                       "transfers overlapped with partitioning and local PHJ)" % (n_gpus, args.exchange_slices))
     elif dist is not None:
         parallelism = "probe side sharded over %d GPU(s), build side replicated each step by RCCL %s%s" % (
             n_gpus, "broadcast" if state["ring"] else "scatter + all-gather",

@@ -10,9 +10,10 @@ This is the distributed counterpart of the reference's thread orchestration:
     gathers partitions [t*P/T, (t+1)*P/T) from every chunk by memcpy,
     cpra2.cpp:1868-1904, 1946-1959):
         local partition of the own chunk with top-level fan-out = #GPUs
-        ->  all_gather(counts)  ->  all_to_all_v(keys), all_to_all_v(payloads)
+        ->  all_to_all(counts)  ->  all_to_all_v(keys), all_to_all_v(payloads)
         ->  local PHJ on the received tuples  ->  all_reduce(count, 3 sums)
-    Every GPU pair exchanges 1/G of a chunk over its direct xGMI link.
+    Every GPU pair exchanges 1/G of a chunk over its direct xGMI link; the probe side travels in
+    slices, so that partitioning, transfer and local join of consecutive slices overlap.
 
 The data path operators are injected (`ops`): on a GPU box they are the C-ABI
 entry points (hjgpu_partition / hjgpu_phj through `GpuOps`); the CPU tests inject
@@ -97,17 +98,17 @@ def phj_replicated_build(dist, torch, ops, r_keys, r_vals, s_keys_local, s_vals_
 MAX_MESSAGE_ELEMS = 1 << 28      # 1 GiB of uint32 per peer and collective call
 
 
-def _all_to_all_v(dist, torch, out, inp, recv_counts, send_counts, max_elems):
-    """all-to-all-v of one column.  A single all_to_all_single moved only half of a 4 GB
-    self-message on RCCL 2.26 (observed at |S| = 1 G on one rank), so per-peer messages are
-    capped at `max_elems` and larger exchanges run in rounds through staging buffers."""
+def _all_to_all_v(dist, torch, out, inp, recv_counts, send_counts, max_elems, biggest, async_op=False):
+    """all-to-all-v of one column; returns the list of outstanding work handles (empty when done).
+    `biggest` = the largest per-peer message of this exchange on ANY rank (every rank must take the
+    same path).  A single all_to_all_single moved only half of a 4 GB self-message on RCCL 2.26
+    (observed at |S| = 1 G on one rank), so per-peer messages are capped at `max_elems` and larger
+    exchanges run in rounds through staging buffers (synchronously)."""
     world = len(send_counts)
-    biggest = torch.tensor([max(send_counts + recv_counts)], dtype=torch.int64, device=inp.device)
-    dist.all_reduce(biggest, op=dist.ReduceOp.MAX)            # every rank runs the same number of rounds
-    rounds = max(1, -(-int(biggest.item()) // max_elems))
+    rounds = max(1, -(-int(biggest) // max_elems))
     if rounds == 1:
-        dist.all_to_all_single(out, inp, recv_counts, send_counts)
-        return
+        work = dist.all_to_all_single(out, inp, recv_counts, send_counts, async_op=async_op)
+        return [work] if async_op else []
     s_off = [sum(send_counts[:g]) for g in range(world)]
     r_off = [sum(recv_counts[:g]) for g in range(world)]
     for r in range(rounds):
@@ -120,32 +121,75 @@ def _all_to_all_v(dist, torch, out, inp, recv_counts, send_counts, max_elems):
         for g in range(world):
             out[r_off[g] + r * max_elems: r_off[g] + r * max_elems + rc[g]].copy_(stage_out[at: at + rc[g]])
             at += rc[g]
+    return []
 
 
-def cpra_exchange(dist, torch, ops, keys, vals, world, rank, max_elems=MAX_MESSAGE_ELEMS):
+class Exchange:
+    """One relation (or slice of one) on its way through the all-to-all: the received columns, the
+    outstanding transfers, and the send buffers, which must stay alive until the transfers are done."""
+
+    def __init__(self, keys, vals, works, keep):
+        self.keys, self.vals, self.works, self.keep = keys, vals, works, keep
+
+    def wait(self):
+        """RCCL: the current stream waits (the host does not); gloo: the host waits."""
+        for w in self.works:
+            w.wait()
+        self.works, self.keep = [], None
+        return self.keys, self.vals
+
+
+def cpra_exchange(dist, torch, ops, keys, vals, world, rank, max_elems=MAX_MESSAGE_ELEMS, async_op=False):
     """Co-partition one relation: local top-level partition + all-to-all-v.
-    Returns (keys, vals) tensors holding every tuple whose top-level partition this rank owns."""
+    Returns an Exchange whose columns hold every tuple whose top-level partition this rank owns;
+    with async_op the payload transfers are still in flight (Exchange.wait)."""
     pk, pv, offsets = ops.partition(keys, vals, TOP_LEVEL_FACTOR, world)   # offsets: world+1 ints
     send_counts = [int(offsets[g + 1] - offsets[g]) for g in range(world)]
+    # counts first, payload second: ONE small collective gives every rank the whole world x world matrix
+    # of message sizes - its own receive counts and the largest message anywhere (one host round trip)
     sc = torch.tensor(send_counts, dtype=torch.int64, device=keys.device)
-    rc = torch.empty(world, dtype=torch.int64, device=keys.device)
-    dist.all_to_all_single(rc, sc)                       # counts first, payload second
-    recv_counts = [int(x) for x in rc.tolist()]
+    rows = [torch.empty(world, dtype=torch.int64, device=keys.device) for _ in range(world)]
+    dist.all_gather(rows, sc)
+    matrix = torch.stack(rows).tolist()                  # matrix[src][dst]
+    recv_counts = [int(matrix[g][rank]) for g in range(world)]
+    biggest = max(max(int(x) for x in row) for row in matrix)
     out_k = torch.empty(sum(recv_counts) + 4, dtype=keys.dtype, device=keys.device)[:sum(recv_counts)]
     out_v = torch.empty(sum(recv_counts) + 4, dtype=vals.dtype, device=vals.device)[:sum(recv_counts)]
-    _all_to_all_v(dist, torch, out_k, pk, recv_counts, send_counts, max_elems)
-    _all_to_all_v(dist, torch, out_v, pv, recv_counts, send_counts, max_elems)
-    return out_k, out_v
+    works = _all_to_all_v(dist, torch, out_k, pk, recv_counts, send_counts, max_elems, biggest, async_op)
+    works += _all_to_all_v(dist, torch, out_v, pv, recv_counts, send_counts, max_elems, biggest, async_op)
+    return Exchange(out_k, out_v, works, (pk, pv))
+
+
+def _add_results(a, b):
+    return tuple((x + y) & ((1 << 64) - 1) for x, y in zip(a, b))
 
 
 def cpra_copartitioned(dist, torch, ops, r_keys_local, r_vals_local, s_keys_local, s_vals_local,
-                       max_elems=MAX_MESSAGE_ELEMS):
-    """Both relations chunked over the ranks; one exchange step, then a local join."""
+                       max_elems=MAX_MESSAGE_ELEMS, slices=4):
+    """Both relations chunked over the ranks; the probe side travels in `slices` pieces so that the
+    exchange - the longest phase on xGMI: at |R| = 1 G, |S| = 16 G on 8 GPUs every GPU sends and
+    receives 15 GB, ~45 ms at 7 x 48 GB/s, against ~10 ms of local partitioning and ~21 ms of local
+    join - overlaps the compute on either side of it:
+        partition(R) -> exchange(R)
+        for slice i of S:  partition(S_i) | exchange(S_i) in flight | join(R', S'_{i-1})
+    R join S = union_i (R join S_i), so the slice results simply add up.  On RCCL the transfers run
+    on the backend's own stream (async_op) and the join of a slice waits for its transfer on the
+    device; the host only synchronises where it needs counts.  Every rank must pass the same
+    `slices` (the number of collective calls depends on it)."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    rk, rv = cpra_exchange(dist, torch, ops, r_keys_local, r_vals_local, world, rank, max_elems)
-    sk, sv = cpra_exchange(dist, torch, ops, s_keys_local, s_vals_local, world, rank, max_elems)
-    local = ops.join(rk, rv, sk, sv)
-    return all_reduce_result(dist, torch, local, r_keys_local.device)
+    rk, rv = cpra_exchange(dist, torch, ops, r_keys_local, r_vals_local, world, rank, max_elems).wait()
+    n = s_keys_local.numel()
+    slices = max(1, int(slices))
+    total = (0, 0, 0, 0)
+    pending = None
+    for b, e in shard_bounds(n, slices):
+        ex = cpra_exchange(dist, torch, ops, s_keys_local[b:e], s_vals_local[b:e], world, rank, max_elems,
+                           async_op=slices > 1)
+        if pending is not None:
+            total = _add_results(total, ops.join(rk, rv, *pending.wait()))
+        pending = ex
+    total = _add_results(total, ops.join(rk, rv, *pending.wait()))
+    return all_reduce_result(dist, torch, total, r_keys_local.device)
 
 
 class GpuOps:
@@ -153,14 +197,19 @@ class GpuOps:
 
     def __init__(self, hj, torch, algorithm="phj", params=None):
         self.hj, self.torch, self.algorithm, self.params = hj, torch, algorithm, params
+        self.join_log = []          # one entry per local join: sizes + the library's phase times (bench.py)
 
     def _stream(self):
         return self.torch.cuda.current_stream().cuda_stream
 
     def join(self, rk, rv, sk, sv):
+        if rk.numel() == 0 or sk.numel() == 0:
+            return (0, 0, 0, 0)
         fn = {"phj": self.hj.phj, "npj": self.hj.npj, "cpra": self.hj.cpra}[self.algorithm]
-        return fn(rk.data_ptr(), rv.data_ptr(), rk.numel(), sk.data_ptr(), sv.data_ptr(), sk.numel(),
-                  self.params, None, self._stream())
+        res = fn(rk.data_ptr(), rv.data_ptr(), rk.numel(), sk.data_ptr(), sv.data_ptr(), sk.numel(),
+                 self.params, None, self._stream())
+        self.join_log.append({"inner": rk.numel(), "outer": sk.numel(), "stats": self.hj.stats()})
+        return res
 
     def partition(self, keys, vals, factor, fanout):
         torch = self.torch
@@ -168,6 +217,8 @@ class GpuOps:
         pk = torch.empty(n + 4, dtype=keys.dtype, device=keys.device)[:n]
         pv = torch.empty(n + 4, dtype=vals.dtype, device=vals.device)[:n]
         off = torch.empty(fanout + 1, dtype=torch.int64, device=keys.device)
+        if n == 0:
+            return pk, pv, [0] * (fanout + 1)
         self.hj.partition(keys.data_ptr(), vals.data_ptr(), n, factor, fanout,
                           pk.data_ptr(), pv.data_ptr(), off.data_ptr(), self._stream())
         return pk, pv, [int(x) for x in off.tolist()]
@@ -183,6 +234,8 @@ class OracleOps:
         return t.numpy().view(np.uint32)
 
     def join(self, rk, rv, sk, sv):
+        if rk.numel() == 0 or sk.numel() == 0:
+            return (0, 0, 0, 0)
         return self.O.join_definition(self._np(rk), self._np(rv), self._np(sk), self._np(sv))
 
     def partition(self, keys, vals, factor, fanout):

@@ -41,17 +41,20 @@ def _worker(rank, world, port, mode, q):
             got = D.phj_replicated_build(dist, torch, ops, rk, rv, as_t(ok[sb[0]:sb[1]]), as_t(ov[sb[0]:sb[1]]))
         else:
             rb = D.shard_bounds(len(ik), world)[rank]
-            # mode "cpra_rounds": force the chunked exchange (several rounds through staging buffers)
+            # mode "cpra_rounds": force the chunked exchange (several rounds through staging buffers);
+            # "cpra": probe side in 4 slices whose transfers are asynchronous; "cpra_tiny_slices": more
+            # slices than 16-tuple units in a shard, so most slices are empty
             got = D.cpra_copartitioned(dist, torch, ops, as_t(ik[rb[0]:rb[1]]), as_t(iv[rb[0]:rb[1]]),
                                        as_t(ok[sb[0]:sb[1]]), as_t(ov[sb[0]:sb[1]]),
-                                       max_elems=(1500 if mode == "cpra_rounds" else D.MAX_MESSAGE_ELEMS))
+                                       max_elems=(1500 if mode == "cpra_rounds" else D.MAX_MESSAGE_ELEMS),
+                                       slices={"cpra": 4, "cpra_rounds": 2, "cpra_one_slice": 1, "cpra_tiny_slices": 300}[mode])
         q.put((rank, got == want, got, want))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", ["phj", "cpra", "cpra_rounds"])
+@pytest.mark.parametrize("mode", ["phj", "cpra", "cpra_rounds", "cpra_one_slice", "cpra_tiny_slices"])
 def test_multi_process_join(world, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
