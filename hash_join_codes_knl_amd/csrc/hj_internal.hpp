@@ -18,6 +18,15 @@ struct ScatterConfig { int block, vpt; bool carry; };
 ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed);
 int hj_scatter_tile(int pass, uint32_t F, bool out_packed);
 constexpr int HJ_JOIN_SLICE    = 1 << 16;       // probe tuples per work item (target)
+// A build partition larger than one LDS table is joined in several table fills; the fills of such a
+// partition are dealt to up to this many work items per probe slice (a heavy build key otherwise leaves
+// hundreds of fills, each re-streaming the probe slice, to ONE workgroup).
+constexpr int HJ_JOIN_FILL_GROUPS = 64;
+// entries of the work-item directory: every partition has >= 1 probe slice, slices of ~HJ_JOIN_SLICE rows
+inline size_t hj_join_items_capacity(size_t partitions, size_t outer_rows)
+{
+    return (partitions + outer_rows / HJ_JOIN_SLICE + 1) * HJ_JOIN_FILL_GROUPS;
+}
 
 // Join-kernel geometry: threads per workgroup, log2 of the LDS table slots, and
 // probe vectors each lane keeps in flight.  Default 512 / 8192 slots (64 KiB) / 4;
@@ -82,7 +91,7 @@ struct JoinArgs {
     const u64 *roff, *soff;              // [chunks*P] first row of every partition, chunk-major
     const u64 *rend, *send;              // [chunks*P] one past its last row (dense layouts: roff + 1, soff + 1)
     const u64 *slice_prefix;             // [P+1] exclusive prefix of work items per partition
-    const u64 *slices;                   // [P]   work items of partition q
+    const u64 *slices;                   // [P]   probe slices of partition q | fill groups << 32
     const uint32_t *item_part;           // [items] partition of work item w
     uint32_t P, chunks;
     uint32_t f1, F1, f2, F2;             // the passes that produced the partitions
@@ -117,11 +126,12 @@ struct PlanArgs {
     uint32_t tdesc_cap;       // tiles the descriptor table holds
     u64 *slice_prefix;        // [P + 1]
     u64 *slices;              // [P]
-    uint32_t *item_part;      // [P + outer/slice + 1] partition of every join work item
+    uint32_t *item_part;      // [hj_join_items_capacity] partition of every join work item
     uint32_t chunks, F1, F2;
     uint32_t in_align[2];     // alignment of the caller's input columns
     uint32_t tile1, tile2;    // tuples per tile in pass 1 / pass 2
     uint32_t slice;
+    uint32_t cap;             // build rows per LDS table fill of the join kernel that will run (JoinConfig::cap)
     uint32_t mask;            // bit 0: plan R, bit 1: plan S, bit 2: join work items
 };
 

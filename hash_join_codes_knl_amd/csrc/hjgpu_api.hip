@@ -297,7 +297,7 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     // ranges of the larger relation bound the per-range tables of both
     const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1, true), gs = make_geom(nullptr, outer, pl->C, pl->F1, true);
     pl->ranges = (size_t)(gr.ranges_per_chunk > gs.ranges_per_chunk ? gr.ranges_per_chunk : gs.ranges_per_chunk) * pl->C;
-    pl->items_extra = outer / HJ_JOIN_SLICE + 1;
+    pl->items_extra = hj_join_items_capacity(pl->P, outer) - pl->P;
     // pass-2 tiles: whole tiles of the relation plus up to two ragged tiles per segment
     const size_t larger = inner > outer ? inner : outer;
     pl->tiles2 = pl->F2 > 1 ? larger / (size_t)hj_scatter_tile(2, pl->F2, true) + 2 * (size_t)pl->C * pl->F1 + 8 : 0;
@@ -344,6 +344,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
     pa.tile1 = (uint32_t)hj_scatter_tile(1, pl.F1, true); pa.tile2 = (uint32_t)hj_scatter_tile(2, pl.F2, true);
     pa.slice = HJ_JOIN_SLICE;
+    pa.cap = (uint32_t)(pl.big_tables ? hj_join_config_big() : hj_join_config()).cap();
 
     // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
     auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
@@ -739,7 +740,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
-    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
+    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)hj_join_config().cap(); pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
     if (n) {
         CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
@@ -787,7 +788,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     HIPCHK(ctx, hipMemcpyAsync(&s_ends[0], soff, sizeof(u64), hipMemcpyDeviceToHost, stream));
     HIPCHK(ctx, hipMemcpyAsync(&s_ends[1], soff + pl.P, sizeof(u64), hipMemcpyDeviceToHost, stream));
     HIPCHK(ctx, hipStreamSynchronize(stream));
-    const size_t items_extra = (size_t)((s_ends[1] - s_ends[0]) / HJ_JOIN_SLICE + 1);
+    const size_t items_extra = hj_join_items_capacity(pl.P, (size_t)(s_ends[1] - s_ends[0])) - pl.P;
     MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P, 1, items_extra);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
@@ -811,7 +812,8 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
-    pa.tile1 = pa.tile2 = (uint32_t)hj_scatter_tile(2, 1, true); pa.slice = HJ_JOIN_SLICE; pa.mask = 7u;
+    pa.tile1 = pa.tile2 = (uint32_t)hj_scatter_tile(2, 1, true); pa.slice = HJ_JOIN_SLICE;
+    pa.cap = (uint32_t)hj_join_config().cap(); pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
     for (int e : {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2, EV_WAITED, EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2}) record(ctx, e, stream);
     JoinArgs ja;

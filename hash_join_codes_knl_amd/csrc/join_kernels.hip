@@ -243,18 +243,40 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     // claims item n+1 into the other slot at the top of the loop; the clear barrier publishes it,
     // and (single-chunk joins) every lane then loads its share of item n+1's build rows into
     // registers right after item n's build, so that they arrive during the probe of item n.
-    __shared__ u64 d_item[2], d_slice[2], d_nslices[2], d_rb[2], d_rn[2];
-    __shared__ uint32_t d_q[2];
+    __shared__ u64 d_item[2], d_rb[2], d_rn[2];
+    __shared__ u64 d_rows_beg[2], d_rows_end[2];      // build rows (of the chunk-concatenated partition) this item inserts
+    __shared__ uint32_t d_q[2], d_slice[2], d_nslices[2];
     auto claim = [&](int slot) {                          // thread 0 only
         const u64 w = atomicAdd(a.work_counter, 1ull);
         d_item[slot] = w;
         if (w < total_items) {
             const uint32_t nq = a.item_part[w];
             d_q[slot] = nq;
-            d_slice[slot] = w - a.slice_prefix[nq];
-            d_nslices[slot] = a.slices[nq];
-            d_rb[slot] = a.roff[nq];
-            d_rn[slot] = a.rend[nq] - a.roff[nq];
+            // item t of partition q = (probe slice t % nslices, fill group t / nslices), see plan_items_kernel;
+            // the divisions are done here, by one thread and one item ahead of use
+            const u64 shape = a.slices[nq];
+            const uint32_t nslices = (uint32_t)shape, groups = (uint32_t)(shape >> 32);
+            const uint32_t t = (uint32_t)(w - a.slice_prefix[nq]);
+            const u64 rb = a.roff[nq], rn = a.rend[nq] - rb;
+            d_rb[slot] = rb;
+            d_rn[slot] = rn;
+            d_nslices[slot] = nslices;
+            u64 rows = rn;
+            for (uint32_t c = 1; c < C; ++c) rows += a.rend[(u64)c * P + nq] - a.roff[(u64)c * P + nq];
+            if (groups == 1) {
+                // the planned case: the partition fits one table (or its few fills stay with one workgroup)
+                d_slice[slot] = t;
+                d_rows_beg[slot] = 0;
+                d_rows_end[slot] = rows;
+            } else {
+                // this item's share of the oversize partition's table fills
+                const uint32_t group = t / nslices;
+                d_slice[slot] = t - group * nslices;
+                const uint32_t fills = (uint32_t)((rows + CAP - 1) >> (LOG2SLOTS - 1));
+                const uint32_t per_group = (fills + groups - 1) / groups;
+                d_rows_beg[slot] = min(rows, (u64)group * per_group * CAP);
+                d_rows_end[slot] = min(rows, (u64)(group + 1) * per_group * CAP);
+            }
         }
     };
     uint32_t pk[RB], pv[RB];                              // prefetched build rows j*BLOCK + tid
@@ -270,6 +292,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
         q = hj_uniform(d_q[par]);
         const u64 slice = hj_uniform(d_slice[par]);
         const u64 nslices = hj_uniform(d_nslices[par]);
+        const u64 rows_beg = hj_uniform(d_rows_beg[par]), rows_end = hj_uniform(d_rows_end[par]);
         if (tid == 0) claim(par ^ 1);                     // published by the clear barrier below
         u64 have_rows = pre_rows;
         pre_rows = 0;
@@ -279,12 +302,8 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
         while (hj_part2(empty, a.f1, a.F1, a.f2, a.F2) == q) ++empty;
         const u64 EMPTY64 = (u64)empty;
 
-        // total build rows of q over all chunks
-        u64 nr = 0;
-        for (uint32_t c = 0; c < C; ++c) nr += a.rend[(u64)c * P + q] - a.roff[(u64)c * P + q];
-
-        for (u64 fill_beg = 0; fill_beg < nr; fill_beg += CAP) {
-            const u64 fill_end = min(nr, fill_beg + CAP);
+        for (u64 fill_beg = rows_beg; fill_beg < rows_end; fill_beg += CAP) {
+            const u64 fill_end = min(rows_end, fill_beg + CAP);
             // ---- clear + cuckoo build --------------------------------------------
             for (uint32_t i = tid; i < SLOTS; i += BLOCK) tab64[i] = EMPTY64;
             if (tid == 0) cuckoo_failed = a.force_chained;
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             }
             __syncthreads();   // table is reused by the next fill / work item
         }
-        if (nr == 0) __syncthreads();      // (cannot happen for planned items) publish the next claim
+        if (rows_beg >= rows_end) __syncthreads();   // no fill (a trailing fill group of an oversize partition): publish the next claim
         par ^= 1;
     }
 

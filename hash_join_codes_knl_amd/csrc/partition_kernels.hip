@@ -347,7 +347,9 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
     }
 }
 
-// K5, step 3: the join's work items: partition q gets ceil(|S_q| / slice) items when both sides are non-empty.
+// K5, step 3: the join's work items.  Partition q with both sides non-empty gets slices(q) = ceil(|S_q| / slice)
+// probe slices times groups(q) = min(HJ_JOIN_FILL_GROUPS, ceil(|R_q| / cap)) groups of table fills: a build
+// partition that fits one LDS table (the planned case) is one group.
 __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
 {
     __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
@@ -356,12 +358,15 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
     {
         const u64 *__restrict__ cr = a.counts[0];
         const u64 *__restrict__ cs = a.counts[1];
-        const uint32_t slice = a.slice;
-        auto items = [&](uint32_t q) -> u64 {
+        const uint32_t slice = a.slice, cap = a.cap ? a.cap : 1u;
+        // (probe slices, fill groups) of partition q; 0 slices = no work
+        auto shape = [&](uint32_t q, u64 &slices, u64 &groups) {
             u64 nr = 0, ns = 0;
             for (uint32_t c = 0; c < C; ++c) { nr += cr[(u64)c * P + q]; ns += cs[(u64)c * P + q]; }
-            return (nr && ns) ? (ns + slice - 1) / slice : 0;
+            slices = (nr && ns) ? (ns + slice - 1) / slice : 0;
+            groups = min((u64)HJ_JOIN_FILL_GROUPS, max((u64)1, (nr + cap - 1) / cap));
         };
+        auto items = [&](uint32_t q) -> u64 { u64 s_, g_; shape(q, s_, g_); return s_ * g_; };
         // a thread's item counts (<= 32 partitions, 32-bit each) are fetched together and kept in registers
         constexpr int MAXPER = HJGPU_MAX_PARTS / PLAN_BLOCK;
         const uint32_t per = (P + PLAN_BLOCK - 1) / PLAN_BLOCK;
@@ -374,9 +379,11 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
         for (int j = 0; j < MAXPER; ++j) sum += v[j];
         u64 run = block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
         for (uint32_t q = lo; q < hi; ++q) {
-            const uint32_t n = (uint32_t)items(q);      // second read: L2 hit, and keeps v[] out of a dynamic index
+            u64 slices, groups;
+            shape(q, slices, groups);                   // second read: L2 hit, and keeps v[] out of a dynamic index
+            const uint32_t n = (uint32_t)(slices * groups);
             a.slice_prefix[q] = run;
-            a.slices[q] = n;
+            a.slices[q] = slices | (groups << 32);
             // item -> partition directory: the join reads one word instead of a binary search
             for (uint32_t s = 0; s < n; ++s) a.item_part[run + s] = q;
             run += n;

@@ -148,3 +148,26 @@ def test_full_size_zipf_probe_side(hj, zipf):
     assert hj.npj(ik, iv, inner, ok, ov, outer) == want
     for c in (ik, iv, ok, ov):
         c.free()
+
+
+def test_one_build_key_with_a_million_copies(hj):
+    """A build partition hundreds of times the LDS table (one key 1 M times among 200 K unique keys), probed by
+    20 K copies of that key: the table of that partition is filled ~250 times and its probe slice re-streamed
+    (J = 2 x 10^10 + the unique matches), all three algorithms, default plans and a forced tiny fan-out."""
+    rng = np.random.default_rng(99)
+    u = np.unique(rng.integers(1, 2**32, size=200_000, dtype=np.uint64).astype(np.uint32))
+    hot = u[1234]
+    ik = np.concatenate([u, np.full(1_000_000, hot, np.uint32)])
+    rng.shuffle(ik)
+    iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+    ok = np.concatenate([u[rng.integers(0, len(u), size=500_000)], np.full(20_000, hot, np.uint32)])
+    rng.shuffle(ok)
+    ov = rng.integers(0, 2**32, size=len(ok), dtype=np.uint64).astype(np.uint32)
+    want = numpy_join(ik, iv, ok, ov)
+    assert want[0] > 2 * 10**10
+    rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+    assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == want
+    assert hj.phj(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(fanout1=3, fanout2=2)) == want
+    assert hj.cpra(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(chunks=5)) == want
+    for c in (rk, rv, sk, sv):
+        c.free()
