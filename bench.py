@@ -168,7 +168,8 @@ def main():
     overlap = dist is not None and args.algo == "phj" and not args.no_overlap
     if copart:
         from hash_join_codes_knl_amd import distributed as D
-        gpu_ops = D.GpuOps(hj, torch, "phj", prm)
+        hj_part = H.HjGpu(local_rank)     # exchange-level partitioning plans in its own workspace (prepared build side)
+        gpu_ops = D.GpuOps(hj, torch, "phj", prm, partition_ctx=hj_part)
         views = (rk[:inner], rv[:inner], sk[:outer], sv[:outer])
 
     exchange_events = []          # (start, stop) of each step's build-side replication, on its own stream

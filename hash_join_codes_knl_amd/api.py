@@ -26,6 +26,7 @@ EXPORTS = [
     "hjgpu_npj_build", "hjgpu_npj_probe",
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
+    "hjgpu_phj_build", "hjgpu_phj_probe", "hjgpu_phj_probe_async",
     "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums", "hjgpu_stream_read_ms",
 ]
 
@@ -141,6 +142,9 @@ def load_library(build_if_missing=True):
     L.hjgpu_phj_async.argtypes = join + [C.POINTER(PhjParams), vp, vp]
     L.hjgpu_cpra_async.argtypes = join + [C.POINTER(PhjParams), vp, vp]
     L.hjgpu_phj_overlapped_async.argtypes = join + [C.POINTER(PhjParams), vp, vp, vp]
+    L.hjgpu_phj_build.argtypes = [vp, vp, vp, sz, sz, C.POINTER(PhjParams), vp]
+    L.hjgpu_phj_probe.argtypes = [vp, vp, vp, sz, C.POINTER(Result), C.POINTER(Output), vp]
+    L.hjgpu_phj_probe_async.argtypes = [vp, vp, vp, sz, vp, vp]
     L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
                                   C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Stats)]
     L.hjgpu_join_host_rows.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
@@ -297,6 +301,21 @@ class HjGpu:
 
     def cpra(self, rk, rv, inner, sk, sv, outer, params=None, out=None, stream=None):
         return self._join(self.lib.hjgpu_cpra, params, rk, rv, inner, sk, sv, outer, out, stream)
+
+    # build side prepared once, probed by batches (results are per batch)
+    def phj_build(self, rk, rv, inner, max_outer, params=None, stream=None):
+        self._check(self.lib.hjgpu_phj_build(self.handle, self._ptr(rk), self._ptr(rv), inner, max_outer,
+                                             C.byref(params) if params is not None else None, stream))
+
+    def phj_probe(self, sk, sv, outer, out=None, stream=None):
+        r = Result()
+        self._check(self.lib.hjgpu_phj_probe(self.handle, self._ptr(sk), self._ptr(sv), outer, C.byref(r),
+                                             self._out(out), stream))
+        return r.as_tuple()
+
+    def phj_probe_async(self, sk, sv, outer, d_result, stream=None):
+        self._check(self.lib.hjgpu_phj_probe_async(self.handle, self._ptr(sk), self._ptr(sv), outer,
+                                                   self._ptr(d_result), stream))
 
     def _join_async(self, fn, params, rk, rv, inner, sk, sv, outer, d_result, stream):
         self._check(fn(self.handle, self._ptr(rk), self._ptr(rv), inner, self._ptr(sk),

@@ -54,6 +54,11 @@ struct hjgpu_ctx {
     bool ev_valid[EV_COUNT];
     hjgpu_stats stats;
     int last_algo = -1;     // 0 npj, 1 phj/cpra
+    // hjgpu_phj_build: the partitioned build side (tmp[0] / tmp[4]) and its plan (meta) stay valid until
+    // another entry point uses the workspace
+    bool prepared = false;
+    size_t prepared_inner = 0, prepared_max_outer = 0;
+    unsigned char prepared_plan[96];
 };
 
 namespace {
@@ -266,10 +271,13 @@ struct PhjPlan {
     uint32_t f1, f2, tf0, tf1;
     bool big_tables;
 };
+static_assert(sizeof(PhjPlan) <= sizeof(hjgpu_ctx::prepared_plan), "prepared_plan too small");
+enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
 
 int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm,
                 uint32_t chunks, PhjPlan *pl)
 {
+    ctx->prepared = false;               // the workspace is about to be re-planned (hjgpu_phj_build sets it again)
     pl->C = chunks;
     choose_fanout(inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
     pl->P = pl->F1 * pl->F2;
@@ -310,7 +318,8 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
 int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *rk, const uint32_t *rv, size_t inner,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
-                const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr)
+                const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr,
+                PhjMode mode = PHJ_WHOLE)
 {
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
@@ -318,8 +327,21 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus, pl.big_tables), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
-    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
-    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+    // counts[0] | counts[1] | tickets are contiguous: a whole join zeroes all, a prepared build its own
+    // histogram and the tickets, a probe of a prepared build the probe side's histogram and the tickets
+    {
+        unsigned char *z0 = reinterpret_cast<unsigned char *>(m.counts[0]);
+        unsigned char *z1 = reinterpret_cast<unsigned char *>(m.counts[1]);
+        unsigned char *zt = reinterpret_cast<unsigned char *>(m.tickets);
+        unsigned char *ze = z0 + m.counts_bytes;
+        if (mode == PHJ_WHOLE) HIPCHK(ctx, hipMemsetAsync(z0, 0, m.counts_bytes, stream));
+        if (mode == PHJ_BUILD_ONLY) {
+            HIPCHK(ctx, hipMemsetAsync(z0, 0, (size_t)(z1 - z0), stream));
+            HIPCHK(ctx, hipMemsetAsync(zt, 0, (size_t)(ze - zt), stream));
+        }
+        if (mode == PHJ_PROBE_ONLY) HIPCHK(ctx, hipMemsetAsync(z1, 0, (size_t)(ze - z1), stream));
+    }
+    if (mode != PHJ_BUILD_ONLY) HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
 
     const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C, pl.F1, true), make_geom(sk, outer, pl.C, pl.F1, true)};
     const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
@@ -387,15 +409,24 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     };
     const int ev_s[4] = {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2};
     const int ev_r[4] = {EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2};
-    CHK(partition_relation(1, 2u, ev_s));                       // probe side first
+    if (mode != PHJ_BUILD_ONLY) CHK(partition_relation(1, 2u, ev_s));       // probe side first
+    else for (int e : ev_s) record(ctx, e, stream);
     if (inner_ready) HIPCHK(ctx, hipStreamWaitEvent(stream, inner_ready, 0));
     record(ctx, EV_WAITED, stream);
-    CHK(partition_relation(0, 1u | 4u, ev_r));                  // build side + join work items
+    if (mode == PHJ_WHOLE) CHK(partition_relation(0, 1u | 4u, ev_r));       // build side + join work items
+    if (mode == PHJ_BUILD_ONLY) CHK(partition_relation(0, 1u, ev_r));       // build side; work items come with a probe
+    if (mode == PHJ_PROBE_ONLY) {
+        // the build side was partitioned by hjgpu_phj_build: only the work items are missing
+        record(ctx, ev_r[0], stream);
+        pa.mask = 4u;
+        CHK(hj_launch_plan(pa, stream));
+        for (int i = 1; i < 4; ++i) record(ctx, ev_r[i], stream);
+    }
     const uint32_t *fin[4] = {t1[0], t1[1], t1[2], t1[3]};
     if (pl.F2 > 1) for (int i = 0; i < 4; ++i) fin[i] = t2[i];
 
     // K7+K8
-    if (inner && outer) {
+    if (inner && outer && mode != PHJ_BUILD_ONLY) {
         JoinArgs ja;
         memset(&ja, 0, sizeof(ja));
         ja.rk = fin[0]; ja.rv = fin[1]; ja.sk = fin[2]; ja.sv = fin[3];
@@ -420,7 +451,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         CHK(hj_launch_join(ja, ctx->cus, stream));
     }
     record(ctx, EV_JOIN, stream);
-    if (bs && inner && outer) {
+    if (bs && inner && outer && mode != PHJ_BUILD_ONLY) {
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
                                     (const u64 *)ctx->final_offsets.p,
                                     (uint32_t)hj_join_workers(ctx->cus, pl.big_tables), bs, &st->block_counter,
@@ -724,6 +755,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const Pass1Geom geom = make_geom(d_keys, n, 1, fanout, false);
     MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
+    ctx->prepared = false;                 // the workspace is re-planned below
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
@@ -790,6 +822,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     HIPCHK(ctx, hipStreamSynchronize(stream));
     const size_t items_extra = hj_join_items_capacity(pl.P, (size_t)(s_ends[1] - s_ends[0])) - pl.P;
     MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P, 1, items_extra);
+    ctx->prepared = false;                 // the workspace is re-planned below
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P, 1, items_extra);
@@ -949,6 +982,58 @@ int hjgpu_phj_overlapped_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_
 {
     return phj_like(ctx, 1, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false,
                     inner_ready_event);
+}
+
+// ---- build side prepared once, probed by any number of batches ---------------------------------
+int hjgpu_phj_build(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner, size_t max_outer,
+                    const hjgpu_phj_params *prm, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    CHK(check_columns(ctx, rk, rv, inner));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PhjPlan pl;
+    CHK(phj_prepare(ctx, inner, max_outer, prm, 1, &pl));        // workspace and plan for the largest batch
+    CHK(phj_enqueue(ctx, pl, rk, rv, inner, nullptr, nullptr, 0, nullptr, stream, nullptr, PHJ_BUILD_ONLY));
+    memcpy(ctx->prepared_plan, &pl, sizeof(pl));
+    ctx->prepared_inner = inner; ctx->prepared_max_outer = max_outer;
+    ctx->prepared = true;
+    return HJGPU_OK;
+}
+
+static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, size_t outer,
+                              hjgpu_result *result, hjgpu_result *d_result, const hjgpu_output *out,
+                              void *stream_, bool blocking)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (!ctx->prepared)
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe: no prepared build side (hjgpu_phj_build), or another "
+                                       "entry point has used the workspace since");
+    if (outer > ctx->prepared_max_outer)
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe: batch larger than the max_outer given to hjgpu_phj_build");
+    CHK(check_columns(ctx, sk, sv, outer));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PhjPlan pl;
+    memcpy(&pl, ctx->prepared_plan, sizeof(pl));
+    // the build columns themselves are not read again: their partitions live in the workspace
+    CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, sk, sv, outer, out, stream, nullptr, PHJ_PROBE_ONLY));
+    if (d_result)
+        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+    if (blocking) return finish_blocking(ctx, result, out, stream);
+    return HJGPU_OK;
+}
+
+int hjgpu_phj_probe(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, size_t outer,
+                    hjgpu_result *result, const hjgpu_output *out, void *stream)
+{
+    return phj_probe_prepared(ctx, sk, sv, outer, result, nullptr, out, stream, true);
+}
+
+int hjgpu_phj_probe_async(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, size_t outer,
+                          hjgpu_result *d_result, void *stream)
+{
+    return phj_probe_prepared(ctx, sk, sv, outer, nullptr, d_result, nullptr, stream, false);
 }
 
 int hjgpu_cpra(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,

@@ -182,21 +182,43 @@ def cpra_copartitioned(dist, torch, ops, r_keys_local, r_vals_local, s_keys_loca
     slices = max(1, int(slices))
     total = (0, 0, 0, 0)
     pending = None
+    # the received build side is partitioned ONCE when the operators offer a prepared build
+    # (hjgpu_phj_build / hjgpu_phj_probe); otherwise every slice runs a whole join against it
+    prepared = slices > 1 and getattr(ops, "supports_prepared_build", False)
+    first = True
+
+    def join_slice(sk, sv):
+        nonlocal first
+        if not prepared:
+            return ops.join(rk, rv, sk, sv)
+        if first:
+            # batches are the slices this rank RECEIVES: about one local slice when the hash spreads the keys
+            # evenly; the workspace is sized for 1.5 of that, larger batches are probed in pieces (GpuOps.probe)
+            ops.prepare_build(rk, rv, max_outer=max(1 << 20, 3 * (n // slices + 16) // 2))
+            first = False
+        return ops.probe(sk, sv)
+
     for b, e in shard_bounds(n, slices):
         ex = cpra_exchange(dist, torch, ops, s_keys_local[b:e], s_vals_local[b:e], world, rank, max_elems,
                            async_op=slices > 1)
         if pending is not None:
-            total = _add_results(total, ops.join(rk, rv, *pending.wait()))
+            total = _add_results(total, join_slice(*pending.wait()))
         pending = ex
-    total = _add_results(total, ops.join(rk, rv, *pending.wait()))
+    total = _add_results(total, join_slice(*pending.wait()))
     return all_reduce_result(dist, torch, total, r_keys_local.device)
 
 
 class GpuOps:
     """Data-path operators on device tensors through the C-ABI (no CPU fallback)."""
 
-    def __init__(self, hj, torch, algorithm="phj", params=None):
+    def __init__(self, hj, torch, algorithm="phj", params=None, partition_ctx=None):
+        """`partition_ctx`: a second library context for the exchange-level partitioning.  A prepared build
+        side (hjgpu_phj_build) lives in its context's workspace until another operator plans in it, and
+        the slices of the probe side are partitioned for the exchange BETWEEN the probes: with its own
+        context for that, the build side received from the peers is partitioned once per join."""
         self.hj, self.torch, self.algorithm, self.params = hj, torch, algorithm, params
+        self.hj_part = partition_ctx if partition_ctx is not None else hj
+        self.supports_prepared_build = algorithm == "phj" and self.hj_part is not hj
         self.join_log = []          # one entry per local join: sizes + the library's phase times (bench.py)
 
     def _stream(self):
@@ -211,6 +233,30 @@ class GpuOps:
         self.join_log.append({"inner": rk.numel(), "outer": sk.numel(), "stats": self.hj.stats()})
         return res
 
+    def prepare_build(self, rk, rv, max_outer):
+        """hjgpu_phj_build: partition the build side once; probe() then joins batches against it."""
+        if self.algorithm != "phj":
+            raise ValueError("a prepared build side exists for PHJ only")
+        self._build = (rk, rv, int(max_outer))           # the columns stay referenced while batches are probed
+        if rk.numel():
+            self.hj.phj_build(rk.data_ptr(), rv.data_ptr(), rk.numel(), int(max_outer), self.params, self._stream())
+            self.hj.synchronize(self._stream())
+            self.join_log.append({"inner": rk.numel(), "outer": 0, "stats": self.hj.stats()})
+
+    def probe(self, sk, sv):
+        rk, rv, max_outer = self._build
+        n = sk.numel()
+        if rk.numel() == 0 or n == 0:
+            return (0, 0, 0, 0)
+        total = (0, 0, 0, 0)
+        step = max(16, max_outer & ~15)                  # pieces start on 64-byte boundaries of the columns
+        for b in range(0, n, step):
+            m = min(step, n - b)
+            res = self.hj.phj_probe(sk.data_ptr() + 4 * b, sv.data_ptr() + 4 * b, m, None, self._stream())
+            self.join_log.append({"inner": 0, "outer": m, "stats": self.hj.stats()})
+            total = tuple((x + y) & ((1 << 64) - 1) for x, y in zip(total, res))
+        return total
+
     def partition(self, keys, vals, factor, fanout):
         torch = self.torch
         n = keys.numel()
@@ -219,8 +265,8 @@ class GpuOps:
         off = torch.empty(fanout + 1, dtype=torch.int64, device=keys.device)
         if n == 0:
             return pk, pv, [0] * (fanout + 1)
-        self.hj.partition(keys.data_ptr(), vals.data_ptr(), n, factor, fanout,
-                          pk.data_ptr(), pv.data_ptr(), off.data_ptr(), self._stream())
+        self.hj_part.partition(keys.data_ptr(), vals.data_ptr(), n, factor, fanout,
+                               pk.data_ptr(), pv.data_ptr(), off.data_ptr(), self._stream())
         return pk, pv, [int(x) for x in off.tolist()]
 
 

@@ -212,6 +212,26 @@ int  hjgpu_cpra_async(hjgpu_ctx *ctx,
                       const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
                       const hjgpu_phj_params *params, hjgpu_result *d_result, void *stream);
 
+/* ---- PHJ with the build side prepared once and probed by any number of batches -------------------
+ * R join S = union over batches S_i of R join S_i, so a probe side that arrives in pieces (slices of a
+ * multi-GPU exchange, batches from the host or from an upstream operator) needs the build side
+ * histogrammed and partitioned only once: hjgpu_phj_build runs build-side K4/K5/K6 (the reference's
+ * run_hj up to the end of the inner relation's passes, phj.cpp:1715-1863) and keeps the partitions in
+ * the context's workspace; every hjgpu_phj_probe partitions one batch and runs build+probe per
+ * partition (phj.cpp:1869-1924) against them.  `max_outer` sizes the workspace: batches may have up
+ * to that many rows.  The prepared state lasts until any other join / partition entry point is called
+ * on the context (hjgpu_phj_probe then fails with HJGPU_EINVAL); the caller's build columns are not
+ * read again after hjgpu_phj_build has completed on `stream`.  Results are per batch: add them up. */
+int  hjgpu_phj_build(hjgpu_ctx *ctx,
+                     const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
+                     size_t max_outer, const hjgpu_phj_params *params, void *stream);
+int  hjgpu_phj_probe(hjgpu_ctx *ctx,
+                     const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+                     hjgpu_result *result, const hjgpu_output *out, void *stream);
+int  hjgpu_phj_probe_async(hjgpu_ctx *ctx,
+                           const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
+                           hjgpu_result *d_result, void *stream);
+
 /* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
  * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates.
  * The upload runs on its own stream: probe side first, build side behind it; PHJ / CPRA

@@ -35,10 +35,16 @@ def main():
             want = numpy_join(ik, iv, okeys, ov)
             t = lambda a: torch.from_numpy(a.view(np.int32).copy()).to(dev)
             ops = D.GpuOps(hj, torch, "phj", None)
+            hj2 = H.HjGpu(0)
+            ops2 = D.GpuOps(hj, torch, "phj", None, partition_ctx=hj2)     # prepared build side across the slices
             cases = [("phj_replicated_build", lambda: D.phj_replicated_build(dist, torch, ops, t(ik), t(iv), t(okeys), t(ov)))]
             for slices, max_elems in ((1, D.MAX_MESSAGE_ELEMS), (4, D.MAX_MESSAGE_ELEMS), (3, 100_000), (5000, D.MAX_MESSAGE_ELEMS)):
                 cases.append(("cpra_copartitioned slices=%d max_elems=%d" % (slices, max_elems),
                               lambda s=slices, m=max_elems: D.cpra_copartitioned(dist, torch, ops, t(ik), t(iv), t(okeys), t(ov),
+                                                                               max_elems=m, slices=s)))
+            for slices, max_elems in ((4, D.MAX_MESSAGE_ELEMS), (7, 100_000)):
+                cases.append(("cpra_copartitioned prepared build, slices=%d max_elems=%d" % (slices, max_elems),
+                              lambda s=slices, m=max_elems: D.cpra_copartitioned(dist, torch, ops2, t(ik), t(iv), t(okeys), t(ov),
                                                                                max_elems=m, slices=s)))
             for name, fn in cases:
                 got = tuple(fn())
@@ -46,6 +52,9 @@ def main():
                 ok = ok and got == want
             # the slice joins were logged with their sizes (bench.py's accounting)
             ok = ok and len(ops.join_log) >= 1 + 1 + 4 + 3
+            # one build + one probe per slice (a batch beyond max_outer would add pieces)
+            ok = ok and [c["inner"] > 0 for c in ops2.join_log].count(True) == 2
+            hj2.close()
     finally:
         dist.destroy_process_group()
     print("ALL OK" if ok else "FAILED", flush=True)

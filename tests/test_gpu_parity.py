@@ -527,3 +527,47 @@ def test_host_programs_materialise_to_host_columns(hj, oracle, tmp_path):
         got = [np.fromfile(tmp_path / ("%s_%s_%d.txt" % (prog, c, want[0])), dtype="<u4") for c in ("jk", "jo", "ji")]
         for a, b in zip(sort_rows(*got), materialised_rows(*cols)):
             assert np.array_equal(a, b)
+
+
+def test_prepared_build_probed_in_batches(hj):
+    """hjgpu_phj_build + hjgpu_phj_probe: the build side is partitioned once, batches of the probe side are
+    joined against it; the batch results add up to the whole join's (R join S = union of R join S_i), for a
+    two-pass and a single-pass plan, ragged batch sizes, an empty batch, and materialised rows per batch."""
+    rng = np.random.default_rng(321)
+    base = np.unique(rng.integers(0, 2**32, size=700_000, dtype=np.uint64).astype(np.uint32))
+    ik = np.concatenate([base, base[:90_000]])
+    iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+    ok = np.where(rng.random(3_000_000) < 0.7, base[rng.integers(0, len(base), size=3_000_000)],
+                  rng.integers(0, 2**32, size=3_000_000, dtype=np.uint64).astype(np.uint32)).astype(np.uint32)
+    ov = rng.integers(0, 2**32, size=len(ok), dtype=np.uint64).astype(np.uint32)
+    want = numpy_join(ik, iv, ok, ov)
+    rk, rv, sk, sv = _cols(hj, ik, iv, ok, ov)
+    mask = (1 << 64) - 1
+    for prm in (None, H.PhjParams(fanout1=37, fanout2=1), H.PhjParams(fanout1=64, fanout2=40)):
+        cuts = [0, 16 * 3, 16 * 40_000, 16 * 40_000, 16 * 100_001, len(ok)]        # batches start on 64-byte boundaries
+        hj.phj_build(rk, rv, len(ik), max(b - a for a, b in zip(cuts, cuts[1:])), prm)
+        total = (0, 0, 0, 0)
+        for a, b in zip(cuts, cuts[1:]):
+            got = hj.phj_probe(sk.ptr + 4 * a, sv.ptr + 4 * a, b - a)
+            assert got == numpy_join(ik, iv, ok[a:b], ov[a:b])
+            total = tuple((x + y) & mask for x, y in zip(total, got))
+        assert total == want
+    # rows of one batch
+    a, b = 16 * 1000, 16 * 9000
+    w = numpy_join(ik, iv, ok[a:b], ov[a:b])
+    block = 1024
+    cap = (w[0] // block + hj.device_info()["compute_units"] * 16 + 8) * block
+    jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+    assert hj.phj_probe(sk.ptr + 4 * a, sv.ptr + 4 * a, b - a, out=(jk, jo, ji, cap, block)) == w
+    rows = sort_rows(jk.download()[:w[0]], jo.download()[:w[0]], ji.download()[:w[0]])
+    for x, y in zip(rows, materialised_rows(ik, iv, ok[a:b], ov[a:b])):
+        assert np.array_equal(x, y)
+    # a batch beyond max_outer is refused; another operator on the context ends the prepared state
+    with pytest.raises(H.HjGpuError) as e:
+        hj.phj_probe(sk, sv, len(ok))
+    assert e.value.status == 1
+    assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == want
+    with pytest.raises(H.HjGpuError) as e:
+        hj.phj_probe(sk, sv, 1024)
+    assert e.value.status == 1
+    _free(rk, rv, sk, sv, jk, jo, ji)
