@@ -15,10 +15,11 @@ This is the distributed counterpart of the reference's thread orchestration:
     Every GPU pair exchanges 1/G of a chunk over its direct xGMI link; the probe side travels in
     slices, so that partitioning, transfer and local join of consecutive slices overlap.
 
-The data path operators are injected (`ops`): on a GPU box they are the C-ABI
-entry points (hjgpu_partition / hjgpu_phj through `GpuOps`); the CPU tests inject
-the oracle so that the host logic (ownership, split sizes, reductions) is covered
-with the gloo backend.  Nothing here computes on tuples itself.
+The data path operators are injected (`ops`): the product's are the C-ABI entry
+points (hjgpu_partition / hjgpu_phj / hjgpu_phj_build + hjgpu_phj_probe through
+`GpuOps`); the CPU tests inject their own (tests/oracle_ops.py) so that the host
+logic (ownership, split sizes, slicing, reductions) is covered with the gloo
+backend.  Nothing here computes on tuples itself.
 """
 import numpy as np
 
@@ -268,24 +269,3 @@ class GpuOps:
         self.hj_part.partition(keys.data_ptr(), vals.data_ptr(), n, factor, fanout,
                                pk.data_ptr(), pv.data_ptr(), off.data_ptr(), self._stream())
         return pk, pv, [int(x) for x in off.tolist()]
-
-
-class OracleOps:
-    """TEST ONLY: the same interface over the CPU oracle (used by the gloo tests)."""
-
-    def __init__(self, oracle, torch):
-        self.O, self.torch = oracle, torch
-
-    def _np(self, t):
-        return t.numpy().view(np.uint32)
-
-    def join(self, rk, rv, sk, sv):
-        if rk.numel() == 0 or sk.numel() == 0:
-            return (0, 0, 0, 0)
-        return self.O.join_definition(self._np(rk), self._np(rv), self._np(sk), self._np(sv))
-
-    def partition(self, keys, vals, factor, fanout):
-        counts, ko, vo = self.O.partition(self._np(keys), self._np(vals), factor, fanout)
-        off = np.concatenate([[0], np.cumsum(counts.astype(np.int64))])
-        return (self.torch.from_numpy(ko.view(np.int32)), self.torch.from_numpy(vo.view(np.int32)),
-                [int(x) for x in off])

@@ -22,9 +22,11 @@ def _free_port():
 
 def _worker(rank, world, port, mode, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
     from oracle import oracle as O
+    from oracle_ops import OracleOps, PreparedOracleOps
     from hash_join_codes_knl_amd import distributed as D
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -32,7 +34,7 @@ def _worker(rank, world, port, mode, q):
     try:
         ik, iv, ok, ov = O.generate(40_000, 9_000, seed=5)
         want = O.join_definition(ik, iv, ok, ov)
-        ops = D.OracleOps(O, torch)
+        ops = PreparedOracleOps(O, torch) if mode == "cpra_prepared" else OracleOps(O, torch)
         as_t = lambda a: torch.from_numpy(a.view(np.int32).copy())
         sb = D.shard_bounds(len(ok), world)[rank]
         if mode == "phj":
@@ -47,14 +49,17 @@ def _worker(rank, world, port, mode, q):
             got = D.cpra_copartitioned(dist, torch, ops, as_t(ik[rb[0]:rb[1]]), as_t(iv[rb[0]:rb[1]]),
                                        as_t(ok[sb[0]:sb[1]]), as_t(ov[sb[0]:sb[1]]),
                                        max_elems=(1500 if mode == "cpra_rounds" else D.MAX_MESSAGE_ELEMS),
-                                       slices={"cpra": 4, "cpra_rounds": 2, "cpra_one_slice": 1, "cpra_tiny_slices": 300}[mode])
+                                       slices={"cpra": 4, "cpra_rounds": 2, "cpra_one_slice": 1, "cpra_tiny_slices": 300,
+                                               "cpra_prepared": 5}[mode])
+            if mode == "cpra_prepared":          # the received build side was prepared once, every slice probed it
+                assert (ops.builds, ops.probes) == (1, 5)
         q.put((rank, got == want, got, want))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", ["phj", "cpra", "cpra_rounds", "cpra_one_slice", "cpra_tiny_slices"])
+@pytest.mark.parametrize("mode", ["phj", "cpra", "cpra_rounds", "cpra_one_slice", "cpra_tiny_slices", "cpra_prepared"])
 def test_multi_process_join(world, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
