@@ -66,7 +66,7 @@ def test_struct_layouts_match_header(tmp_path):
 
 def test_product_package_never_uses_the_oracle():
     """Nothing under the product package imports, links, includes or calls the oracle
-    (comments may mention it); distributed.OracleOps only receives it as an argument."""
+    (comments may mention it); the stand-in operators of the gloo tests live in tests/oracle_ops.py."""
     pkg = os.path.join(ROOT, "hash_join_codes_knl_amd")
     banned = [r"^\s*(import|from)\s+oracle\b", r"libhjoracle", r"libhjref", r"#\s*include\s*[<\"].*hj_oracle",
               r"\bhjo_[a-z0-9_]+\s*\(", r"\bhjref_[a-z0-9_]+\s*\("]
