@@ -37,9 +37,11 @@ def parse():
                     help="Zipf exponent of the probe side's repeat picks (0 = uniform, the headline workload)")
     ap.add_argument("--fanout1", type=int, default=0)
     ap.add_argument("--fanout2", type=int, default=0)
-    ap.add_argument("--cpu-outer", type=int, default=256_000_000,
-                    help="probe tuples of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
+    ap.add_argument("--cpu-outer", type=int, default=1_000_000_000,
+                    help="probe tuples of the CPU-baseline sample (0 = skip); the default is the whole per-GPU "
+                         "workload: ~1 s on the 16 CPUs of a GPU box with the AVX-512 operators")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota)")
     ap.add_argument("--materialize", action="store_true",
                     help="additionally run the materialising PHJ (3 result columns + close_gaps) and report it")
     ap.add_argument("--force-dist", action="store_true",
@@ -63,6 +65,19 @@ def relaunch_under_torchrun(args):
     sys.exit(subprocess.call(cmd))
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands
+    a one-GPU job 16 CPUs' worth of time out of 256 online ones; 256 runnable threads would only be throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(hj, H, args, algo):
     """The oracle's restatement of the reference's CPU algorithm ("port"), timed on
     this host's cores on a bounded sample of the same workload shape."""
@@ -70,7 +85,7 @@ def cpu_baseline(hj, H, args, algo):
     from oracle import oracle as O
     outer = min(args.cpu_outer, args.outer)
     inner = max(1, int(args.inner * (outer / args.outer)))
-    threads = args.cpu_threads or (os.cpu_count() or 1)
+    threads = args.cpu_threads or usable_cpus()
     ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
     hj.generate(1, inner, outer, 0, outer, INNER_FACTOR, OUTER_FACTOR, ik, iv, ok, ov)
     hik, hiv, hok, hov = ik.download(), iv.download(), ok.download(), ov.download()
@@ -90,9 +105,10 @@ def cpu_baseline(hj, H, args, algo):
     return {"value": outer / tm.seconds / 1e9, "unit": "Gtuples/s", "cores": threads,
             "kind": "port",
             "sample": "%s |R|=%d join |S|=%d (same generator, 1/%g of the per-GPU workload), "
-                      "oracle/hj_oracle.c pthreads restatement of run_hj with %s operators, %.3f s, checksum %s"
+                      "oracle/hj_oracle.c pthreads restatement of run_hj with %s operators, %d threads "
+                      "(%d CPUs online, cgroup quota applied), %.3f s, checksum %s"
                       % (algo, inner, outer, args.outer / outer,
-                         "AVX-512 (oracle/hj_oracle_avx512.c)" if simd else "scalar", tm.seconds,
+                         "AVX-512 (oracle/hj_oracle_avx512.c)" if simd else "scalar", threads, os.cpu_count() or 0, tm.seconds,
                          "ok" if ok_ else "MISMATCH"),
             "seconds": tm.seconds}
 
