@@ -248,6 +248,34 @@ __device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 
 }
 
 
+// The plan kernels walk arrays of P <= 32768 counters with ONE workgroup.  With a blocked split (thread t owns
+// partitions [t * per, (t + 1) * per)) every load and store instruction of a wave touches 64 different cache
+// lines, and a single CU's address path then needs ~50 us for the ~10^5 line accesses of a plan step.  The
+// two-pass plan kernels therefore walk in tiles of 2 * PLAN_BLOCK partitions: thread t handles partitions
+// tile + 2t and tile + 2t + 1 (a wave covers 1 KiB of consecutive counters per instruction), one block scan per
+// tile, running totals carried in registers.
+// Exclusive scan of (a, b) over the workgroup, ONE barrier; totals returned; scratch = [2][2][NW] (parity-buffered:
+// the slots of a call are rewritten two calls later, when every thread has passed another barrier).
+__device__ __forceinline__ void plan_scan2(u64 &a, u64 &b, u64 &total_a, u64 &total_b, u64 *scratch, int parity)
+{
+    constexpr int NW = PLAN_BLOCK / 64;
+    const int lane = hj_lane(), wave = threadIdx.x >> 6;
+    const u64 ia = wave_inclusive_scan(a), ib = wave_inclusive_scan(b);
+    u64 *sa = scratch + (parity * 2) * NW, *sb = sa + NW;
+    if (lane == 63) { sa[wave] = ia; sb[wave] = ib; }
+    __syncthreads();
+    u64 before_a = 0, before_b = 0;
+    total_a = 0; total_b = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const u64 xa = sa[w], xb = sb[w];
+        total_a += xa; total_b += xb;
+        if (w < wave) { before_a += xa; before_b += xb; }
+    }
+    a = ia - a + before_a;
+    b = ib - b + before_b;
+}
+
 // K5, step 1: one workgroup per (chunk, relation).  A chunk's final offsets are its
 // own exclusive scan plus the chunk's first row (known on the host), so the chunks
 // scan in parallel.
@@ -278,30 +306,30 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
         // Two passes: the pass-1 output (= pass-2 input) stays dense, the FINAL layout starts every
         // partition on a 128-byte line (K6 pass 2 then claims whole lines from the front of a partition
         // and the few leftover tuples of a tile from its back).
-        const uint32_t per = (P + PLAN_BLOCK - 1) / PLAN_BLOCK;
-        const uint32_t lo = min(P, threadIdx.x * per), hi = min(P, lo + per);
+        __shared__ u64 scratch2[4 * (PLAN_BLOCK / 64)];
         auto padded = [](u64 n) { return (n + HJ_LINE_TUPLES - 1) & ~(u64)(HJ_LINE_TUPLES - 1); };
-        u64 dsum = 0, psum = 0;
-#pragma unroll 8
-        for (uint32_t q = lo; q < hi; ++q) { const u64 n = cnt[q]; dsum += n; psum += padded(n); }
-        u64 drun = base + block_exclusive_scan<PLAN_BLOCK, u64>(dsum, scratch);
-        __syncthreads();
-        const u64 base2 = base + (u64)c * HJ_LINE_TUPLES * P;        // room for every partition's padding
-        u64 prun = base2 + block_exclusive_scan<PLAN_BLOCK, u64>(psum, scratch);
-        uint32_t p1 = (lo + a.F2 - 1) / a.F2;                         // next pass-1 partition that starts at or after lo
-        uint32_t p1_first = p1 * a.F2;                                // ... and its first final partition
-#pragma unroll 8
-        for (uint32_t q = lo; q < hi; ++q) {
-            const u64 n = cnt[q];                                    // second read: L2
-            if (q == p1_first) {                                     // first partition of a pass-1 partition: dense offset
-                a.off1[r][(u64)c * a.F1 + p1] = drun;
-                a.cur1[r][(u64)c * a.F1 + p1] = drun;
-                ++p1; p1_first += a.F2;
+        u64 drun = base;                                              // dense offset of the tile's first partition
+        u64 prun = base + (u64)c * HJ_LINE_TUPLES * P;                // padded one: room for every partition's padding
+        const uint32_t F2 = a.F2;
+        int parity = 0;
+        for (uint32_t tile = 0; tile < P; tile += 2 * PLAN_BLOCK, parity ^= 1) {
+            const uint32_t q0 = tile + 2 * threadIdx.x, q1 = q0 + 1;
+            const u64 n0 = q0 < P ? cnt[q0] : 0, n1 = q1 < P ? cnt[q1] : 0;
+            u64 d = n0 + n1, pd = padded(n0) + padded(n1), dt, pt;
+            plan_scan2(d, pd, dt, pt, scratch2, parity);
+            d += drun; pd += prun;
+            if (q0 < P) {
+                if (q0 % F2 == 0) { a.off1[r][(u64)c * a.F1 + q0 / F2] = d; a.cur1[r][(u64)c * a.F1 + q0 / F2] = d; }
+                off2[q0] = pd; end2[q0] = pd + n0;
+                a.cur2[r][(u64)c * P + q0] = 0;                       // lines claimed | tail tuples << 32
             }
-            off2[q] = prun; end2[q] = prun + n;
-            a.cur2[r][(u64)c * P + q] = 0;                           // lines claimed | tail tuples << 32
-            drun += n;
-            prun += padded(n);
+            if (q1 < P) {
+                const u64 d1 = d + n0, p1 = pd + padded(n0);
+                if (q1 % F2 == 0) { a.off1[r][(u64)c * a.F1 + q1 / F2] = d1; a.cur1[r][(u64)c * a.F1 + q1 / F2] = d1; }
+                off2[q1] = p1; end2[q1] = p1 + n1;
+                a.cur2[r][(u64)c * P + q1] = 0;
+            }
+            drun += dt; prun += pt;
         }
     }
     if (threadIdx.x == 0) {
@@ -352,44 +380,51 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
 // partition that fits one LDS table (the planned case) is one group.
 __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
 {
-    __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
     const uint32_t P = a.F1 * a.F2;
     const uint32_t C = a.chunks;
-    {
-        const u64 *__restrict__ cr = a.counts[0];
-        const u64 *__restrict__ cs = a.counts[1];
-        const uint32_t slice = a.slice, cap = a.cap ? a.cap : 1u;
-        // (probe slices, fill groups) of partition q; 0 slices = no work
-        auto shape = [&](uint32_t q, u64 &slices, u64 &groups) {
-            u64 nr = 0, ns = 0;
-            for (uint32_t c = 0; c < C; ++c) { nr += cr[(u64)c * P + q]; ns += cs[(u64)c * P + q]; }
-            slices = (nr && ns) ? (ns + slice - 1) / slice : 0;
-            groups = min((u64)HJ_JOIN_FILL_GROUPS, max((u64)1, (nr + cap - 1) / cap));
-        };
-        auto items = [&](uint32_t q) -> u64 { u64 s_, g_; shape(q, s_, g_); return s_ * g_; };
-        // a thread's item counts (<= 32 partitions, 32-bit each) are fetched together and kept in registers
-        constexpr int MAXPER = HJGPU_MAX_PARTS / PLAN_BLOCK;
-        const uint32_t per = (P + PLAN_BLOCK - 1) / PLAN_BLOCK;
-        const uint32_t lo = min(P, threadIdx.x * per), hi = min(P, lo + per);
-        uint32_t v[MAXPER];
-        u64 sum = 0;
-#pragma unroll
-        for (int j = 0; j < MAXPER; ++j) { v[j] = 0; if (lo + j < hi) v[j] = (uint32_t)items(lo + j); }
-#pragma unroll
-        for (int j = 0; j < MAXPER; ++j) sum += v[j];
-        u64 run = block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
-        for (uint32_t q = lo; q < hi; ++q) {
-            u64 slices, groups;
-            shape(q, slices, groups);                   // second read: L2 hit, and keeps v[] out of a dynamic index
-            const uint32_t n = (uint32_t)(slices * groups);
-            a.slice_prefix[q] = run;
-            a.slices[q] = slices | (groups << 32);
+    const u64 *__restrict__ cr = a.counts[0];
+    const u64 *__restrict__ cs = a.counts[1];
+    // slice and cap are powers of two (checked by hj_launch_plan): shifts, no 64-bit divisions
+    static_assert((HJ_JOIN_SLICE & (HJ_JOIN_SLICE - 1)) == 0, "slice must be a power of two");
+    constexpr int SLICE_SHIFT = __builtin_ctz(HJ_JOIN_SLICE);
+    const uint32_t cap = a.cap ? a.cap : 1u, cap_shift = 31u - (uint32_t)__clz((int)cap);
+    // (probe slices | fill groups << 32) of a partition with nr build and ns probe rows; 0 slices = no work
+    auto shape_of = [&](u64 nr, u64 ns) -> u64 {
+        const u64 slices = (nr && ns) ? (ns + HJ_JOIN_SLICE - 1) >> SLICE_SHIFT : 0;
+        const u64 groups = min((u64)HJ_JOIN_FILL_GROUPS, max((u64)1, (nr + cap - 1) >> cap_shift));
+        return slices | (groups << 32);
+    };
+    // tiles of 2 * PLAN_BLOCK partitions, thread t takes partitions tile + 2t and tile + 2t + 1 (see plan_scan2)
+    __shared__ u64 scratch2[4 * (PLAN_BLOCK / 64)];
+    auto rows_of = [&](const u64 *__restrict__ cnt, uint32_t q) -> u64 {
+        u64 n = cnt[q];
+        for (uint32_t c = 1; c < C; ++c) n += cnt[(u64)c * P + q];
+        return n;
+    };
+    u64 run = 0;
+    int parity = 0;
+    for (uint32_t tile = 0; tile < P; tile += 2 * PLAN_BLOCK, parity ^= 1) {
+        const uint32_t q0 = tile + 2 * threadIdx.x, q1 = q0 + 1;
+        const u64 s0 = q0 < P ? shape_of(rows_of(cr, q0), rows_of(cs, q0)) : 0;
+        const u64 s1 = q1 < P ? shape_of(rows_of(cr, q1), rows_of(cs, q1)) : 0;
+        const u64 n0 = (s0 & 0xFFFFFFFFull) * (s0 >> 32), n1 = (s1 & 0xFFFFFFFFull) * (s1 >> 32);
+        u64 first = n0 + n1, unused = 0, total, t2;
+        plan_scan2(first, unused, total, t2, scratch2, parity);
+        first += run;
+        if (q0 < P) {
+            a.slice_prefix[q0] = first;
+            a.slices[q0] = s0;
             // item -> partition directory: the join reads one word instead of a binary search
-            for (uint32_t s = 0; s < n; ++s) a.item_part[run + s] = q;
-            run += n;
+            for (u64 i = 0; i < n0; ++i) a.item_part[first + i] = q0;
         }
-        if (threadIdx.x == PLAN_BLOCK - 1) a.slice_prefix[P] = run;
+        if (q1 < P) {
+            a.slice_prefix[q1] = first + n0;
+            a.slices[q1] = s1;
+            for (u64 i = 0; i < n1; ++i) a.item_part[first + n0 + i] = q1;
+        }
+        run += total;
     }
+    if (threadIdx.x == 0) a.slice_prefix[P] = run;
 }
 
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
@@ -399,6 +434,7 @@ int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
         else hipLaunchKernelGGL(plan_offsets_kernel<false>, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
     }
     if (a.mask & 3u) hipLaunchKernelGGL(plan_tiles_kernel, dim3(2), dim3(PLAN_BLOCK), 0, stream, a);
+    if ((a.mask & 4u) && ((a.cap & (a.cap - 1)) || a.slice != (uint32_t)HJ_JOIN_SLICE)) return HJGPU_EINVAL;
     if (a.mask & 4u) hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
