@@ -356,21 +356,29 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
         const u64 *off1 = a.off1[r];
         plan_scan<8>(C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile2); },
                      a.tp2[r], 0, scratch);
-        // per-tile descriptors of pass 2: K6 then needs ONE independent 32-byte load per tile instead
-        // of a search in tp2 followed by dependent reads of off1 (exposed latency on every tile)
-        if (a.tdesc[r]) {
-            const u64 *tp2 = a.tp2[r];
-            uint4 *td = a.tdesc[r];
-            // one wave per segment, one lane per tile (a segment of the probe side has hundreds of tiles)
-            for (uint32_t sgm = threadIdx.x >> 6; sgm < C * a.F1; sgm += PLAN_BLOCK / 64) {
-                const u64 gb = off1[sgm], ge = off1[sgm + 1];
-                const u64 t0 = tp2[sgm], t1 = min(tp2[sgm + 1], (u64)a.tdesc_cap);
-                for (u64 t = t0 + (threadIdx.x & 63); t < t1; t += 64) {
-                    const u64 g0 = (gb & ~3ull) + (t - t0) * tile2;
-                    td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
-                    td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), sgm * a.F2, sgm);
-                }
-            }
+    }
+}
+
+// K5, step 2b: per-tile descriptors of pass 2: K6 then needs ONE independent 32-byte load per tile instead of a
+// search in tp2 followed by dependent reads of off1 (exposed latency on every tile).  One wave per segment, one
+// lane per tile (a segment of the probe side has hundreds of tiles); 2 MB of descriptors at 64 M x 1 G, which
+// one workgroup needed 20 us to write: grid of TDESC_BLOCKS workgroups per relation.
+constexpr int TDESC_BLOCKS = 32;
+__global__ __launch_bounds__(PLAN_BLOCK) void tile_desc_kernel(PlanArgs a)
+{
+    const int r = blockIdx.y;
+    if (!((a.mask >> r) & 1u) || !a.tdesc[r]) return;
+    const uint32_t nseg = a.chunks * a.F1, tile2 = a.tile2;
+    const u64 *__restrict__ off1 = a.off1[r];
+    const u64 *__restrict__ tp2 = a.tp2[r];
+    uint4 *td = a.tdesc[r];
+    for (uint32_t sgm = blockIdx.x * (PLAN_BLOCK / 64) + (threadIdx.x >> 6); sgm < nseg; sgm += TDESC_BLOCKS * (PLAN_BLOCK / 64)) {
+        const u64 gb = off1[sgm], ge = off1[sgm + 1];
+        const u64 t0 = tp2[sgm], t1 = min(tp2[sgm + 1], (u64)a.tdesc_cap);
+        for (u64 t = t0 + (threadIdx.x & 63); t < t1; t += 64) {
+            const u64 g0 = (gb & ~3ull) + (t - t0) * tile2;
+            td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
+            td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), sgm * a.F2, sgm);
         }
     }
 }
@@ -434,6 +442,8 @@ int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
         else hipLaunchKernelGGL(plan_offsets_kernel<false>, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
     }
     if (a.mask & 3u) hipLaunchKernelGGL(plan_tiles_kernel, dim3(2), dim3(PLAN_BLOCK), 0, stream, a);
+    if ((a.mask & 3u) && (a.tdesc[0] || a.tdesc[1]))
+        hipLaunchKernelGGL(tile_desc_kernel, dim3(TDESC_BLOCKS, 2), dim3(PLAN_BLOCK), 0, stream, a);
     if ((a.mask & 4u) && ((a.cap & (a.cap - 1)) || a.slice != (uint32_t)HJ_JOIN_SLICE)) return HJGPU_EINVAL;
     if (a.mask & 4u) hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
