@@ -68,6 +68,12 @@ def test_random_join_matches_numpy(hj, case):
         prm = H.PhjParams(fanout1=case["f1"], fanout2=case["f2"], chunks=case["chunks"])
         assert hj.phj(rk, rv, len(ik), sk, sv, len(ok), prm) == want
         assert hj.cpra(rk, rv, len(ik), sk, sv, len(ok), prm) == want
+        # the same join with the build side prepared once and the probe side in two batches
+        cut = (len(ok) // 3) & ~15
+        hj.phj_build(rk, rv, len(ik), max(cut, len(ok) - cut), prm)
+        a = hj.phj_probe(sk, sv, cut)
+        b = hj.phj_probe(sk.ptr + 4 * cut, sv.ptr + 4 * cut, len(ok) - cut)
+        assert tuple((x + y) & ((1 << 64) - 1) for x, y in zip(a, b)) == want
         if not case["key_zero"] and want[0] < 400_000_000:
             assert hj.npj(rk, rv, len(ik), sk, sv, len(ok)) == want
         # rows, for results small enough to sort on the host
