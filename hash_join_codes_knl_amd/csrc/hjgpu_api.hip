@@ -197,6 +197,18 @@ void record(hjgpu_ctx *ctx, int which, hipStream_t s)
     ctx->ev_valid[which] = (hipEventRecord(ctx->ev[which], s) == hipSuccess);
 }
 
+// The enqueue paths are not valid inside a HIP stream capture: a replayed graph of one PHJ step faulted on
+// gfx950 / ROCm 7.0 (kernels with > 64 KiB of dynamic LDS among the nodes), so a capturing stream is refused
+// instead of handing the caller a graph that may corrupt memory.
+int refuse_capture(hjgpu_ctx *ctx, hipStream_t stream)
+{
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &status) != hipSuccess) { (void)hipGetLastError(); return HJGPU_OK; }
+    if (status != hipStreamCaptureStatusNone)
+        return fail(ctx, HJGPU_EINVAL, "the stream is capturing a HIP graph: hjgpu joins cannot be captured");
+    return HJGPU_OK;
+}
+
 int check_columns(hjgpu_ctx *ctx, const uint32_t *k, const uint32_t *v, size_t n)
 {
     if (n == 0) return HJGPU_OK;
@@ -321,6 +333,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr,
                 PhjMode mode = PHJ_WHOLE)
 {
+    CHK(refuse_capture(ctx, stream));
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
@@ -531,6 +544,7 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
                 size_t buckets, uint32_t factor, const hjgpu_output *out, hipStream_t stream)
 {
+    CHK(refuse_capture(ctx, stream));
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 *table = reinterpret_cast<u64 *>(ctx->table.p);
     record(ctx, EV_BEGIN, stream);

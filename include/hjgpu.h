@@ -187,8 +187,10 @@ int  hjgpu_cpra(hjgpu_ctx *ctx,
                 const hjgpu_phj_params *params,
                 hjgpu_result *result, const hjgpu_output *out, void *stream);
 /* Enqueue-only forms: the aggregates land in d_result (device memory, 32 bytes);
- * no host synchronisation, so a caller can time with its own events or capture
- * the sequence.  Workspace must have been reserved (hjgpu_reserve). */
+ * no host synchronisation, so a caller can time with its own events and keep several
+ * joins in flight on one stream.  Workspace must have been reserved (hjgpu_reserve).
+ * Not valid inside a HIP stream capture (HJGPU_EINVAL on a capturing stream): a
+ * replayed graph of a join faulted on gfx950 / ROCm 7.0. */
 int  hjgpu_npj_async(hjgpu_ctx *ctx,
                      const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
                      const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,

@@ -571,3 +571,34 @@ def test_prepared_build_probed_in_batches(hj):
         hj.phj_probe(sk, sv, 1024)
     assert e.value.status == 1
     _free(rk, rv, sk, sv, jk, jo, ji)
+
+
+def test_async_joins_back_to_back_on_a_side_stream_and_no_graph_capture(hj, oracle):
+    """Twenty hjgpu_phj_async joins enqueued on a non-default stream without host synchronisation in between
+    (every join re-zeroes its histograms, tickets and result block in stream order); a capturing stream is
+    refused with HJGPU_EINVAL (a replayed graph of a join faulted on gfx950 / ROCm 7.0, include/hjgpu.h)."""
+    import torch
+    ik, iv, ok, ov = oracle.generate(700_000, 150_000, seed=47)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    rk, rv, sk, sv = _cols(hj, ik, iv, ok, ov)
+    hj.reserve(len(ik), len(ok))
+    d_res = torch.zeros(4, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    for _ in range(20):
+        hj.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, d_res.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert tuple(int(x) & ((1 << 64) - 1) for x in d_res.tolist()) == want
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        try:
+            for fn, prm in ((hj.phj_async, None), (hj.npj_async, None), (hj.cpra_async, H.PhjParams(chunks=2))):
+                with pytest.raises(H.HjGpuError) as e:
+                    fn(rk, rv, len(ik), sk, sv, len(ok), prm, d_res.data_ptr(), s.cuda_stream)
+                assert e.value.status == 1
+        finally:
+            g.capture_end()
+    s.synchronize()
+    assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == want       # the context is still usable
+    _free(rk, rv, sk, sv)
