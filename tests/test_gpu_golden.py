@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import hash_join_codes_knl_amd as H
-from helpers import mulhi_hash
+from helpers import mulhi_hash, numpy_join
 
 pytestmark = pytest.mark.gpu
 
@@ -179,4 +179,28 @@ def test_beyond_2_32_probe_tuples_64m_4g4(hj):
     assert hj.phj(ik, iv, inner, ok, ov, outer) == want
     assert hj.npj(ik, iv, inner, ok, ov, outer) == want
     for c in (ik, iv, ok, ov):
+        c.free()
+
+
+def test_config1_npj_1m_probe_16m_build(hj, oracle):
+    """BASELINE.json configs[0], `./npj 64 1000000 16000000`: outer = 1 M probe tuples, inner = 16 M build
+    tuples over 1 M distinct keys (16 copies per key, write.cpp semantics), J = 16 M.  All three algorithms
+    against the independent numpy definition, aggregates and the dense materialised row count."""
+    ik, iv, ok, ov = oracle.generate(1_000_000, 16_000_000, seed=1)
+    assert len(ik) == 16_000_000 and len(ok) == 1_000_000
+    want = numpy_join(ik, iv, ok, ov)
+    assert 15_000_000 < want[0] < 17_000_000
+    rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+    assert hj.npj(rk, rv, len(ik), sk, sv, len(ok), H.NpjParams(load=0.9)) == want      # npj.cpp:944 load factor
+    assert hj.npj(rk, rv, len(ik), sk, sv, len(ok)) == want
+    assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == want
+    assert hj.cpra(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(chunks=8)) == want
+    block = 65536
+    cap = (want[0] // block + hj.device_info()["compute_units"] * 32 + 8) * block
+    jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+    assert hj.npj(rk, rv, len(ik), sk, sv, len(ok), out=(jk, jo, ji, cap, block)) == want
+    assert hj.column_sums(jk, want[0], 1, 1)[0] == want[1]
+    assert hj.column_sums(jo, want[0], 1, 1)[0] == want[2]
+    assert hj.column_sums(ji, want[0], 1, 1)[0] == want[3]
+    for c in (rk, rv, sk, sv, jk, jo, ji):
         c.free()
