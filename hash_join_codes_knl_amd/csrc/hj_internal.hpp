@@ -106,6 +106,10 @@ struct JoinArgs {
     u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
     uint32_t *overflow;                  // device flag
     uint32_t big_tables;                 // hj_join_config_big() instead of hj_join_config()
+    // broadcast join (tiny build side, nothing partitioned): P = 1, the relations are the caller's columns, the
+    // empty sentinel is *sentinel (a value no build key equals, found by hj_launch_broadcast_meta)
+    uint32_t broadcast;
+    const uint32_t *sentinel;
     uint32_t force_chained;              // tests: skip the cuckoo fast path (HJGPU_FORCE_CHAINED=1)
 };
 
@@ -176,6 +180,15 @@ int hj_launch_close_gaps_ex(uint32_t *k, uint32_t *ov, uint32_t *iv, const u64 *
                             u64 *dense_count, int cus, hipStream_t stream);
 int hj_join_grid(int cus);
 int hj_join_workers(int cus, bool big_tables = false);
+// Metadata of a broadcast join, written on the device: one partition holding all of R ([0, inner)) and all of S
+// ([0, outer)), `nslices` probe slices x `groups` fill groups (item_part must be zeroed by the caller), and a
+// sentinel: a value whose low 14 bits no build key shares (inner <= 16383).
+struct BroadcastMeta {
+    u64 *roff, *rend, *soff, *send, *slice_prefix, *slices;
+    uint32_t *sentinel;
+};
+int hj_launch_broadcast_meta(const uint32_t *inner_keys, size_t inner, size_t outer, uint32_t nslices,
+                             uint32_t groups, const BroadcastMeta &m, hipStream_t stream);
 int hj_npj_probe_grid(int cus, size_t n);
 
 // generator / checksums

@@ -155,7 +155,14 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                 const uint32_t val[4] = {PACKED ? kk[u].y : vv[u].x, PACKED ? kk[u].w : vv[u].y, PACKED ? vv[u].y : vv[u].z, vv[u].w};
                 bool valid[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) valid[j] = (g + j >= gb) && (g + j < ge);
+                for (int j = 0; j < 4; ++j) {
+                    valid[j] = (g + j >= gb) && (g + j < ge);
+                    // A probe key that equals the empty sentinel must not "match" empty slots.  In partitioned
+                    // joins no tuple of partition q carries that value (it hashes elsewhere); in a broadcast
+                    // join the probe side is the caller's unpartitioned column and may hold it (no build key
+                    // does).  Only the separate-column instance serves broadcast joins.
+                    if (!PACKED) valid[j] = valid[j] && key[j] != empty;
+                }
                 probe4(key, val, valid);
             }
         }
@@ -297,9 +304,13 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
         u64 have_rows = pre_rows;
         pre_rows = 0;
 
-        // empty sentinel: smallest value whose partition is not q (P >= 2)
-        empty = 0;
-        while (hj_part2(empty, a.f1, a.F1, a.f2, a.F2) == q) ++empty;
+        // empty sentinel: smallest value whose partition is not q (P >= 2); broadcast join: a value that no
+        // build key equals, found once by broadcast_meta_kernel
+        if (a.broadcast) empty = hj_uniform(*a.sentinel);
+        else {
+            empty = 0;
+            while (hj_part2(empty, a.f1, a.F1, a.f2, a.F2) == q) ++empty;
+        }
         const u64 EMPTY64 = (u64)empty;
 
         for (u64 fill_beg = rows_beg; fill_beg < rows_end; fill_beg += CAP) {
@@ -385,6 +396,43 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 #include <stdlib.h>
 #include <stdio.h>
 
+// Broadcast join metadata (see BroadcastMeta).  One workgroup: a bitmap of the build keys' low 14 bits in LDS
+// (inner < 16384 keys cannot occupy all 16384 residues), the first free residue is the sentinel.
+__global__ __launch_bounds__(1024) void broadcast_meta_kernel(const uint32_t *__restrict__ keys, u64 inner, u64 outer,
+                                                               uint32_t nslices, uint32_t groups, BroadcastMeta m)
+{
+    __shared__ uint32_t bits[512];
+    __shared__ uint32_t first_free;
+    for (uint32_t i = threadIdx.x; i < 512; i += 1024) bits[i] = 0;
+    if (threadIdx.x == 0) first_free = 0xFFFFFFFFu;
+    __syncthreads();
+    for (u64 i = threadIdx.x; i < inner; i += 1024) {
+        const uint32_t r = keys[i] & 16383u;
+        atomicOr(&bits[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
+    if (threadIdx.x < 512) {
+        const uint32_t free_bits = ~bits[threadIdx.x];
+        if (free_bits) atomicMin(&first_free, threadIdx.x * 32 + (uint32_t)__builtin_ctz(free_bits));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *m.sentinel = first_free;
+        m.roff[0] = 0; m.rend[0] = inner; m.soff[0] = 0; m.send[0] = outer;
+        m.slice_prefix[0] = 0; m.slice_prefix[1] = (u64)nslices * groups;
+        m.slices[0] = (u64)nslices | ((u64)groups << 32);
+    }
+}
+
+int hj_launch_broadcast_meta(const uint32_t *inner_keys, size_t inner, size_t outer, uint32_t nslices,
+                             uint32_t groups, const BroadcastMeta &m, hipStream_t stream)
+{
+    if (inner == 0 || inner > 16383 || nslices == 0 || groups == 0) return HJGPU_EINVAL;
+    hipLaunchKernelGGL(broadcast_meta_kernel, dim3(1), dim3(1024), 0, stream, inner_keys, (u64)inner, (u64)outer,
+                       nslices, groups, m);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
 const JoinConfig &hj_join_config()
 {
     static JoinConfig cfg;
@@ -427,7 +475,7 @@ int hj_join_workers(int cus, bool big_tables)
 
 int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream)
 {
-    if (a.P < 2 || a.chunks == 0) return HJGPU_EINVAL;
+    if ((a.P < 2 && !a.broadcast) || a.P < 1 || a.chunks == 0) return HJGPU_EINVAL;
     const JoinConfig &c = a.big_tables ? hj_join_config_big() : hj_join_config();
     const char *ex = getenv("HJGPU_FORCE_CHAINED");     // tests: exercise the fallback table everywhere
     JoinArgs b = a;

@@ -37,7 +37,11 @@ def _relations(rng, case):
     else:
         ok = base[rng.integers(0, len(base), size=outer)]
     miss = rng.random(outer) > case["selectivity"]
-    ok = np.where(miss, rng.integers(1, 2**32, size=outer, dtype=np.uint64).astype(np.uint32), ok)
+    # keys that match nothing: random ones, and small integers (the values a broadcast join picks its empty
+    # sentinel from: a probe key equal to the sentinel must not match empty slots)
+    strangers = np.where(rng.random(outer) < 0.5, rng.integers(1, 2**32, size=outer, dtype=np.uint64),
+                         rng.integers(0 if case["key_zero"] else 1, 64, size=outer, dtype=np.uint64)).astype(np.uint32)
+    ok = np.where(miss, strangers, ok)
     iv = rng.integers(0, 2**32, size=inner, dtype=np.uint64).astype(np.uint32)
     ov = rng.integers(0, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)
     return ik, iv, ok.astype(np.uint32), ov

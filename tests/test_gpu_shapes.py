@@ -1,11 +1,13 @@
 """GPU tests of workload shapes away from the benchmark's: tiny build side against
 a large probe side (slices), build side larger than probe side, heavy skew
 (multi-fill overflow + chained fallback), selectivity 0, many duplicates on both sides."""
+import os
+
 import numpy as np
 import pytest
 
 import hash_join_codes_knl_amd as H
-from helpers import numpy_join
+from helpers import numpy_join, materialised_rows, sort_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -170,4 +172,46 @@ def test_one_build_key_with_a_million_copies(hj):
     assert hj.phj(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(fanout1=3, fanout2=2)) == want
     assert hj.cpra(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(chunks=5)) == want
     for c in (rk, rv, sk, sv):
+        c.free()
+
+
+@pytest.mark.parametrize("inner", [1, 17, 4095, 4096, 4097])
+def test_broadcast_join_of_a_build_side_that_fits_one_table(hj, inner):
+    """Build sides of at most one LDS table (4096 rows) take the broadcast path: nothing is partitioned, every
+    slice of the caller's probe columns builds the table and probes.  Around the threshold, with duplicates,
+    key 0, misses, probe columns that start inside an allocation, rows materialised; HJGPU_NO_BROADCAST=1
+    (the partitioned plan) must agree."""
+    rng = np.random.default_rng(1000 + inner)
+    base = np.unique(np.concatenate([[0], rng.integers(0, 2**32, size=max(1, inner // 2), dtype=np.uint64)]).astype(np.uint32))
+    ik = base[rng.integers(0, len(base), size=inner)]
+    iv = rng.integers(0, 2**32, size=inner, dtype=np.uint64).astype(np.uint32)
+    outer = 1_300_003
+    ok = np.where(rng.random(outer) < 0.6, base[rng.integers(0, len(base), size=outer)],
+                  rng.integers(0, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)).astype(np.uint32)
+    ov = rng.integers(0, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)
+    rk, rv = hj.column(ik), hj.column(iv)
+    pad = 4                                             # probe columns start 16 bytes into their allocations
+    sk_all, sv_all = hj.column(np.concatenate([np.zeros(pad, np.uint32), ok])), hj.column(np.concatenate([np.zeros(pad, np.uint32), ov]))
+    sk, sv = sk_all.ptr + 4 * pad, sv_all.ptr + 4 * pad
+    want = numpy_join(ik, iv, ok, ov)
+    assert hj.phj(rk, rv, inner, sk, sv, outer) == want
+    st = hj.stats()
+    assert ((st["fanout1"], st["fanout2"]) == (1, 1)) == (inner <= 4096)
+    os.environ["HJGPU_NO_BROADCAST"] = "1"
+    try:
+        assert hj.phj(rk, rv, inner, sk, sv, outer) == want
+        assert hj.stats()["fanout1"] >= 2
+    finally:
+        del os.environ["HJGPU_NO_BROADCAST"]
+    if want[0] <= 20_000_000:
+        block = 1024
+        cap = (want[0] // block + hj.device_info()["compute_units"] * 16 + 8) * block
+        jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+        assert hj.phj(rk, rv, inner, sk, sv, outer, out=(jk, jo, ji, cap, block)) == want
+        rows = sort_rows(jk.download()[:want[0]], jo.download()[:want[0]], ji.download()[:want[0]])
+        for a, b in zip(rows, materialised_rows(ik, iv, ok, ov)):
+            assert np.array_equal(a, b)
+        for c in (jk, jo, ji):
+            c.free()
+    for c in (rk, rv, sk_all, sv_all):
         c.free()
