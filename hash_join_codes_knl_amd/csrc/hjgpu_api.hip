@@ -961,12 +961,19 @@ int hjgpu_npj(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inn
 // 1000 x 100 M: 0.76 -> 0.25 ms.  Two fills (8000 rows: every table filled to exactly half, where cuckoo hashing
 // gives up and the chained fallback takes over, and the probe side read twice) measured 7.1 ms against 5.5 ms
 // for the partitioned plan: one fill only.
+// Largest build side of a broadcast join: one fill of the 8 K-slot table, or - up to a load of 0.42, where
+// cuckoo insertion still converges quickly - one fill of the 16 K-slot table (one 1024-thread workgroup per CU).
+static size_t broadcast_rows(bool big_tables)
+{
+    return big_tables ? (size_t)(hj_join_config_big().cap() * 0.85) : (size_t)hj_join_config().cap();
+}
+
 static bool broadcast_applies(size_t inner, size_t outer, uint32_t chunks, const hjgpu_phj_params *prm)
 {
     const char *off = getenv("HJGPU_NO_BROADCAST");
     if (off && atoi(off)) return false;
     if (chunks != 1 || (prm && (prm->fanout1 || prm->fanout2))) return false;    // an explicit plan is honoured
-    return inner && outer && inner <= (size_t)hj_join_config().cap() && inner <= 16383;
+    return inner && outer && inner <= broadcast_rows(true) && inner <= 16383;
 }
 
 static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
@@ -979,7 +986,8 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     const uint32_t tf0 = (prm && prm->table_factor[0]) ? prm->table_factor[0] : DEFAULT_TF0;
     const uint32_t tf1 = (prm && prm->table_factor[1]) ? prm->table_factor[1] : DEFAULT_TF1;
     if (!(tf0 & 1) || !(tf1 & 1)) return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
-    const size_t cap = (size_t)hj_join_config().cap();
+    const bool big = inner > broadcast_rows(false);
+    const size_t cap = (size_t)(big ? hj_join_config_big() : hj_join_config()).cap();
     const size_t nslices = (outer + HJ_JOIN_SLICE - 1) / HJ_JOIN_SLICE;
     const size_t fills = (inner + cap - 1) / cap;
     const size_t groups = fills < (size_t)HJ_JOIN_FILL_GROUPS ? fills : (size_t)HJ_JOIN_FILL_GROUPS;
@@ -995,7 +1003,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     uint32_t *item_part = reinterpret_cast<uint32_t *>(d + 16);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus, false), &bs, &bl));
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus, big), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
@@ -1014,7 +1022,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     ja.P = 1; ja.chunks = 1; ja.f1 = ja.f2 = 1; ja.F1 = ja.F2 = 1;
     ja.tf0 = tf0; ja.tf1 = tf1;
     ja.s_align = align_of(sk); ja.packed = 0;
-    ja.broadcast = 1; ja.sentinel = bm.sentinel;
+    ja.broadcast = 1; ja.sentinel = bm.sentinel; ja.big_tables = big ? 1u : 0u;
     ja.result = &st->result; ja.work_counter = &st->work_counter;
     if (bs) {
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
@@ -1025,7 +1033,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     record(ctx, EV_JOIN, stream);
     if (bs)
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
-                                    (const u64 *)ctx->final_offsets.p, (uint32_t)hj_join_workers(ctx->cus, false), bs,
+                                    (const u64 *)ctx->final_offsets.p, (uint32_t)hj_join_workers(ctx->cus, big), bs,
                                     &st->block_counter, &st->overflow, ctx->moves.p, &st->nmoves, &st->dense,
                                     ctx->cus, stream));
     record(ctx, EV_GAPS, stream);

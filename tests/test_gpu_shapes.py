@@ -175,10 +175,11 @@ def test_one_build_key_with_a_million_copies(hj):
         c.free()
 
 
-@pytest.mark.parametrize("inner", [1, 17, 4095, 4096, 4097])
+@pytest.mark.parametrize("inner", [1, 17, 4095, 4096, 4097, 6963, 6964])
 def test_broadcast_join_of_a_build_side_that_fits_one_table(hj, inner):
-    """Build sides of at most one LDS table (4096 rows) take the broadcast path: nothing is partitioned, every
-    slice of the caller's probe columns builds the table and probes.  Around the threshold, with duplicates,
+    """Build sides of at most one LDS table (4096 rows in the 8 K-slot table, 6963 in the 16 K-slot one) take the
+    broadcast path: nothing is partitioned, every slice of the caller's probe columns builds the table and
+    probes.  Around the thresholds, with duplicates,
     key 0, misses, probe columns that start inside an allocation, rows materialised; HJGPU_NO_BROADCAST=1
     (the partitioned plan) must agree."""
     rng = np.random.default_rng(1000 + inner)
@@ -196,7 +197,7 @@ def test_broadcast_join_of_a_build_side_that_fits_one_table(hj, inner):
     want = numpy_join(ik, iv, ok, ov)
     assert hj.phj(rk, rv, inner, sk, sv, outer) == want
     st = hj.stats()
-    assert ((st["fanout1"], st["fanout2"]) == (1, 1)) == (inner <= 4096)
+    assert ((st["fanout1"], st["fanout2"]) == (1, 1)) == (inner <= 6963)
     os.environ["HJGPU_NO_BROADCAST"] = "1"
     try:
         assert hj.phj(rk, rv, inner, sk, sv, outer) == want
