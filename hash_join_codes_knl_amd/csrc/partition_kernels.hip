@@ -405,9 +405,10 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
     // tiles of 2 * PLAN_BLOCK partitions, thread t takes partitions tile + 2t and tile + 2t + 1 (see plan_scan2)
     __shared__ u64 scratch2[4 * (PLAN_BLOCK / 64)];
     auto rows_of = [&](const u64 *__restrict__ cnt, uint32_t q) -> u64 {
-        u64 n = cnt[q];
-        for (uint32_t c = 1; c < C; ++c) n += cnt[(u64)c * P + q];
-        return n;
+        u64 v[8];                                   // chunks <= 8: all loads are requested before the first add
+#pragma unroll
+        for (uint32_t c = 0; c < 8; ++c) v[c] = c < C ? cnt[(u64)c * P + q] : 0;
+        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     };
     u64 run = 0;
     int parity = 0;
