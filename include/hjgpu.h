@@ -263,8 +263,10 @@ int  hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm /* 0 npj, 1 phj, 2 cpra 
                           const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats);
 
 /* ---- data generator (write.cpp / generate_data_for_join, cpra2.cpp:1578-1696):
- * statistical contract only — unique non-zero build keys, probe keys drawn from
- * them (every build key at least once when outer >= inner), payload = key*factor,
+ * statistical contract only — non-zero build keys, unique when outer_total >= inner_total
+ * (write.cpp's semantics otherwise: min(inner, outer) distinct keys, the build side repeats
+ * them — BASELINE configs[0], 1 M probe x 16 M build, has 16 copies per key), probe keys drawn
+ * from them (every build key at least once when outer >= inner), payload = key*factor,
  * both sides in pseudo-random order; counter-based, so any shard
  * [outer_begin, outer_begin+outer_count) of the probe side can be produced
  * independently on its own GPU. */
