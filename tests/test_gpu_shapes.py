@@ -216,3 +216,32 @@ def test_broadcast_join_of_a_build_side_that_fits_one_table(hj, inner):
             c.free()
     for c in (rk, rv, sk_all, sv_all):
         c.free()
+
+
+@pytest.mark.parametrize("algorithm", ["phj", "cpra"])
+def test_oversize_build_partition_materialised(hj, algorithm):
+    """A build key with 30 000 copies (seven table fills, dealt to several work items as fill groups) probed by
+    200 copies: the 6 M rows of that key and all others are materialised and compared row by row."""
+    rng = np.random.default_rng(4321)
+    u = np.unique(rng.integers(1, 2**32, size=60_000, dtype=np.uint64).astype(np.uint32))
+    hot = u[77]
+    ik = np.concatenate([u, np.full(30_000, hot, np.uint32)])
+    rng.shuffle(ik)
+    iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+    ok = np.concatenate([u[rng.integers(0, len(u), size=150_000)], np.full(200, hot, np.uint32)])
+    rng.shuffle(ok)
+    ov = rng.integers(0, 2**32, size=len(ok), dtype=np.uint64).astype(np.uint32)
+    want = numpy_join(ik, iv, ok, ov)
+    assert want[0] > 6_000_000
+    rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+    block = 4096
+    cap = (want[0] // block + hj.device_info()["compute_units"] * 16 + 8) * block
+    jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+    fn = hj.phj if algorithm == "phj" else hj.cpra
+    prm = None if algorithm == "phj" else H.PhjParams(chunks=3)
+    assert fn(rk, rv, len(ik), sk, sv, len(ok), prm, out=(jk, jo, ji, cap, block)) == want
+    rows = sort_rows(jk.download()[:want[0]], jo.download()[:want[0]], ji.download()[:want[0]])
+    for a, b in zip(rows, materialised_rows(ik, iv, ok, ov)):
+        assert np.array_equal(a, b)
+    for c in (rk, rv, sk, sv, jk, jo, ji):
+        c.free()
