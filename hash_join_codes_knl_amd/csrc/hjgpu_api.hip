@@ -446,7 +446,8 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.roff = m.off2[0]; ja.soff = m.off2[1];
         ja.rend = m.end2[0]; ja.send = m.end2[1];
         ja.slice_prefix = m.slice_prefix; ja.slices = m.slices; ja.item_part = m.item_part;
-        ja.P = pl.P; ja.chunks = pl.C;
+        // line-aligned two-pass layout: the chunks' pass-2 tiles wrote every final partition as ONE region
+        ja.P = pl.P; ja.chunks = pad2 ? 1u : pl.C;
         ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2;
         ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
         ja.s_align = 0;

@@ -335,28 +335,41 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
         // Two passes: the pass-1 output (= pass-2 input) stays dense, the FINAL layout starts every
         // partition on a 128-byte line (K6 pass 2 then claims whole lines from the front of a partition
         // and the few leftover tuples of a tile from its back).
+        // The pass-1 layout is per chunk (every chunk is partitioned on its own, cpra2.cpp:1757-1827); the FINAL
+        // layout is shared by all chunks: partition q is ONE line-aligned region sized for the sum of the chunks'
+        // counts, and the pass-2 tiles of every chunk claim lines (front) and tail slots (back) from the same
+        // cursor.  The reference reaches the same state with its memcpy gather (cpra2.cpp:1891-1959); here the
+        // join then sees one piece per partition, exactly as after PHJ's passes.  Block 0 lays the final
+        // partitions out (entries [0, P) of off2 / end2 / cur2), every block its own chunk's pass-1 partitions.
         __shared__ u64 scratch2[4 * (PLAN_BLOCK / 64)];
         auto padded = [](u64 n) { return (n + HJ_LINE_TUPLES - 1) & ~(u64)(HJ_LINE_TUPLES - 1); };
         u64 drun = base;                                              // dense offset of the tile's first partition
-        u64 prun = base + (u64)c * HJ_LINE_TUPLES * P;                // padded one: room for every partition's padding
+        u64 prun = 0;                                                 // padded one (block 0; the relation starts at row 0)
         const uint32_t F2 = a.F2;
+        const u64 *__restrict__ all = a.counts[r];
+        u64 *fo = a.off2[r], *fe = a.end2[r], *fc = a.cur2[r];
+        auto total_of = [&](uint32_t q) -> u64 {
+            u64 v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) v[k] = k < C ? all[(u64)k * P + q] : 0;
+            return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        };
         int parity = 0;
         for (uint32_t tile = 0; tile < P; tile += 2 * PLAN_BLOCK, parity ^= 1) {
             const uint32_t q0 = tile + 2 * threadIdx.x, q1 = q0 + 1;
             const u64 n0 = q0 < P ? cnt[q0] : 0, n1 = q1 < P ? cnt[q1] : 0;
-            u64 d = n0 + n1, pd = padded(n0) + padded(n1), dt, pt;
+            const u64 t0 = (c == 0 && q0 < P) ? total_of(q0) : 0, t1 = (c == 0 && q1 < P) ? total_of(q1) : 0;
+            u64 d = n0 + n1, pd = padded(t0) + padded(t1), dt, pt;
             plan_scan2(d, pd, dt, pt, scratch2, parity);
             d += drun; pd += prun;
             if (q0 < P) {
                 if (q0 % F2 == 0) { a.off1[r][(u64)c * a.F1 + q0 / F2] = d; a.cur1[r][(u64)c * a.F1 + q0 / F2] = d; }
-                off2[q0] = pd; end2[q0] = pd + n0;
-                a.cur2[r][(u64)c * P + q0] = 0;                       // lines claimed | tail tuples << 32
+                if (c == 0) { fo[q0] = pd; fe[q0] = pd + t0; fc[q0] = 0; }      // cursor: lines claimed | tail tuples << 32
             }
             if (q1 < P) {
-                const u64 d1 = d + n0, p1 = pd + padded(n0);
+                const u64 d1 = d + n0, p1 = pd + padded(t0);
                 if (q1 % F2 == 0) { a.off1[r][(u64)c * a.F1 + q1 / F2] = d1; a.cur1[r][(u64)c * a.F1 + q1 / F2] = d1; }
-                off2[q1] = p1; end2[q1] = p1 + n1;
-                a.cur2[r][(u64)c * P + q1] = 0;
+                if (c == 0) { fo[q1] = p1; fe[q1] = p1 + t1; fc[q1] = 0; }
             }
             drun += dt; prun += pt;
         }
@@ -407,7 +420,9 @@ __global__ __launch_bounds__(PLAN_BLOCK) void tile_desc_kernel(PlanArgs a)
         for (u64 t = t0 + (threadIdx.x & 63); t < t1; t += 64) {
             const u64 g0 = (gb & ~3ull) + (t - t0) * tile2;
             td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
-            td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), sgm * a.F2, sgm);
+            // third word: first entry of the segment's final partitions in the cursor / offset tables - shared by
+            // all chunks in the line-aligned layout, per (chunk, pass-1 partition) in the dense one
+            td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), (a.pad2 ? sgm % a.F1 : sgm) * a.F2, sgm);
         }
     }
 }
