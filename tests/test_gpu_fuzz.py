@@ -58,7 +58,9 @@ def _cases():
                         outer_max=int(rng.choice([500, 200_000, 3_000_000])),
                         dups=int(rng.choice([1, 1, 2, 3, 40])), zipf=float(rng.choice([0, 0, 1.1, 2.0])),
                         selectivity=float(rng.choice([1.0, 0.5, 0.0])), key_zero=bool(rng.integers(2)),
-                        chunks=int(rng.integers(1, 9))))
+                        chunks=int(rng.integers(1, 9)),
+                        # every sixth case: the dense final layout (HJGPU_DENSE2), per-chunk pieces in CPRA's join
+                        dense2=bool(rng.integers(6) == 0)))
     return out
 
 
@@ -68,6 +70,8 @@ def test_random_join_matches_numpy(hj, case):
     ik, iv, ok, ov = _relations(rng, case)
     want = numpy_join(ik, iv, ok, ov)
     rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+    if case["dense2"]:
+        os.environ["HJGPU_DENSE2"] = "1"
     try:
         prm = H.PhjParams(fanout1=case["f1"], fanout2=case["f2"], chunks=case["chunks"])
         assert hj.phj(rk, rv, len(ik), sk, sv, len(ok), prm) == want
@@ -93,5 +97,6 @@ def test_random_join_matches_numpy(hj, case):
             for c in (jk, jo, ji):
                 c.free()
     finally:
+        os.environ.pop("HJGPU_DENSE2", None)
         for c in (rk, rv, sk, sv):
             c.free()
