@@ -1,0 +1,50 @@
+"""CPU tests of bench.py's host-side logic (no GPU): argument defaults of the contract, the CPU allowance
+the CPU baseline uses, and that a GPU-less run fails loudly instead of falling back to anything."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_usable_cpus_respects_affinity_and_quota(tmp_path, monkeypatch):
+    import bench
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert n <= len(os.sched_getaffinity(0))
+    # a cgroup quota of 2.5 CPUs caps an 8-CPU affinity mask at 3 threads; "max" leaves it alone
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return real_open(tmp_path / "cpu.max", *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(8)))
+    monkeypatch.setattr("builtins.open", fake_open)
+    (tmp_path / "cpu.max").write_text("250000 100000\n")
+    assert bench.usable_cpus() == 3
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.usable_cpus() == 8
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert bench.usable_cpus() == 8
+
+
+def test_bench_defaults_follow_the_contract():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag, default in (("--gpus", "default=1"), ("--steps", "default=10"), ("--warmup", "default=2"),
+                          ("--inner", "default=64_000_000"), ("--outer", "default=1_000_000_000")):
+        line = [l for l in src.splitlines() if 'add_argument("%s"' % flag in l]
+        assert line and default in line[0], (flag, line)
+
+
+def test_bench_without_a_gpu_fails_loudly():
+    """No CPU fallback: on a box without a GPU the bench must exit non-zero, not print a number."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--cpu-outer", "0",
+                        "--inner", "1000", "--outer", "10000"], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{") and '"value"' in l]
