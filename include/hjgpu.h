@@ -21,6 +21,11 @@
  *     (npj.cpp:200-201, phj.cpp:83-100, 721-722); factors must be odd.
  *   - Join result = order-free aggregates over the three output columns
  *     join_keys / join_outer_vals / join_inner_vals.
+ *   - A context owns one workspace: calls on the SAME context must not overlap in
+ *     time from several host threads, and joins enqueued on different streams through
+ *     one context would share that workspace - use one context per stream / thread
+ *     (contexts are cheap; several may live on one device).  Joins enqueued on ONE
+ *     stream may be queued back to back without host synchronisation.
  */
 #ifndef HJGPU_H
 #define HJGPU_H
