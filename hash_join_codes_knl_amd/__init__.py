@@ -6,8 +6,8 @@ package holds its sources (csrc/), the C++ hosts that keep the reference's
 ctypes binding used by tests and bench.py.  No CPU fallback exists anywhere.
 """
 from .api import (HjGpu, HjGpuError, DeviceColumn, NpjParams, PhjParams, Output, Result, Stats,
-                  load_library, EXPORTS)
+                  load_library, EXPORTS, FLAG_UNIQUE)
 from . import build
 
 __all__ = ["HjGpu", "HjGpuError", "DeviceColumn", "NpjParams", "PhjParams", "Output", "Result",
-           "Stats", "load_library", "EXPORTS", "build"]
+           "Stats", "load_library", "EXPORTS", "FLAG_UNIQUE", "build"]

@@ -16,10 +16,11 @@ from . import build as _build
 OK, EINVAL, EALIGN, ENOMEM, EHIP, EZEROKEY, EOVERFLOW, ENODEVICE = range(8)
 MAX_FANOUT = 1024
 MAX_PARTS = 32768
+FLAG_UNIQUE = 1
 
 EXPORTS = [
     "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
-    "hjgpu_get_device_info", "hjgpu_reserve", "hjgpu_get_stats",
+    "hjgpu_get_device_info", "hjgpu_set_option", "hjgpu_reserve", "hjgpu_get_stats",
     "hjgpu_malloc", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
     "hjgpu_host_alloc", "hjgpu_host_free",
     "hjgpu_histogram", "hjgpu_partition", "hjgpu_join_partitions",
@@ -53,11 +54,11 @@ class PhjParams(C.Structure):
     _fields_ = [("fanout1", C.c_uint32), ("fanout2", C.c_uint32),
                 ("factor1", C.c_uint32), ("factor2", C.c_uint32),
                 ("table_factor", C.c_uint32 * 2),
-                ("chunks", C.c_uint32), ("reserved", C.c_uint32)]
+                ("chunks", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class NpjParams(C.Structure):
-    _fields_ = [("load", C.c_double), ("factor", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("load", C.c_double), ("factor", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -117,6 +118,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_status_string.restype = C.c_char_p
     L.hjgpu_status_string.argtypes = [C.c_int]
     L.hjgpu_get_device_info.argtypes = [vp, C.POINTER(DeviceInfo)]
+    L.hjgpu_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.hjgpu_reserve.argtypes = [vp, sz, sz]
     L.hjgpu_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.hjgpu_malloc.argtypes = [vp, C.POINTER(vp), sz]
@@ -233,6 +235,12 @@ class HjGpu:
         return {"name": info.name.decode(), "arch": info.arch.decode(),
                 "compute_units": info.compute_units,
                 "lds_bytes_per_block": info.lds_bytes_per_block, "hbm_bytes": info.hbm_bytes}
+
+    def set_option(self, name, value):
+        """hjgpu_set_option: tuning / test switch of this context ("unique", "force_chained", "dense2", ...)."""
+        if isinstance(value, bool):
+            value = int(value)
+        self._check(self.lib.hjgpu_set_option(self.handle, name.encode(), str(value).encode()))
 
     def reserve(self, inner, outer):
         self._check(self.lib.hjgpu_reserve(self.handle, inner, outer))

@@ -15,8 +15,9 @@ constexpr uint32_t HJ_LINE_TUPLES = 16;          // packed (8-byte) tuples per 1
 constexpr uint32_t HJ_STREAM_UNIT = 256;         // output slots one 16-lane group streams out at a time
 constexpr uint32_t HJ_MAX_HEAVY = 128;           // listed units per tile: <= (16384 + 30 * 209) / HJ_STREAM_UNIT (carry + line offsets)
 struct ScatterConfig { int block, vpt; bool carry; };
-ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed);
-int hj_scatter_tile(int pass, uint32_t F, bool out_packed);
+struct HjTuning;
+ScatterConfig hj_scatter_config(const HjTuning &t, int pass, uint32_t F, bool out_packed);
+int hj_scatter_tile(const HjTuning &t, int pass, uint32_t F, bool out_packed);
 constexpr int HJ_JOIN_SLICE    = 1 << 16;       // probe tuples per work item (target)
 // A build partition larger than one LDS table is joined in several table fills; the fills of such a
 // partition are dealt to up to this many work items per probe slice (a heavy build key otherwise leaves
@@ -29,17 +30,41 @@ inline size_t hj_join_items_capacity(size_t partitions, size_t outer_rows)
 }
 
 // Join-kernel geometry: threads per workgroup, log2 of the LDS table slots, and
-// probe vectors each lane keeps in flight.  Default 512 / 8192 slots (64 KiB) / 4;
-// HJGPU_JOIN_CFG="block,log2slots,batch" selects another built variant (tuning).
+// probe vectors each lane keeps in flight.  Default 512 / 8192 slots (64 KiB) / 2;
+// the "join_cfg" option ("block,log2slots,batch") selects another built variant (tuning).
 struct JoinConfig {
     int block, log2slots, batch;
     int slots() const { return 1 << log2slots; }
     int cap() const { return slots() / 2; }      // max build tuples per table fill (load <= 0.5)
 };
-const JoinConfig &hj_join_config();
 // 16 K-slot tables (128 KiB of LDS, one 1024-thread workgroup per CU): half the partitions for the same build
 // side.  Chosen when the 8 K-slot tables would need more than HJGPU_MAX_PARTS partitions (|R| > ~114 M).
 const JoinConfig &hj_join_config_big();
+
+// Tuning / test switches of ONE context.  They are read from the environment once, in hjgpu_create
+// (HJGPU_<NAME>), and can be set per context with hjgpu_set_option; nothing on a launch path looks at
+// the environment or at mutable process-wide state, so contexts on different host threads (and on
+// different devices) do not share anything.
+struct HjTuning {
+    int range_tiles = 0;            // "range_tiles": tiles per pass-1 range (0 = planned)
+    bool dense2 = false;            // "dense2": dense final layout instead of line-aligned partitions
+    bool npj_refhash = false;       // "npj_refhash": whole-join NPJ with the reference's bucket hash
+    bool no_broadcast = false;      // "no_broadcast": no broadcast join for tiny build sides
+    bool force_chained = false;     // "force_chained": chained fallback tables everywhere (tests)
+    bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
+    bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
+    JoinConfig join = {512, 13, 2}; // "join_cfg"
+    int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned
+};
+void hj_tuning_from_env(HjTuning *t);
+// returns false for an unknown name or a malformed value
+bool hj_tuning_set(HjTuning *t, const char *name, const char *value);
+inline const JoinConfig &hj_join_config_of(const HjTuning &t, bool big_tables) { return big_tables ? hj_join_config_big() : t.join; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: one flag per
+// (kernel instance, device), so a process that drives several GPUs opts in on each of them.
+struct HjPerDeviceOnce { unsigned char done[64]; };
+int hj_allow_dynamic_lds(const void *kernel, int bytes, HjPerDeviceOnce *once);
 
 // Geometry of partitioning pass 1, known on the host (sizes + alignment only):
 // each chunk (segment) is cut into `ranges_per_chunk` contiguous ranges of whole
@@ -110,7 +135,8 @@ struct JoinArgs {
     // empty sentinel is *sentinel (a value no build key equals, found by hj_launch_broadcast_meta)
     uint32_t broadcast;
     const uint32_t *sentinel;
-    uint32_t force_chained;              // tests: skip the cuckoo fast path (HJGPU_FORCE_CHAINED=1)
+    uint32_t force_chained;              // tests: skip the cuckoo fast path (option "force_chained")
+    uint32_t unique;                     // _UNIQUE (npj.cpp:288-290): a probe key reports its first match only
 };
 
 struct PlanArgs {
@@ -137,6 +163,7 @@ struct PlanArgs {
     uint32_t slice;
     uint32_t cap;             // build rows per LDS table fill of the join kernel that will run (JoinConfig::cap)
     uint32_t mask;            // bit 0: plan R, bit 1: plan S, bit 2: join work items
+    uint32_t unique;          // _UNIQUE joins: all table fills of a probe slice stay with ONE work item (see join_kernel)
 };
 
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
@@ -146,8 +173,8 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
 int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
                          uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream);
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream);
-int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream);
-int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream);
+int hj_launch_scatter(const ScatterArgs &a, const HjTuning &t, int cus, hipStream_t stream);
+int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t stream);
 int hj_launch_exscan(const u64 *in, u64 *out, uint32_t n, hipStream_t stream);
 int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStream_t stream);
 
@@ -162,6 +189,7 @@ struct NpjProbeArgs {
     size_t buckets;
     uint32_t factor;
     uint32_t line_hash;                  // 1: walks start on 64-byte lines (the library's own tables)
+    uint32_t unique;                     // _UNIQUE (npj.cpp:288-290): the walk ends at the key's first match
     hjgpu_result *result;
     uint32_t *ok, *oov, *oiv;
     u64 block_size, block_limit;
@@ -178,8 +206,7 @@ int hj_launch_close_gaps_ex(uint32_t *k, uint32_t *ov, uint32_t *iv, const u64 *
                             uint32_t nworkers, u64 block_size, const u64 *block_counter,
                             const uint32_t *overflow, void *moves, uint32_t *nmoves,
                             u64 *dense_count, int cus, hipStream_t stream);
-int hj_join_grid(int cus);
-int hj_join_workers(int cus, bool big_tables = false);
+int hj_join_workers(const HjTuning &t, int cus, bool big_tables = false);
 // Metadata of a broadcast join, written on the device: one partition holding all of R ([0, inner)) and all of S
 // ([0, outer)), `nslices` probe slices x `groups` fill groups (item_part must be zeroed by the caller), and a
 // sentinel: a value whose low 14 bits no build key shares (inner <= 16383).

@@ -59,6 +59,7 @@ struct hjgpu_ctx {
     bool prepared = false;
     size_t prepared_inner = 0, prepared_max_outer = 0;
     unsigned char prepared_plan[96];
+    HjTuning tune;          // tuning / test switches: environment at hjgpu_create, hjgpu_set_option afterwards
 };
 
 namespace {
@@ -157,12 +158,12 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
 // table and derives 1-4 passes of equal fan-out (phj.cpp:1791-1808); here the
 // partition size comes from the LDS table (HJ_JOIN_CAP tuples at load 0.5) and
 // two passes of ~sqrt(P) reach every |R| the 32768-partition cap allows.
-void choose_fanout(size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint32_t *F2, bool *big_tables)
+void choose_fanout(const HjTuning &tune, size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint32_t *F2, bool *big_tables)
 {
     uint32_t f1 = prm ? prm->fanout1 : 0, f2 = prm ? prm->fanout2 : 0;
     *big_tables = false;
     if (f1 == 0) {
-        double target = hj_join_config().cap() * 0.85;   // mean fill; Poisson tail stays below CAP
+        double target = tune.join.cap() * 0.85;   // mean fill; Poisson tail stays below CAP
         double parts = ceil((double)inner / target);
         // more partitions than K4's LDS histogram holds: 16 K-slot tables, half as many partitions
         // (|R| = 128 M x |S| = 2.2 G, join phase 5.2 -> 4.3 ms: no table is filled twice)
@@ -238,11 +239,10 @@ int setup_output(hjgpu_ctx *ctx, const hjgpu_output *out, uint32_t workers, u64 
 // Tiles per range (a range = the unit that owns private pass-1 write cursors).
 // Measured at |S| = 1G, F1 = 136: 1..32 tiles per range all land within run-to-run
 // noise for K6, while K4/K5b grow from 1.03+0.08 ms to 1.28+0.41 ms at 1 tile per
-// range.  HJGPU_RANGE_TILES overrides (tuning).
-uint32_t range_tiles_for(u64 max_tiles, uint32_t F1)
+// range.  Option "range_tiles" overrides (tuning).
+uint32_t range_tiles_for(const HjTuning &tune, u64 max_tiles, uint32_t F1)
 {
-    const char *e = getenv("HJGPU_RANGE_TILES");
-    const int forced = e ? atoi(e) : 0;
+    const int forced = tune.range_tiles;
     // default: ~4096 ranges per relation - fine-grained enough that concurrently running
     // workgroups write neighbouring regions, coarse enough that K4/K5b stay negligible
     u64 k = forced > 0 ? (u64)forced : (max_tiles + 4095) / 4096;
@@ -254,7 +254,27 @@ uint32_t range_tiles_for(u64 max_tiles, uint32_t F1)
     return (uint32_t)k;
 }
 
-Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1, bool out_packed)
+uint32_t ranges_of(const HjTuning &tune, u64 max_tiles, uint32_t F1)
+{
+    const uint32_t k = range_tiles_for(tune, max_tiles, F1);
+    return (uint32_t)((max_tiles + k - 1) / k);
+}
+
+// Largest ranges_of() over every tile count <= max_tiles.  The tiles per range jump at multiples of 512 and of
+// 4096 tiles (range_tiles_for), so a SMALLER relation can have MORE ranges than a larger one (733 ranges at
+// 12 M tuples, 550 at 18 M): the per-range tables of a prepared build side (hjgpu_phj_build) are sized for any
+// batch up to max_outer, not for max_outer itself.  Between two jumps the count grows with the tiles, so the
+// maximum sits at max_tiles or right before / at a jump.
+uint32_t ranges_capacity(const HjTuning &tune, u64 max_tiles, uint32_t F1)
+{
+    uint32_t best = ranges_of(tune, max_tiles, F1);
+    for (u64 t = 512; t - 1 <= max_tiles && t <= 8192; t += 512) best = std::max(best, ranges_of(tune, t - 1, F1));
+    for (u64 t = 4096; t <= max_tiles; t += 4096) best = std::max(best, ranges_of(tune, t, F1));
+    return best;
+}
+
+Pass1Geom make_geom(const HjTuning &tune, const void *keys, size_t n, uint32_t C, uint32_t F1, bool out_packed,
+                    bool capacity = false)
 {
     // chunk ranges = thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
     Pass1Geom g;
@@ -263,14 +283,14 @@ Pass1Geom make_geom(const void *keys, size_t n, uint32_t C, uint32_t F1, bool ou
     for (uint32_t c = C; c < 9; ++c) g.b[c] = n;
     g.chunks = C;
     g.align = align_of(keys);
-    g.tile = (uint32_t)hj_scatter_tile(1, F1, out_packed);
+    g.tile = (uint32_t)hj_scatter_tile(tune, 1, F1, out_packed);
     u64 max_tiles = 1;
     for (uint32_t c = 0; c < C; ++c) {
-        const u64 t = hj_tiles_of(g.b[c], g.b[c + 1], g.align, g.tile);
+        // sizing (keys == nullptr): any alignment of the column may follow, one more tile per chunk
+        const u64 t = hj_tiles_of(g.b[c], g.b[c + 1], g.align, g.tile) + (keys ? 0 : 1);
         if (t > max_tiles) max_tiles = t;
     }
-    const uint32_t k = range_tiles_for(max_tiles, F1);
-    g.ranges_per_chunk = (uint32_t)((max_tiles + k - 1) / k);
+    g.ranges_per_chunk = capacity ? ranges_capacity(tune, max_tiles, F1) : ranges_of(tune, max_tiles, F1);
     return g;
 }
 
@@ -282,6 +302,7 @@ struct PhjPlan {
     uint32_t C, F1, F2, P;
     uint32_t f1, f2, tf0, tf1;
     bool big_tables;
+    bool unique;             // HJGPU_FLAG_UNIQUE / option "unique"
 };
 static_assert(sizeof(PhjPlan) <= sizeof(hjgpu_ctx::prepared_plan), "prepared_plan too small");
 enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
@@ -291,7 +312,8 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
 {
     ctx->prepared = false;               // the workspace is about to be re-planned (hjgpu_phj_build sets it again)
     pl->C = chunks;
-    choose_fanout(inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
+    pl->unique = ctx->tune.unique || (prm && (prm->flags & HJGPU_FLAG_UNIQUE));
+    choose_fanout(ctx->tune, inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
     pl->P = pl->F1 * pl->F2;
     if (pl->F1 < 1 || pl->F2 < 1 || pl->F1 > HJGPU_MAX_FANOUT || pl->F2 > HJGPU_MAX_FANOUT ||
         pl->P < 2 || pl->P > HJGPU_MAX_PARTS)
@@ -315,12 +337,13 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
         CHK(ensure(ctx, ctx->tmp[6], sb + pad));
     }
     // ranges of the larger relation bound the per-range tables of both
-    const Pass1Geom gr = make_geom(nullptr, inner, pl->C, pl->F1, true), gs = make_geom(nullptr, outer, pl->C, pl->F1, true);
+    // (sized for every relation up to these sizes: a batch of a prepared build side may be smaller than max_outer)
+    const Pass1Geom gr = make_geom(ctx->tune, nullptr, inner, pl->C, pl->F1, true, true), gs = make_geom(ctx->tune, nullptr, outer, pl->C, pl->F1, true, true);
     pl->ranges = (size_t)(gr.ranges_per_chunk > gs.ranges_per_chunk ? gr.ranges_per_chunk : gs.ranges_per_chunk) * pl->C;
     pl->items_extra = hj_join_items_capacity(pl->P, outer) - pl->P;
     // pass-2 tiles: whole tiles of the relation plus up to two ragged tiles per segment
     const size_t larger = inner > outer ? inner : outer;
-    pl->tiles2 = pl->F2 > 1 ? larger / (size_t)hj_scatter_tile(2, pl->F2, true) + 2 * (size_t)pl->C * pl->F1 + 8 : 0;
+    pl->tiles2 = pl->F2 > 1 ? larger / (size_t)hj_scatter_tile(ctx->tune, 2, pl->F2, true) + 2 * (size_t)pl->C * pl->F1 + 8 : 0;
     MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges, pl->items_extra, pl->tiles2);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
@@ -337,7 +360,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus, pl.big_tables), &bs, &bl));
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
     // counts[0] | counts[1] | tickets are contiguous: a whole join zeroes all, a prepared build its own
@@ -356,7 +379,10 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     }
     if (mode != PHJ_BUILD_ONLY) HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
 
-    const Pass1Geom geom[2] = {make_geom(rk, inner, pl.C, pl.F1, true), make_geom(sk, outer, pl.C, pl.F1, true)};
+    const Pass1Geom geom[2] = {make_geom(ctx->tune, rk, inner, pl.C, pl.F1, true), make_geom(ctx->tune, sk, outer, pl.C, pl.F1, true)};
+    for (int r = 0; r < 2; ++r)
+        if ((size_t)geom[r].ranges_per_chunk * pl.C > pl.ranges)
+            return fail(ctx, HJGPU_EINVAL, "internal: the relation needs more pass-1 ranges than the plan's tables hold");
     const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
     const size_t nn[2] = {inner, outer};
     uint32_t *t1[4] = {(uint32_t *)ctx->tmp[0].p, nullptr, (uint32_t *)ctx->tmp[2].p, nullptr};
@@ -368,18 +394,18 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r]; pa.tdesc[r] = m.tdesc[r];
     }
     pa.tdesc_cap = (uint32_t)m.tdesc_cap;
-    // two-pass plans: final partitions start on 128-byte lines (pass 2 claims whole lines); HJGPU_DENSE2=1: dense
-    const char *dense2 = getenv("HJGPU_DENSE2");
-    const bool pad2 = pl.F2 > 1 && !(dense2 && atoi(dense2));
+    pa.unique = pl.unique ? 1u : 0u;
+    // two-pass plans: final partitions start on 128-byte lines (pass 2 claims whole lines); option "dense2": dense
+    const bool pad2 = pl.F2 > 1 && !ctx->tune.dense2;
     pa.pad2 = pad2 ? 1u : 0u;
     pa.n[0] = inner; pa.n[1] = outer;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
     pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
     pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
-    pa.tile1 = (uint32_t)hj_scatter_tile(1, pl.F1, true); pa.tile2 = (uint32_t)hj_scatter_tile(2, pl.F2, true);
+    pa.tile1 = (uint32_t)hj_scatter_tile(ctx->tune, 1, pl.F1, true); pa.tile2 = (uint32_t)hj_scatter_tile(ctx->tune, 2, pl.F2, true);
     pa.slice = HJ_JOIN_SLICE;
-    pa.cap = (uint32_t)(pl.big_tables ? hj_join_config_big() : hj_join_config()).cap();
+    pa.cap = (uint32_t)hj_join_config_of(ctx->tune, pl.big_tables).cap();
 
     // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
     auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
@@ -402,7 +428,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
             sa.ranged = 1; sa.work_counter = m.tickets + 16 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
             sa.in_packed = 0; sa.out_packed = 1;
-            CHK(hj_launch_scatter(sa, ctx->cus, stream));
+            CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
         }
         record(ctx, ev[2], stream);
         // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
@@ -415,7 +441,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
             sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
             sa.in_packed = 1; sa.out_packed = 1;
-            CHK(hj_launch_scatter(sa, ctx->cus, stream));
+            CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
         }
         record(ctx, ev[3], stream);
         return HJGPU_OK;
@@ -453,6 +479,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.s_align = 0;
         ja.packed = 1;
         ja.big_tables = pl.big_tables ? 1u : 0u;
+        ja.unique = pl.unique ? 1u : 0u;
         ja.result = &st->result;
         ja.work_counter = &st->work_counter;
         if (bs) {
@@ -462,13 +489,13 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             ja.final_offsets = (u64 *)ctx->final_offsets.p;
             ja.overflow = &st->overflow;
         }
-        CHK(hj_launch_join(ja, ctx->cus, stream));
+        CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     }
     record(ctx, EV_JOIN, stream);
     if (bs && inner && outer && mode != PHJ_BUILD_ONLY) {
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
                                     (const u64 *)ctx->final_offsets.p,
-                                    (uint32_t)hj_join_workers(ctx->cus, pl.big_tables), bs, &st->block_counter,
+                                    (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables), bs, &st->block_counter,
                                     &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
     }
     record(ctx, EV_GAPS, stream);
@@ -493,6 +520,11 @@ int finish_blocking(hjgpu_ctx *ctx, hjgpu_result *result, const hjgpu_output *ou
 // ---------------------------------------------------------------------------
 // NPJ
 // ---------------------------------------------------------------------------
+bool npj_unique(const hjgpu_ctx *ctx, const hjgpu_npj_params *prm)
+{
+    return ctx->tune.unique || (prm && (prm->flags & HJGPU_FLAG_UNIQUE));
+}
+
 int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_t *buckets,
                 uint32_t *factor)
 {
@@ -512,7 +544,7 @@ int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_
 
 int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, size_t outer,
                       const u64 *table, size_t buckets, uint32_t factor, const hjgpu_output *out,
-                      hipStream_t stream, bool line_hash = false)
+                      hipStream_t stream, bool line_hash = false, bool unique = false)
 {
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
@@ -522,7 +554,7 @@ int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, si
         NpjProbeArgs pa;
         memset(&pa, 0, sizeof(pa));
         pa.keys = sk; pa.vals = sv; pa.n = outer; pa.table = table; pa.buckets = buckets;
-        pa.factor = factor; pa.line_hash = line_hash ? 1u : 0u; pa.result = &st->result;
+        pa.factor = factor; pa.line_hash = line_hash ? 1u : 0u; pa.unique = unique ? 1u : 0u; pa.result = &st->result;
         if (bs) {
             pa.ok = out->d_keys; pa.oov = out->d_outer_vals; pa.oiv = out->d_inner_vals;
             pa.block_size = bs; pa.block_limit = bl; pa.block_counter = &st->block_counter;
@@ -543,7 +575,7 @@ int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, si
 
 int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
-                size_t buckets, uint32_t factor, const hjgpu_output *out, hipStream_t stream)
+                size_t buckets, uint32_t factor, const hjgpu_output *out, hipStream_t stream, bool unique)
 {
     CHK(refuse_capture(ctx, stream));
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
@@ -554,10 +586,10 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
     HIPCHK(ctx, hipMemsetAsync(table, 0, buckets * sizeof(u64), stream));
     // whole joins own their table: line-hashed layout (operator-level hjgpu_npj_build / _probe keep
     // the reference's hash so that their tables stay interchangeable with the reference's)
-    const bool line = getenv("HJGPU_NPJ_REFHASH") == nullptr;
+    const bool line = !ctx->tune.npj_refhash;
     if (inner) CHK(hj_launch_npj_build(rk, rv, inner, table, buckets, factor, &st->zero_key, ctx->cus, stream, line));
     record(ctx, EV_R_HIST, stream);     // reused as "end of build"
-    CHK(npj_probe_enqueue(ctx, sk, sv, outer, table, buckets, factor, out, stream, line));
+    CHK(npj_probe_enqueue(ctx, sk, sv, outer, table, buckets, factor, out, stream, line, unique));
     ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets;
     ctx->last_algo = 0;
     return HJGPU_OK;
@@ -600,6 +632,7 @@ int hjgpu_create(int device, hjgpu_ctx **out)
     if (hipSetDevice(device) != hipSuccess ||
         hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) { delete ctx; return HJGPU_ENODEVICE; }
     ctx->cus = ctx->prop.multiProcessorCount;
+    hj_tuning_from_env(&ctx->tune);          // the only place the library looks at the environment
     for (int i = 0; i < EV_COUNT; ++i) {
         ctx->ev_valid[i] = false;
         if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return HJGPU_EHIP; }
@@ -623,6 +656,21 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
 }
 
 const char *hjgpu_last_error(const hjgpu_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value)
+{
+    if (!ctx || !name || !value) return HJGPU_EINVAL;
+    HjTuning t = ctx->tune;
+    if (!hj_tuning_set(&t, name, value)) return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: unknown option or malformed value");
+    // the join kernels exist in a fixed set of geometries
+    const JoinConfig &j = t.join;
+    const bool built = (j.block == 512 && j.log2slots == 13 && (j.batch == 1 || j.batch == 2 || j.batch == 4)) ||
+                       (j.block == 1024 && j.log2slots == 14 && j.batch == 2) || (j.block == 256 && j.log2slots == 12 && j.batch == 2);
+    if (!built) return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: join_cfg names a geometry that is not built");
+    ctx->tune = t;
+    ctx->prepared = false;                   // a prepared build side was planned under the old options
+    return HJGPU_OK;
+}
 
 int hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info)
 {
@@ -746,7 +794,7 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
     HIPCHK(ctx, hipMemsetAsync(d_counts, 0, (size_t)fanout * sizeof(u64), stream));
     if (n) {
         // the per-range counts are a by-product here; they go to scratch
-        const Pass1Geom g = make_geom(d_keys, n, 1, 1, false);
+        const Pass1Geom g = make_geom(ctx->tune, d_keys, n, 1, 1, false);
         CHK(ensure(ctx, ctx->moves, ((size_t)g.ranges_per_chunk + 16) * sizeof(uint32_t)));
         uint32_t *ticket = (uint32_t *)ctx->moves.p + g.ranges_per_chunk;
         HIPCHK(ctx, hipMemsetAsync(ticket, 0, 8 * sizeof(uint32_t), stream));
@@ -768,7 +816,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     CHK(check_columns(ctx, d_keys, d_vals, n));
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const Pass1Geom geom = make_geom(d_keys, n, 1, fanout, false);
+    const Pass1Geom geom = make_geom(ctx->tune, d_keys, n, 1, fanout, false);
     MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
     ctx->prepared = false;                 // the workspace is re-planned below
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
@@ -782,12 +830,12 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
-    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0;
+    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = 0;
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
-    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)hj_join_config().cap(); pa.mask = 7u;
+    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
     if (n) {
         CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
@@ -799,7 +847,7 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
         sa.ranged = 1; sa.work_counter = m.tickets + 16; sa.geom = geom; sa.range_base = m.range_base[0];
         sa.in_packed = 0; sa.out_packed = 0;
-        CHK(hj_launch_scatter(sa, ctx->cus, stream));
+        CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
                                hipMemcpyDeviceToDevice, stream));
@@ -843,7 +891,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P, 1, items_extra);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus), &bs, &bl));
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus), &bs, &bl));
     record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
     // counts = adjacent differences of the caller's offsets, then the usual plan
@@ -856,12 +904,13 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
-    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0;
+    const bool unique = ctx->tune.unique || (passes->flags & HJGPU_FLAG_UNIQUE);
+    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = unique ? 1u : 0u;
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
-    pa.tile1 = pa.tile2 = (uint32_t)hj_scatter_tile(2, 1, true); pa.slice = HJ_JOIN_SLICE;
-    pa.cap = (uint32_t)hj_join_config().cap(); pa.mask = 7u;
+    pa.tile1 = pa.tile2 = (uint32_t)hj_scatter_tile(ctx->tune, 2, 1, true); pa.slice = HJ_JOIN_SLICE;
+    pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 7u;
     CHK(hj_launch_plan(pa, stream));
     for (int e : {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2, EV_WAITED, EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2}) record(ctx, e, stream);
     JoinArgs ja;
@@ -873,17 +922,18 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     ja.P = pl.P; ja.chunks = 1;
     ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2; ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
     ja.s_align = 0; ja.result = &st->result; ja.work_counter = &st->work_counter;
+    ja.unique = unique ? 1u : 0u;
     if (bs) {
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
         ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
     }
-    CHK(hj_launch_join(ja, ctx->cus, stream));
+    CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     record(ctx, EV_JOIN, stream);
     if (bs)
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
                                     (const u64 *)ctx->final_offsets.p,
-                                    (uint32_t)hj_join_workers(ctx->cus), bs, &st->block_counter,
+                                    (uint32_t)hj_join_workers(ctx->tune, ctx->cus), bs, &st->block_counter,
                                     &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
     record(ctx, EV_GAPS, stream);
     ctx->last_algo = 1;
@@ -917,7 +967,7 @@ int hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     HIPCHK(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(DevState), stream));
     record(ctx, EV_BEGIN, stream); record(ctx, EV_R_HIST, stream);
-    CHK(npj_probe_enqueue(ctx, d_keys, d_vals, n, (const u64 *)d_table, buckets, factor, out, stream));
+    CHK(npj_probe_enqueue(ctx, d_keys, d_vals, n, (const u64 *)d_table, buckets, factor, out, stream, false, ctx->tune.unique));
     ctx->last_algo = 0;
     return finish_blocking(ctx, result, out, stream);
 }
@@ -934,7 +984,7 @@ int hjgpu_npj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size
     HIPCHK(ctx, hipSetDevice(ctx->device));
     size_t buckets; uint32_t factor;
     CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
-    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, nullptr, stream));
+    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, nullptr, stream, npj_unique(ctx, prm)));
     if (d_result)
         HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
     return HJGPU_OK;
@@ -951,7 +1001,7 @@ int hjgpu_npj(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inn
     HIPCHK(ctx, hipSetDevice(ctx->device));
     size_t buckets; uint32_t factor;
     CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
-    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream));
+    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream, npj_unique(ctx, prm)));
     return finish_blocking(ctx, result, out, stream);
 }
 
@@ -964,17 +1014,16 @@ int hjgpu_npj(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inn
 // for the partitioned plan: one fill only.
 // Largest build side of a broadcast join: one fill of the 8 K-slot table, or - up to a load of 0.42, where
 // cuckoo insertion still converges quickly - one fill of the 16 K-slot table (one 1024-thread workgroup per CU).
-static size_t broadcast_rows(bool big_tables)
+static size_t broadcast_rows(const HjTuning &tune, bool big_tables)
 {
-    return big_tables ? (size_t)(hj_join_config_big().cap() * 0.85) : (size_t)hj_join_config().cap();
+    return big_tables ? (size_t)(hj_join_config_big().cap() * 0.85) : (size_t)tune.join.cap();
 }
 
-static bool broadcast_applies(size_t inner, size_t outer, uint32_t chunks, const hjgpu_phj_params *prm)
+static bool broadcast_applies(const HjTuning &tune, size_t inner, size_t outer, uint32_t chunks, const hjgpu_phj_params *prm)
 {
-    const char *off = getenv("HJGPU_NO_BROADCAST");
-    if (off && atoi(off)) return false;
+    if (tune.no_broadcast) return false;
     if (chunks != 1 || (prm && (prm->fanout1 || prm->fanout2))) return false;    // an explicit plan is honoured
-    return inner && outer && inner <= broadcast_rows(true) && inner <= 16383;
+    return inner && outer && inner <= broadcast_rows(tune, true) && inner <= 16383;
 }
 
 static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
@@ -987,11 +1036,12 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     const uint32_t tf0 = (prm && prm->table_factor[0]) ? prm->table_factor[0] : DEFAULT_TF0;
     const uint32_t tf1 = (prm && prm->table_factor[1]) ? prm->table_factor[1] : DEFAULT_TF1;
     if (!(tf0 & 1) || !(tf1 & 1)) return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
-    const bool big = inner > broadcast_rows(false);
-    const size_t cap = (size_t)(big ? hj_join_config_big() : hj_join_config()).cap();
+    const bool big = inner > broadcast_rows(ctx->tune, false);
+    const size_t cap = (size_t)hj_join_config_of(ctx->tune, big).cap();
     const size_t nslices = (outer + HJ_JOIN_SLICE - 1) / HJ_JOIN_SLICE;
     const size_t fills = (inner + cap - 1) / cap;
-    const size_t groups = fills < (size_t)HJ_JOIN_FILL_GROUPS ? fills : (size_t)HJ_JOIN_FILL_GROUPS;
+    const bool unique = ctx->tune.unique || (prm && (prm->flags & HJGPU_FLAG_UNIQUE));
+    const size_t groups = unique ? 1 : (fills < (size_t)HJ_JOIN_FILL_GROUPS ? fills : (size_t)HJ_JOIN_FILL_GROUPS);
     const size_t items = nslices * groups;
     if (nslices >= (1ull << 32)) return fail(ctx, HJGPU_EINVAL, "probe side too large for a broadcast join");
     // meta: 8 u64 of descriptors, the sentinel, the (all-zero) item directory
@@ -1004,7 +1054,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     uint32_t *item_part = reinterpret_cast<uint32_t *>(d + 16);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->cus, big), &bs, &bl));
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, big), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
@@ -1023,18 +1073,18 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     ja.P = 1; ja.chunks = 1; ja.f1 = ja.f2 = 1; ja.F1 = ja.F2 = 1;
     ja.tf0 = tf0; ja.tf1 = tf1;
     ja.s_align = align_of(sk); ja.packed = 0;
-    ja.broadcast = 1; ja.sentinel = bm.sentinel; ja.big_tables = big ? 1u : 0u;
+    ja.broadcast = 1; ja.sentinel = bm.sentinel; ja.big_tables = big ? 1u : 0u; ja.unique = unique ? 1u : 0u;
     ja.result = &st->result; ja.work_counter = &st->work_counter;
     if (bs) {
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
         ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
     }
-    CHK(hj_launch_join(ja, ctx->cus, stream));
+    CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     record(ctx, EV_JOIN, stream);
     if (bs)
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
-                                    (const u64 *)ctx->final_offsets.p, (uint32_t)hj_join_workers(ctx->cus, big), bs,
+                                    (const u64 *)ctx->final_offsets.p, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, big), bs,
                                     &st->block_counter, &st->overflow, ctx->moves.p, &st->nmoves, &st->dense,
                                     ctx->cus, stream));
     record(ctx, EV_GAPS, stream);
@@ -1055,7 +1105,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     if (chunks < 1 || chunks > 8) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 8]");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (broadcast_applies(inner, outer, chunks, prm)) {
+    if (broadcast_applies(ctx->tune, inner, outer, chunks, prm)) {
         CHK(broadcast_enqueue(ctx, rk, rv, inner, sk, sv, outer, prm, out, stream, (hipEvent_t)inner_ready));
     } else {
         PhjPlan pl;
@@ -1269,7 +1319,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
     if (rows && inner && outer) {
         const size_t workers = algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, outer) * 4
-                                              : (size_t)std::max(hj_join_workers(ctx->cus, false), hj_join_workers(ctx->cus, true));
+                                              : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true));
         dev_out.block_size = rows->capacity >= (64u << 20) ? 65536 : 1024;
         dev_out.capacity = (rows->capacity / dev_out.block_size + 1 + workers) * dev_out.block_size;
         for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_rows[i], dev_out.capacity * sizeof(uint32_t));
@@ -1311,7 +1361,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
             if (algorithm == 0) {
                 // NPJ builds first: it needs R, which arrives last
                 hip_ok(hipStreamWaitEvent(run, r_ready, 0), "hipStreamWaitEvent");
-                if (rc == HJGPU_OK) rc = npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, run);
+                if (rc == HJGPU_OK) rc = npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, run, npj_unique(ctx, np));
             } else {
                 hip_ok(hipStreamWaitEvent(run, s_ready, 0), "hipStreamWaitEvent");
                 if (rc == HJGPU_OK) rc = phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, out, run, r_ready);

@@ -37,7 +37,12 @@
 
 // PACKED: the relations arrive as payload << 32 | key tuples (the library's own
 // partition passes); !PACKED: separate key / payload columns (hjgpu_join_partitions).
-template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED>
+// UNIQUE: the reference's _UNIQUE build (npj.cpp:288-290, phj.cpp:459, 635): a probe tuple reports its FIRST
+// match only.  Inside one table that is "one of the key's two cuckoo slots" / "the first hit of the chain";
+// a build partition that takes several table fills keeps one bit per probe row of the work item in LDS
+// (`matched`), so that a row reported by an earlier fill is skipped by the later ones (such partitions
+// are then planned as ONE fill group: all fills of a probe slice stay with one workgroup).
+template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE>
 __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 {
     constexpr uint32_t SLOTS = 1u << LOG2SLOTS;
@@ -51,6 +56,10 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     __shared__ u64 red[4][NW];
     __shared__ u64 wave_cursor[NW];
     __shared__ uint32_t cuckoo_failed;
+    // UNIQUE: one bit per probe row of the current work item (<= HJ_JOIN_SLICE + 1 rows per chunk piece)
+    constexpr uint32_t MATCHED_WORDS = UNIQUE ? (HJ_JOIN_SLICE + 64) / 32 + 2 : 1;
+    __shared__ uint32_t matched[MATCHED_WORDS];
+    bool dedup = false;                          // UNIQUE and this item's build rows take more than one fill (uniform)
     uint2 *tab = reinterpret_cast<uint2 *>(tab64);   // chained view: .x = key, .y = payload
 
     const int tid = threadIdx.x;
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
     };
 
     // ---- stream the S rows [gb, ge): BATCH key + BATCH payload vectors in flight per lane ----
-    auto for_each_probe_vector = [&](u64 gb, u64 ge, auto probe4) {
+    // `row0`: index of row gb among the probe rows of this work item (UNIQUE's `matched` bits)
+    auto for_each_probe_vector = [&](u64 gb, u64 ge, u64 row0, auto probe4) {
         for (u64 g0 = (gb & ~3ull) + (u64)tid * 4; g0 < ge; g0 += (u64)BLOCK * 4 * BATCH) {
             uint4 kk[BATCH], vv[BATCH];
 #pragma unroll
@@ -163,14 +173,28 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                     // does).  Only the separate-column instance serves broadcast joins.
                     if (!PACKED) valid[j] = valid[j] && key[j] != empty;
                 }
-                probe4(key, val, valid);
+                if (UNIQUE && dedup) {
+                    // rows an earlier fill of this partition has already reported are done
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t row = (uint32_t)(row0 + (g + j - gb));
+                        if (valid[j]) valid[j] = !((matched[row >> 5] >> (row & 31)) & 1u);
+                    }
+                    const uint32_t hits = probe4(key, val, valid);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t row = (uint32_t)(row0 + (g + j - gb));
+                        if ((hits >> j) & 1u) atomicOr(&matched[row >> 5], 1u << (row & 31));
+                    }
+                } else (void)probe4(key, val, valid);
             }
         }
     };
 
     // cuckoo probe: two independent slot reads per key, no loop
-    auto probe4_cuckoo = [&](const uint32_t (&key)[4], const uint32_t (&val)[4], const bool (&valid)[4]) {
+    auto probe4_cuckoo = [&](const uint32_t (&key)[4], const uint32_t (&val)[4], const bool (&valid)[4]) -> uint32_t {
         u64 t1[4], t2[4];
+        uint32_t hits = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t a1 = (key[j] * tf0) >> SHIFT;
@@ -183,8 +207,9 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
-            const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]);
+            const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]) && !(UNIQUE && h1);
             const uint32_t m = (h1 ? 1u : 0u) + (h2 ? 1u : 0u);
+            hits |= m ? 1u << j : 0u;
             n += m;
             sk_ += (u64)key[j] * m;
             so_ += (u64)val[j] * m;
@@ -198,13 +223,15 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             }
         }
         acc_n += n; acc_k += sk_; acc_o += so_; acc_i += si_;
+        return hits;
     };
 
     // chained probe: 4 chains per lane advanced in lock step to the first empty slot
-    auto probe4_chained = [&](const uint32_t (&key)[4], const uint32_t (&val)[4], const bool (&valid)[4]) {
+    auto probe4_chained = [&](const uint32_t (&key)[4], const uint32_t (&val)[4], const bool (&valid)[4]) -> uint32_t {
         uint32_t slot[4], step[4];
         uint2 t[4];
         bool live[4];
+        uint32_t hits = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             live[j] = valid[j];
@@ -222,16 +249,19 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
                 acc_o += hit ? val[j] : 0u;
                 acc_i += hit ? t[j].y : 0u;
                 if (a.ok) { if (hit) em.emit(key[j], val[j], t[j].y); }
-                live[j] = live[j] && (t[j].x != empty);
+                hits |= hit ? 1u << j : 0u;
+                live[j] = live[j] && (t[j].x != empty) && !(UNIQUE && hit);
                 slot[j] = (slot[j] + step[j]) & MASK;
             }
             if (!(live[0] | live[1] | live[2] | live[3])) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (live[j]) t[j] = tab[slot[j]];
         }
+        return hits;
     };
 
     auto probe_item = [&](u64 slice, u64 nslices, auto probe4) {
+        u64 row0 = 0;
         for (uint32_t c = 0; c < C; ++c) {
             const u64 b = a.soff[(u64)c * P + q], e = a.send[(u64)c * P + q];
             const u64 len = e - b;
@@ -240,7 +270,8 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             const u64 sb = b + (len * slice) / nslices;
             const u64 se = b + (len * (slice + 1)) / nslices;
             if (se <= sb) continue;
-            for_each_probe_vector(a.s_align + sb, a.s_align + se, probe4);
+            for_each_probe_vector(a.s_align + sb, a.s_align + se, row0, probe4);
+            row0 += se - sb;
         }
     };
 
@@ -312,6 +343,10 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             while (hj_part2(empty, a.f1, a.F1, a.f2, a.F2) == q) ++empty;
         }
         const u64 EMPTY64 = (u64)empty;
+        if (UNIQUE) {
+            dedup = rows_end - rows_beg > CAP;
+            if (dedup) for (uint32_t i = tid; i < MATCHED_WORDS; i += BLOCK) matched[i] = 0;    // published by the clear barrier
+        }
 
         for (u64 fill_beg = rows_beg; fill_beg < rows_end; fill_beg += CAP) {
             const u64 fill_end = min(rows_end, fill_beg + CAP);
@@ -433,16 +468,6 @@ int hj_launch_broadcast_meta(const uint32_t *inner_keys, size_t inner, size_t ou
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
-const JoinConfig &hj_join_config()
-{
-    static JoinConfig cfg;
-    cfg.block = 512; cfg.log2slots = 13; cfg.batch = 2;
-    const char *e = getenv("HJGPU_JOIN_CFG");
-    int b, l, u;
-    if (e && sscanf(e, "%d,%d,%d", &b, &l, &u) == 3) { cfg.block = b; cfg.log2slots = l; cfg.batch = u; }
-    return cfg;
-}
-
 const JoinConfig &hj_join_config_big()
 {
     static const JoinConfig cfg = {1024, 14, 2};
@@ -452,40 +477,40 @@ const JoinConfig &hj_join_config_big()
 // workgroups per CU the LDS table allows (160 KiB per CU), capped by 2048 threads per CU
 static int join_wgs_per_cu(const JoinConfig &c)
 {
-    int by_lds = (160 * 1024) / (c.slots() * 8 + 1024);
+    // + 9 KiB: the UNIQUE instances' `matched` bits; the same grid for both keeps hj_join_workers one number
+    int by_lds = (160 * 1024) / (c.slots() * 8 + 1024 + 9 * 1024);
     int by_threads = 2048 / c.block;
     int n = by_lds < by_threads ? by_lds : by_threads;
     return n < 1 ? 1 : n;
 }
 
 static int join_grid(int cus, const JoinConfig &c) { return cus * join_wgs_per_cu(c); }
-int hj_join_grid(int cus) { return join_grid(cus, hj_join_config()); }
-int hj_join_workers(int cus, bool big_tables)
+int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
 {
-    const JoinConfig &c = big_tables ? hj_join_config_big() : hj_join_config();
+    const JoinConfig &c = hj_join_config_of(t, big_tables);
     return join_grid(cus, c) * (c.block / 64);
 }
 
-#define JOIN_CASE(B, L, U)                                                                        \
-    if (c.block == B && c.log2slots == L && c.batch == U) {                                       \
-        if (a.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, a);  \
-        else hipLaunchKernelGGL((join_kernel<B, L, U, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, a);          \
+#define JOIN_CASE(B, L, U, UNQ)                                                                   \
+    if (c.block == B && c.log2slots == L && c.batch == U && (b.unique != 0) == UNQ) {             \
+        if (b.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true, UNQ>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
+        else hipLaunchKernelGGL((join_kernel<B, L, U, false, UNQ>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);          \
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
     }
 
-int hj_launch_join(const JoinArgs &a, int cus, hipStream_t stream)
+int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t stream)
 {
     if ((a.P < 2 && !a.broadcast) || a.P < 1 || a.chunks == 0) return HJGPU_EINVAL;
-    const JoinConfig &c = a.big_tables ? hj_join_config_big() : hj_join_config();
-    const char *ex = getenv("HJGPU_FORCE_CHAINED");     // tests: exercise the fallback table everywhere
+    const JoinConfig &c = hj_join_config_of(t, a.big_tables != 0);
     JoinArgs b = a;
-    b.force_chained = (ex && atoi(ex)) ? 1u : 0u;
-#define a b
-    JOIN_CASE(512, 13, 2)
-    JOIN_CASE(512, 13, 1)
-    JOIN_CASE(512, 13, 4)
-    JOIN_CASE(1024, 14, 2)
-    JOIN_CASE(256, 12, 2)
-#undef a
+    b.force_chained = t.force_chained ? 1u : 0u;       // tests: exercise the fallback table everywhere
+    b.unique = (a.unique || t.unique) ? 1u : 0u;
+    JOIN_CASE(512, 13, 2, false)
+    JOIN_CASE(512, 13, 2, true)
+    JOIN_CASE(512, 13, 1, false)
+    JOIN_CASE(512, 13, 4, false)
+    JOIN_CASE(1024, 14, 2, false)
+    JOIN_CASE(1024, 14, 2, true)
+    JOIN_CASE(256, 12, 2, false)
     return HJGPU_EINVAL;
 }

@@ -72,7 +72,8 @@ constexpr int NPJ_PROBE_BLOCK = 256;
 // average at load 0.5: with one bucket per load that is 2.5 dependent memory round
 // trips per probe; a group resolves most walks in one.  Needs buckets % 4 == 0
 // (the library's own tables; any other table takes the bucket-at-a-time path).
-template <bool GROUPED>
+// UNIQUE: the reference's _UNIQUE build (npj.cpp:288-290, 436-438): the walk of a probe key ends at its first match.
+template <bool GROUPED, bool UNIQUE>
 __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs a)
 {
     constexpr int NW = NPJ_PROBE_BLOCK / 64;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs
                             else if (in && bk[b] == key[j]) {
                                 acc_n += 1; acc_k += key[j]; acc_o += val[j]; acc_i += bv[b];
                                 em.emit(key[j], val[j], bv[b]);
+                                if (UNIQUE) open = false;
                             }
                         }
                         if (!open) act[j] = false;
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs
                                 const uint32_t iv = (uint32_t)(t[j] >> 32);
                                 acc_n += 1; acc_k += key[j]; acc_o += val[j]; acc_i += iv;
                                 em.emit(key[j], val[j], iv);
+                                if (UNIQUE) { act[j] = false; continue; }
                             }
                             if (++h[j] == buckets) h[j] = 0;
                             t[j] = table[h[j]];
@@ -199,7 +202,7 @@ __device__ __forceinline__ uint32_t quad_perm(uint32_t x)
 // the -O3 build evaluated that (uniform) test per lane at a loop header that the continuation
 // re-enters with only the walking lanes enabled, and later rounds of other lanes then took the
 // emit path with a.ok == NULL (memory access fault; -O1 was fine).
-template <bool MATERIALIZE>
+template <bool MATERIALIZE, bool UNIQUE>
 __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_line_kernel(NpjProbeArgs a)
 {
     constexpr int NW = NPJ_PROBE_BLOCK / 64;
@@ -263,8 +266,19 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_line_kernel(NpjProb
                     uint32_t fe = q[i].x == 0u ? 2 * sub : (q[i].z == 0u ? 2 * sub + 1 : 8u);
                     fe = min(fe, quad_perm<0xB1>(fe));                  // lanes 0<->1, 2<->3
                     fe = min(fe, quad_perm<0x4E>(fe));                  // lanes 0<->2, 1<->3
-                    const bool m0 = q[i].x == key[i] && 2 * sub < fe;
-                    const bool m1 = q[i].z == key[i] && 2 * sub + 1 < fe;
+                    bool m0 = q[i].x == key[i] && 2 * sub < fe;
+                    bool m1 = q[i].z == key[i] && 2 * sub + 1 < fe;
+                    bool found = false;                                 // UNIQUE: some lane of the quad holds a match
+                    if (UNIQUE) {
+                        // only the FIRST match of the walk counts: the lowest matching bucket of the line
+                        uint32_t fm = m0 ? 2 * sub : (m1 ? 2 * sub + 1 : 8u);
+                        const uint32_t mine = fm;
+                        fm = min(fm, quad_perm<0xB1>(fm));
+                        fm = min(fm, quad_perm<0x4E>(fm));
+                        found = fm < 8u;
+                        m0 = m0 && mine == fm && fm == 2 * sub;
+                        m1 = m1 && mine == fm && fm == 2 * sub + 1;
+                    }
                     const uint32_t m = (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
                     acc_n += m; acc_k += (u64)key[i] * m; acc_o += (u64)val[i] * m;
                     acc_i += (m0 ? q[i].y : 0u); acc_i += (m1 ? q[i].w : 0u);
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_line_kernel(NpjProb
                         if (m0) em.emit(key[i], val[i], q[i].y);
                         if (m1) em.emit(key[i], val[i], q[i].w);
                     }
-                    if (fe < 8u) break;                                 // the walk ends at the first empty bucket
+                    if (fe < 8u || (UNIQUE && found)) break;            // the walk ends at the first empty bucket (UNIQUE: first match)
                     if (++ln[i] == lines) ln[i] = 0;                    // full line: the walk goes on in the next one
                     q[i] = t4[4 * ln[i] + sub];
                 }
@@ -306,13 +320,17 @@ int hj_launch_npj_probe(const NpjProbeArgs &a, int cus, hipStream_t stream, int 
     if (grid_out) *grid_out = grid;
     if (a.line_hash) {
         if (a.buckets % 8 != 0 || ((uintptr_t)a.table & 63)) return HJGPU_EINVAL;
-        if (a.ok) hipLaunchKernelGGL(npj_probe_line_kernel<true>, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL(npj_probe_line_kernel<false>, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+        if (a.ok && a.unique) hipLaunchKernelGGL((npj_probe_line_kernel<true, true>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+        else if (a.ok) hipLaunchKernelGGL((npj_probe_line_kernel<true, false>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+        else if (a.unique) hipLaunchKernelGGL((npj_probe_line_kernel<false, true>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((npj_probe_line_kernel<false, false>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
     }
     const bool grouped = (a.buckets % 4 == 0) && (((uintptr_t)a.table & 31) == 0);
-    if (grouped) hipLaunchKernelGGL(npj_probe_kernel<true>, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL(npj_probe_kernel<false>, dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+    if (grouped && a.unique) hipLaunchKernelGGL((npj_probe_kernel<true, true>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+    else if (grouped) hipLaunchKernelGGL((npj_probe_kernel<true, false>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+    else if (a.unique) hipLaunchKernelGGL((npj_probe_kernel<false, true>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((npj_probe_kernel<false, false>), dim3(grid), dim3(NPJ_PROBE_BLOCK), 0, stream, a);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 

@@ -22,6 +22,7 @@
 #include "hj_internal.hpp"
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 #include <type_traits>
 
 // --------------------------------------------------------------------------
@@ -191,13 +192,9 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
     const uint32_t P = F1 * F2;
     const size_t lds = ((size_t)P + F1) * sizeof(uint32_t);
     if (geom.chunks == 0 || geom.chunks > 8 || lds > 140 * 1024) return HJGPU_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&hist2_kernel<BLOCK>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
-            return HJGPU_EHIP;
-        attr_set = true;
-    }
+    static HjPerDeviceOnce once;
+    if (hj_allow_dynamic_lds(reinterpret_cast<const void *>(&hist2_kernel<BLOCK>), 140 * 1024, &once) != HJGPU_OK)
+        return HJGPU_EHIP;
     const uint32_t per_cu = (lds > 72 * 1024) ? 1 : 2;
     uint32_t gx = ((uint32_t)cus * per_cu + geom.chunks - 1) / geom.chunks;
     if (gx > geom.ranges_per_chunk) gx = geom.ranges_per_chunk;
@@ -443,7 +440,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
     // (probe slices | fill groups << 32) of a partition with nr build and ns probe rows; 0 slices = no work
     auto shape_of = [&](u64 nr, u64 ns) -> u64 {
         const u64 slices = (nr && ns) ? (ns + HJ_JOIN_SLICE - 1) >> SLICE_SHIFT : 0;
-        const u64 groups = min((u64)HJ_JOIN_FILL_GROUPS, max((u64)1, (nr + cap - 1) >> cap_shift));
+        const u64 groups = a.unique ? (u64)1 : min((u64)HJ_JOIN_FILL_GROUPS, max((u64)1, (nr + cap - 1) >> cap_shift));
         return slices | (groups << 32);
     };
     // tiles of 2 * PLAN_BLOCK partitions, thread t takes partitions tile + 2t and tile + 2t + 1 (see plan_scan2)
@@ -987,15 +984,14 @@ constexpr size_t HJ_LDS_LIMIT = 160 * 1024;          // gfx950: 160 KiB per CU, 
 // <= 421: 12288, <= 640: 8192); beyond that, and for separate output columns, no carry.
 // pass 2: 16384-tuple tiles, shared atomic cursors (a workgroup visits a segment about once,
 // so there is no "next tile" to complete a line).
-// HJGPU_SCATTER_CFG / HJGPU_SCATTER2_CFG = "block,vpt[,carry]" override (tuning).
-ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed)
+// options "scatter_cfg" / "scatter2_cfg" = "block,vpt[,carry]" override (tuning).
+ScatterConfig hj_scatter_config(const HjTuning &t, int pass, uint32_t F, bool out_packed)
 {
     ScatterConfig cfg = {1024, 4, false};
-    const char *e = getenv(pass == 1 ? "HJGPU_SCATTER_CFG" : "HJGPU_SCATTER2_CFG");
-    int b, v, c = -1;
-    if (e && sscanf(e, "%d,%d,%d", &b, &v, &c) >= 2) {
-        cfg.block = b; cfg.vpt = v;
-        cfg.carry = pass == 1 && out_packed && c != 0 && scatter_lds(b, v, F, true) <= HJ_LDS_LIMIT;
+    const int *o = t.scatter_cfg[pass == 1 ? 0 : 1];
+    if (o[0] > 0) {
+        cfg.block = o[0]; cfg.vpt = o[1];
+        cfg.carry = pass == 1 && out_packed && o[2] != 0 && scatter_lds(o[0], o[1], F, true) <= HJ_LDS_LIMIT;
         return cfg;
     }
     if (pass == 1 && out_packed) {
@@ -1005,24 +1001,21 @@ ScatterConfig hj_scatter_config(int pass, uint32_t F, bool out_packed)
     return cfg;
 }
 
-int hj_scatter_tile(int pass, uint32_t F, bool out_packed)
+int hj_scatter_tile(const HjTuning &t, int pass, uint32_t F, bool out_packed)
 {
-    const ScatterConfig c = hj_scatter_config(pass, F, out_packed);
+    const ScatterConfig c = hj_scatter_config(t, pass, F, out_packed);
     return c.block * c.vpt * 4;
 }
 
 template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY>
-static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
+static int launch_scatter_t(const ScatterArgs &a, bool want_prof, int cus, hipStream_t stream)
 {
     const size_t lds = scatter_lds(BLOCK, VPT, a.F, CARRY, !RANGED);
     if (lds > HJ_LDS_LIMIT) return HJGPU_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HJ_LDS_LIMIT) != hipSuccess)
-            return HJGPU_EHIP;
-        attr_set = true;
-    }
+    static HjPerDeviceOnce once;
+    if (hj_allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY>),
+                             (int)HJ_LDS_LIMIT, &once) != HJGPU_OK)
+        return HJGPU_EHIP;
     // persistent grid: as many workgroups per CU as LDS (160 KiB) and threads (2048) allow
     int per_cu = (int)(HJ_LDS_LIMIT / (lds + 512));
     if (per_cu > 2048 / BLOCK) per_cu = 2048 / BLOCK;
@@ -1032,12 +1025,11 @@ static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
     // pass-2 tiles are claimed in order, so all workgroups sit inside the same one or two pass-1
     // partitions, whose output region stays in the Infinity Cache (contiguous ownership instead:
     // 4.45-4.65 vs 3.9-4.0 ms in the first version)
-    // diagnostics only: HJGPU_SCATTER_PROF=1 prints where a workgroup's time goes (synchronises!)
-    static u64 *prof = nullptr;
-    const char *pe = getenv("HJGPU_SCATTER_PROF");
+    // diagnostics only: option "scatter_prof" prints where a workgroup's time goes (synchronises!)
+    u64 *prof = nullptr;
     b.prof = nullptr;
-    if (pe && atoi(pe)) {
-        if (!prof && hipMalloc(&prof, 8 * sizeof(u64)) != hipSuccess) return HJGPU_ENOMEM;
+    if (want_prof) {
+        if (hipMalloc(&prof, 8 * sizeof(u64)) != hipSuccess) return HJGPU_ENOMEM;
         (void)hipMemsetAsync(prof, 0, 8 * sizeof(u64), stream);
         b.prof = prof;
     }
@@ -1050,6 +1042,7 @@ static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
         fprintf(stderr, "scatter<%d,%d,%s%s> F=%u grid=%d: zero %.1f%% rank(+load wait) %.1f%% scan %.1f%% sort %.1f%% stream-out %.1f%%  (%.0f ticks/wg)\n",
                 BLOCK, VPT, RANGED ? "ranged" : "atomic", CARRY ? ",carry" : "", a.F, grid, 100 * h[0] / tot, 100 * h[1] / tot,
                 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, tot / grid);
+        (void)hipFree(prof);
     }
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
@@ -1059,17 +1052,17 @@ static int launch_scatter_t(const ScatterArgs &a, int cus, hipStream_t stream)
 // pass 2: packed in, packed out, atomic cursors
 #define SCATTER_CASE(B, V)                                                                   \
     if (c.block == B && c.vpt == V) {                                                        \
-        if (a.ranged && !a.in_packed && a.out_packed && c.carry) return launch_scatter_t<B, V, true, false, true, true>(a, cus, stream);   \
-        if (a.ranged && !a.in_packed && a.out_packed) return launch_scatter_t<B, V, true, false, true, false>(a, cus, stream);  \
-        if (a.ranged && !a.in_packed && !a.out_packed) return launch_scatter_t<B, V, true, false, false, false>(a, cus, stream); \
-        if (!a.ranged && a.in_packed && a.out_packed) return launch_scatter_t<B, V, false, true, true, false>(a, cus, stream);   \
+        if (a.ranged && !a.in_packed && a.out_packed && c.carry) return launch_scatter_t<B, V, true, false, true, true>(a, t.scatter_prof, cus, stream);   \
+        if (a.ranged && !a.in_packed && a.out_packed) return launch_scatter_t<B, V, true, false, true, false>(a, t.scatter_prof, cus, stream);  \
+        if (a.ranged && !a.in_packed && !a.out_packed) return launch_scatter_t<B, V, true, false, false, false>(a, t.scatter_prof, cus, stream); \
+        if (!a.ranged && a.in_packed && a.out_packed) return launch_scatter_t<B, V, false, true, true, false>(a, t.scatter_prof, cus, stream);   \
         return HJGPU_EINVAL;                                                                 \
     }
 
-int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream)
+int hj_launch_scatter(const ScatterArgs &a, const HjTuning &t, int cus, hipStream_t stream)
 {
     if (a.F == 0 || a.F > HJGPU_MAX_FANOUT) return HJGPU_EINVAL;
-    const ScatterConfig c = hj_scatter_config(a.ranged ? 1 : 2, a.F, a.out_packed != 0);
+    const ScatterConfig c = hj_scatter_config(t, a.ranged ? 1 : 2, a.F, a.out_packed != 0);
     if (a.ranged && a.geom.tile != (uint32_t)(c.block * c.vpt * 4)) return HJGPU_EINVAL;
     SCATTER_CASE(1024, 4)
     SCATTER_CASE(1024, 3)
@@ -1080,4 +1073,75 @@ int hj_launch_scatter(const ScatterArgs &a, int cus, hipStream_t stream)
     SCATTER_CASE(256, 4)
     SCATTER_CASE(256, 2)
     return HJGPU_EINVAL;
+}
+
+// ---- per-context tuning (hj_internal.hpp) --------------------------------------------------------
+int hj_allow_dynamic_lds(const void *kernel, int bytes, HjPerDeviceOnce *once)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return HJGPU_EHIP;
+    const bool tracked = dev >= 0 && dev < (int)sizeof(once->done);
+    if (tracked && __atomic_load_n(&once->done[dev], __ATOMIC_ACQUIRE)) return HJGPU_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return HJGPU_EHIP;
+    if (tracked) __atomic_store_n(&once->done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+    return HJGPU_OK;
+}
+
+static bool parse_flag(const char *v, bool *out)
+{
+    if (!v) return false;
+    char *end = nullptr;
+    const long x = strtol(v, &end, 10);
+    if (end == v || *end) return false;
+    *out = x != 0;
+    return true;
+}
+
+bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
+{
+    if (!t || !name || !value) return false;
+    auto is = [&](const char *n) { return strcmp(name, n) == 0; };
+    if (is("dense2")) return parse_flag(value, &t->dense2);
+    if (is("npj_refhash")) return parse_flag(value, &t->npj_refhash);
+    if (is("no_broadcast")) return parse_flag(value, &t->no_broadcast);
+    if (is("force_chained")) return parse_flag(value, &t->force_chained);
+    if (is("scatter_prof")) return parse_flag(value, &t->scatter_prof);
+    if (is("unique")) return parse_flag(value, &t->unique);
+    if (is("range_tiles")) {
+        char *end = nullptr;
+        const long x = strtol(value, &end, 10);
+        if (end == value || *end || x < 0 || x > (1 << 20)) return false;
+        t->range_tiles = (int)x;
+        return true;
+    }
+    if (is("join_cfg")) {
+        int b, l, u;
+        if (!*value) { t->join = JoinConfig{512, 13, 2}; return true; }
+        if (sscanf(value, "%d,%d,%d", &b, &l, &u) != 3) return false;
+        t->join = JoinConfig{b, l, u};
+        return true;
+    }
+    if (is("scatter_cfg") || is("scatter2_cfg")) {
+        int *o = t->scatter_cfg[is("scatter_cfg") ? 0 : 1];
+        int b, v, c = -1;
+        if (!*value) { o[0] = 0; o[1] = 0; o[2] = -1; return true; }
+        if (sscanf(value, "%d,%d,%d", &b, &v, &c) < 2 || b <= 0 || v <= 0) return false;
+        o[0] = b; o[1] = v; o[2] = c;
+        return true;
+    }
+    return false;
+}
+
+void hj_tuning_from_env(HjTuning *t)
+{
+    static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
+                                        "unique", "range_tiles", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+    for (const char *n : names) {
+        char env[64] = "HJGPU_";
+        size_t at = strlen(env);
+        for (const char *c = n; *c && at + 1 < sizeof(env); ++c) env[at++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+        env[at] = 0;
+        const char *v = getenv(env);
+        if (v && *v) (void)hj_tuning_set(t, n, v);
+    }
 }

@@ -47,6 +47,15 @@ extern "C" {
                                  (reference: assert(o <= block_limit), npj.cpp:245)          */
 #define HJGPU_ENODEVICE   7   /* no gfx950-class device visible                             */
 
+/* params->flags */
+#define HJGPU_FLAG_UNIQUE 1u      /* the reference's -D_UNIQUE build (npj.cpp:288-290, 436-438; phj.cpp:459,
+                                     635; cpra2.cpp:456, 625, 698): a probe tuple reports its FIRST match only
+                                     and its walk ends there.  With unique build keys the result is the same
+                                     as without the flag; with duplicate build keys count / sum_keys /
+                                     sum_outer_vals count every probe tuple that has a match once, and
+                                     sum_inner_vals adds the payload of ONE of its build tuples (which one
+                                     depends on insertion order, in the reference as here).               */
+
 #define HJGPU_MAX_FANOUT  1024u   /* per partitioning pass                                   */
 #define HJGPU_MAX_PARTS   32768u  /* fanout1 * fanout2                                       */
 
@@ -77,13 +86,13 @@ typedef struct {
     uint32_t table_factor[2];  /* odd table hash / step multipliers; 0 = defaults            */
     uint32_t chunks;           /* CPRA only: number of independently partitioned chunks
                                   (the reference's #threads, cpra2.cpp:1757-1827); 0 = 8     */
-    uint32_t reserved;
+    uint32_t flags;            /* HJGPU_FLAG_*                                               */
 } hjgpu_phj_params;
 
 typedef struct {
     double   load;             /* buckets = inner/load (npj.cpp:944-947); 0 = 0.25           */
     uint32_t factor;           /* odd multiplier; 0 = default                                */
-    uint32_t reserved;
+    uint32_t flags;            /* HJGPU_FLAG_*                                               */
 } hjgpu_npj_params;
 
 /* Per-phase device times of the last join on this context (hipEvent based). */
@@ -119,6 +128,14 @@ int  hjgpu_destroy(hjgpu_ctx *ctx);
 const char *hjgpu_last_error(const hjgpu_ctx *ctx);
 const char *hjgpu_status_string(int status);
 int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
+/* Tuning / test switches of ONE context (the reference's compile-time macros and hard-coded constants,
+ * SURVEY.md section 5 "Config / flags").  hjgpu_create reads HJGPU_<NAME> from the environment once;
+ * nothing else in the library looks at the environment, and nothing on a launch path reads mutable
+ * process-wide state.  Names: "unique" (as HJGPU_FLAG_UNIQUE, for every join of the context,
+ * including the operator-level hjgpu_npj_probe), "force_chained", "no_broadcast", "dense2", "npj_refhash",
+ * "scatter_prof" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
+ * "scatter2_cfg" ("block,vectors[,carry]").  Unknown names and malformed values: HJGPU_EINVAL. */
+int  hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value);
 /* Pre-size the internal workspace (partition scratch twins = hj.h's [1]
  * columns, NPJ table) so that no allocation happens inside a timed join. */
 int  hjgpu_reserve(hjgpu_ctx *ctx, size_t inner_tuples, size_t outer_tuples);

@@ -230,6 +230,15 @@ int hjo_set_simd(int on)
     return g_simd;
 }
 
+/* The reference's -D_UNIQUE build (npj.cpp:288-290, 436-438; phj.cpp:459, 635-637; cpra2.cpp:456, 625, 698):
+ * a compile-time switch there, a run-time one here.  The walk of a probe tuple ends at its first match. */
+static int g_unique = 0;
+int hjo_set_unique(int on)
+{
+    g_unique = on ? 1 : 0;
+    return g_unique;
+}
+
 /* phj.cpp:1295-1306 (scalar), vector form 693-772 */
 void hjo_histogram(const uint32_t *keys, size_t size, uint32_t *counts,
                    uint32_t factor, size_t partitions)
@@ -364,7 +373,8 @@ void hjo_npj_build(const uint32_t *keys, const uint32_t *vals, size_t size,
 }
 
 /* npj.cpp:412-445 (scalar form of 216-364): walk to the first empty bucket,
- * every key match is reported (no _UNIQUE). */
+ * every key match is reported; under hjo_set_unique(1) the walk ends at the first
+ * match (#ifdef _UNIQUE break, npj.cpp:436-438). */
 void hjo_npj_probe(const uint32_t *keys, const uint32_t *vals, size_t size,
                    const uint64_t *table, size_t buckets, uint32_t factor,
                    uint32_t empty, hjo_result *agg, const hjo_output *out,
@@ -377,8 +387,10 @@ void hjo_npj_probe(const uint32_t *keys, const uint32_t *vals, size_t size,
         size_t h = hash_wide(key * factor, buckets);
         uint64_t tab = table[h];
         while ((uint32_t)tab != empty) {
-            if ((uint32_t)tab == key)
+            if ((uint32_t)tab == key) {
                 emit(agg, out, &o, key, val, (uint32_t)(tab >> 32));
+                if (g_unique) break;
+            }
             if (++h == buckets) h = 0;
             tab = table[h];
         }
@@ -455,14 +467,14 @@ void hjo_phj_build(const uint32_t *keys, const uint32_t *vals, size_t size,
     }
 }
 
-/* phj.cpp:605-647 (scalar form of 399-571) */
+/* phj.cpp:605-647 (scalar form of 399-571); hjo_set_unique(1): first match only */
 void hjo_phj_probe(const uint32_t *keys, const uint32_t *vals, size_t size,
                    const uint64_t *table, size_t buckets, const uint32_t factor[2],
                    uint32_t empty, hjo_result *agg, const hjo_output *out,
                    size_t *o_inout)
 {
 #if defined(__x86_64__)
-    if (g_simd && !out && !o_inout && agg && buckets >= 3 && buckets < (1u << 31)) {
+    if (g_simd && !g_unique && !out && !o_inout && agg && buckets >= 3 && buckets < (1u << 31)) {
         hjo_phj_probe_avx512(keys, vals, size, table, buckets, factor, empty, agg);
         return;
     }
@@ -476,8 +488,10 @@ void hjo_phj_probe(const uint32_t *keys, const uint32_t *vals, size_t size,
         if ((uint32_t)t == empty) continue;
         size_t h2 = hash_wide(k * factor[1], buckets - 1) + 1;
         do {
-            if ((uint32_t)t == k)
+            if ((uint32_t)t == k) {
                 emit(agg, out, &o, k, v, (uint32_t)(t >> 32));
+                if (g_unique) break;                   /* phj.cpp:635-637 */
+            }
             h1 += h2;
             if (h1 >= buckets) h1 -= buckets;
             t = table[h1];

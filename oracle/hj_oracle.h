@@ -50,6 +50,10 @@ typedef struct {
  * returns what is in effect.  Results are identical to the scalar definitions. */
 int hjo_simd_available(void);
 int hjo_set_simd(int on);
+/* The reference's -D_UNIQUE build (npj.cpp:288-290, 436-438; phj.cpp:459, 635-637): a probe tuple
+ * reports its FIRST match only.  Off by default; applies to every probe below (operators and whole
+ * joins); returns what is in effect.  At one thread "first" is the build tuple inserted first. */
+int hjo_set_unique(int on);
 
 /* ---- primitives ------------------------------------------------------- */
 /* mulhi32: ((uint64)x * n) >> 32   (npj.cpp:200-201, phj.cpp:83-100, 721-722) */

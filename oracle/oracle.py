@@ -54,6 +54,8 @@ def lib():
         L.hjo_simd_available.restype = C.c_int
         L.hjo_set_simd.restype = C.c_int
         L.hjo_set_simd.argtypes = [C.c_int]
+        L.hjo_set_unique.restype = C.c_int
+        L.hjo_set_unique.argtypes = [C.c_int]
         for f in (L.hjo_thread_beg, L.hjo_thread_end):
             f.restype = C.c_size_t
             f.argtypes = [C.c_size_t] * 4
@@ -119,6 +121,19 @@ def set_simd(on):
     """Selects the AVX-512 operator forms (the timed CPU baseline) or the scalar definitions
     (default); returns what is in effect.  Results are identical either way."""
     return bool(lib().hjo_set_simd(1 if on else 0))
+
+
+def set_unique(on):
+    """The reference's -D_UNIQUE build: every probe reports its first match only (default off)."""
+    return bool(lib().hjo_set_unique(1 if on else 0))
+
+
+def join_definition_unique(ik, iv, ok, ov):
+    """What a _UNIQUE join must return whatever the table layout: every probe tuple with at least one
+    match counts once -> (count, sum_keys, sum_outer); the build payload is one of the key's payloads."""
+    ik, ok, ov = _c(ik), _c(ok), _c(ov)
+    hit = np.isin(ok, ik)
+    return (int(hit.sum()), int(ok[hit].astype(np.uint64).sum()), int(ov[hit].astype(np.uint64).sum()))
 
 
 def generate(outer, inner, selectivity=1.0, seed=1, unique_factor=0x9E3779B1,
@@ -206,45 +221,56 @@ def cpra(ik, iv, ok, ov, threads=1, load=0.4, num_partitions=4096, seed=7, timin
 _ref = None
 
 
+_ref_unique = None
+
+
 def ref_available():
     return os.path.exists(os.path.join(HERE, "_ref", "libhjref.so"))
 
 
-def ref():
-    """libhjref.so built by oracle/build_ref.py from /root/reference."""
-    global _ref
+def ref(unique=False):
+    """libhjref.so built by oracle/build_ref.py from /root/reference (unique: the same functions
+    compiled with -D_UNIQUE, libhjref_unique.so)."""
+    global _ref, _ref_unique
+    if unique:
+        if _ref_unique is None:
+            _ref_unique = _bind_ref(C.CDLL(os.path.join(HERE, "_ref", "libhjref_unique.so")))
+        return _ref_unique
     if _ref is None:
-        R = C.CDLL(os.path.join(HERE, "_ref", "libhjref.so"))
-        R.hjref_rand32_init.restype = C.c_void_p
-        R.hjref_rand32_init.argtypes = [C.c_uint32]
-        R.hjref_rand32_next.restype = C.c_uint32
-        R.hjref_rand32_next.argtypes = [C.c_void_p]
-        R.hjref_rand32_free.argtypes = [C.c_void_p]
-        R.hjref_shuffle.argtypes = [_u32p, C.c_size_t, C.c_void_p]
-        R.hjref_unique.argtypes = [_u32p, C.c_size_t, _u32p, C.c_size_t, C.c_uint32,
-                                   C.c_uint32, C.c_void_p]
-        for f in (R.hjref_thread_beg, R.hjref_thread_end):
-            f.restype = C.c_size_t
-            f.argtypes = [C.c_size_t] * 4
-        R.hjref_odd_prime.restype = C.c_int
-        R.hjref_odd_prime.argtypes = [C.c_uint64]
-        R.hjref_npj_build.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t,
-                                      C.c_uint32, C.c_uint32]
-        R.hjref_npj_probe.restype = C.c_size_t
-        R.hjref_npj_probe.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t, C.c_uint32,
-                                      C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t, C.c_size_t,
-                                      C.POINTER(C.c_size_t)]
-        R.hjref_close_gaps.restype = C.c_size_t
-        R.hjref_close_gaps.argtypes = [_u32p, _u32p, _u32p, C.POINTER(C.c_size_t), C.c_size_t,
-                                       C.c_size_t]
-        R.hjref_phj_build.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t,
-                                      C.POINTER(C.c_uint32), C.c_uint32]
-        R.hjref_phj_probe.restype = C.c_size_t
-        R.hjref_phj_probe.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t,
-                                      C.POINTER(C.c_uint32), C.c_uint32, _u32p, _u32p, _u32p,
-                                      C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]
-        R.hjref_histogram.argtypes = [_u32p, C.c_size_t, _u32p, C.c_uint32, C.c_size_t]
-        R.hjref_partition.argtypes = [_u32p, _u32p, C.c_size_t, _u32p, _u32p, _u32p,
-                                      C.c_uint32, C.c_size_t]
-        _ref = R
+        _ref = _bind_ref(C.CDLL(os.path.join(HERE, "_ref", "libhjref.so")))
     return _ref
+
+
+def _bind_ref(R):
+    R.hjref_rand32_init.restype = C.c_void_p
+    R.hjref_rand32_init.argtypes = [C.c_uint32]
+    R.hjref_rand32_next.restype = C.c_uint32
+    R.hjref_rand32_next.argtypes = [C.c_void_p]
+    R.hjref_rand32_free.argtypes = [C.c_void_p]
+    R.hjref_shuffle.argtypes = [_u32p, C.c_size_t, C.c_void_p]
+    R.hjref_unique.argtypes = [_u32p, C.c_size_t, _u32p, C.c_size_t, C.c_uint32,
+                               C.c_uint32, C.c_void_p]
+    for f in (R.hjref_thread_beg, R.hjref_thread_end):
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_size_t] * 4
+    R.hjref_odd_prime.restype = C.c_int
+    R.hjref_odd_prime.argtypes = [C.c_uint64]
+    R.hjref_npj_build.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t,
+                                  C.c_uint32, C.c_uint32]
+    R.hjref_npj_probe.restype = C.c_size_t
+    R.hjref_npj_probe.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t, C.c_uint32,
+                                  C.c_uint32, _u32p, _u32p, _u32p, C.c_size_t, C.c_size_t,
+                                  C.POINTER(C.c_size_t)]
+    R.hjref_close_gaps.restype = C.c_size_t
+    R.hjref_close_gaps.argtypes = [_u32p, _u32p, _u32p, C.POINTER(C.c_size_t), C.c_size_t,
+                                   C.c_size_t]
+    R.hjref_phj_build.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t,
+                                  C.POINTER(C.c_uint32), C.c_uint32]
+    R.hjref_phj_probe.restype = C.c_size_t
+    R.hjref_phj_probe.argtypes = [_u32p, _u32p, C.c_size_t, _u64p, C.c_size_t,
+                                  C.POINTER(C.c_uint32), C.c_uint32, _u32p, _u32p, _u32p,
+                                  C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t)]
+    R.hjref_histogram.argtypes = [_u32p, C.c_size_t, _u32p, C.c_uint32, C.c_size_t]
+    R.hjref_partition.argtypes = [_u32p, _u32p, C.c_size_t, _u32p, _u32p, _u32p,
+                                  C.c_uint32, C.c_size_t]
+    return R

@@ -11,6 +11,8 @@ is stored.  Reference functions exercised, per fixture:
   histogram_s / partition_s (cpra2.cpp:730-796)                  -> hist_*, part_*
   build / probe / close_gaps (npj.cpp:190-212, 412-445, 475-514) -> npj_*
   build_s / probe_s (phj.cpp:577-647)                            -> phj_*
+  the same probe / probe_s compiled with -D_UNIQUE (libhjref_unique.so: npj.cpp:436-438,
+  phj.cpp:635-637)                                               -> npj_result_unique, phj_result_unique
 """
 import ctypes as C
 import os
@@ -80,7 +82,8 @@ def part_sums(keys, vals, counts):
     return sk, sv
 
 
-def expected_from_reference(R, ik, iv, ok, ov, allow_npj=True):
+def expected_from_reference(R, ik, iv, ok, ov, allow_npj=True, U=None):
+    """U: the -D_UNIQUE build of the same reference functions (first match only)."""
     out = {}
     # ---- histogram_s / partition_s ----
     for idx, (f, F) in enumerate(HIST_CASES):
@@ -114,6 +117,15 @@ def expected_from_reference(R, ik, iv, ok, ov, allow_npj=True):
         out["npj_table_sorted"] = np.sort(table)
         out["npj_result"] = np.array([n, jk[:n].astype(np.uint64).sum(), jo[:n].astype(np.uint64).sum(),
                                       ji[:n].astype(np.uint64).sum()], np.uint64)
+        if U is not None:
+            jk[:] = 0; jo[:] = 0; ji[:] = 0
+            counter = C.c_size_t(0)
+            end = U.hjref_npj_probe(ok, ov, len(ok), table, buckets, NPJ_FACTOR, 0, jk, jo, ji,
+                                    block, cap // block, C.byref(counter))
+            offs = (C.c_size_t * 1)(end)
+            n = U.hjref_close_gaps(jk, jo, ji, offs, 1, block)
+            out["npj_result_unique"] = np.array([n, jk[:n].astype(np.uint64).sum(), jo[:n].astype(np.uint64).sum(),
+                                                 ji[:n].astype(np.uint64).sum()], np.uint64)
     # ---- PHJ operators on the whole relation as one partition ----
     buckets = int(O.lib().hjo_next_odd_prime(int(len(ik) / PHJ_LOAD)))
     table = np.zeros(buckets, np.uint64)
@@ -134,6 +146,15 @@ def expected_from_reference(R, ik, iv, ok, ov, allow_npj=True):
     out["phj_table_sorted"] = np.sort(table)
     out["phj_result"] = np.array([n, jk[:n].astype(np.uint64).sum(), jo[:n].astype(np.uint64).sum(),
                                   ji[:n].astype(np.uint64).sum()], np.uint64)
+    if U is not None:
+        jk[:] = 0; jo[:] = 0; ji[:] = 0
+        counter = C.c_size_t(1)
+        end = U.hjref_phj_probe(ok, ov, len(ok), table, buckets, fac, empty, jk, jo, ji, 0,
+                                block, cap // block, C.byref(counter))
+        offs = (C.c_size_t * 1)(end)
+        n = U.hjref_close_gaps(jk, jo, ji, offs, 1, block)
+        out["phj_result_unique"] = np.array([n, jk[:n].astype(np.uint64).sum(), jo[:n].astype(np.uint64).sum(),
+                                             ji[:n].astype(np.uint64).sum()], np.uint64)
     return out
 
 
@@ -141,6 +162,7 @@ def main():
     if not O.ref_available():
         sys.exit("oracle/_ref/libhjref.so missing: run oracle/build_ref.py where /root/reference exists")
     R = O.ref()
+    U = O.ref(unique=True)
     gen = R.hjref_rand32_init(5489)
     stream = np.array([R.hjref_rand32_next(gen) for _ in range(1000)], np.uint32)
     R.hjref_rand32_free(gen)
@@ -155,12 +177,21 @@ def main():
     for name, (outer, inner, sel, seed) in fixtures.items():
         uf, fi, fo = 0x9E3779B1, 0x2545F491, 0x85EBCA6B
         ik, iv, ok, ov = ref_generate(R, outer, inner, sel, seed, uf, fi, fo)
-        exp = expected_from_reference(R, ik, iv, ok, ov)
+        exp = expected_from_reference(R, ik, iv, ok, ov, U=U)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), inner_keys=ik, inner_vals=iv,
                             outer_keys=ok, outer_vals=ov,
                             gen_params=np.array([outer, inner, int(sel * 1000), seed, uf, fi, fo], np.uint64),
                             **exp)
-        print(name, "npj", exp["npj_result"], "phj", exp["phj_result"])
+        print(name, "npj", exp["npj_result"], "phj", exp["phj_result"], "unique", exp["npj_result_unique"], exp["phj_result_unique"])
+    # _UNIQUE with build duplicates that carry DIFFERENT payloads: which duplicate a probe reports is then
+    # visible in sum_inner_vals.  At one thread the reference's tables hold a key's duplicates in insertion
+    # order along the probe sequence, so "first match" = the build tuple that comes first in the relation.
+    ik, iv, ok, ov = ref_generate(R, 3000, 12000, 0.75, 14, 0x9E3779B1, 0x2545F491, 0x85EBCA6B)
+    iv = ((np.arange(len(ik), dtype=np.uint64) * 0x9E3779B97F4A7C15 >> np.uint64(29)) & 0xFFFFFFFF).astype(np.uint32)
+    exp = expected_from_reference(R, ik, iv, ok, ov, U=U)
+    np.savez_compressed(os.path.join(HERE, "dups4_distinct_payloads.npz"), inner_keys=ik, inner_vals=iv,
+                        outer_keys=ok, outer_vals=ov, **exp)
+    print("dups4_distinct_payloads npj", exp["npj_result"], "unique", exp["npj_result_unique"], exp["phj_result_unique"])
     # sentinel edge case: key 0 and extreme keys present (PHJ/CPRA only; NPJ reserves key 0)
     rng = np.random.default_rng(99)
     ik = np.unique(rng.integers(1, 2**32, size=1500, dtype=np.uint64).astype(np.uint32))[:1000].copy()
@@ -170,7 +201,7 @@ def main():
     ok[:4] = [0, 0, 0xFFFFFFFF, 1]
     iv = (ik.astype(np.uint64) * 0x2545F491 + 7).astype(np.uint32)
     ov = (ok.astype(np.uint64) * 0x85EBCA6B + 3).astype(np.uint32)
-    exp = expected_from_reference(R, ik, iv, ok, ov, allow_npj=False)
+    exp = expected_from_reference(R, ik, iv, ok, ov, allow_npj=False, U=U)
     np.savez_compressed(os.path.join(HERE, "key_zero_and_extremes.npz"), inner_keys=ik, inner_vals=iv,
                         outer_keys=ok, outer_vals=ov, **exp)
     print("key_zero_and_extremes phj", exp["phj_result"], exp["phj_buckets"])

@@ -71,7 +71,7 @@ def test_random_join_matches_numpy(hj, case):
     want = numpy_join(ik, iv, ok, ov)
     rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
     if case["dense2"]:
-        os.environ["HJGPU_DENSE2"] = "1"
+        hj.set_option("dense2", 1)
     try:
         prm = H.PhjParams(fanout1=case["f1"], fanout2=case["f2"], chunks=case["chunks"])
         assert hj.phj(rk, rv, len(ik), sk, sv, len(ok), prm) == want
@@ -97,6 +97,6 @@ def test_random_join_matches_numpy(hj, case):
             for c in (jk, jo, ji):
                 c.free()
     finally:
-        os.environ.pop("HJGPU_DENSE2", None)
+        hj.set_option("dense2", 0)
         for c in (rk, rv, sk, sv):
             c.free()

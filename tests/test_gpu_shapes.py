@@ -198,12 +198,12 @@ def test_broadcast_join_of_a_build_side_that_fits_one_table(hj, inner):
     assert hj.phj(rk, rv, inner, sk, sv, outer) == want
     st = hj.stats()
     assert ((st["fanout1"], st["fanout2"]) == (1, 1)) == (inner <= 6963)
-    os.environ["HJGPU_NO_BROADCAST"] = "1"
+    hj.set_option("no_broadcast", 1)
     try:
         assert hj.phj(rk, rv, inner, sk, sv, outer) == want
         assert hj.stats()["fanout1"] >= 2
     finally:
-        del os.environ["HJGPU_NO_BROADCAST"]
+        hj.set_option("no_broadcast", 0)
     if want[0] <= 20_000_000:
         block = 1024
         cap = (want[0] // block + hj.device_info()["compute_units"] * 16 + 8) * block
@@ -245,3 +245,68 @@ def test_oversize_build_partition_materialised(hj, algorithm):
         assert np.array_equal(a, b)
     for c in (rk, rv, sk, sv, jk, jo, ji):
         c.free()
+
+
+def test_prepared_build_probed_by_a_batch_with_more_ranges_than_max_outer(hj):
+    """The tiles per pass-1 range jump at 512-tile multiples, so a 12 M-row batch has MORE ranges (733) than the
+    18 M rows the build side was prepared for (550): the per-range tables are sized for every batch up to
+    max_outer (round 1 sized them for max_outer itself and the smaller batch wrote past them)."""
+    inner, outer = 3_000_000, 30_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(21, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    for prm in (None, H.PhjParams(fanout1=128, fanout2=8)):
+        hj.phj_build(ik, iv, inner, 18_000_000, prm)
+        total = (0, 0, 0, 0)
+        for b, e in ((0, 12_000_000), (12_000_000, 30_000_000)):
+            part = hj.phj_probe(ok.ptr + 4 * b, ov.ptr + 4 * b, e - b)
+            assert part[0] == e - b
+            total = tuple((x + y) & ((1 << 64) - 1) for x, y in zip(total, part))
+        assert total == want
+    for c in (ik, iv, ok, ov):
+        c.free()
+
+
+def test_two_contexts_on_two_host_threads_with_different_options(hj, oracle):
+    """hjgpu.h: "thread-safe per context".  Two contexts, two host threads, overlapping joins, each context with
+    its own options (one forces the chained tables and _UNIQUE): nothing on a launch path reads the environment
+    or mutable process-wide state any more (round 1: a function-local static rewritten per call and eight
+    getenv()s), so the results of one thread do not depend on what the other one does."""
+    import threading
+    ik, iv, ok, ov = oracle.generate(400_000, 1_600_000, seed=6)                 # 4 copies per build key
+    want_all = numpy_join(ik, iv, ok, ov)
+    hit = np.isin(ok, ik)
+    want_unique = oracle.join_definition_unique(ik, iv, ok, ov)
+    errors = []
+
+    def worker(unique):
+        try:
+            with H.HjGpu() as ctx:
+                if unique:
+                    ctx.set_option("unique", 1)
+                    ctx.set_option("force_chained", 1)
+                    ctx.set_option("dense2", 1)
+                rk, rv, sk, sv = (ctx.column(c) for c in (ik, iv, ok, ov))
+                for i in range(12):
+                    prm = H.PhjParams(fanout1=8 + i, fanout2=1 + i % 3, chunks=1 + i % 4)
+                    for fn in (ctx.phj, ctx.cpra):
+                        got = fn(rk, rv, len(ik), sk, sv, len(ok), prm)
+                        if (got[:3] != want_unique) if unique else (got != want_all):
+                            errors.append((unique, i, got))
+                    got = ctx.npj(rk, rv, len(ik), sk, sv, len(ok))
+                    if (got[:3] != want_unique) if unique else (got != want_all):
+                        errors.append((unique, i, "npj", got))
+                for c in (rk, rv, sk, sv):
+                    c.free()
+        except Exception as ex:          # surfaces in the main thread
+            errors.append((unique, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(u,)) for u in (False, True)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    assert int(hit.sum()) == want_unique[0]
