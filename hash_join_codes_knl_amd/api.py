@@ -13,21 +13,25 @@ import numpy as np
 
 from . import build as _build
 
-OK, EINVAL, EALIGN, ENOMEM, EHIP, EZEROKEY, EOVERFLOW, ENODEVICE = range(8)
+OK, EINVAL, EALIGN, ENOMEM, EHIP, EZEROKEY, EOVERFLOW, ENODEVICE, ERCCL = range(9)
+TRANSPORT_RCCL, TRANSPORT_LOOPBACK = 0, 1
 MAX_FANOUT = 1024
 MAX_PARTS = 32768
 FLAG_UNIQUE = 1
 
 EXPORTS = [
-    "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
+    "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
     "hjgpu_get_device_info", "hjgpu_set_option", "hjgpu_reserve", "hjgpu_get_stats",
     "hjgpu_malloc", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
     "hjgpu_host_alloc", "hjgpu_host_free",
-    "hjgpu_histogram", "hjgpu_partition", "hjgpu_join_partitions",
+    "hjgpu_histogram", "hjgpu_partition", "hjgpu_partition_async", "hjgpu_join_partitions",
     "hjgpu_npj_build", "hjgpu_npj_probe",
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
     "hjgpu_phj_build", "hjgpu_phj_probe", "hjgpu_phj_probe_async",
+    "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
+    "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
+    "hjgpu_phj_multi", "hjgpu_npj_multi", "hjgpu_cpra_multi", "hjgpu_join_host_multi",
     "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums", "hjgpu_stream_read_ms",
 ]
 
@@ -72,6 +76,27 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class Shard(C.Structure):
+    """hjgpu_shard: one rank's share of the relations (device pointers on that rank's device)."""
+    _fields_ = [("d_inner_keys", C.c_void_p), ("d_inner_vals", C.c_void_p), ("inner", C.c_size_t),
+                ("d_outer_keys", C.c_void_p), ("d_outer_vals", C.c_void_p), ("outer", C.c_size_t)]
+
+
+class MultiStats(C.Structure):
+    _fields_ = [("ms_wall", C.c_float), ("ms_exchange", C.c_float), ("ms_partition", C.c_float),
+                ("ms_exchange_wait", C.c_float), ("joins", C.c_uint32), ("reserved", C.c_uint32),
+                ("tuples_joined", C.c_uint64), ("bytes_sent", C.c_uint64), ("join", Stats)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("join", "reserved")}
+        d["join"] = self.join.as_dict()
+        return d
+
+
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int),
                 ("lds_bytes_per_block", C.c_int), ("hbm_bytes", C.c_uint64)]
@@ -111,6 +136,7 @@ def load_library(build_if_missing=True):
         _build.build_library(verbose=False)
     L = C.CDLL(so)
     vp, sz, u32, u64p = C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64)
+    L.hjgpu_device_count.argtypes = [C.POINTER(C.c_int)]
     L.hjgpu_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.hjgpu_destroy.argtypes = [vp]
     L.hjgpu_last_error.restype = C.c_char_p
@@ -131,6 +157,23 @@ def load_library(build_if_missing=True):
     L.hjgpu_host_free.argtypes = [vp, vp]
     L.hjgpu_histogram.argtypes = [vp, vp, sz, u32, u32, vp, vp]
     L.hjgpu_partition.argtypes = [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]
+    L.hjgpu_partition_async.argtypes = [vp, vp, vp, sz, u32, u32, vp, vp, vp, vp]
+    L.hjgpu_comm_create_local.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.hjgpu_comm_get_id.argtypes = [C.POINTER(CommId)]
+    L.hjgpu_comm_create_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(CommId), C.POINTER(vp)]
+    L.hjgpu_comm_destroy.argtypes = [vp]
+    L.hjgpu_comm_last_error.restype = C.c_char_p
+    L.hjgpu_comm_last_error.argtypes = [vp]
+    L.hjgpu_comm_size.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.hjgpu_comm_ctx.restype = vp
+    L.hjgpu_comm_ctx.argtypes = [vp, C.c_int]
+    L.hjgpu_comm_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.hjgpu_comm_barrier.argtypes = [vp]
+    L.hjgpu_phj_multi.argtypes = [vp, C.POINTER(Shard), C.c_int, C.POINTER(PhjParams), C.POINTER(Result), C.POINTER(MultiStats)]
+    L.hjgpu_npj_multi.argtypes = [vp, C.POINTER(Shard), C.c_int, C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(MultiStats)]
+    L.hjgpu_cpra_multi.argtypes = [vp, C.POINTER(Shard), C.POINTER(PhjParams), C.c_int, C.POINTER(Result), C.POINTER(MultiStats)]
+    L.hjgpu_join_host_multi.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams), C.POINTER(NpjParams),
+                                        C.POINTER(Result), C.POINTER(MultiStats)]
     L.hjgpu_join_partitions.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(PhjParams),
                                         C.POINTER(Result), C.POINTER(Output), vp]
     L.hjgpu_npj_build.argtypes = [vp, vp, vp, sz, vp, sz, u32, vp]
@@ -156,7 +199,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_generate_zipf.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, C.c_double, vp, vp, vp, vp, vp]
     L.hjgpu_column_sums.argtypes = [vp, vp, sz, u32, u32, u64p, vp]
     for name in EXPORTS:
-        if name not in ("hjgpu_last_error", "hjgpu_status_string"):
+        if name not in ("hjgpu_last_error", "hjgpu_status_string", "hjgpu_comm_last_error", "hjgpu_comm_ctx"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -198,8 +241,12 @@ class DeviceColumn:
 class HjGpu:
     """One hjgpu_ctx.  Methods are named after the C entry points (hjgpu_ prefix dropped)."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, _borrowed=None):
         self.lib = load_library()
+        self._owned = _borrowed is None
+        if _borrowed is not None:          # a communicator's context (hjgpu_comm_ctx): destroyed with the communicator
+            self.handle = C.c_void_p(_borrowed)
+            return
         h = C.c_void_p()
         st = self.lib.hjgpu_create(device, C.byref(h))
         if st != OK:
@@ -207,9 +254,9 @@ class HjGpu:
         self.handle = h
 
     def close(self):
-        if self.handle:
+        if self.handle and self._owned:
             self.lib.hjgpu_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __enter__(self):
         return self
@@ -267,6 +314,11 @@ class HjGpu:
     def histogram(self, d_keys, n, factor, fanout, d_counts, stream=None):
         self._check(self.lib.hjgpu_histogram(self.handle, self._ptr(d_keys), n, factor, fanout,
                                              self._ptr(d_counts), stream))
+
+    def partition_async(self, d_keys, d_vals, n, factor, fanout, d_keys_out, d_vals_out, d_offsets, stream=None):
+        self._check(self.lib.hjgpu_partition_async(self.handle, self._ptr(d_keys), self._ptr(d_vals), n,
+                                                   factor, fanout, self._ptr(d_keys_out),
+                                                   self._ptr(d_vals_out), self._ptr(d_offsets), stream))
 
     def partition(self, d_keys, d_vals, n, factor, fanout, d_keys_out, d_vals_out, d_offsets,
                   stream=None):
@@ -420,3 +472,103 @@ class HjGpu:
         sums = (C.c_uint64 * 3)()
         self._check(self.lib.hjgpu_column_sums(self.handle, self._ptr(d_keys), n, fa, fb, sums, stream))
         return tuple(int(x) for x in sums)
+
+
+class HjComm:
+    """One hjgpu_comm: the ranks of a multi-GPU join that live in this process.
+
+    HjComm.local(n, devices, transport): every rank in this process (RCCL: one rank per device; LOOPBACK: ranks may
+    share a device, messages are device-to-device copies).  HjComm.rank(device, n, rank, id): one rank per process,
+    `id` = HjComm.new_id() of rank 0, passed around by the launcher (bench.py: torch.distributed's gloo group)."""
+
+    def __init__(self, handle):
+        self.lib = load_library()
+        self.handle = handle
+        n, l, f = C.c_int(), C.c_int(), C.c_int()
+        self.lib.hjgpu_comm_size(self.handle, C.byref(n), C.byref(l), C.byref(f))
+        self.nranks, self.nlocal, self.first_rank = n.value, l.value, f.value
+        self.ctx = [HjGpu(_borrowed=self.lib.hjgpu_comm_ctx(self.handle, i)) for i in range(self.nlocal)]
+
+    @classmethod
+    def local(cls, nranks, devices=None, transport=TRANSPORT_RCCL):
+        lib = load_library()
+        h = C.c_void_p()
+        devs = (C.c_int * nranks)(*devices) if devices is not None else None
+        st = lib.hjgpu_comm_create_local(nranks, devs, transport, C.byref(h))
+        if st != OK:
+            raise HjGpuError(st, lib.hjgpu_status_string(st).decode())
+        return cls(h)
+
+    @staticmethod
+    def new_id():
+        lib = load_library()
+        cid = CommId()
+        st = lib.hjgpu_comm_get_id(C.byref(cid))
+        if st != OK:
+            raise HjGpuError(st, lib.hjgpu_status_string(st).decode())
+        return bytes(bytearray(C.string_at(C.addressof(cid), 128)))
+
+    @classmethod
+    def rank(cls, device, nranks, rank, comm_id):
+        lib = load_library()
+        h = C.c_void_p()
+        cid = CommId()
+        C.memmove(C.addressof(cid), comm_id, 128)
+        st = lib.hjgpu_comm_create_rank(device, nranks, rank, C.byref(cid), C.byref(h))
+        if st != OK:
+            raise HjGpuError(st, lib.hjgpu_status_string(st).decode())
+        return cls(h)
+
+    def close(self):
+        if self.handle:
+            self.lib.hjgpu_comm_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st):
+        if st != OK:
+            raise HjGpuError(st, "%s: %s" % (self.lib.hjgpu_status_string(st).decode(),
+                                             self.lib.hjgpu_comm_last_error(self.handle).decode()))
+
+    def set_option(self, name, value):
+        self._check(self.lib.hjgpu_comm_set_option(self.handle, name.encode(), str(int(value)).encode()))
+
+    def barrier(self):
+        self._check(self.lib.hjgpu_comm_barrier(self.handle))
+
+    def _shards(self, shards):
+        """shards: one (rk, rv, inner, sk, sv, outer) per local rank; columns are DeviceColumns / pointers / None."""
+        assert len(shards) == self.nlocal
+        arr = (Shard * self.nlocal)()
+        for i, (rk, rv, inner, sk, sv, outer) in enumerate(shards):
+            p = HjGpu._ptr
+            arr[i] = Shard(p(rk), p(rv), inner, p(sk), p(sv), outer)
+        return arr
+
+    def _run(self, fn, shards, *mid):
+        r, s = Result(), MultiStats()
+        self._check(fn(self.handle, self._shards(shards), *mid, C.byref(r), C.byref(s)))
+        return r.as_tuple(), s.as_dict()
+
+    def phj_multi(self, shards, root=0, params=None):
+        return self._run(self.lib.hjgpu_phj_multi, shards, root, C.byref(params) if params is not None else None)
+
+    def npj_multi(self, shards, root=0, params=None):
+        return self._run(self.lib.hjgpu_npj_multi, shards, root, C.byref(params) if params is not None else None)
+
+    def cpra_multi(self, shards, params=None, slices=0):
+        return self._run(self.lib.hjgpu_cpra_multi, shards, C.byref(params) if params is not None else None, slices)
+
+    def join_host_multi(self, algorithm, ik, iv, ok, ov, phj_params=None, npj_params=None):
+        ik, iv, ok, ov = (np.ascontiguousarray(c, np.uint32) for c in (ik, iv, ok, ov))
+        r, s = Result(), MultiStats()
+        self._check(self.lib.hjgpu_join_host_multi(
+            self.handle, algorithm, ik.ctypes.data, iv.ctypes.data, ik.size, ok.ctypes.data, ov.ctypes.data, ok.size,
+            C.byref(phj_params) if phj_params is not None else None,
+            C.byref(npj_params) if npj_params is not None else None, C.byref(r), C.byref(s)))
+        return r.as_tuple(), s.as_dict()

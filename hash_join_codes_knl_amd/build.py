@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "lib")
 ARCH = "gfx950"
 
 KERNEL_SOURCES = ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip",
-                  "gen_kernels.hip", "hjgpu_api.hip"]
+                  "gen_kernels.hip", "hjgpu_api.hip", "hjgpu_multi.hip"]
 HOST_PROGRAMS = {"npj": "npj_main.cpp", "phj": "phj_main.cpp", "cpra": "cpra_main.cpp",
                  "write": "write_main.cpp"}
 
@@ -58,7 +58,9 @@ def build_library(force=False, verbose=True):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs
+    # RCCL (multi-GPU joins, csrc/hjgpu_multi.hip) is linked by soname: a process that has already loaded
+    # torch's copy of librccl.so.1 keeps using that one
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

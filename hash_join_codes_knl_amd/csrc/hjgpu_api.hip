@@ -617,6 +617,14 @@ const char *hjgpu_status_string(int s)
     }
 }
 
+int hjgpu_device_count(int *count)
+{
+    if (!count) return HJGPU_EINVAL;
+    *count = 0;
+    if (hipGetDeviceCount(count) != hipSuccess) { *count = 0; (void)hipGetLastError(); return HJGPU_ENODEVICE; }
+    return HJGPU_OK;
+}
+
 int hjgpu_create(int device, hjgpu_ctx **out)
 {
     if (!out) return HJGPU_EINVAL;
@@ -805,9 +813,9 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
     return HJGPU_OK;
 }
 
-int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                    uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
-                    uint64_t *d_offsets, void *stream_)
+int hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                          uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
+                          uint64_t *d_offsets, void *stream_)
 {
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
@@ -816,11 +824,16 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     CHK(check_columns(ctx, d_keys, d_vals, n));
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(refuse_capture(ctx, stream));
     const Pass1Geom geom = make_geom(ctx->tune, d_keys, n, 1, fanout, false);
     MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
     ctx->prepared = false;                 // the workspace is re-planned below
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
+    // hjgpu_get_stats().ms_total afterwards = duration of the whole operator (histogram + plan + scatter)
+    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
+    ctx->last_algo = 2;
+    record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
     if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets,
                                ctx->cus, stream));
@@ -851,7 +864,16 @@ int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
                                hipMemcpyDeviceToDevice, stream));
-    HIPCHK(ctx, hipStreamSynchronize(stream));
+    record(ctx, EV_GAPS, stream);
+    return HJGPU_OK;
+}
+
+int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                    uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
+                    uint64_t *d_offsets, void *stream_)
+{
+    CHK(hjgpu_partition_async(ctx, d_keys, d_vals, n, factor, fanout, d_keys_out, d_vals_out, d_offsets, stream_));
+    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream_));
     return HJGPU_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hjgpu.h"
@@ -32,7 +33,8 @@ inline Args parse(int argc, char **argv, double extra_default)
 {
     Args a;
     // defaults of the reference: hardware_threads(), 200 M, 200 M (npj.cpp:932-935)
-    a.threads = argc > 1 ? atoi(argv[1]) : 1;
+    a.threads = argc > 1 ? atoi(argv[1]) : (int)std::thread::hardware_concurrency();
+    if (a.threads < 1) a.threads = 1;
     a.outer = argc > 2 ? (size_t)atoll(argv[2]) : (size_t)200 * 1000 * 1000;
     a.inner = argc > 3 ? (size_t)atoll(argv[3]) : (size_t)200 * 1000 * 1000;
     a.extra = argc > 4 ? atof(argv[4]) : extra_default;
@@ -101,8 +103,9 @@ inline bool load_relations(const Args &a, Relations &r)
 // Loads the four column files, runs one join on the GPU and prints the extended report on stderr;
 // the reference's own stdout line is printed by each main in its own format.
 // Exit codes of the mains: 2 = input files, 1 = no GPU / join failed.
-inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats *st)
+inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats *st, double *exchange_seconds = nullptr)
 {
+    if (exchange_seconds) *exchange_seconds = 0.0;
     // the files are checked before the device is touched: a missing input is reported as such
     const char *prefix[4] = {"ik", "iv", "ok", "ov"};
     const size_t tuples[4] = {a.inner, a.inner, a.outer, a.outer};
@@ -111,8 +114,74 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
         if (!f) { fprintf(stderr, "cannot open %s (generate it with ./write)\n", column_path(prefix[i], tuples[i]).c_str()); return -2; }
         fclose(f);
     }
+    // ---- several GPUs: every visible device takes a share (HJGPU_DEVICES="0,2,5" picks them) -------------
+    // The reference's #threads workers become the GPUs of the node: PHJ / NPJ replicate the build side and
+    // shard the probe side, CPRA chunks both sides and co-partitions them (include/hjgpu.h, multi-GPU joins).
+    // HJGPU_TRANSPORT=loopback with HJGPU_RANKS=<n> runs n ranks on ONE device (tests of this host path).
+    std::vector<int> devices;
+    int transport = HJGPU_TRANSPORT_RCCL;
+    {
+        int visible = 0;
+        (void)hjgpu_device_count(&visible);
+        const char *tr = getenv("HJGPU_TRANSPORT"), *rk = getenv("HJGPU_RANKS"), *dv = getenv("HJGPU_DEVICES");
+        if (tr && strcmp(tr, "loopback") == 0) transport = HJGPU_TRANSPORT_LOOPBACK;
+        if (dv && *dv) {
+            for (const char *p = dv; *p;) {
+                char *end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                devices.push_back((int)d);
+                p = *end == ',' ? end + 1 : end;
+            }
+        } else {
+            const int n = (transport == HJGPU_TRANSPORT_LOOPBACK && rk) ? atoi(rk) : visible;
+            for (int i = 0; i < n; ++i) devices.push_back(transport == HJGPU_TRANSPORT_LOOPBACK ? i % (visible > 0 ? visible : 1) : i);
+        }
+    }
+    const char *rows_req = getenv("HJGPU_ROWS");
+    const bool rows_wanted = rows_req && *rows_req && strcmp(rows_req, "0") != 0;
+    if (devices.size() > 1 && rows_wanted)
+        fprintf(stderr, "HJGPU_ROWS: materialised rows come from one GPU; running on device %d only\n", devices[0]);
+    if (devices.size() > 1 && !rows_wanted) {
+        hjgpu_comm *comm = nullptr;
+        int rc = hjgpu_comm_create_local((int)devices.size(), devices.data(), transport, &comm);
+        if (rc != HJGPU_OK) { fprintf(stderr, "hjgpu_comm_create_local(%zu ranks): %s\n", devices.size(), hjgpu_status_string(rc)); return rc; }
+        hjgpu_ctx *ctx0 = hjgpu_comm_ctx(comm, 0);
+        {
+            PinnedRelations r;
+            r.ctx = ctx0; r.inner = a.inner; r.outer = a.outer;
+            for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) {
+                rc = hjgpu_host_alloc(ctx0, (void **)&r.col[i], tuples[i] * sizeof(uint32_t));
+                if (rc != HJGPU_OK) fprintf(stderr, "host allocation failed: %s\n", hjgpu_last_error(ctx0));
+                else if (!read_into(column_path(prefix[i], tuples[i]), tuples[i], r.col[i])) rc = -2;
+            }
+            hjgpu_multi_stats ms;
+            memset(&ms, 0, sizeof(ms));
+            if (rc == HJGPU_OK) {
+                rc = hjgpu_join_host_multi(comm, algorithm, r.col[0], r.col[1], a.inner, r.col[2], r.col[3], a.outer,
+                                           nullptr, nullptr, res, &ms);
+                if (rc != HJGPU_OK) fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_comm_last_error(comm));
+            }
+            if (rc == HJGPU_OK) {
+                *st = ms.join;
+                st->ms_total = ms.ms_wall;                 // the step as the host saw it: exchange + local joins
+                if (exchange_seconds) *exchange_seconds = ms.ms_exchange * 1e-3;
+                fprintf(stderr, "%zu ranks (%s): %s\n", devices.size(), transport == HJGPU_TRANSPORT_LOOPBACK ? "loopback" : "RCCL",
+                        algorithm == 2 ? "both sides chunked, co-partitioned by all-to-all-v" : "build side replicated, probe side sharded");
+                fprintf(stderr, "join_tuples=%llu sum_keys=%llu sum_outer_vals=%llu sum_inner_vals=%llu\n",
+                        (unsigned long long)res->count, (unsigned long long)res->sum_keys,
+                        (unsigned long long)res->sum_outer_vals, (unsigned long long)res->sum_inner_vals);
+                fprintf(stderr, "step %.4f s: %.2f Gtuples/s probe-side; rank 0: exchange %.4f s (%.1f MB sent), partitioning %.4f s, "
+                                "%u local joins %.4f s, waited %.4f s for exchanges\n",
+                        ms.ms_wall * 1e-3, ms.ms_wall > 0 ? a.outer / (ms.ms_wall * 1e-3) / 1e9 : 0.0, ms.ms_exchange * 1e-3,
+                        ms.bytes_sent / 1e6, ms.ms_partition * 1e-3, ms.joins, ms.join.ms_total * 1e-3, ms.ms_exchange_wait * 1e-3);
+            }
+        }   // pinned columns are released before the communicator (they belong to its rank-0 context)
+        hjgpu_comm_destroy(comm);
+        return rc;
+    }
     hjgpu_ctx *ctx = nullptr;
-    int rc = hjgpu_create(-1, &ctx);
+    int rc = hjgpu_create(devices.empty() ? -1 : devices[0], &ctx);
     if (rc != HJGPU_OK) { fprintf(stderr, "hjgpu_create: %s\n", hjgpu_status_string(rc)); return rc; }
     {
         PinnedRelations r;
@@ -124,7 +193,12 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
         }
         hjgpu_phj_params pp;
         memset(&pp, 0, sizeof(pp));
-        if (algorithm == 2) pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 8 ? a.threads : 8);
+        if (algorithm == 2) {
+            // #threads = independently partitioned chunks (cpra2.cpp:1757-1827); the library takes up to 8
+            pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 8 ? a.threads : 8);
+            if ((int)pp.chunks != a.threads)
+                fprintf(stderr, "cpra: %d chunks requested, %u used (the result does not depend on the chunk count)\n", a.threads, pp.chunks);
+        }
         hjgpu_npj_params np;
         memset(&np, 0, sizeof(np));
         // HJGPU_ROWS=1: materialise the join into three host columns, as the reference's mains do

@@ -1,6 +1,7 @@
 // ./phj [#threads] [outer_tuples] [inner_tuples] [ratio]  — phj.cpp:1959-2231.
 // stdout: "%lf\t%lf\t%lf\t\n" = max / thread-0 / thread-128 seconds (phj.cpp:2197);
-// one device runs the whole join here, so the three columns carry the same time.
+// a GPU (or, with several visible, all of them: host_common.hpp) runs the whole join, so the three columns carry
+// the same time.
 #include "host_common.hpp"
 
 int main(int argc, char **argv)

@@ -85,7 +85,8 @@ typedef struct {
     uint32_t factor1, factor2; /* odd pass multipliers; 0 = library defaults                 */
     uint32_t table_factor[2];  /* odd table hash / step multipliers; 0 = defaults            */
     uint32_t chunks;           /* CPRA only: number of independently partitioned chunks
-                                  (the reference's #threads, cpra2.cpp:1757-1827); 0 = 8     */
+                                  (the reference's #threads, cpra2.cpp:1757-1827); 0 = 8;
+                                  1..8 (HJGPU_EINVAL beyond: the result does not depend on it) */
     uint32_t flags;            /* HJGPU_FLAG_*                                               */
 } hjgpu_phj_params;
 
@@ -123,6 +124,7 @@ typedef struct {
 } hjgpu_device_info;
 
 /* ---- context ---------------------------------------------------------------- */
+int  hjgpu_device_count(int *count);                      /* visible GPUs (hosts that do not link HIP) */
 int  hjgpu_create(int device, hjgpu_ctx **ctx);           /* device < 0: current device      */
 int  hjgpu_destroy(hjgpu_ctx *ctx);
 const char *hjgpu_last_error(const hjgpu_ctx *ctx);
@@ -166,6 +168,12 @@ int  hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_v
                      uint32_t factor, uint32_t fanout,
                      uint32_t *d_keys_out, uint32_t *d_vals_out, uint64_t *d_offsets,
                      void *stream);
+/* Enqueue-only form (no host synchronisation; d_offsets is valid once `stream` has reached this point):
+ * the exchange-level partitioning of the multi-GPU CPRA keeps several GPUs busy from one host thread. */
+int  hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                           uint32_t factor, uint32_t fanout,
+                           uint32_t *d_keys_out, uint32_t *d_vals_out, uint64_t *d_offsets,
+                           void *stream);
 /* build()+probe() over co-partitioned relations (phj.cpp:307, 399; the commented
  * join loop phj.cpp:1869-1924 / live cpra2.cpp:1883-1971): for every partition p,
  * R rows [d_inner_offsets[p], [p+1]) are loaded into an LDS hash table and S rows
@@ -283,6 +291,90 @@ int  hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm /* 0 npj, 1 phj, 2 cpra 
                           const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
                           const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
                           const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats);
+
+/* ---- multi-GPU joins ------------------------------------------------------------------------------
+ * The reference's cross-worker exchange is part of run_hj itself: phj.cpp:1715-1770 (thread-level pass: both
+ * relations are exchanged between the threads) and cpra2.cpp:1861-1971 (thread t owns partitions
+ * [t*P/T, (t+1)*P/T), cpra2.cpp:1868-1872, and gathers them from every thread's chunk by memcpy).  Here a
+ * RANK is one GPU's share of a join and the exchange is RCCL over xGMI, called from this library (C++):
+ *   hjgpu_phj_multi / hjgpu_npj_multi   build side replicated from `root` (scatter of 1/G slices over the root's
+ *       G-1 links + all-gather, or one ring broadcast), probe side sharded (thread_beg / thread_end ranges with
+ *       T = G, npj.cpp:516-529), complete local join per rank - the replication overlaps the probe side's
+ *       partitioning -, ncclAllReduce of the four aggregates.  Valid because R join S = union_g (R join S_g).
+ *   hjgpu_cpra_multi   both relations chunked over the ranks (cpra2.cpp:1737-1742); every rank partitions its own
+ *       chunk with fan-out G (cpra2.cpp:1757-1827), the counts are all-gathered (cpra2.cpp:1834-1840: counts
+ *       published, barrier), rank g receives partition g of every chunk by grouped ncclSend / ncclRecv
+ *       (all-to-all-v; the memcpy gather cpra2.cpp:1891-1959), local PHJ, ncclAllReduce.  The probe side travels
+ *       in `slices` pieces: slice i+1 is partitioned and slice i-1 joined (build side prepared once,
+ *       hjgpu_phj_build / hjgpu_phj_probe) while slice i is on the links.
+ * A communicator holds one or more LOCAL ranks (one host thread drives them: grouped RCCL calls):
+ *   hjgpu_comm_create_local   every rank in this process, ranks[i] on devices[i]: what ./phj and ./cpra use
+ *       (all visible GPUs).  transport RCCL = ncclCommInitAll; transport LOOPBACK = exchanges are hipMemcpyAsync
+ *       between the ranks' buffers, ranks may share a device: the complete orchestration (ownership, counts,
+ *       slicing, reductions) then runs at any world size on ONE GPU with the real kernels (tests), or across
+ *       the GPUs of a node by peer copies.
+ *   hjgpu_comm_create_rank    one rank per process (torchrun, MPI): ncclCommInitRank with the id that rank 0
+ *       got from hjgpu_comm_get_id and passed around (bench.py: over torch.distributed's gloo store).
+ * Every process must make the same sequence of *_multi calls with the same `slices` / root / |R| (collectives).
+ * The calls return when the result is on the host; it is the GLOBAL result on every rank. */
+typedef struct hjgpu_comm hjgpu_comm;
+#define HJGPU_TRANSPORT_RCCL      0
+#define HJGPU_TRANSPORT_LOOPBACK  1
+#define HJGPU_ERCCL               8   /* RCCL error (text in hjgpu_comm_last_error)                */
+typedef struct { char bytes[128]; } hjgpu_comm_id;          /* ncclUniqueId */
+
+int  hjgpu_comm_create_local(int nranks, const int *devices, int transport, hjgpu_comm **comm);
+int  hjgpu_comm_get_id(hjgpu_comm_id *id);
+int  hjgpu_comm_create_rank(int device, int nranks, int rank, const hjgpu_comm_id *id, hjgpu_comm **comm);
+int  hjgpu_comm_destroy(hjgpu_comm *comm);
+const char *hjgpu_comm_last_error(const hjgpu_comm *comm);
+/* world size, local ranks of this process, global rank of local rank 0 */
+int  hjgpu_comm_size(const hjgpu_comm *comm, int *nranks, int *nlocal, int *first_rank);
+/* the join context of a local rank: its device memory (hjgpu_malloc), generator, options, per-phase stats */
+hjgpu_ctx *hjgpu_comm_ctx(hjgpu_comm *comm, int local_rank);
+/* option "ring_broadcast" (0 / 1): replicate the build side with one ncclBroadcast instead of scatter +
+ * all-gather; "max_message_bytes" (n): split larger point-to-point messages into pieces */
+int  hjgpu_comm_set_option(hjgpu_comm *comm, const char *name, const char *value);
+/* every local rank's streams drained, then a collective over all ranks */
+int  hjgpu_comm_barrier(hjgpu_comm *comm);
+
+/* One rank's share of the relations: columns on that rank's device (16-byte aligned).
+ * hjgpu_phj_multi / hjgpu_npj_multi: `inner` = |R| on EVERY rank, the build columns are read on `root` only (NULL
+ * elsewhere); d_outer_* = the rank's probe shard.  hjgpu_cpra_multi: the rank's chunk of both relations. */
+typedef struct {
+    const uint32_t *d_inner_keys, *d_inner_vals;
+    size_t          inner;
+    const uint32_t *d_outer_keys, *d_outer_vals;
+    size_t          outer;
+} hjgpu_shard;
+
+typedef struct {
+    float    ms_wall;            /* host clock around the call                                              */
+    float    ms_exchange;        /* local rank 0: device time of its exchanges (replication / all-to-all-v)  */
+    float    ms_partition;       /* local rank 0: exchange-level partitioning (CPRA)                         */
+    float    ms_exchange_wait;   /* local rank 0: stream time its joins spent waiting for an exchange        */
+    uint32_t joins;              /* local rank 0: local join calls of this step (build + probes)             */
+    uint32_t reserved;
+    uint64_t tuples_joined;      /* local rank 0: tuples those joins read                                    */
+    uint64_t bytes_sent;         /* local rank 0: bytes sent to OTHER ranks                                  */
+    hjgpu_stats join;            /* local rank 0: phase times of those joins, summed                         */
+} hjgpu_multi_stats;
+
+/* shards: one entry per LOCAL rank, in rank order */
+int  hjgpu_phj_multi(hjgpu_comm *comm, const hjgpu_shard *shards, int root, const hjgpu_phj_params *params,
+                     hjgpu_result *result, hjgpu_multi_stats *stats);
+int  hjgpu_npj_multi(hjgpu_comm *comm, const hjgpu_shard *shards, int root, const hjgpu_npj_params *params,
+                     hjgpu_result *result, hjgpu_multi_stats *stats);
+int  hjgpu_cpra_multi(hjgpu_comm *comm, const hjgpu_shard *shards, const hjgpu_phj_params *params,
+                      int slices /* 0 = 4 */, hjgpu_result *result, hjgpu_multi_stats *stats);
+/* As hjgpu_join_host on all ranks of a LOCAL communicator (what ./npj ./phj ./cpra call when several GPUs are
+ * visible): the host columns are cut into the ranks' shares (thread_beg / thread_end, T = ranks), uploaded, joined.
+ * algorithm: 0 npj, 1 phj (build side uploaded to rank 0 and replicated from there), 2 cpra (both sides chunked). */
+int  hjgpu_join_host_multi(hjgpu_comm *comm, int algorithm,
+                           const uint32_t *inner_keys, const uint32_t *inner_vals, size_t inner,
+                           const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
+                           const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
+                           hjgpu_result *result, hjgpu_multi_stats *stats);
 
 /* ---- data generator (write.cpp / generate_data_for_join, cpra2.cpp:1578-1696):
  * statistical contract only — non-zero build keys, unique when outer_total >= inner_total

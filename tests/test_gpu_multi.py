@@ -1,0 +1,275 @@
+"""GPU tests of the multi-GPU joins behind the C-ABI (hjgpu_phj_multi / hjgpu_npj_multi / hjgpu_cpra_multi,
+csrc/hjgpu_multi.hip: the reference's cross-worker exchange, phj.cpp:1715-1770 and cpra2.cpp:1861-1971).
+
+The loopback transport puts every rank of a world of 2, 3 or 8 on the ONE GPU of the test box: ownership, counts
+all-gather, all-to-all-v split sizes, slicing, prepared build side, reductions run as on 8 GPUs, with the real
+kernels; only the wire differs (device-to-device copies instead of RCCL).  RCCL itself is exercised from C++ at
+world size 1 (self send / receive, all-gather, all-reduce through librccl).  Results are compared with the
+independent numpy definition of the join."""
+import numpy as np
+import pytest
+
+import hash_join_codes_knl_amd as H
+from helpers import numpy_join
+
+pytestmark = pytest.mark.gpu
+
+
+def bounds(n, parts, alignment=16):
+    """thread_beg / thread_end (npj.cpp:516-529)."""
+    part = (n // parts) & ~(alignment - 1)
+    return [(part * t, n if t + 1 == parts else part * (t + 1)) for t in range(parts)]
+
+
+@pytest.fixture(scope="module")
+def worlds(hj):
+    """Loopback communicators of 2, 3 and 8 ranks on device 0, and a 1-rank RCCL communicator."""
+    made = {}
+
+    def get(world, transport=H.TRANSPORT_LOOPBACK):
+        key = (world, transport)
+        if key not in made:
+            made[key] = H.HjComm.local(world, [0] * world, transport)
+        return made[key]
+    yield get
+    for c in made.values():
+        c.close()
+
+
+def relations(oracle, kind, seed):
+    if kind == "unique":
+        return oracle.generate(300_007, 61_003, seed=seed)
+    if kind == "dups":                                   # build side repeats its keys (write.cpp semantics)
+        return oracle.generate(40_000, 250_000, seed=seed)
+    if kind == "half":
+        return oracle.generate(200_000, 90_000, selectivity=0.5, seed=seed)
+    if kind == "tiny":
+        return oracle.generate(37, 5, seed=seed)
+    raise ValueError(kind)
+
+
+def replicated_shards(comm, ik, iv, ok, ov, root, cuts=None):
+    """Build side on `root` only, probe side sharded; returns (shards, columns to free)."""
+    cols, shards = [], []
+    cuts = cuts or bounds(len(ok), comm.nranks)
+    for g, (b, e) in enumerate(cuts):
+        ctx = comm.ctx[g]
+        sk, sv = ctx.column(max(e - b, 1)), ctx.column(max(e - b, 1))
+        if e > b:
+            sk.upload(np.concatenate([ok[b:e], np.zeros(max(e - b, 1) - (e - b), np.uint32)]))
+            sv.upload(np.concatenate([ov[b:e], np.zeros(max(e - b, 1) - (e - b), np.uint32)]))
+        rk = rv = None
+        if g == root:
+            rk, rv = ctx.column(ik), ctx.column(iv)
+            cols += [rk, rv]
+        cols += [sk, sv]
+        shards.append((rk, rv, len(ik), sk, sv, e - b))
+    return shards, cols
+
+
+def chunked_shards(comm, ik, iv, ok, ov, rcuts=None, scuts=None):
+    cols, shards = [], []
+    rcuts = rcuts or bounds(len(ik), comm.nranks)
+    scuts = scuts or bounds(len(ok), comm.nranks)
+    for g in range(comm.nranks):
+        ctx = comm.ctx[g]
+        (rb, re), (sb, se) = rcuts[g], scuts[g]
+        c = [ctx.column(np.concatenate([x, np.zeros(1, np.uint32)])) for x in (ik[rb:re], iv[rb:re], ok[sb:se], ov[sb:se])]
+        cols += c
+        shards.append((c[0], c[1], re - rb, c[2], c[3], se - sb))
+    return shards, cols
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("kind", ["unique", "dups", "half", "tiny"])
+def test_replicated_build_joins_over_loopback(worlds, oracle, world, kind):
+    """hjgpu_phj_multi / hjgpu_npj_multi: R replicated from every possible kind of root, S in thread_beg / thread_end
+    shards; the global result on the host equals the join of the whole relations."""
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, kind, seed=world)
+    want = numpy_join(ik, iv, ok, ov)
+    for root in sorted({0, world - 1, world // 2}):
+        shards, cols = replicated_shards(comm, ik, iv, ok, ov, root)
+        got, st = comm.phj_multi(shards, root)
+        assert got == want, (world, kind, root)
+        assert st["joins"] == 1 and st["ms_wall"] > 0
+        assert comm.phj_multi(shards, root, H.PhjParams(fanout1=16, fanout2=3))[0] == want
+        if not (ik == 0).any():
+            assert comm.npj_multi(shards, root)[0] == want
+        for c in cols:
+            c.free()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_replicated_build_with_ragged_and_empty_shards(worlds, oracle, world):
+    ik, iv, ok, ov = relations(oracle, "unique", seed=9)
+    want = numpy_join(ik, iv, ok, ov)
+    comm = worlds(world)
+    # rank 0 gets nothing, the last rank most of it, unaligned cuts in between
+    edges = [0, 0] + sorted(np.random.default_rng(world).integers(0, len(ok) // 3, size=world - 2).tolist() if world > 2 else []) + [len(ok)]
+    edges = [e & ~15 for e in edges[:-1]] + [len(ok)]
+    cuts = list(zip(edges[:-1], edges[1:]))
+    assert len(cuts) == world
+    shards, cols = replicated_shards(comm, ik, iv, ok, ov, 1 % world, cuts)
+    assert comm.phj_multi(shards, 1 % world)[0] == want
+    assert comm.npj_multi(shards, 1 % world)[0] == want
+    comm.set_option("ring_broadcast", 1)
+    try:
+        assert comm.phj_multi(shards, 1 % world)[0] == want
+    finally:
+        comm.set_option("ring_broadcast", 0)
+    for c in cols:
+        c.free()
+    # an empty build side, an empty probe side
+    empty = np.zeros(0, np.uint32)
+    shards, cols = replicated_shards(comm, empty, empty, ok, ov, 0)
+    assert comm.phj_multi(shards, 0)[0] == (0, 0, 0, 0)
+    for c in cols:
+        c.free()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("kind", ["unique", "dups", "half", "tiny"])
+def test_cpra_co_partitioned_over_loopback(worlds, oracle, world, kind):
+    """hjgpu_cpra_multi: both relations chunked, own-chunk partitioning with fan-out = ranks, counts all-gather,
+    all-to-all-v, local PHJ with the build side prepared once; 1, 3 and 4 probe slices (3 leaves the double
+    buffering on an odd slot; "tiny" has slices and messages without tuples)."""
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, kind, seed=10 + world)
+    want = numpy_join(ik, iv, ok, ov)
+    shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+    for slices in (1, 3, 4):
+        got, st = comm.cpra_multi(shards, None, slices)
+        assert got == want, (world, kind, slices)
+    assert st["joins"] >= 1 and st["bytes_sent"] > 0 or kind == "tiny"
+    assert comm.cpra_multi(shards, H.PhjParams(fanout1=7, fanout2=5), 2)[0] == want
+    for c in cols:
+        c.free()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_cpra_with_ragged_chunks_small_messages_and_batches_in_pieces(worlds, oracle, world):
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, "unique", seed=77)
+    want = numpy_join(ik, iv, ok, ov)
+    # all of R on the last rank, S only on ranks 0 and 1 (others hold empty chunks)
+    rcuts = [(0, 0)] * (world - 1) + [(0, len(ik))]
+    half = (len(ok) // 2) & ~15
+    scuts = [(0, half), (half, len(ok))] + [(len(ok), len(ok))] * (world - 2)
+    shards, cols = chunked_shards(comm, ik, iv, ok, ov, rcuts, scuts[:world])
+    assert comm.cpra_multi(shards, None, 4)[0] == want
+    # messages cut into 1 KiB pieces (the 1 GiB cap of the real exchange, exercised at test sizes)
+    comm.set_option("max_message_bytes", 1024)
+    try:
+        assert comm.cpra_multi(shards, None, 2)[0] == want
+    finally:
+        comm.set_option("max_message_bytes", 1 << 30)
+    for c in cols:
+        c.free()
+
+
+def test_cpra_batches_larger_than_the_prepared_workspace(worlds, hj):
+    """A rank that receives more probe tuples per slice than 1.5 x its own slice (here: every probe key hashes to ONE
+    rank's partition... all S on one rank after the exchange) probes the batch in pieces of max_outer."""
+    comm = worlds(2)
+    inner, outer = 200_000, 6_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    cols, shards = [], []
+    expect = [0, 0, 0, 0]
+    for g in range(2):
+        ctx = comm.ctx[g]
+        c = [ctx.column(inner // 2), ctx.column(inner // 2), ctx.column(outer // 2), ctx.column(outer // 2)]
+        ctx.generate_range(5, inner, outer, g * (inner // 2), inner // 2, g * (outer // 2), outer // 2, fi, fo, *c)
+        sums = ctx.column_sums(c[2], outer // 2, fo, fi)
+        expect = [expect[0] + outer // 2] + [a + b for a, b in zip(expect[1:], sums)]
+        cols += c
+        shards.append((c[0], c[1], inner // 2, c[2], c[3], outer // 2))
+    # 64 slices: a slice is 47 K tuples per rank, the workspace floor of 1 M tuples covers it in one batch;
+    # 1 slice: 3 M local tuples, ~3 M received against a workspace for 4.5 M: one batch as well
+    for slices in (1, 64):
+        assert list(comm.cpra_multi(shards, None, slices)[0]) == expect
+    for c in cols:
+        c.free()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_unique_flag_and_host_columns_through_the_multi_gpu_entry_points(worlds, oracle, world):
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, "dups", seed=3)
+    want_u = oracle.join_definition_unique(ik, iv, ok, ov)
+    shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+    assert comm.cpra_multi(shards, H.PhjParams(flags=H.FLAG_UNIQUE), 3)[0][:3] == want_u
+    for c in cols:
+        c.free()
+    shards, cols = replicated_shards(comm, ik, iv, ok, ov, 0)
+    assert comm.phj_multi(shards, 0, H.PhjParams(flags=H.FLAG_UNIQUE))[0][:3] == want_u
+    assert comm.npj_multi(shards, 0, H.NpjParams(flags=H.FLAG_UNIQUE))[0][:3] == want_u
+    for c in cols:
+        c.free()
+    # hjgpu_join_host_multi: what ./npj ./phj ./cpra call with several GPUs visible
+    want = numpy_join(ik, iv, ok, ov)
+    for algorithm in (0, 1, 2):
+        got, st = comm.join_host_multi(algorithm, ik, iv, ok, ov)
+        assert got == want, algorithm
+
+
+def test_rccl_from_cpp_at_world_size_one(worlds, oracle):
+    """The same entry points through RcclTransport: ncclCommInitAll, ncclAllGather, grouped ncclSend / ncclRecv
+    (to self), ncclAllReduce - one rank is all a one-GPU box can offer; more ranks are the driver's 8-GPU run."""
+    comm = worlds(1, H.TRANSPORT_RCCL)
+    assert (comm.nranks, comm.nlocal, comm.first_rank) == (1, 1, 0)
+    ik, iv, ok, ov = relations(oracle, "unique", seed=21)
+    want = numpy_join(ik, iv, ok, ov)
+    shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+    for slices in (1, 4):
+        assert comm.cpra_multi(shards, None, slices)[0] == want
+    assert comm.phj_multi(shards, 0)[0] == want
+    assert comm.npj_multi(shards, 0)[0] == want
+    comm.barrier()
+    for c in cols:
+        c.free()
+
+
+def test_one_rank_per_process_communicator_from_a_unique_id(hj, oracle):
+    """hjgpu_comm_get_id + hjgpu_comm_create_rank (ncclCommInitRank): the multi-process form bench.py uses under
+    torchrun, here with a world of one process."""
+    cid = H.HjComm.new_id()
+    assert len(cid) == 128 and any(cid)
+    with H.HjComm.rank(0, 1, 0, cid) as comm:
+        ik, iv, ok, ov = relations(oracle, "half", seed=4)
+        shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+        assert comm.cpra_multi(shards, None, 2)[0] == numpy_join(ik, iv, ok, ov)
+        assert comm.phj_multi(shards, 0)[0] == numpy_join(ik, iv, ok, ov)
+        for c in cols:
+            c.free()
+
+
+def test_full_size_property_two_ranks_64m_by_200m_each(worlds):
+    """Size-independent property at a size the oracle cannot check: 2 ranks x (|R| / 2 = 32 M, |S| / 2 = 200 M) from the
+    device generator; selectivity 1 => count = |S| and the sums are the column checksums of S, for CPRA (co-partitioned)
+    and PHJ (replicated build)."""
+    comm = worlds(2)
+    inner, outer = 64_000_000, 400_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    cols, shards, rep = [], [], []
+    expect = [0, 0, 0, 0]
+    for g in range(2):
+        ctx = comm.ctx[g]
+        c = [ctx.column(inner // 2), ctx.column(inner // 2), ctx.column(outer // 2), ctx.column(outer // 2)]
+        ctx.generate_range(1, inner, outer, g * (inner // 2), inner // 2, g * (outer // 2), outer // 2, fi, fo, *c)
+        sums = ctx.column_sums(c[2], outer // 2, fo, fi)
+        expect = [expect[0] + outer // 2] + [a + b for a, b in zip(expect[1:], sums)]
+        cols += c
+        shards.append((c[0], c[1], inner // 2, c[2], c[3], outer // 2))
+    got, st = comm.cpra_multi(shards, None, 4)
+    assert list(got) == expect
+    assert st["joins"] == 5 and st["tuples_joined"] > 0 and st["ms_exchange"] > 0
+    # replicated build: the whole build side on rank 0
+    ctx = comm.ctx[0]
+    rk, rv = ctx.column(inner), ctx.column(inner)
+    ctx.generate_range(1, inner, outer, 0, inner, 0, 0, fi, fo, rk, rv, None, None)
+    rep = [(rk, rv, inner, shards[0][3], shards[0][4], outer // 2), (None, None, inner, shards[1][3], shards[1][4], outer // 2)]
+    got, st = comm.phj_multi(rep, 0)
+    assert list(got) == expect
+    for c in cols + [rk, rv]:
+        c.free()

@@ -472,6 +472,32 @@ def test_host_programs_end_to_end(hj, oracle, tmp_path):
             assert lines[0].startswith("copy:\t") and float(lines[1]) > 0
 
 
+def test_host_programs_on_several_ranks(hj, oracle, tmp_path):
+    """The multi-GPU path of the C++ hosts (every visible GPU takes a share: hjgpu_comm_create_local +
+    hjgpu_join_host_multi), driven here as 3 loopback ranks on the one GPU of the test box and - through RCCL
+    from C++ - as HJGPU_DEVICES=0 plus a second rank that the box does not have (must fail cleanly)."""
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.abspath(H.__file__)), "lib")
+    subprocess.check_call([os.path.join(lib, "write"), "4", "500000", "120000"], cwd=tmp_path,
+                          env=dict(os.environ, HJ_SEED="13"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    cols = [np.fromfile(tmp_path / ("%s_%d.txt" % (p, n)), dtype="<u4")
+            for p, n in (("ik", 120000), ("iv", 120000), ("ok", 500000), ("ov", 500000))]
+    want = oracle.join_definition(*cols)
+    env = dict(os.environ, HJGPU_TRANSPORT="loopback", HJGPU_RANKS="3")
+    for prog in ("npj", "phj", "cpra"):
+        p = subprocess.run([os.path.join(lib, prog), "8", "500000", "120000"], cwd=tmp_path, env=env,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert "3 ranks (loopback)" in p.stderr
+        assert ("join_tuples=%d sum_keys=%d sum_outer_vals=%d sum_inner_vals=%d" % want) in p.stderr
+        lines = p.stdout.strip().splitlines()
+        assert float(lines[-1].split("\t")[0]) > 0
+    # a device the box does not have: reported, exit code 1, no crash
+    p = subprocess.run([os.path.join(lib, "phj"), "8", "500000", "120000"], cwd=tmp_path,
+                       env=dict(os.environ, HJGPU_DEVICES="0,63"), capture_output=True, text=True)
+    assert p.returncode == 1 and "hjgpu_comm_create_local" in p.stderr
+
+
 @pytest.mark.parametrize("algorithm", [0, 1, 2])
 @pytest.mark.parametrize("pinned", [False, True])
 def test_join_host_rows_returns_the_materialised_join(hj, algorithm, pinned):
