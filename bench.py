@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — PHJ |R|=64M join |S|=1G per GPU on MI355X (BASELINE.json configs[2];
-with --gpus N: configs[3], build side RCCL-broadcast, probe side sharded).
+with --gpus N: configs[3], build side replicated over RCCL, probe side sharded; --algo cpra --gpus N: configs[4]'s
+shape, both sides chunked and co-partitioned by an all-to-all-v).
 
 One "step" = one complete partitioned hash join over HBM-resident columns:
 fused histogram (R,S) -> plan -> scatter pass 1 -> scatter pass 2 -> LDS
@@ -8,10 +9,15 @@ build+probe, aggregates (count + 3 checksums) resident in HBM at the end.
 Nothing is skipped or cached between steps; the join result of every step is
 checked against the analytic aggregates of the generated relations.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task).
+N > 1: one process per GPU (torchrun); the data path - exchange over RCCL, local joins, all-reduce - is the
+library's C++ (hjgpu_phj_multi / hjgpu_cpra_multi, include/hjgpu.h); torch.distributed is the control plane only
+(gloo: the ncclUniqueId reaches the ranks, barriers around the timed region, max over ranks of the time).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task).  At N = 1 the line also carries, measured in
+the same process: NPJ (configs[1]) and one-GPU CPRA (`secondary`), the materialising PHJ (`materialized`), the
+CPU restatement of the same PHJ (`cpu_baseline`) and of configs[0] (`cpu_baseline_config0`).
 """
 import argparse
-import ctypes
 import json
 import os
 import subprocess
@@ -23,36 +29,39 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 INNER_FACTOR, OUTER_FACTOR = 0x2545F491, 0x9E3779B1
+# PMC traffic of the kernels (tools/collect_traffic.py): THIS file, and only while its kernel hash is the
+# running library's (hjgpu_kernel_hash) and it was taken on the workload being run
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+MASK64 = (1 << 64) - 1
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--algo", choices=["phj", "npj", "cpra"], default="phj")
-    ap.add_argument("--inner", type=int, default=64_000_000, help="|R| build tuples (replicated)")
+    ap.add_argument("--inner", type=int, default=64_000_000, help="|R| build tuples (replicated; --algo cpra --gpus N: per GPU)")
     ap.add_argument("--outer", type=int, default=1_000_000_000, help="|S| probe tuples PER GPU")
     ap.add_argument("--zipf", type=float, default=0.0,
                     help="Zipf exponent of the probe side's repeat picks (0 = uniform, the headline workload)")
     ap.add_argument("--fanout1", type=int, default=0)
     ap.add_argument("--fanout2", type=int, default=0)
     ap.add_argument("--cpu-outer", type=int, default=1_000_000_000,
-                    help="probe tuples of the CPU-baseline sample (0 = skip); the default is the whole per-GPU "
-                         "workload: ~1 s on the 16 CPUs of a GPU box with the AVX-512 operators")
+                    help="probe tuples of the CPU-baseline sample (0 = skip every CPU leg); the default is the whole per-GPU "
+                         "workload: ~1 s (~18 CPU-seconds) on the 16 CPUs of a GPU box with the AVX-512 operators")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota)")
-    ap.add_argument("--materialize", action="store_true",
-                    help="additionally run the materialising PHJ (3 result columns + close_gaps) and report it")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra N = 1 measurements (NPJ, one-GPU CPRA, materialising PHJ, configs[0] on the CPU)")
+    ap.add_argument("--materialize", action="store_true", help="kept for compatibility: the materialising PHJ is on by default")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed even at --gpus 1 (exercises the multi-GPU code path)")
+                    help="at --gpus 1: go through the multi-GPU entry points with a one-rank RCCL communicator")
     ap.add_argument("--ring-broadcast", action="store_true",
-                    help="multi-GPU: replicate the build side with dist.broadcast instead of scatter + all-gather")
+                    help="multi-GPU: replicate the build side with one ncclBroadcast instead of scatter + all-gather")
     ap.add_argument("--exchange-slices", type=int, default=4,
                     help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="multi-GPU: broadcast the build side on the join's own stream (no overlap)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def relaunch_under_torchrun(args):
@@ -78,10 +87,34 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(hj, H, args, algo):
+def connect_ranks(dist, H, local_rank, rank, world):
+    """Control plane -> data plane: rank 0 draws the ncclUniqueId (hjgpu_comm_get_id), the gloo group carries it to
+    every rank, each rank joins the library's communicator (hjgpu_comm_create_rank = ncclCommInitRank)."""
+    box = [H.HjComm.new_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return H.HjComm.rank(local_rank, world, rank, box[0])
+
+
+def max_over_ranks(dist, torch, seconds):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist, torch, values):
+    """uint64 aggregates as int64 bit patterns (wrap-around addition is the same)."""
+    if dist is None:
+        return [int(v) & MASK64 for v in values]
+    t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in values], dtype=torch.int64)
+    dist.all_reduce(t)
+    return [int(v) & MASK64 for v in t.tolist()]
+
+
+def cpu_baseline(hj, args, algo):
     """The oracle's restatement of the reference's CPU algorithm ("port"), timed on
     this host's cores on a bounded sample of the same workload shape."""
-    import numpy as np
     from oracle import oracle as O
     outer = min(args.cpu_outer, args.outer)
     inner = max(1, int(args.inner * (outer / args.outer)))
@@ -105,12 +138,74 @@ def cpu_baseline(hj, H, args, algo):
     return {"value": outer / tm.seconds / 1e9, "unit": "Gtuples/s", "cores": threads,
             "kind": "port",
             "sample": "%s |R|=%d join |S|=%d (same generator, 1/%g of the per-GPU workload), "
-                      "oracle/hj_oracle.c pthreads restatement of run_hj with %s operators, %d threads "
+                      "oracle/hj_oracle.c pthreads restatement of run_hj with %s operators "
+                      "(histogram and probe vectorised as the reference's; the partition computes 16 partition ids per "
+                      "vector and moves the tuples with scalar stores into the write-combining lines, where the "
+                      "reference serialises conflicts with a vector scatter, phj.cpp:1099-1160), %d threads "
                       "(%d CPUs online, cgroup quota applied), %.3f s, checksum %s"
                       % (algo, inner, outer, args.outer / outer,
                          "AVX-512 (oracle/hj_oracle_avx512.c)" if simd else "scalar", threads, os.cpu_count() or 0, tm.seconds,
                          "ok" if ok_ else "MISMATCH"),
             "seconds": tm.seconds}
+
+
+def cpu_baseline_config0(hj, args):
+    """BASELINE.json configs[0]: `./npj 64 1000000 16000000` (npj.cpp:929-935: 64 threads, 1 M probe tuples, 16 M
+    build tuples = 16 copies per key) as the oracle's restatement of run() (npj.cpp:769-927, load 0.90,
+    npj.cpp:944) on this host; threads = min(64, usable CPUs) (npj.cpp:952 asserts threads <= hardware threads).
+    The same relations are joined on the GPU and the aggregates compared."""
+    from oracle import oracle as O
+    threads = min(64, args.cpu_threads or usable_cpus())
+    ik, iv, ok, ov = O.generate(1_000_000, 16_000_000, seed=1)
+    tm = O.Timing()
+    res = O.npj(ik, iv, ok, ov, threads=threads, load=0.90, timing=tm)
+    rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+    gpu = hj.npj(rk, rv, len(ik), sk, sv, len(ok))
+    gpu_ms = hj.stats()["ms_total"]
+    for c in (rk, rv, sk, sv):
+        c.free()
+    return {"value": len(ok) / tm.seconds / 1e9, "unit": "Gtuples/s (probe side)", "cores": threads, "kind": "port",
+            "seconds": tm.seconds, "join_tuples": res[0],
+            "phase_seconds": {"init_build": tm.seconds_phase[0], "probe": tm.seconds_phase[1], "close_gaps": tm.seconds_phase[2]},
+            "sample": "./npj %d 1000000 16000000: oracle/hj_oracle.c restatement of run() (npj.cpp:769-927), load 0.90, "
+                      "relations of the T = 1 generator (cpra2.cpp:1578-1696, seed 1), J = %d, %.4f s; the same relations "
+                      "on the GPU (hjgpu_npj, %.3f ms): aggregates %s" % (threads, res[0], tm.seconds, gpu_ms,
+                                                                         "equal" if gpu == res else "DIFFER"),
+            "gpu_ms": gpu_ms, "checksum_ok": gpu == res}
+
+
+def roof(bytes_per_step, ms, launches, stream_read_gbs, bound="hbm"):
+    """roofline entry of one kernel: algorithmic bytes / measured time"""
+    if ms <= 0 or launches <= 0:
+        return None
+    gbs = bytes_per_step / (ms * 1e-3) / 1e9
+    return {"bound": bound, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac_of_stream_read": round(gbs / stream_read_gbs, 4) if stream_read_gbs else None,
+            "avg_launch_ms": round(ms / launches, 4), "launches_per_step": launches,
+            "algorithmic_bytes_per_launch": int(bytes_per_step / launches)}
+
+
+def attach_traffic(H, kernels, args, n_gpus):
+    """HBM bytes per launch from the PMC passes of tools/collect_traffic.py: only from TRAFFIC_FILE, only when it
+    was measured with the kernels that are running now and on this workload."""
+    if (args.inner, args.outer, args.algo, n_gpus, args.zipf) != (64_000_000, 1_000_000_000, "phj", 1, 0.0):
+        return "none: PMC traffic exists for the default workload only"
+    if not os.path.exists(TRAFFIC_FILE):
+        return "none: %s is missing" % os.path.relpath(TRAFFIC_FILE, ROOT)
+    t = json.load(open(TRAFFIC_FILE))
+    name = os.path.relpath(TRAFFIC_FILE, ROOT)
+    if t.get("kernel_hash") != H.kernel_hash():
+        return "refused: %s was measured with kernels %s, this library is %s" % (name, t.get("kernel_hash"), H.kernel_hash())
+    if t.get("bench_args"):
+        return "refused: %s was measured with bench.py %s" % (name, " ".join(t["bench_args"]))
+    for kname, entry in kernels.items():
+        hit = [v for k, v in t["kernels"].items() if k.startswith(kname)]
+        if hit:
+            # several template instances (pass 1 / pass 2) share a launch name prefix
+            entry["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["launches_seen"] for h in hit)
+                                   / max(1, sum(h["launches_seen"] for h in hit)))
+    return "%s (kernels %s)" % (name, t["kernel_hash"])
 
 
 def main():
@@ -127,13 +222,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if n_gpus > 1 or args.force_dist:
+    comm = None
+    multi = n_gpus > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=max(world, 1), device_id=dev)   # nccl == RCCL on ROCm
-
-    hj = H.HjGpu(local_rank)
+        dist.init_process_group("gloo", rank=rank, world_size=max(world, 1))      # control plane only
+        comm = connect_ranks(dist, H, local_rank, rank, max(world, 1))             # data plane: RCCL from C++
+        if args.ring_broadcast:
+            comm.set_option("ring_broadcast", 1)
+        hj = comm.ctx[0]
+    else:
+        hj = H.HjGpu(local_rank)
     info = hj.device_info()
     inner, outer = args.inner, args.outer
     outer_total = outer * n_gpus
@@ -141,210 +242,134 @@ def main():
     # ---- relations resident in HBM (torch owns the memory; the library borrows pointers)
     def col(n):
         return torch.empty(n + 4, dtype=torch.int32, device=dev)
-    # the two build columns are halves of ONE buffer: the multi-GPU path replicates it with one
-    # scatter + one all-gather (each RCCL kernel has to find free CUs next to the persistent
-    # partitioning kernels: two get in during the first millisecond of a step, four would not)
-    stride_r = (inner + 4 + 3) // 4 * 4                 # keeps the payload column 16-byte aligned
-    r_both = torch.empty(2 * stride_r, dtype=torch.int32, device=dev)
-    rk, rv = r_both[:stride_r], r_both[stride_r:]
-    sk, sv = col(outer), col(outer)
     stream = torch.cuda.current_stream().cuda_stream
     # CPRA across GPUs (BASELINE configs[4]): every rank owns a chunk of BOTH relations and the
     # tuples are co-partitioned with one all-to-all; PHJ / NPJ: R replicated, S sharded.
-    copart = dist is not None and args.algo == "cpra"
+    copart = multi and args.algo == "cpra"
     inner_total = inner * n_gpus if copart else inner
+    rk, rv, sk, sv = col(inner), col(inner), col(outer), col(outer)
     if copart:
         hj.generate_range(1, inner_total, outer_total, rank * inner, inner, rank * outer, outer,
                           INNER_FACTOR, OUTER_FACTOR, rk.data_ptr(), rv.data_ptr(), sk.data_ptr(),
                           sv.data_ptr(), stream)
     else:
-        # every rank generates R (identical) and its own shard of S
+        # the build side lives on rank 0 (the others only hold room for it); every rank generates its probe shard
         hj.generate_zipf(1, inner, outer_total, 0, inner, rank * outer, outer, INNER_FACTOR, OUTER_FACTOR,
                          args.zipf, rk.data_ptr(), rv.data_ptr(), sk.data_ptr(), sv.data_ptr(), stream)
     sums = hj.column_sums(sk.data_ptr(), outer, OUTER_FACTOR, INNER_FACTOR, stream)
-    # uint64 aggregates as int64 bit patterns (sums stay far below 2^63 at these sizes)
     expect_local = [outer, sums[0], sums[1], sums[2]]
-    if dist is not None:
-        e = torch.tensor(expect_local, dtype=torch.int64, device=dev)
-        dist.all_reduce(e)
-        expect_global = [int(x) for x in e.tolist()]
-        # the build side lives on rank 0 and is broadcast each step (measured, not assumed)
-        r_src = r_both.clone()
-    else:
-        expect_global = expect_local
+    expect_global = sum_over_ranks(dist, torch, expect_local)
 
     hj.reserve(inner, outer)
     prm = H.PhjParams(fanout1=args.fanout1, fanout2=args.fanout2)
     nprm = H.NpjParams()                       # library default load factor (0.25)
     d_result = torch.zeros(4, dtype=torch.int64, device=dev)
+    if multi:
+        # replicated build: only the root's build columns are read, every step replicates them again (measured,
+        # not assumed); co-partitioned: the rank's chunk of both relations
+        root_cols = (rk.data_ptr(), rv.data_ptr()) if (copart or rank == 0) else (None, None)
+        shards = [(root_cols[0], root_cols[1], inner, sk.data_ptr(), sv.data_ptr(), outer)]
 
-    from hash_join_codes_knl_amd import distributed as DD
-    state = {"ring": bool(args.ring_broadcast)}
-    side = torch.cuda.Stream(device=dev) if dist is not None else None
-    overlap = dist is not None and args.algo == "phj" and not args.no_overlap
-    if copart:
-        from hash_join_codes_knl_amd import distributed as D
-        hj_part = H.HjGpu(local_rank)     # exchange-level partitioning plans in its own workspace (prepared build side)
-        gpu_ops = D.GpuOps(hj, torch, "phj", prm, partition_ctx=hj_part)
-        views = (rk[:inner], rv[:inner], sk[:outer], sv[:outer])
-
-    exchange_events = []          # (start, stop) of each step's build-side replication, on its own stream
+    last = {}
 
     def step():
-        if copart:
-            # local top-level partition -> all-to-all-v over xGMI -> local PHJ -> all-reduce
-            res = D.cpra_copartitioned(dist, torch, gpu_ops, *views, slices=args.exchange_slices)
-            d_result.copy_(torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in res],
-                                        dtype=torch.int64, device=dev))
+        if multi:
+            if copart:
+                res, ms = comm.cpra_multi(shards, prm, args.exchange_slices)
+            elif args.algo == "npj":
+                res, ms = comm.npj_multi(shards, 0, nprm)
+            else:
+                res, ms = comm.phj_multi(shards, 0, prm)
+            last["result"], last["multi"] = list(res), ms
             return
-        main = torch.cuda.current_stream()
-        ready = None
-        if dist is not None:
-            # exchange step of the multi-GPU path: replicate the build side over xGMI.
-            # With overlap the broadcast runs on a side stream while the probe shard is
-            # histogrammed and partitioned; the library waits for `ready` before it reads R.
-            bs = side if overlap else main
-            if overlap:
-                side.wait_stream(main)              # the previous step's join is done reading R
-            with torch.cuda.stream(bs):
-                x0 = torch.cuda.Event(enable_timing=True)
-                x1 = torch.cuda.Event(enable_timing=True)
-                if rank == 0:
-                    r_both.copy_(r_src)
-                x0.record(bs)
-                if state["ring"]:
-                    dist.broadcast(r_both, 0)
-                else:                       # scatter + all-gather: all 7 xGMI links of every GPU
-                    try:
-                        DD.replicate(dist, torch, r_both, 0)
-                    except Exception as ex:                    # argument/backend errors are raised on every rank
-                        print("replicate() failed (%r): falling back to dist.broadcast" % (ex,), file=sys.stderr)
-                        state["ring"] = True
-                        dist.broadcast(r_both, 0)
-                x1.record(bs)
-                exchange_events.append((x0, x1))
-                if overlap:
-                    ready = torch.cuda.Event()
-                    ready.record(bs)
-        s = main.cuda_stream
+        s = torch.cuda.current_stream().cuda_stream
         a = (rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer)
-        if args.algo == "phj" and ready is not None:
-            hj.phj_overlapped_async(*a, prm, d_result.data_ptr(), s, ready.cuda_event)
-        elif args.algo == "phj":
+        if args.algo == "phj":
             hj.phj_async(*a, prm, d_result.data_ptr(), s)
         elif args.algo == "cpra":
             hj.cpra_async(*a, prm, d_result.data_ptr(), s)
         else:
             hj.npj_async(*a, nprm, d_result.data_ptr(), s)
-        if dist is not None:
-            dist.all_reduce(d_result)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join",
               "ms_build", "ms_close_gaps", "ms_inner_wait"]
-    acc = {p: 0.0 for p in phases}
     per_step = {p: [] for p in phases}
+    multi_steps = []
     for _ in range(args.warmup):
         step()
     barrier()
-    got = [int(x) for x in d_result.tolist()] if args.warmup else None
-    del exchange_events[:]
     # empirical streaming-read ceiling of this box: a plain 16-byte-load sweep of the
     # 4 GB probe-key column (nothing computed), outside the timed region
     best = 1e9
     for _ in range(4):
         best = min(best, hj.stream_read_ms(sk.data_ptr(), 4 * outer // 65536 * 65536, stream))
-    stream_read_gbs = (4 * outer // 65536 * 65536) / (best * 1e-3) / 1e9
+    stream_read_gbs = (4 * outer // 65536 * 65536) / (best * 1e-3) / 1e9 if outer >= 65536 else None
     barrier()
-    joins_done = 0
-    tuples_joined = 0                   # co-partitioned mode: tuples the local joins of the timed steps read
-    if copart:
-        gpu_ops.join_log = []
+    results_ok = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if copart:
-            # several local joins per step (one per probe-side slice): their phase times add up
-            calls, gpu_ops.join_log = gpu_ops.join_log, []
-            st = {p: sum(c["stats"][p] for c in calls) for p in phases}
-            tuples_joined += sum(c["inner"] + c["outer"] for c in calls)
-            joins_done += len(calls)
+        if multi:
+            ms = last["multi"]
+            multi_steps.append(ms)
+            for p in phases:
+                per_step[p].append(ms["join"][p])
+            results_ok = results_ok and last["result"] == expect_global
         else:
             st = hj.stats()             # hipEvent spans of this step's kernels (same stream)
-        for p in phases:
-            acc[p] += st[p]
-            per_step[p].append(st[p])
+            for p in phases:
+                per_step[p].append(st[p])
     barrier()
-    elapsed = time.perf_counter() - t0
-    got = [int(x) for x in d_result.tolist()]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(dist, torch, time.perf_counter() - t0)
+    got = last["result"] if multi else [int(x) & MASK64 for x in d_result.tolist()]
     # the analytic aggregates assume unique build keys, i.e. at least as many probe as build tuples
-    checksum_ok = (got == expect_global) if outer_total >= inner_total else None
+    checksum_ok = (got == expect_global and results_ok) if outer_total >= inner_total else None
 
     ms_per_step = elapsed / args.steps * 1e3
     value = outer_total / (elapsed / args.steps) / 1e9
-    avg = {p: acc[p] / args.steps for p in phases}
-    # tuples the kernels of one step read, per GPU (co-partitioned: what this rank's local joins were handed,
-    # the received build side once per probe-side slice)
-    n_tuples = tuples_joined / args.steps if copart else inner + outer
-    jps = max(1, round(joins_done / args.steps)) if copart else 1          # local joins per step
-    st = hj.stats()
+    avg = {p: sum(v) / max(1, len(v)) for p, v in per_step.items()}
+    st = multi_steps[-1]["join"] if multi else hj.stats()
+    # tuples the kernels of one step read on this rank, and the local join calls they were read by
+    if multi:
+        n_tuples = sum(m["tuples_joined"] for m in multi_steps) / args.steps
+        jps = max(1, round(sum(m["joins"] for m in multi_steps) / args.steps))
+    else:
+        n_tuples, jps = inner + outer, 1
 
-    # ---- roofline of each kernel: algorithmic bytes / measured time ----
-    def roof(bytes_per_step, ms, launches, bound="hbm"):
-        if ms <= 0:
-            return None
-        gbs = bytes_per_step / (ms * 1e-3) / 1e9
-        return {"bound": bound, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "frac_of_stream_read": round(gbs / stream_read_gbs, 4),
-                "avg_launch_ms": round(ms / launches, 4), "launches_per_step": launches,
-                "algorithmic_bytes_per_launch": int(bytes_per_step / launches)}
     kernels = {}
     if args.algo in ("phj", "cpra"):
         two = st["fanout2"] > 1
-        kernels["hist2_kernel"] = roof(4 * n_tuples, avg["ms_histogram"], 2 * jps)
-        kernels["scatter_kernel"] = roof((2 if two else 1) * 16 * n_tuples,
-                                         avg["ms_scatter1"] + avg["ms_scatter2"], (4 if two else 2) * jps)
-        kernels["join_kernel"] = roof(8 * n_tuples, avg["ms_join"], jps)
-        join_ms = avg["ms_join"]
+        # a prepared build side (co-partitioned CPRA) is one call for R and one per probe slice: one launch each
+        per_call = 1 if copart else 2
+        kernels["hist2_kernel"] = roof(4 * n_tuples, avg["ms_histogram"], per_call * jps, stream_read_gbs)
+        kernels["scatter_kernel"] = roof((2 if two else 1) * 16 * n_tuples, avg["ms_scatter1"] + avg["ms_scatter2"],
+                                         (2 if two else 1) * per_call * jps, stream_read_gbs)
+        kernels["join_kernel"] = roof(8 * n_tuples, avg["ms_join"], max(1, jps - 1) if copart else jps, stream_read_gbs)
     else:
-        kernels["npj_build_kernel"] = roof(8 * inner + 8 * st["buckets"] + 8 * inner, avg["ms_build"], 1)
-        kernels["npj_probe_kernel"] = roof(16 * outer, avg["ms_join"], 1)
-        join_ms = avg["ms_join"]
+        kernels["npj_build_kernel"] = roof(8 * inner + 8 * st["buckets"] + 8 * inner, avg["ms_build"], 1, stream_read_gbs)
+        kernels["npj_probe_kernel"] = roof(16 * outer, avg["ms_join"], 1, stream_read_gbs)
+    join_ms = avg["ms_join"]
     kernels = {k: v for k, v in kernels.items() if v}
-    # HBM bytes per launch from the PMC passes of tools/collect_traffic.py (same workload only)
-    traffic_src = None
-    if (args.inner, args.outer, args.algo, n_gpus) == (64_000_000, 1_000_000_000, "phj", 1):
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        if files:
-            traffic_src = os.path.basename(files[-1])
-            tk = json.load(open(files[-1]))["kernels"]
-            for name, entry in kernels.items():
-                hit = [v for k, v in tk.items() if k.startswith(name)]
-                if hit:
-                    # several template instances (pass 1 / pass 2) share a launch name prefix
-                    entry["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["launches_seen"] for h in hit)
-                                           / max(1, sum(h["launches_seen"] for h in hit)))
+    traffic_src = attach_traffic(H, kernels, args, n_gpus)
     dominant = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"] * kernels[k]["launches_per_step"])
     roofline = dict(kernels[dominant])
     roofline["kernel"] = dominant
 
+    transport = "RCCL from C++ (hjgpu_%s_multi)" % ("cpra" if copart else args.algo)
     if copart:
-        parallelism = ("both sides chunked over %d GPU(s), RCCL all-to-all-v co-partitioning (probe side in %d slices, "
-                       "transfers overlapped with partitioning and local PHJ)" % (n_gpus, args.exchange_slices))
-    elif dist is not None:
-        parallelism = "probe side sharded over %d GPU(s), build side replicated each step by RCCL %s%s" % (
-            n_gpus, "broadcast" if state["ring"] else "scatter + all-gather",
-            ", overlapped with probe-side partitioning" if overlap else "")
+        parallelism = ("both sides chunked over %d GPU(s), %s: own-chunk partitioning, counts all-gather, all-to-all-v "
+                       "(probe side in %d slices, transfers overlapped with partitioning and local PHJ), all-reduce"
+                       % (n_gpus, transport, args.exchange_slices))
+    elif multi:
+        parallelism = "probe side sharded over %d GPU(s), build side replicated each step by %s, %s, overlapped with " \
+                      "probe-side partitioning, all-reduce" % (n_gpus, "one ncclBroadcast" if args.ring_broadcast else
+                                                               "scatter + all-gather", transport)
     else:
         parallelism = "probe side sharded over 1 GPU(s), build side local"
     out = {
@@ -356,7 +381,8 @@ def main():
         "config": {"workload": "%s end-to-end (histogram + %s + LDS build/probe, aggregate output), "
                                "%s unique 32-bit keys, |R|=%d %s, |S|=%d per GPU, selectivity 1"
                                % (args.algo.upper(), "2 scatter passes" if st["fanout2"] > 1 else "1 scatter pass",
-                                  "uniform" if args.zipf <= 0 else "Zipf(%g) probe side," % args.zipf, inner, "per GPU (co-partitioned)" if copart else "replicated", outer),
+                                  "uniform" if args.zipf <= 0 else "Zipf(%g) probe side," % args.zipf, inner,
+                                  "per GPU (co-partitioned)" if copart else "replicated", outer),
                    "algorithm": args.algo, "inner_tuples": inner, "outer_tuples_per_gpu": outer,
                    "outer_tuples_total": outer_total,
                    "fanout": [st["fanout1"], st["fanout2"]],
@@ -364,20 +390,69 @@ def main():
         "roofline": roofline,
         "roofline_kernels": kernels,
         "traffic_source": traffic_src,
+        "kernel_hash": H.kernel_hash(),
         "join_phase": {"gtuples_per_s_per_gpu": round(outer / (join_ms * 1e-3) / 1e9, 2) if join_ms > 0 else None,
                        "ms": round(join_ms, 4),
                        "hbm_read_frac": round(8 * n_tuples / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if join_ms > 0 else None},
         "phase_ms": {k: round(v, 4) for k, v in avg.items()},
         "phase_ms_min": {k: round(min(v), 4) for k, v in per_step.items() if v},
         "phase_ms_max": {k: round(max(v), 4) for k, v in per_step.items() if v},
-        "empirical_stream_read_GBs": round(stream_read_gbs, 1),
-        "exchange_ms": (round(sum(a.elapsed_time(b) for a, b in exchange_events) / max(1, len(exchange_events)), 4)
-                        if exchange_events else None),
+        "empirical_stream_read_GBs": round(stream_read_gbs, 1) if stream_read_gbs else None,
         "checksum_ok": checksum_ok,
         "result": {"count": got[0], "sum_keys": got[1], "sum_outer_vals": got[2], "sum_inner_vals": got[3]},
         "device": info["name"], "arch": info["arch"],
     }
-    if args.materialize and args.algo == "phj":
+    if multi:
+        k = len(multi_steps)
+        out["exchange"] = {  # rank 0's view, averaged over the timed steps
+            "ms": round(sum(m["ms_exchange"] for m in multi_steps) / k, 4),
+            "ms_partition": round(sum(m["ms_partition"] for m in multi_steps) / k, 4),
+            "ms_joins_waited_for_it": round(sum(m["ms_exchange_wait"] for m in multi_steps) / k, 4),
+            "MB_sent": round(sum(m["bytes_sent"] for m in multi_steps) / k / 1e6, 1),
+            "local_join_calls": jps, "ms_wall_inside_library": round(sum(m["ms_wall"] for m in multi_steps) / k, 4)}
+
+    # ---- the other BASELINE configurations, same process, N = 1 ---------------------------------------------------
+    extras = (not multi and rank == 0 and not args.no_secondary and args.algo == "phj" and args.zipf <= 0
+              and (args.inner, args.outer) == (64_000_000, 1_000_000_000))
+    if extras:
+        def time_steps(fn, warm=1, steps=5):
+            """ms per call (host clock over `steps` back-to-back enqueues + one synchronise) and the per-phase stats"""
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            acc = {}
+            for _ in range(steps):
+                fn()
+                for key, val in hj.stats().items():          # waits for this call's last event
+                    acc[key] = acc.get(key, 0.0) + val
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / steps * 1e3, {key: val / steps for key, val in acc.items()}
+
+        a = (rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer)
+        sec = {}
+        # configs[1]: NPJ build + probe on one GPU
+        ms, ph = time_steps(lambda: hj.npj_async(*a, nprm, d_result.data_ptr(), stream))
+        ok_ = [int(x) & MASK64 for x in d_result.tolist()] == expect_local
+        sec["npj"] = {"workload": "NPJ |R|=%d join |S|=%d, global line-hashed table, load %.2f (%d buckets)"
+                                  % (inner, outer, 0.25, int(ph["buckets"])),
+                      "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2),
+                      "ms_build": round(ph["ms_build"], 4), "ms_probe": round(ph["ms_join"], 4), "checksum_ok": ok_,
+                      # SURVEY 8d: 16 B per probe tuple (8 B streamed + one 8-byte bucket); a bucket costs its whole
+                      # 64-byte line at the memory side: 8 + 64 B "sector-granular"
+                      "roofline_probe": roof(16 * outer, ph["ms_join"], 1, stream_read_gbs),
+                      "roofline_probe_line_granular": roof(72 * outer, ph["ms_join"], 1, stream_read_gbs),
+                      "roofline_build": roof(8 * inner + 8 * ph["buckets"] + 8 * inner, ph["ms_build"], 1, stream_read_gbs)}
+        # one-GPU CPRA: 8 chunks partitioned independently (cpra2.cpp:1757-1827), gathered in place
+        cprm = H.PhjParams(chunks=8)
+        ms, ph = time_steps(lambda: hj.cpra_async(*a, cprm, d_result.data_ptr(), stream))
+        ok_ = [int(x) & MASK64 for x in d_result.tolist()] == expect_local
+        sec["cpra"] = {"workload": "CPRA |R|=%d join |S|=%d, 8 chunks, fan-out %d x %d" % (inner, outer, int(ph["fanout1"]), int(ph["fanout2"])),
+                       "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2), "checksum_ok": ok_,
+                       "phase_ms": {k2: round(ph[k2], 4) for k2 in phases if k2 in ph},
+                       "roofline_scatter": roof(2 * 16 * (inner + outer), ph["ms_scatter1"] + ph["ms_scatter2"], 4, stream_read_gbs),
+                       "roofline_join": roof(8 * (inner + outer), ph["ms_join"], 1, stream_read_gbs)}
+        out["secondary"] = sec
         # SURVEY 8f row 2: rows (key, outer payload, inner payload) written through the block
         # protocol, compacted by close_gaps; priced against read + written bytes.
         block = 16384
@@ -389,8 +464,8 @@ def main():
                          out=(jk.data_ptr(), jo.data_ptr(), ji.data_ptr(), cap, block),
                          stream=torch.cuda.current_stream().cuda_stream)
             stx = hj.stats()
-            for k in mt:
-                mt[k].append(stx[k])
+            for k2 in mt:
+                mt[k2].append(stx[k2])
         j = res[0]
         ok_rows = (list(res) == expect_local and
                    int(jk[:j].to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) == expect_local[1])
@@ -398,22 +473,33 @@ def main():
         out["materialized"] = {"rows": j, "ms_join": round(min(mt["ms_join"]), 4),
                                "ms_close_gaps": round(min(mt["ms_close_gaps"]), 4),
                                "ms_total": round(min(mt["ms_total"]), 4),
+                               "gtuples_per_s": round(outer / min(mt["ms_total"]) / 1e6, 2),
                                "join_phase_rw_GBs": round((8 * n_tuples + 12 * j) / (tj * 1e-3) / 1e9, 1),
                                "join_phase_rw_frac": round((8 * n_tuples + 12 * j) / (tj * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "rows_checksum_ok": bool(ok_rows)}
         del jk, jo, ji
-    if rank == 0 and n_gpus == 1 and args.cpu_outer > 0:
+    if rank == 0 and not multi and args.cpu_outer > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(hj, H, args, args.algo)
+            out["cpu_baseline"] = cpu_baseline(hj, args, args.algo)
         except Exception as ex:          # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "Gtuples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (ex,)}
+        if extras:
+            try:
+                out["cpu_baseline_config0"] = cpu_baseline_config0(hj, args)
+            except Exception as ex:
+                out["cpu_baseline_config0"] = {"value": None, "unit": "Gtuples/s (probe side)", "cores": 0, "kind": "port",
+                                               "sample": "failed: %r" % (ex,)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+    if comm is not None:
+        comm.close()
+    else:
+        hj.close()
+    if dist is not None:
         dist.destroy_process_group()
-    hj.close()
     if checksum_ok is False:
         sys.exit("join result does not match the analytic aggregates: got %r want %r" % (got, expect_global))
 

@@ -20,7 +20,7 @@ MAX_PARTS = 32768
 FLAG_UNIQUE = 1
 
 EXPORTS = [
-    "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
+    "hjgpu_kernel_hash", "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
     "hjgpu_get_device_info", "hjgpu_set_option", "hjgpu_reserve", "hjgpu_get_stats",
     "hjgpu_malloc", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
     "hjgpu_host_alloc", "hjgpu_host_free",
@@ -136,6 +136,8 @@ def load_library(build_if_missing=True):
         _build.build_library(verbose=False)
     L = C.CDLL(so)
     vp, sz, u32, u64p = C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64)
+    L.hjgpu_kernel_hash.restype = C.c_char_p
+    L.hjgpu_kernel_hash.argtypes = []
     L.hjgpu_device_count.argtypes = [C.POINTER(C.c_int)]
     L.hjgpu_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.hjgpu_destroy.argtypes = [vp]
@@ -199,10 +201,15 @@ def load_library(build_if_missing=True):
     L.hjgpu_generate_zipf.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, C.c_double, vp, vp, vp, vp, vp]
     L.hjgpu_column_sums.argtypes = [vp, vp, sz, u32, u32, u64p, vp]
     for name in EXPORTS:
-        if name not in ("hjgpu_last_error", "hjgpu_status_string", "hjgpu_comm_last_error", "hjgpu_comm_ctx"):
+        if name not in ("hjgpu_last_error", "hjgpu_status_string", "hjgpu_comm_last_error", "hjgpu_comm_ctx", "hjgpu_kernel_hash"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def kernel_hash():
+    """hjgpu_kernel_hash(): which kernel sources the loaded library was built from."""
+    return load_library().hjgpu_kernel_hash().decode()
 
 
 class DeviceColumn:

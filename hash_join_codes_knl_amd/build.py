@@ -28,6 +28,21 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libhjgpu)")
 
 
+KERNEL_HASH_FILES = ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip", "hj_device.hpp",
+                     "hj_emit.hpp", "hj_internal.hpp"]
+
+
+def kernel_hash():
+    """Identifies the kernels a measurement was taken with (profiles/*_traffic.json carry it; bench.py attaches
+    PMC traffic to its roofline only when it equals the running library's, hjgpu_kernel_hash())."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_HASH_FILES:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -53,7 +68,7 @@ def build_library(force=False, verbose=True):
         obj = os.path.join(LIB, os.path.basename(src) + ".o")
         if force or _newer(obj, deps):
             cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++20", "-fPIC",
-                   "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+                   "-Wall", "-Wno-unused-function", "-DHJGPU_KERNEL_HASH=\"%s\"" % kernel_hash(), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

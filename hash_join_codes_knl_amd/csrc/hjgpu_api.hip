@@ -617,6 +617,11 @@ const char *hjgpu_status_string(int s)
     }
 }
 
+#ifndef HJGPU_KERNEL_HASH
+#define HJGPU_KERNEL_HASH "unknown"
+#endif
+const char *hjgpu_kernel_hash(void) { return HJGPU_KERNEL_HASH; }
+
 int hjgpu_device_count(int *count)
 {
     if (!count) return HJGPU_EINVAL;

@@ -124,6 +124,9 @@ typedef struct {
 } hjgpu_device_info;
 
 /* ---- context ---------------------------------------------------------------- */
+/* hash of the kernel sources this library was built from: measurements (profiles/ traffic files) name the
+ * kernels they were taken with, bench.py refuses counters of other kernels */
+const char *hjgpu_kernel_hash(void);
 int  hjgpu_device_count(int *count);                      /* visible GPUs (hosts that do not link HIP) */
 int  hjgpu_create(int device, hjgpu_ctx **ctx);           /* device < 0: current device      */
 int  hjgpu_destroy(hjgpu_ctx *ctx);

@@ -44,7 +44,8 @@ def test_struct_layouts_match_header(tmp_path):
     from hash_join_codes_knl_amd import api
     pairs = [("hjgpu_result", H.Result), ("hjgpu_phj_params", H.PhjParams), ("hjgpu_npj_params", H.NpjParams),
              ("hjgpu_output", H.Output), ("hjgpu_stats", H.Stats), ("hjgpu_host_rows", api.HostRows),
-             ("hjgpu_device_info", api.DeviceInfo)]
+             ("hjgpu_device_info", api.DeviceInfo), ("hjgpu_shard", api.Shard), ("hjgpu_multi_stats", api.MultiStats),
+             ("hjgpu_comm_id", api.CommId)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hjgpu.h"', 'int main(void){']
     for cname, cls in pairs:
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

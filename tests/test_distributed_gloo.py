@@ -115,3 +115,54 @@ def test_shard_bounds_and_ownership():
     b = D.shard_bounds(1000, 3)
     assert b == [(0, 320), (320, 640), (640, 1000)]           # npj.cpp:516-529 with alignment 16
     assert [D.owner_of_partition(p, 10, 4) for p in range(10)] == [0, 0, 1, 1, 2, 2, 3, 3, 3, 3]
+
+
+def _control_plane_worker(rank, world, port, q):
+    """bench.py's control plane under torchrun, on the gloo group it really uses: the ncclUniqueId drawn on rank 0
+    reaches every rank unchanged (the data plane - hjgpu_comm_create_rank - is replaced by a recorder: no GPU here),
+    the step time is the maximum over the ranks, the expected aggregates add up with uint64 wrap-around."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class FakeComm:
+            @staticmethod
+            def new_id():
+                return bytes(range(128))               # drawn on rank 0 only
+
+            @staticmethod
+            def rank(device, nranks, r, comm_id):
+                return ("joined", device, nranks, r, comm_id)
+
+        class FakeH:
+            HjComm = FakeComm
+        joined = bench.connect_ranks(dist, FakeH, 10 + rank, rank, world)
+        slowest = bench.max_over_ranks(dist, torch, 0.5 + rank)
+        sums = bench.sum_over_ranks(dist, torch, [1_000, (1 << 64) - 5, 7, 1 << 63])
+        q.put((rank, joined, slowest, sums))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_control_plane_over_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_control_plane_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mask = (1 << 64) - 1
+    for rank, joined, slowest, sums in results:
+        assert joined == ("joined", 10 + rank, world, rank, bytes(range(128)))
+        assert slowest == 0.5 + world - 1
+        assert sums == [1_000 * world, ((1 << 64) - 5) * world & mask, 7 * world, (1 << 63) * world & mask]

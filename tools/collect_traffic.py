@@ -6,8 +6,9 @@ KiB, and on gfx950 FETCH_SIZE reports exactly half of a wide coalesced read stre
     bytes_written =     WRITE_SIZE * 1024
 Run on the GPU box (rocprofv3 gets the program itself after `--`):
     python tools/collect_traffic.py [bench.py args...]
-Writes gpurun_out/traffic.json; copy it to profiles/rNN_traffic.json (bench.py reads
-profiles/*_traffic.json for its `roofline.traffic` field)."""
+Writes gpurun_out/traffic.json; copy it to the file bench.py names (TRAFFIC_FILE, profiles/rNN_traffic.json).
+The file records the kernel-source hash of the library it was measured with (hjgpu_kernel_hash); bench.py attaches
+the counters to its `roofline.traffic` field only when that equals the running library's."""
 import collections
 import csv
 import glob
@@ -45,7 +46,10 @@ def main():
         res[k] = {"launches_seen": nf, "read_bytes_per_launch": 2.0 * f * 1024.0,
                   "written_bytes_per_launch": w * 1024.0,
                   "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0}
-    out = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
+    sys.path.insert(0, ROOT)
+    import hash_join_codes_knl_amd as H
+    out = {"kernel_hash": H.kernel_hash(),
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
                      "`bench.py --steps 2 --warmup 1`, averaged over all launches of a kernel; "
                      "read = 2*FETCH_SIZE KiB (gfx950 correction), written = WRITE_SIZE KiB",
            "bench_args": extra, "kernels": res}
