@@ -32,7 +32,7 @@ EXPORTS = [
     "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
     "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
     "hjgpu_phj_multi", "hjgpu_npj_multi", "hjgpu_cpra_multi", "hjgpu_join_host_multi",
-    "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_column_sums", "hjgpu_stream_read_ms",
+    "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_generate_select", "hjgpu_column_sums", "hjgpu_stream_read_ms",
 ]
 
 
@@ -70,7 +70,7 @@ class Stats(C.Structure):
                 ("ms_scatter1", C.c_float), ("ms_scatter2", C.c_float), ("ms_join", C.c_float),
                 ("ms_build", C.c_float), ("ms_close_gaps", C.c_float),
                 ("ms_inner_wait", C.c_float), ("ms_upload", C.c_float), ("ms_download", C.c_float),
-                ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("buckets", C.c_uint64)]
+                ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("batches", C.c_uint32), ("buckets", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -199,6 +199,8 @@ def load_library(build_if_missing=True):
     L.hjgpu_generate.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
     L.hjgpu_generate_range.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
     L.hjgpu_generate_zipf.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, C.c_double, vp, vp, vp, vp, vp]
+    L.hjgpu_generate_select.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, C.c_double, C.c_double,
+                                        vp, vp, vp, vp, C.POINTER(Result), vp]
     L.hjgpu_column_sums.argtypes = [vp, vp, sz, u32, u32, u64p, vp]
     for name in EXPORTS:
         if name not in ("hjgpu_last_error", "hjgpu_status_string", "hjgpu_comm_last_error", "hjgpu_comm_ctx", "hjgpu_kernel_hash"):
@@ -469,6 +471,17 @@ class HjGpu:
                                                  inner_count, outer_begin, outer_count, inner_factor,
                                                  outer_factor, float(zipf), self._ptr(ik), self._ptr(iv),
                                                  self._ptr(ok), self._ptr(ov), stream))
+
+    def generate_select(self, seed, inner_total, outer_total, inner_begin, inner_count, outer_begin, outer_count,
+                        inner_factor, outer_factor, zipf, selectivity, ik, iv, ok, ov, expected=True, stream=None):
+        """hjgpu_generate_select: write.cpp's selectivity; returns the analytic aggregates of the generated probe
+        range (None when expected is False)."""
+        r = Result()
+        self._check(self.lib.hjgpu_generate_select(self.handle, seed, inner_total, outer_total, inner_begin, inner_count,
+                                                   outer_begin, outer_count, inner_factor, outer_factor, float(zipf),
+                                                   float(selectivity), self._ptr(ik), self._ptr(iv), self._ptr(ok),
+                                                   self._ptr(ov), C.byref(r) if expected else None, stream))
+        return r.as_tuple() if expected else None
 
     def stream_read_ms(self, d_ptr, nbytes, stream=None):
         ms = C.c_float()

@@ -42,6 +42,10 @@ struct GenArgs {
     uint32_t inner_factor, outer_factor;
     double zipf;                // > 0: repeat picks of the probe side follow a Zipf law over the distinct keys
     double zipf_a, zipf_b;      // rank = (a*x + 1)^b for x uniform in (0,1)   (s != 1);  distinct^x  (s == 1)
+    // selectivity (write.cpp:1685-1689): the build side draws from unique[0, d), the probe side from
+    // unique[d - join_d, 2d - join_d): probe rank r is build rank d - join_d + r, a match iff r < join_d
+    u64 join_d, outer_shift;    // outer_shift = d - join_d
+    u64 *expect;                // device [4] or NULL: count, sum key, sum key * outer_factor, sum key * inner_factor of the matching probe tuples
     uint32_t *ik, *iv, *ok, *ov;
 };
 
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
         }
     }
     if (a.ok) {
+        u64 e_n = 0, e_k = 0, e_o = 0, e_i = 0;
         for (u64 j = tid; j < a.outer_count; j += stride) {
             const u64 pos = a.outer_begin + j;
             const u64 jp = (pos * a.mul + a.add) % a.outer_total;     // "shuffle": a bijection of positions
@@ -76,9 +81,18 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
                 r = rank >= 1.0 ? (u64)rank - 1 : 0;
                 if (r >= a.distinct) r = a.distinct - 1;
             } else r = __umul64hi(splitmix64(jp ^ a.seed), a.distinct);  // then uniform picks
-            const uint32_t k = mix32(a.key_base + (uint32_t)r);
+            const uint32_t k = mix32(a.key_base + (uint32_t)(a.outer_shift + r));
             a.ok[j] = k;
             a.ov[j] = k * a.outer_factor;
+            if (r < a.join_d) { e_n += 1; e_k += k; e_o += (uint32_t)(k * a.outer_factor); e_i += (uint32_t)(k * a.inner_factor); }
+        }
+        if (a.expect) {
+            // the aggregates the join of this probe range with the (unique-key) build side must return
+            e_n = wave_reduce_sum(e_n); e_k = wave_reduce_sum(e_k); e_o = wave_reduce_sum(e_o); e_i = wave_reduce_sum(e_i);
+            if (hj_lane() == 0 && e_n) {
+                atomicAdd(&a.expect[0], e_n); atomicAdd(&a.expect[1], e_k);
+                atomicAdd(&a.expect[2], e_o); atomicAdd(&a.expect[3], e_i);
+            }
         }
     }
 }
@@ -88,8 +102,10 @@ static u64 gcd_u64(u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } re
 int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_count,
                        size_t outer_total, size_t outer_begin,
                        size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
-                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream, double zipf)
+                       uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream, double zipf,
+                       double selectivity, u64 *d_expect)
 {
+    if (!(selectivity >= 0.0) || selectivity > 1.0) return HJGPU_EINVAL;
     if (inner == 0 || inner >= 0xFFFFFFFFull) return HJGPU_EINVAL;
     if (ik && inner_begin + inner_count > inner) return HJGPU_EINVAL;
     if (ok && (outer_total == 0 || outer_begin + outer_count > outer_total)) return HJGPU_EINVAL;
@@ -108,7 +124,12 @@ int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_
     a.add_r = (a.seed >> 13) % inner;
     a.distinct = (outer_total && outer_total < inner) ? outer_total : inner;
     a.add = (a.seed >> 7) % a.outer_total;
-    a.key_base = 1u + (uint32_t)((a.seed >> 11) % (0xFFFFFFFFull - a.distinct));
+    a.join_d = (u64)((double)a.distinct * selectivity);           // write.cpp:1689
+    if (a.join_d > a.distinct) a.join_d = a.distinct;
+    a.outer_shift = a.distinct - a.join_d;
+    a.expect = d_expect;
+    if (2 * a.distinct - a.join_d >= 0xFFFFFFFFull) return HJGPU_EINVAL;
+    a.key_base = 1u + (uint32_t)((a.seed >> 11) % (0xFFFFFFFFull - (2 * a.distinct - a.join_d)));
     a.inner_factor = inner_factor | 1u; a.outer_factor = outer_factor | 1u;
     a.zipf = zipf > 0.0 ? zipf : 0.0; a.zipf_a = a.zipf_b = 0.0;
     if (a.zipf > 0.0 && fabs(a.zipf - 1.0) >= 1e-9) {

@@ -53,6 +53,7 @@ struct HjTuning {
     bool force_chained = false;     // "force_chained": chained fallback tables everywhere (tests)
     bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
+    long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned
 };
@@ -106,6 +107,7 @@ struct ScatterArgs {
     uint32_t ranged;
     uint32_t *work_counter;         // device, zeroed per launch: ticket of the next unclaimed range (pass 1) / tile (pass 2)
     Pass1Geom geom;
+    uint32_t range_begin, range_count;   // pass 1: this launch covers ranges [range_begin, +range_count) (0, 0 = all)
     const u64 *range_base;          // [ranges][F] absolute output position of each (range, partition)
     u64 *prof;                      // diagnostics (HJGPU_SCATTER_PROF=1): s_memtime ticks per phase, else NULL
 };
@@ -173,6 +175,22 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
 int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
                          uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream);
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream);
+// Batched partitioning of ONE relation (single chunk): the relation's pass-1 ranges are cut into batches of
+// `ranges_per_batch`; pass 1 of a batch writes into a small REUSED buffer (dense layout starting at 0) and pass 2 of
+// the batch reads it right away, while it is still in the 256 MiB Infinity Cache - the intermediate copy of the
+// relation (16 of PHJ's 44 bytes per probe tuple) then mostly never reaches HBM.  This kernel derives, from K4's
+// per-range counts: boff[b][F1 + 1] (the batch's pass-1 layout), range_base[range][F1] (write bases inside the batch
+// buffer), tp2b[b][F1 + 1] (pass-2 tile prefix of the batch) and tdesc[b][cap][2] (its pass-2 tile descriptors).
+struct BatchPlanArgs {
+    const uint32_t *range_counts;   // [ranges][F1]
+    u64 *range_base;                // [ranges][F1]
+    u64 *boff;                      // [batches][F1 + 1]
+    u64 *tp2b;                      // [batches][F1 + 1]
+    uint4 *tdesc;                   // [batches][tdesc_cap][2]
+    uint32_t tdesc_cap;
+    uint32_t ranges, ranges_per_batch, F1, F2, tile2;
+};
+int hj_launch_batch_plan(const BatchPlanArgs &a, uint32_t batches, hipStream_t stream);
 int hj_launch_scatter(const ScatterArgs &a, const HjTuning &t, int cus, hipStream_t stream);
 int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t stream);
 int hj_launch_exscan(const u64 *in, u64 *out, uint32_t n, hipStream_t stream);
@@ -223,7 +241,7 @@ int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_
                        size_t outer_total, size_t outer_begin,
                        size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
                        uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream,
-                       double zipf = 0.0);
+                       double zipf = 0.0, double selectivity = 1.0, u64 *d_expect = nullptr);
 int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hipStream_t stream);
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
                           hipStream_t stream);

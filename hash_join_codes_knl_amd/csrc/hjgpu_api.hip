@@ -116,12 +116,18 @@ struct MetaLayout {
     size_t tdesc_cap;
     uint32_t *range_counts[2];   // [ranges][F1] pass-1 counts per range (K4 -> K5b)
     u64 *range_base[2];          // [ranges][F1] pass-1 write bases per range (K5b -> K6)
+    // batched probe-side partitioning (hj_launch_batch_plan): per-batch pass-1 layout, pass-2 tile prefix,
+    // pass-2 tile descriptors, and one ticket word per launch (pass 1 / pass 2 of every batch)
+    u64 *boff, *tp2b;
+    uint4 *tdescb;
+    uint32_t *btickets;
+    size_t btickets_bytes;
     size_t counts_bytes;    // both relations, contiguous (zeroed per join)
     size_t total_bytes;
 };
 
 MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges, size_t items_extra = 0,
-                 size_t tiles2 = 0)
+                 size_t tiles2 = 0, size_t batches = 0, size_t tdesc_b_cap = 0)
 {
     MetaLayout m;
     u64 *p = reinterpret_cast<u64 *>(base);
@@ -150,6 +156,11 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
     }
     m.tdesc_cap = tiles2;
     for (int r = 0; r < 2; ++r) m.tdesc[r] = reinterpret_cast<uint4 *>(take(tiles2 * 4));
+    m.boff = take(batches * ((size_t)F1 + 1));
+    m.tp2b = take(batches * ((size_t)F1 + 1));
+    m.tdescb = reinterpret_cast<uint4 *>(take(batches * tdesc_b_cap * 4));
+    m.btickets = reinterpret_cast<uint32_t *>(take(batches + 1));            // 2 x u32 per batch
+    m.btickets_bytes = (batches + 1) * sizeof(u64);
     m.total_bytes = at * sizeof(u64);
     return m;
 }
@@ -303,6 +314,12 @@ struct PhjPlan {
     uint32_t f1, f2, tf0, tf1;
     bool big_tables;
     bool unique;             // HJGPU_FLAG_UNIQUE / option "unique"
+    // batched probe-side partitioning: 0 batches = off
+    uint32_t batch_ranges;   // pass-1 ranges per batch
+    uint32_t batch_cap;      // batches the tables hold
+    uint32_t batch_tile_cap; // tiles per range the batch buffers are sized for
+    size_t tdesc_b_cap;      // pass-2 tile descriptors per batch
+    size_t batch_bytes;      // one batch buffer (packed tuples)
 };
 static_assert(sizeof(PhjPlan) <= sizeof(hjgpu_ctx::prepared_plan), "prepared_plan too small");
 enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
@@ -344,7 +361,31 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     // pass-2 tiles: whole tiles of the relation plus up to two ragged tiles per segment
     const size_t larger = inner > outer ? inner : outer;
     pl->tiles2 = pl->F2 > 1 ? larger / (size_t)hj_scatter_tile(ctx->tune, 2, pl->F2, true) + 2 * (size_t)pl->C * pl->F1 + 8 : 0;
-    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges, pl->items_extra, pl->tiles2);
+    // Batched probe-side partitioning (option "batch_tuples" > 0; two-pass, single-chunk plans with line-aligned final
+    // partitions): pass 1 of a batch writes into one of two small reused buffers and pass 2 reads it straight away, so
+    // the intermediate copy of the probe side can stay in the 256 MiB Infinity Cache.  Plain copies gain from that
+    // (tools/ubench_mall_chain.hip: 5.1 ms per 8 GiB through a reused 128-192 MiB buffer against 6.7 ms through an
+    // 8 GiB one); K6 does NOT (profiles/r02_batch_sweep.txt: 7.2-9.8 ms for both passes against 6.9 ms unbatched at
+    // every batch size, i.e. ~30 us per extra launch and nothing back): K6 is bound by its per-tile work on the CU,
+    // not by HBM.  Kept as an option (it also needs no full-size pass-1 twin of the probe side), off by default.
+    pl->batch_ranges = pl->batch_cap = pl->batch_tile_cap = 0; pl->tdesc_b_cap = 0; pl->batch_bytes = 0;
+    if (pl->F2 > 1 && pl->C == 1 && !ctx->tune.dense2 && ctx->tune.batch_tuples > 0 && pl->F1 <= 1024) {
+        const u64 target = (u64)ctx->tune.batch_tuples;
+        const u64 tile = gs.tile;
+        const u64 tiles = hj_tiles_of(0, outer, 0, (uint32_t)tile) + 1;
+        const u64 k = (tiles + ranges_of(ctx->tune, tiles, pl->F1) - 1) / ranges_of(ctx->tune, tiles, pl->F1) + 1;   // tiles per range, with slack
+        const u64 rpb = std::max<u64>(1, target / (k * tile));
+        const u64 nb = (gs.ranges_per_chunk + rpb - 1) / rpb + 1;
+        if (outer >= 3 * target) {
+            pl->batch_ranges = (uint32_t)rpb; pl->batch_cap = (uint32_t)nb; pl->batch_tile_cap = (uint32_t)k;
+            const u64 bound = rpb * k * tile;                                  // tuples of the largest possible batch
+            pl->tdesc_b_cap = (size_t)(bound / (u64)hj_scatter_tile(ctx->tune, 2, pl->F2, true) + 2 * (u64)pl->F1 + 8);
+            pl->batch_bytes = (size_t)(bound + 64) * sizeof(u64);
+            CHK(ensure(ctx, ctx->tmp[1], pl->batch_bytes));
+            CHK(ensure(ctx, ctx->tmp[3], pl->batch_bytes));
+        }
+    }
+    MetaLayout sz = carve(nullptr, pl->C, pl->F1, pl->P, pl->ranges, pl->items_extra, pl->tiles2, pl->batch_cap, pl->tdesc_b_cap);
     CHK(ensure(ctx, ctx->meta, sz.total_bytes));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     return HJGPU_OK;
@@ -357,7 +398,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 PhjMode mode = PHJ_WHOLE)
 {
     CHK(refuse_capture(ctx, stream));
-    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2);
+    MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2, pl.batch_cap, pl.tdesc_b_cap);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables), &bs, &bl));
@@ -407,6 +448,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.slice = HJ_JOIN_SLICE;
     pa.cap = (uint32_t)hj_join_config_of(ctx->tune, pl.big_tables).cap();
 
+    uint32_t batches_used = 0;
     // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
     auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
         // K4: one read of the key column gives the histograms of both passes
@@ -416,6 +458,52 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         // K5 (+ the join's work items once both histograms exist), K5b
         pa.mask = plan_mask;
         CHK(hj_launch_plan(pa, stream));
+        // batched probe side: the tables must hold this relation's batches and tiles per range
+        uint32_t batches = 0;
+        if (r == 1 && pl.batch_ranges && nn[r]) {
+            const u64 tiles = hj_tiles_of(0, nn[r], geom[r].align, geom[r].tile);
+            const u64 k = (tiles + geom[r].ranges_per_chunk - 1) / geom[r].ranges_per_chunk;
+            const u64 nb = (geom[r].ranges_per_chunk + pl.batch_ranges - 1) / pl.batch_ranges;
+            if (k + 1 <= pl.batch_tile_cap && nb <= pl.batch_cap && nb >= 2) batches = (uint32_t)nb;
+        }
+        if (batches) {
+            BatchPlanArgs ba;
+            ba.range_counts = m.range_counts[r]; ba.range_base = m.range_base[r]; ba.boff = m.boff; ba.tp2b = m.tp2b;
+            ba.tdesc = m.tdescb; ba.tdesc_cap = (uint32_t)pl.tdesc_b_cap; ba.ranges = geom[r].ranges_per_chunk;
+            ba.ranges_per_batch = pl.batch_ranges; ba.F1 = pl.F1; ba.F2 = pl.F2;
+            ba.tile2 = (uint32_t)hj_scatter_tile(ctx->tune, 2, pl.F2, true);
+            CHK(hj_launch_batch_plan(ba, batches, stream));
+            HIPCHK(ctx, hipMemsetAsync(m.btickets, 0, m.btickets_bytes, stream));
+            record(ctx, ev[1], stream);
+            for (uint32_t b = 0; b < batches; ++b) {
+                uint32_t *tbuf = (uint32_t *)ctx->tmp[1 + 2 * (b & 1)].p;
+                ScatterArgs sa;
+                memset(&sa, 0, sizeof(sa));
+                // pass 1 of the batch: the caller's columns -> the batch buffer (dense, from offset 0)
+                sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = tbuf; sa.vout = nullptr;
+                sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
+                sa.nseg = 1; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
+                sa.ranged = 1; sa.work_counter = m.btickets + 2 * b; sa.geom = geom[r]; sa.range_base = m.range_base[r];
+                sa.range_begin = b * pl.batch_ranges;
+                sa.range_count = std::min(pl.batch_ranges, geom[r].ranges_per_chunk - sa.range_begin);
+                sa.in_packed = 0; sa.out_packed = 1;
+                CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
+                // pass 2 of the batch: the batch buffer -> the relation's final, line-aligned partitions
+                memset(&sa, 0, sizeof(sa));
+                sa.kin = tbuf; sa.vin = nullptr; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
+                sa.seg_off = m.boff + (size_t)b * (pl.F1 + 1); sa.tile_prefix = m.tp2b + (size_t)b * (pl.F1 + 1);
+                sa.cursors = m.cur2[r]; sa.tile_desc = m.tdescb + (size_t)b * pl.tdesc_b_cap * 2;
+                sa.nseg = pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
+                sa.ranged = 0; sa.work_counter = m.btickets + 2 * b + 1; sa.geom = geom[r]; sa.range_base = nullptr;
+                sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = 1u;
+                sa.in_packed = 1; sa.out_packed = 1;
+                CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
+            }
+            record(ctx, ev[2], stream);         // both passes interleaved: reported as pass 1, pass 2 = 0
+            record(ctx, ev[3], stream);
+            batches_used = batches;
+            return HJGPU_OK;
+        }
         if (nn[r]) CHK(hj_launch_range_base(m.range_counts[r], m.off1[r], m.range_base[r], pl.C,
                                             geom[r].ranges_per_chunk, pl.F1, stream));
         record(ctx, ev[1], stream);
@@ -499,7 +587,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                                     &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
     }
     record(ctx, EV_GAPS, stream);
-    ctx->stats.fanout1 = pl.F1; ctx->stats.fanout2 = pl.F2; ctx->stats.buckets = 0;
+    ctx->stats.fanout1 = pl.F1; ctx->stats.fanout2 = pl.F2; ctx->stats.buckets = 0; ctx->stats.batches = batches_used;
     ctx->last_algo = 1;
     return HJGPU_OK;
 }
@@ -590,7 +678,7 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
     if (inner) CHK(hj_launch_npj_build(rk, rv, inner, table, buckets, factor, &st->zero_key, ctx->cus, stream, line));
     record(ctx, EV_R_HIST, stream);     // reused as "end of build"
     CHK(npj_probe_enqueue(ctx, sk, sv, outer, table, buckets, factor, out, stream, line, unique));
-    ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets;
+    ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets; ctx->stats.batches = 0;
     ctx->last_algo = 0;
     return HJGPU_OK;
 }
@@ -1115,7 +1203,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
                                     &st->block_counter, &st->overflow, ctx->moves.p, &st->nmoves, &st->dense,
                                     ctx->cus, stream));
     record(ctx, EV_GAPS, stream);
-    ctx->stats.fanout1 = 1; ctx->stats.fanout2 = 1; ctx->stats.buckets = 0;
+    ctx->stats.fanout1 = 1; ctx->stats.fanout2 = 1; ctx->stats.buckets = 0; ctx->stats.batches = 0;
     ctx->last_algo = 1;
     return HJGPU_OK;
 }
@@ -1453,6 +1541,35 @@ int hjgpu_generate_zipf(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_
     int rc = hj_launch_generate(seed, inner_total, inner_begin, inner_count, outer_total, outer_begin,
                                 outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream, zipf);
     if (rc != HJGPU_OK) return fail(ctx, rc, "generate: bad sizes or launch failure");
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    return HJGPU_OK;
+}
+
+int hjgpu_generate_select(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
+                          size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
+                          uint32_t inner_factor, uint32_t outer_factor, double zipf, double selectivity,
+                          uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hjgpu_result *expected, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (!(zipf >= 0.0) || zipf > 8.0) return fail(ctx, HJGPU_EINVAL, "zipf exponent must be in [0, 8]");
+    if (!(selectivity >= 0.0) || selectivity > 1.0) return fail(ctx, HJGPU_EINVAL, "selectivity must be in [0, 1]");
+    if ((ik && !iv) || (ok && !ov)) return fail(ctx, HJGPU_EINVAL, "key column without payload column");
+    if (expected && outer_total < inner_total)
+        return fail(ctx, HJGPU_EINVAL, "analytic aggregates need unique build keys (outer_total >= inner_total)");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    u64 *d_expect = nullptr;
+    if (expected) {
+        memset(expected, 0, sizeof(*expected));
+        CHK(ensure(ctx, ctx->moves, 64));
+        d_expect = (u64 *)ctx->moves.p;
+        HIPCHK(ctx, hipMemsetAsync(d_expect, 0, 4 * sizeof(u64), stream));
+    }
+    int rc = hj_launch_generate(seed, inner_total, inner_begin, inner_count, outer_total, outer_begin,
+                                outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream, zipf, selectivity,
+                                ok ? d_expect : nullptr);
+    if (rc != HJGPU_OK) return fail(ctx, rc, "generate: bad sizes or launch failure");
+    if (expected) HIPCHK(ctx, hipMemcpyAsync(expected, d_expect, sizeof(*expected), hipMemcpyDeviceToHost, stream));
     HIPCHK(ctx, hipStreamSynchronize(stream));
     return HJGPU_OK;
 }

@@ -477,6 +477,47 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
     if (threadIdx.x == 0) a.slice_prefix[P] = run;
 }
 
+// Batch plan (see BatchPlanArgs): one workgroup per batch, thread p = pass-1 partition p (F1 <= 1024).
+__global__ __launch_bounds__(PLAN_BLOCK) void batch_plan_kernel(BatchPlanArgs a)
+{
+    __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
+    const uint32_t b = blockIdx.x, p = threadIdx.x, F1 = a.F1;
+    const uint32_t rb = b * a.ranges_per_batch, re = min(a.ranges, rb + a.ranges_per_batch);
+    const bool mine = p < F1;
+    u64 total = 0;
+    if (mine) for (uint32_t r = rb; r < re; ++r) total += a.range_counts[(u64)r * F1 + p];       // coalesced over p
+    const u64 off = block_exclusive_scan<PLAN_BLOCK, u64>(total, scratch);
+    u64 *boff = a.boff + (u64)b * (F1 + 1);
+    if (mine) {
+        boff[p] = off;
+        if (p == F1 - 1) boff[F1] = off + total;
+        u64 run = off;
+        for (uint32_t r = rb; r < re; ++r) { a.range_base[(u64)r * F1 + p] = run; run += a.range_counts[(u64)r * F1 + p]; }
+    }
+    __syncthreads();
+    const u64 tiles = mine ? hj_tiles_of(off, off + total, 0, a.tile2) : 0;
+    const u64 t0 = block_exclusive_scan<PLAN_BLOCK, u64>(tiles, scratch);
+    u64 *tp = a.tp2b + (u64)b * (F1 + 1);
+    if (mine) {
+        tp[p] = t0;
+        if (p == F1 - 1) tp[F1] = t0 + tiles;
+        uint4 *td = a.tdesc + (u64)b * a.tdesc_cap * 2;
+        const u64 gb = off, ge = off + total;
+        for (u64 t = t0; t < t0 + tiles && t < a.tdesc_cap; ++t) {
+            const u64 g0 = (gb & ~3ull) + (t - t0) * a.tile2;
+            td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
+            td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), p * a.F2, p);
+        }
+    }
+}
+
+int hj_launch_batch_plan(const BatchPlanArgs &a, uint32_t batches, hipStream_t stream)
+{
+    if (a.F1 == 0 || a.F1 > (uint32_t)PLAN_BLOCK || batches == 0) return HJGPU_EINVAL;
+    hipLaunchKernelGGL(batch_plan_kernel, dim3(batches), dim3(PLAN_BLOCK), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
 {
     if (a.mask & 3u) {
@@ -635,10 +676,11 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         if (exhausted) return t;
         if (RANGED) {
             const uint32_t Rc = a.geom.ranges_per_chunk;
-            const uint32_t nranges = Rc * a.geom.chunks;
+            const uint32_t nranges = a.range_count ? a.range_count : Rc * a.geom.chunks;
             if (!r_open || rt >= rt_end) {
                 r_cur = take_ticket();
                 if (r_cur >= nranges) { exhausted = true; return t; }
+                r_cur += a.range_begin;
                 const uint32_t c = r_cur / Rc, j = r_cur - c * Rc;
                 u64 cb = 0, ce = 0;
 #pragma unroll
@@ -1107,6 +1149,13 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("force_chained")) return parse_flag(value, &t->force_chained);
     if (is("scatter_prof")) return parse_flag(value, &t->scatter_prof);
     if (is("unique")) return parse_flag(value, &t->unique);
+    if (is("batch_tuples")) {
+        char *end = nullptr;
+        const long long x = strtoll(value, &end, 10);
+        if (end == value || *end) return false;
+        t->batch_tuples = x;
+        return true;
+    }
     if (is("range_tiles")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1135,7 +1184,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "range_tiles", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "range_tiles", "batch_tuples", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

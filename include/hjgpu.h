@@ -112,6 +112,9 @@ typedef struct {
                                   with the probe side's partitioning for PHJ / CPRA)         */
     float    ms_download;      /* hjgpu_join_host_rows: result columns -> host (wall clock)  */
     uint32_t fanout1, fanout2; /* what was used                                              */
+    uint32_t batches;          /* PHJ: batches the probe side was partitioned in (both passes of a batch
+                                  back to back, its intermediate copy kept in the Infinity Cache; their
+                                  time is reported as ms_scatter1, ms_scatter2 = 0); 0 = unbatched    */
     uint64_t buckets;          /* NPJ table size                                             */
 } hjgpu_stats;
 
@@ -411,6 +414,18 @@ int  hjgpu_generate_zipf(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size
                          uint32_t inner_factor, uint32_t outer_factor, double zipf,
                          uint32_t *d_inner_keys, uint32_t *d_inner_vals,
                          uint32_t *d_outer_keys, uint32_t *d_outer_vals, void *stream);
+/* As hjgpu_generate_zipf, with write.cpp's SELECTIVITY (write.cpp:1685-1689: with d = min(inner, outer) distinct
+ * keys per side, join_d = d * selectivity of them are common: the build side draws from unique[0, d), the probe
+ * side from unique[d - join_d, 2d - join_d)), so a full-size workload can hold probe tuples WITHOUT a match.
+ * `expected` (may be NULL; needs outer_total >= inner_total, i.e. unique build keys): the aggregates that the join
+ * of the generated probe range [outer_begin, +outer_count) with the WHOLE build side must return, accumulated
+ * while the tuples are generated ("accumulate the expected aggregates during generation");
+ * the ranges of several GPUs add up. */
+int  hjgpu_generate_select(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
+                           size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
+                           uint32_t inner_factor, uint32_t outer_factor, double zipf, double selectivity,
+                           uint32_t *d_inner_keys, uint32_t *d_inner_vals,
+                           uint32_t *d_outer_keys, uint32_t *d_outer_vals, hjgpu_result *expected, void *stream);
 /* sum over a column of key, key*f_a, key*f_b (mod 2^32 per term, uint64 sums):
  * the analytic join aggregates of a selectivity-1 workload.
  * The kernel is a plain 16-byte-load streaming read; hjgpu_get_stats().ms_total after

@@ -310,3 +310,106 @@ def test_two_contexts_on_two_host_threads_with_different_options(hj, oracle):
         t.join()
     assert not errors, errors[:3]
     assert int(hit.sum()) == want_unique[0]
+
+
+@pytest.mark.parametrize("selectivity,zipf", [(1.0, 0.0), (0.5, 0.0), (0.25, 1.2), (0.0, 0.0)])
+def test_device_generator_selectivity_and_its_analytic_aggregates(hj, selectivity, zipf):
+    """hjgpu_generate_select (write.cpp:1685-1689): join_d = d * selectivity common keys.  Small enough for numpy:
+    unique non-zero build keys, the share of distinct probe keys with a partner is the selectivity, the aggregates
+    accumulated during generation equal the join of the generated relations, and shards generated independently
+    (the per-GPU ranges of a multi-GPU run) are the pieces of the whole."""
+    inner, outer = 50_000, 400_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    want = hj.generate_select(7, inner, outer, 0, inner, 0, outer, fi, fo, zipf, selectivity, ik, iv, ok, ov)
+    hik, hiv, hok, hov = ik.download(), iv.download(), ok.download(), ov.download()
+    assert len(np.unique(hik)) == inner and (hik != 0).all() and (hok != 0).all()
+    assert np.array_equal(hiv, hik * np.uint32(fi)) and np.array_equal(hov, hok * np.uint32(fo))
+    assert want == numpy_join(hik, hiv, hok, hov)
+    distinct_probe = np.unique(hok)
+    assert len(distinct_probe) <= inner
+    assert int(np.isin(distinct_probe, hik).sum()) == min(int(inner * selectivity), len(distinct_probe)) or zipf > 0
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    # three shards of the probe side, generated on their own
+    total = (0, 0, 0, 0)
+    for b, e in ((0, 100_000), (100_000, 100_016), (100_016, outer)):
+        part = hj.generate_select(7, inner, outer, 0, 0, b, e - b, fi, fo, zipf, selectivity, None, None,
+                                  ok.ptr + 4 * b, ov.ptr + 4 * b)
+        total = tuple((x + y) & ((1 << 64) - 1) for x, y in zip(total, part))
+    assert total == want and np.array_equal(ok.download(), hok)
+    for c in (ik, iv, ok, ov):
+        c.free()
+
+
+@pytest.mark.parametrize("selectivity", [0.5, 0.0])
+def test_full_size_64m_1g_with_non_matching_probe_keys(hj, selectivity):
+    """BASELINE's size with write.cpp's selectivity below 1: half (none) of the probe side's distinct keys have a
+    partner, so the probe kernels see misses at full size; the result must equal the aggregates accumulated while
+    the relations were generated, for PHJ, CPRA and NPJ."""
+    inner, outer = 64_000_000, 1_000_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    want = hj.generate_select(3, inner, outer, 0, inner, 0, outer, fi, fo, 0.0, selectivity, ik, iv, ok, ov)
+    if selectivity == 0.0:
+        assert want == (0, 0, 0, 0)
+    else:
+        assert 0.45 * outer < want[0] < 0.55 * outer
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=8)) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    for c in (ik, iv, ok, ov):
+        c.free()
+
+
+@pytest.mark.parametrize("batch_tuples", [40_000, 300_000, 2_000_000])
+def test_batched_probe_side_partitioning(hj, batch_tuples):
+    """Two-pass plans partition the probe side in batches (pass 1 of a batch into a small reused buffer, pass 2
+    straight from it: the intermediate copy stays in the Infinity Cache).  Forced here at test sizes through
+    option "batch_tuples": ragged last batch, batches of a single range, unaligned probe columns, misses, duplicate
+    build keys, materialised rows, prepared build side probed in pieces."""
+    rng = np.random.default_rng(batch_tuples)
+    base = np.unique(rng.integers(0, 2**32, size=400_000, dtype=np.uint64).astype(np.uint32))
+    ik = np.concatenate([base, base[:30_000]])
+    iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+    outer = 7_300_003
+    ok = np.where(rng.random(outer) < 0.8, base[rng.integers(0, len(base), size=outer)],
+                  rng.integers(0, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)).astype(np.uint32)
+    ov = rng.integers(0, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)
+    want = numpy_join(ik, iv, ok, ov)
+    rk, rv = hj.column(ik), hj.column(iv)
+    pad = 3                                             # probe columns start 12 bytes into their allocations
+    sk_all = hj.column(np.concatenate([np.zeros(pad + 1, np.uint32), ok]))
+    sv_all = hj.column(np.concatenate([np.zeros(pad + 1, np.uint32), ov]))
+    hj.set_option("batch_tuples", batch_tuples)
+    try:
+        for off in (pad + 1, 0):                        # 16-byte aligned start, then the whole allocation (4 extra zeros join nothing... key 0 absent)
+            sk, sv, n = sk_all.ptr + 4 * off, sv_all.ptr + 4 * off, outer + (pad + 1 - off)
+            extra = (pad + 1 - off)
+            w = want if extra == 0 else numpy_join(ik, iv, np.concatenate([np.zeros(extra, np.uint32), ok]), np.concatenate([np.zeros(extra, np.uint32), ov]))
+            for prm in (H.PhjParams(fanout1=16, fanout2=9), H.PhjParams(fanout1=128, fanout2=3), None):
+                assert hj.phj(rk, rv, len(ik), sk, sv, n, prm) == w
+                st = hj.stats()
+                if prm is not None:
+                    assert st["batches"] >= 2 and st["fanout2"] > 1
+        sk, sv = sk_all.ptr + 4 * (pad + 1), sv_all.ptr + 4 * (pad + 1)
+        prm = H.PhjParams(fanout1=32, fanout2=5)
+        block = 1024
+        cap = (want[0] // block + hj.device_info()["compute_units"] * 16 + 8) * block
+        jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+        assert hj.phj(rk, rv, len(ik), sk, sv, outer, prm, out=(jk, jo, ji, cap, block)) == want
+        rows = sort_rows(jk.download()[:want[0]], jo.download()[:want[0]], ji.download()[:want[0]])
+        for a, b in zip(rows, materialised_rows(ik, iv, ok, ov)):
+            assert np.array_equal(a, b)
+        # prepared build side, probe side in two pieces (each batched on its own)
+        cut = 3_000_000 & ~15
+        hj.phj_build(rk, rv, len(ik), outer - cut, prm)
+        a = hj.phj_probe(sk, sv, cut)
+        b = hj.phj_probe(sk + 4 * cut, sv + 4 * cut, outer - cut)
+        assert tuple((x + y) & ((1 << 64) - 1) for x, y in zip(a, b)) == want
+        for c in (jk, jo, ji):
+            c.free()
+    finally:
+        hj.set_option("batch_tuples", 0)
+    for c in (rk, rv, sk_all, sv_all):
+        c.free()

@@ -14,6 +14,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 
@@ -22,10 +23,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_pass(counter, extra):
     out = os.path.join(ROOT, "gpurun_out", "traffic_" + counter)
+    shutil.rmtree(out, ignore_errors=True)          # a previous run's dispatches must not be averaged in
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-outer", "0"] + extra
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-outer", "0", "--no-secondary"] + extra
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -45,12 +47,15 @@ def main():
         w, _ = write.get(k, (0.0, 0))
         res[k] = {"launches_seen": nf, "read_bytes_per_launch": 2.0 * f * 1024.0,
                   "written_bytes_per_launch": w * 1024.0,
-                  "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0}
+                  "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0,
+                  # uncorrected counter: what applies to 64-byte random line reads (NPJ's table walks), which are
+                  # 64-byte requests and counted at their size; only wide coalesced streams are tallied at half
+                  "fetch_size_bytes_raw": f * 1024.0}
     sys.path.insert(0, ROOT)
     import hash_join_codes_knl_amd as H
     out = {"kernel_hash": H.kernel_hash(),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
-                     "`bench.py --steps 2 --warmup 1`, averaged over all launches of a kernel; "
+                     "`bench.py --steps 2 --warmup 1 --cpu-outer 0 --no-secondary`, averaged over all launches of a kernel; "
                      "read = 2*FETCH_SIZE KiB (gfx950 correction), written = WRITE_SIZE KiB",
            "bench_args": extra, "kernels": res}
     path = os.path.join(ROOT, "gpurun_out", "traffic.json")

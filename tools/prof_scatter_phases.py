@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a scatter workgroup's time goes (HJGPU_SCATTER_PROF=1: s_memtime stamps between the
+"""Where a scatter workgroup's time goes (option scatter_prof: s_memtime stamps between the
 barriers of K6, printed by the library).  usage: python tools/prof_scatter_phases.py [zipf]"""
 import os
 import sys
@@ -14,5 +14,5 @@ ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column
 hj.generate_zipf(1, inner, outer, 0, inner, 0, outer, 0x2545F491, 0x9E3779B1, zipf, ik, iv, ok, ov)
 for i in range(2):
     hj.phj(ik, iv, inner, ok, ov, outer)
-os.environ["HJGPU_SCATTER_PROF"] = "1"
+hj.set_option("scatter_prof", 1)
 hj.phj(ik, iv, inner, ok, ov, outer)

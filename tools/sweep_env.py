@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""A/B timing of library tuning knobs INSIDE ONE PROCESS (same device, same
+"""A/B timing of library options (hjgpu_set_option) INSIDE ONE PROCESS (same device, same
 buffers): boxes differ by +-10 % and even processes on one box differ, so only
 interleaved rounds in one process are comparable (cdna_hip_programming.md rule 24).
 
-usage: python tools/sweep_env.py VAR v1 v2 ... [--inner N --outer N --rounds R --algo phj]
+usage: python tools/sweep_env.py OPTION v1 v2 ...   (e.g. dense2 0 1; scatter_cfg 1024,4 1024,3; "" resets a cfg)
+       python tools/sweep_env.py OPTION v1 v2 ... [--inner N --outer N --rounds R --algo phj]
 Prints the median / min of every phase per value."""
 import argparse
 import os
@@ -34,7 +35,7 @@ def main():
     data = {v: {p: [] for p in phases} for v in a.values}
     for rnd in range(a.rounds):
         for v in a.values:
-            os.environ[a.var] = v
+            hj.set_option(a.var.lower().replace("hjgpu_", ""), v)
             for _ in range(a.reps):
                 got = fn(ik, iv, a.inner, ok, ov, a.outer)
                 assert got == want, (v, got, want)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of (fanout1, fanout2[, env]) choices INSIDE ONE PROCESS (same device, same
 buffers; boxes and even processes differ by +-10 %).
-usage: python tools/sweep_fanout.py 136x136 512x37 "512x37:HJGPU_SCATTER_CFG=1024,2,0" ...
+usage: python tools/sweep_fanout.py 136x136 512x37 "512x37:scatter_cfg=1024,2,0" ...   (options: hjgpu_set_option)
        [--inner N --outer N --rounds R --reps K]
 Every run is checked against the analytic aggregates."""
 import argparse
@@ -34,10 +34,11 @@ def main():
             spec, _, envs = case.partition(":")
             f1, f2 = (int(x) for x in spec.split("x"))
             for k in touched:
-                os.environ.pop(k, None)
+                hj.set_option(k, "" if k.endswith("_cfg") else 0)
             for kv in filter(None, envs.split(";")):
                 k, v = kv.split("=", 1)
-                os.environ[k] = v
+                k = k.lower().replace("hjgpu_", "")
+                hj.set_option(k, v)
                 touched.add(k)
             prm = H.PhjParams(fanout1=f1, fanout2=f2)
             for _ in range(a.reps):
