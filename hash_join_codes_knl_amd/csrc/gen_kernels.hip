@@ -205,3 +205,19 @@ int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hi
     hipLaunchKernelGGL(stream_read_kernel, dim3(cus * 2), dim3(1024), 0, stream, (const uint4 *)p, pieces, (uint4 *)sink16);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
+
+// Placement probe (hjgpu_api.hip, ensure_placed): a plain streaming fill of a freshly allocated buffer.  Its rate
+// differs by up to 26 % between allocations of the same size on one MI355X (physical placement; profiles/r02_placement.txt)
+// and predicts how fast K6 pass 1 will write into that buffer.
+__global__ __launch_bounds__(1024) void fill_probe_kernel(uint4 *__restrict__ out, u64 n)
+{
+    const uint4 v = make_uint4(0, 0, 0, 0);
+    for (u64 i = (u64)blockIdx.x * 1024 + threadIdx.x; i < n; i += (u64)gridDim.x * 1024) out[i] = v;
+}
+
+int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream)
+{
+    if (((uintptr_t)p & 15) || bytes < 16) return HJGPU_EINVAL;
+    hipLaunchKernelGGL(fill_probe_kernel, dim3(1024), dim3(1024), 0, stream, (uint4 *)p, (u64)(bytes / 16));
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}

@@ -53,6 +53,7 @@ struct HjTuning {
     bool force_chained = false;     // "force_chained": chained fallback tables everywhere (tests)
     bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
+    int placement = 6;              // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned
@@ -243,5 +244,6 @@ int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_
                        uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream,
                        double zipf = 0.0, double selectivity = 1.0, u64 *d_expect = nullptr);
 int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hipStream_t stream);
+int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream);
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
                           hipStream_t stream);

@@ -104,6 +104,49 @@ int ensure(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     return HJGPU_OK;
 }
 
+// Placement-aware allocation of a large buffer that K6 pass 1 scatters into.  On one MI355X the same kernel on the
+// same data takes 2.95 or 3.4 ms depending on WHICH allocation the 8 GB pass-1 twin of the probe side lives in: the
+// offset inside the allocation does not matter, a fresh hipMalloc of the same size does (physical placement;
+// tools/alloc_luck.py, profiles/r02_alloc_luck.txt, r02_shift_sweep.txt), and a plain streaming fill of the buffer shows
+// the same split - 1.47 to 1.99 ms per 8.5 GB - and predicts it (tools/ubench_placement.hip, profiles/r02_placement.txt).
+// So a large twin is chosen among up to `placement` candidate allocations (all held until the choice is made, so that
+// every candidate is different memory) by that fill: the first one that fills at >= 5.3 TB/s is taken, else the
+// fastest.  This runs when the workspace grows (hjgpu_reserve / first join), never inside a timed join afterwards.
+int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return HJGPU_OK;
+    const int tries = ctx->tune.placement;
+    if (tries <= 1 || bytes < ((size_t)1 << 30)) return ensure(ctx, b, bytes);
+    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = (bytes + 255) / 256 * 256 + 256;
+    void *cand[16];
+    float ms[16];
+    int n = 0, best = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    for (; n < tries; ++n) {
+        size_t free_b = 0, total_b = 0;
+        if (n && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < want + ((size_t)2 << 30))) break;   // no room for another candidate
+        if (hipMalloc(&cand[n], want) != hipSuccess) { (void)hipGetLastError(); break; }
+        ms[n] = 1e30f;
+        for (int rep = 0; rep < 2; ++rep) {                                  // the first touch of fresh memory is slower
+            float t = 1e30f;
+            if (hipEventRecord(e0, 0) == hipSuccess && hj_launch_fill_probe(cand[n], want, 0) == HJGPU_OK &&
+                hipEventRecord(e1, 0) == hipSuccess && hipEventSynchronize(e1) == hipSuccess)
+                (void)hipEventElapsedTime(&t, e0, e1);
+            if (t < ms[n]) ms[n] = t;
+        }
+        if (best < 0 || ms[n] < ms[best]) best = n;
+        if ((double)want / (ms[n] * 1e-3) >= 5.3e12) { ++n; break; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (best < 0) return fail(ctx, HJGPU_ENOMEM, "hipMalloc(workspace)");
+    for (int i = 0; i < n; ++i) if (i != best) (void)hipFree(cand[i]);
+    b.p = cand[best]; b.cap = want;
+    return HJGPU_OK;
+}
+
 inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) & 3); }
 
 // Carves the meta buffer; must match between sizing and use.
@@ -346,7 +389,7 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     // tmp[4] / tmp[6] = pass-2 output
     const size_t rb = (inner + 4) * sizeof(u64), sb = (outer + 4) * sizeof(u64);
     CHK(ensure(ctx, ctx->tmp[0], rb));
-    CHK(ensure(ctx, ctx->tmp[2], sb));
+    CHK(ensure_placed(ctx, ctx->tmp[2], sb));
     if (pl->F2 > 1) {
         // the final layout starts every partition on a 128-byte line: < 16 tuples of padding each
         const size_t pad = (size_t)pl->C * pl->P * HJ_LINE_TUPLES * sizeof(u64);

@@ -91,7 +91,16 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
             constexpr bool HOT = decltype(hot_tag)::value;
             constexpr int U = 4;                       // key vectors per lane and batch; two batches in flight
             const u64 step = (u64)BLOCK * 4 * U;
-            auto fetch = [&](u64 g0, uint4 (&kv)[U]) {
+            // A batch is WHOLE when all its BLOCK * 4 * U keys lie inside the range and the chunk (uniform test): no
+            // per-vector and per-key predicates then, i.e. no exec-mask bookkeeping around the loads and LDS adds
+            // (all batches of a range but the chunk's first and the range's last).
+            auto whole = [&](u64 base) { return base >= gb && base + step <= g_hi && base + step <= ge; };
+            auto fetch = [&](u64 g0, uint4 (&kv)[U], bool all) {
+                if (all) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) kv[u] = k4[(g0 + (u64)u * BLOCK * 4) >> 2];
+                    return;
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const u64 g = g0 + (u64)u * BLOCK * 4;
@@ -99,7 +108,23 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
                     if (g < g_hi) kv[u] = k4[g >> 2];
                 }
             };
-            auto count = [&](u64 g0, const uint4 (&kv)[U]) {
+            auto add_key = [&](uint32_t key) {
+                const uint32_t p1 = part1(key);
+                if (HOT) {
+                    const uint32_t bin = p1 * F2 + hj_hash(key, f2, F2);
+                    const bool is_hot = bin == hot_bin;
+                    const u64 m = __ballot(is_hot);             // over the lanes with a valid key here
+                    if (!is_hot) atomicAdd(&lds_hist[bin], 1u);
+                    else if (hj_lane() == (uint32_t)__builtin_ctzll(m)) atomicAdd(&lds_hist[hot_bin], (uint32_t)__popcll(m));
+                } else if (F2 > 1) atomicAdd(&lds_hist[p1 * F2 + hj_hash(key, f2, F2)], 1u);
+                else atomicAdd(&range_hist[p1], 1u);
+            };
+            auto count = [&](u64 g0, const uint4 (&kv)[U], bool all) {
+                if (all) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { add_key(kv[u].x); add_key(kv[u].y); add_key(kv[u].z); add_key(kv[u].w); }
+                    return;
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const u64 g = g0 + (u64)u * BLOCK * 4;
@@ -107,34 +132,27 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
                     const uint32_t kk[4] = {kv[u].x, kv[u].y, kv[u].z, kv[u].w};
                     const bool full = (g >= gb) && (g + 4 <= ge);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (full || (g + e >= gb && g + e < ge)) {
-                            const uint32_t p1 = part1(kk[e]);
-                            if (HOT) {
-                                const uint32_t bin = p1 * F2 + hj_hash(kk[e], f2, F2);
-                                const bool is_hot = bin == hot_bin;
-                                const u64 m = __ballot(is_hot);             // over the lanes with a valid key here
-                                if (!is_hot) atomicAdd(&lds_hist[bin], 1u);
-                                else if (hj_lane() == (uint32_t)__builtin_ctzll(m)) atomicAdd(&lds_hist[hot_bin], (uint32_t)__popcll(m));
-                            } else if (F2 > 1) atomicAdd(&lds_hist[p1 * F2 + hj_hash(kk[e], f2, F2)], 1u);
-                            else atomicAdd(&range_hist[p1], 1u);
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (full || (g + e >= gb && g + e < ge)) add_key(kk[e]);
                 }
             };
             // the next batch's loads are issued before the current batch is counted: the lane always has
             // 4-8 loads outstanding (one workgroup per CU at fan-outs whose histogram takes > 72 KiB of LDS)
             uint4 ka[U], kb[U];
-            u64 g0 = g_lo + (u64)threadIdx.x * 4;
-            fetch(g0, ka);
-            while (g0 < g_hi) {
-                fetch(g0 + step, kb);
-                count(g0, ka);
-                g0 += step;
-                if (g0 >= g_hi) break;
-                fetch(g0 + step, ka);
-                count(g0, kb);
-                g0 += step;
+            u64 base = g_lo;                                            // first key of the batch (uniform)
+            const u64 mine = (u64)threadIdx.x * 4;
+            bool wa = whole(base), wb;
+            fetch(base + mine, ka, wa);
+            while (base < g_hi) {
+                wb = whole(base + step);
+                fetch(base + step + mine, kb, wb);
+                count(base + mine, ka, wa);
+                base += step;
+                if (base >= g_hi) break;
+                wa = whole(base + step);
+                fetch(base + step + mine, ka, wa);
+                count(base + mine, kb, wb);
+                base += step;
             }
         };
         if (t_end > t_beg) {
@@ -802,38 +820,57 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         uint32_t hot_n = 0;                                             // heavy-partition tuples of this wave
         // interior tiles (all but the first and last of a segment) need no per-tuple bounds checks
         const bool interior = cur.g0 >= cur.gb && cur.g0 + (u64)TILE <= cur.ge;
-        auto partition_ids = [&](auto checked) {
+        // Interior tiles without a hot partition (all but the first / last tile of a segment, uniform keys) take a
+        // straight-line path: no validity predicates, i.e. no exec-mask bookkeeping around every LDS atomic (the
+        // scalar unit issues ~750 instructions per lane and tile in the general path, one scalar unit per CU).
+        if (interior && !hot) {
+            // (the power-of-two test is hoisted: as a per-tuple select it became a scalar branch per tuple)
+            auto rank_all = [&](auto pow2) {
 #pragma unroll
-            for (int j = 0; j < VPT; ++j) {
-                const u64 g = cur.g0 + (u64)(j * BLOCK + tid) * 4;
+                for (int j = 0; j < VPT; ++j) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool valid = !decltype(checked)::value || ((g + c >= cur.gb) && (g + c < cur.ge));
-                    const uint32_t p = valid ? part_of(key_of(j, c)) : 0xFFFFFFFFu;
-                    pr[j * 4 + c] = p;
-                    if (hot) hot_n += (uint32_t)__popcll(__ballot(p == hot_p));
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t x = key_of(j, c) * factor;
+                        const uint32_t p = decltype(pow2)::value ? x >> f_shift : __umulhi(x, F);
+                        pr[j * 4 + c] = (p << 16) | atomicAdd(&hist[p], 1u);
+                    }
                 }
+            };
+            if (f_pow2) rank_all(std::true_type()); else rank_all(std::false_type());
+        } else {
+            auto partition_ids = [&](auto checked) {
+    #pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    const u64 g = cur.g0 + (u64)(j * BLOCK + tid) * 4;
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const bool valid = !decltype(checked)::value || ((g + c >= cur.gb) && (g + c < cur.ge));
+                        const uint32_t p = valid ? part_of(key_of(j, c)) : 0xFFFFFFFFu;
+                        pr[j * 4 + c] = p;
+                        if (hot) hot_n += (uint32_t)__popcll(__ballot(p == hot_p));
+                    }
+                }
+            };
+            if (interior) partition_ids(std::false_type()); else partition_ids(std::true_type());
+            uint32_t hot_base = 0;
+            if (hot && hot_n) {                                             // ONE add per wave for all its heavy tuples
+                if (hj_lane() == 0) hot_base = atomicAdd(&hist[hot_p], hot_n);
+                hot_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)hot_base);
             }
-        };
-        if (interior) partition_ids(std::false_type()); else partition_ids(std::true_type());
-        uint32_t hot_base = 0;
-        if (hot && hot_n) {                                             // ONE add per wave for all its heavy tuples
-            if (hj_lane() == 0) hot_base = atomicAdd(&hist[hot_p], hot_n);
-            hot_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)hot_base);
-        }
-#pragma unroll
-        for (int k = 0; k < VPT * 4; ++k) {
-            const uint32_t p = pr[k];
-            uint32_t code = 0xFFFFFFFFu;
-            if (hot) {
-                const u64 grp = __ballot(p == hot_p);
-                if (p == hot_p)
-                    code = (p << 16) | (hot_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32),
-                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u)));
-                hot_base += (uint32_t)__popcll(grp);
+    #pragma unroll
+            for (int k = 0; k < VPT * 4; ++k) {
+                const uint32_t p = pr[k];
+                uint32_t code = 0xFFFFFFFFu;
+                if (hot) {
+                    const u64 grp = __ballot(p == hot_p);
+                    if (p == hot_p)
+                        code = (p << 16) | (hot_base + __builtin_amdgcn_mbcnt_hi((uint32_t)(grp >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u)));
+                    hot_base += (uint32_t)__popcll(grp);
+                }
+                if (p != 0xFFFFFFFFu && !(hot && p == hot_p)) code = (p << 16) | atomicAdd(&hist[p], 1u);
+                pr[k] = code;
             }
-            if (p != 0xFFFFFFFFu && !(hot && p == hot_p)) code = (p << 16) | atomicAdd(&hist[p], 1u);
-            pr[k] = code;
         }
         hj_barrier_lds();
         stamp(1);
@@ -912,14 +949,29 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         const uint32_t tile_count = wsum[NW];
 
         // ---- counting sort inside LDS --------------------------------------------
+        if (interior) {                                                // every tuple of the tile is valid
+            // all partition bases are requested before the first is used (one LDS round trip per tile, not 16)
+            uint32_t pbase[VPT * 4];
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
+            for (int k = 0; k < VPT * 4; ++k) pbase[k] = hist[pr[k] >> 16];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t code = pr[j * 4 + c];
-                if (code != 0xFFFFFFFFu) {
-                    const uint32_t pos = hist[code >> 16] + (code & 0xFFFFu);
+            for (int j = 0; j < VPT; ++j) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t pos = pbase[j * 4 + c] + (pr[j * 4 + c] & 0xFFFFu);
                     stage[pos] = (u64)key_of(j, c) | ((u64)val_of(j, c) << 32);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t code = pr[j * 4 + c];
+                    if (code != 0xFFFFFFFFu) {
+                        const uint32_t pos = hist[code >> 16] + (code & 0xFFFFu);
+                        stage[pos] = (u64)key_of(j, c) | ((u64)val_of(j, c) << 32);
+                    }
                 }
             }
         }
@@ -971,16 +1023,31 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 const uint32_t lim = off + e, s_end = min(lim, (c + 1) * UNIT);
                 const u64 base = d0 - off;
                 const uint32_t src0 = hist[p];                      // sorted index of the first fresh tuple
-                auto fetch = [&](uint32_t k) -> u64 { return k < fc ? carry[p * LINE + k] : stage[src0 + (k - fc)]; };
-                for (uint32_t s = c * UNIT + sub * 2; s < s_end; s += 32) {
-                    const bool v0 = s >= off, v1 = s + 1 >= off && s + 1 < lim;
-                    if (v0 && v1) {
-                        const u64 t0 = fetch(s - off), t1 = fetch(s + 1 - off);
-                        *reinterpret_cast<uint4 *>(out64 + base + s) =
-                            make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
-                    } else if (v0) out64[base + s] = fetch(s - off);
-                    else if (v1) out64[base + s + 1] = fetch(s + 1 - off);
+                // ONE LDS read per tuple: the address is selected, not the value
+                auto fetch = [&](uint32_t k) -> u64 { const u64 *src = k < fc ? &carry[p * LINE + k] : &stage[src0 + (k - fc)]; return *src; };
+                uint32_t s = c * UNIT + sub * 2;
+                if (c == 0) {
+                    // the unit's first sweep: the run may start inside a line and its first tuples may be carried ones
+                    if (s < s_end) {
+                        const bool v0 = s >= off, v1 = s + 1 >= off && s + 1 < lim;
+                        if (v0 && v1) {
+                            const u64 t0 = fetch(s - off), t1 = fetch(s + 1 - off);
+                            *reinterpret_cast<uint4 *>(out64 + base + s) =
+                                make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
+                        } else if (v0) out64[base + s] = fetch(s - off);
+                        else if (v1) out64[base + s + 1] = fetch(s + 1 - off);
+                    }
+                    s += 32;
                 }
+                // every later slot (s >= 32 > off + carried) holds fresh tuples, neighbours in the sorted tile: two
+                // adjacent LDS words, one 16-byte store, no predicates
+                const u64 *__restrict__ src = stage + src0 - off - fc;
+                for (; s + 1 < s_end; s += 32) {
+                    const u64 t0 = src[s], t1 = src[s + 1];
+                    *reinterpret_cast<uint4 *>(out64 + base + s) =
+                        make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
+                }
+                if (s < s_end) out64[base + s] = src[s];            // the run ends on an even slot
             };
             const uint32_t nunits = F + wsum[NW + 1];
             for (uint32_t u = gid; u < nunits; u += NG) {
@@ -1149,6 +1216,13 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("force_chained")) return parse_flag(value, &t->force_chained);
     if (is("scatter_prof")) return parse_flag(value, &t->scatter_prof);
     if (is("unique")) return parse_flag(value, &t->unique);
+    if (is("placement")) {
+        char *end = nullptr;
+        const long x = strtol(value, &end, 10);
+        if (end == value || *end || x < 1 || x > 16) return false;
+        t->placement = (int)x;
+        return true;
+    }
     if (is("batch_tuples")) {
         char *end = nullptr;
         const long long x = strtoll(value, &end, 10);
@@ -1184,7 +1258,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "range_tiles", "batch_tuples", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "range_tiles", "batch_tuples", "placement", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);
