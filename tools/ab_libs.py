@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--algo", default="phj")
+    ap.add_argument("--no-check", action="store_true", help="timing experiments with deliberately wrong variants")
     a = ap.parse_args()
     import hash_join_codes_knl_amd as H
     from hash_join_codes_knl_amd import api
@@ -38,7 +39,7 @@ def main():
         for path, c in zip(a.libs, ctxs):
             for _ in range(a.reps):
                 got = getattr(c, a.algo)(ik, iv, a.inner, ok, ov, a.outer)
-                assert got == want, (path, got, want)
+                assert a.no_check or got == want, (path, got, want)
                 st = c.stats()
                 if rnd > 0 or a.rounds == 1:
                     for ph in phases:
