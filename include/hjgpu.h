@@ -142,7 +142,8 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * process-wide state.  Names: "unique" (as HJGPU_FLAG_UNIQUE, for every join of the context,
  * including the operator-level hjgpu_npj_probe), "force_chained", "no_broadcast", "dense2", "npj_refhash",
  * "scatter_prof" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
- * "scatter2_cfg" ("block,vectors[,carry]").  Unknown names and malformed values: HJGPU_EINVAL. */
+ * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
+ * twin, 1..16); "batch_tuples" (n, 0 = off).  Unknown names and malformed values: HJGPU_EINVAL. */
 int  hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value);
 /* Pre-size the internal workspace (partition scratch twins = hj.h's [1]
  * columns, NPJ table) so that no allocation happens inside a timed join. */
@@ -222,7 +223,9 @@ int  hjgpu_cpra(hjgpu_ctx *ctx,
                 const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
                 const hjgpu_phj_params *params,
                 hjgpu_result *result, const hjgpu_output *out, void *stream);
-/* Enqueue-only forms: the aggregates land in d_result (device memory, 32 bytes);
+/* hjgpu_npj_async cannot report HJGPU_EZEROKEY (a build key of 0 is skipped by the build, npj.cpp:583, and the
+ * blocking hjgpu_npj says so): callers of the enqueue-only form must keep key 0 out of the build side themselves.
+ * Enqueue-only forms: the aggregates land in d_result (device memory, 32 bytes);
  * no host synchronisation, so a caller can time with its own events and keep several
  * joins in flight on one stream.  Workspace must have been reserved (hjgpu_reserve).
  * Not valid inside a HIP stream capture (HJGPU_EINVAL on a capturing stream): a

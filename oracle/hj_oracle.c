@@ -224,10 +224,12 @@ int hjo_simd_available(void)
 #endif
 }
 
+void hjo_avx512_vector_scatter(int on);
 int hjo_set_simd(int on)
 {
     g_simd = (on && hjo_simd_available()) ? 1 : 0;
-    return g_simd;
+    hjo_avx512_vector_scatter(g_simd && on == 2);         /* 2: the partition's conflict-serialised vector scatter */
+    return g_simd ? on : 0;
 }
 
 /* The reference's -D_UNIQUE build (npj.cpp:288-290, 436-438; phj.cpp:459, 635-637; cpra2.cpp:456, 625, 698):

@@ -47,7 +47,9 @@ typedef struct {
 
 /* AVX-512 forms of histogram / partition / probe (hj_oracle_avx512.c) for the timed CPU
  * baseline: off by default; hjo_set_simd(1) turns them on where the CPU has AVX-512 and
- * returns what is in effect.  Results are identical to the scalar definitions. */
+ * returns what is in effect; hjo_set_simd(2) additionally moves the partition's tuples with the
+ * reference's conflict-serialised vector scatter (phj.cpp:1099-1160) instead of scalar stores.
+ * Results are identical to the scalar definitions. */
 int hjo_simd_available(void);
 int hjo_set_simd(int on);
 /* The reference's -D_UNIQUE build (npj.cpp:288-290, 436-438; phj.cpp:459, 635-637): a probe tuple

@@ -11,9 +11,11 @@
  *
  *   histogram  16 lane-private counter rows (index p*16 + lane never collides inside a vector;
  *              the reference gets the same effect from 16 replicated 8-bit counters, phj.cpp:735-752)
- *   partition  per-partition 16-tuple write-combining lines flushed with non-temporal 64-byte
- *              stores (the reference: BUFFER_SIZE-tuple interleaved buffers + _mm512_stream_ps,
- *              phj.cpp:1115-1160); stable, so the output equals the scalar counting sort
+ *   partition  16 partition ids per vector, same-partition lanes serialised with vpconflictd, masked
+ *              gather / scatter of the line slots and of key and payload into per-partition 16-tuple
+ *              write-combining lines, flushed with non-temporal 64-byte stores (the reference: lane-id
+ *              scatter / gather-back, BUFFER_SIZE-tuple interleaved buffers + _mm512_stream_ps,
+ *              phj.cpp:1099-1160); stable, so the output equals the scalar counting sort
  *   probe      16 chains advanced in lock step under a mask, 64-bit gathers of the buckets
  *              (the reference refills finished lanes instead, phj.cpp:427-435); aggregates only
  */
@@ -64,6 +66,12 @@ void hjo_histogram_avx512(const uint32_t *keys, size_t size, uint32_t *counts,
  * [16w, 16w + 16); a line leaves with a non-temporal store when its last slot is filled, or
  * with a masked store when it is only partly ours (first line of a range that starts in the
  * middle of a line, last lines at the end). */
+static int g_vector_scatter = 0;
+/* 0: 16 partition ids per vector, tuples moved with scalar stores into the write-combining lines (the faster form on
+ * the CPUs measured: 0.46 against 0.30 Gtuples/s for the whole PHJ, 8 threads of a Xeon with slow scatters);
+ * 1: the reference's shape, conflict-serialised masked gather / scatter (phj.cpp:1099-1160).  Same output. */
+void hjo_avx512_vector_scatter(int on) { g_vector_scatter = on ? 1 : 0; }
+
 static void partition_wc(const uint32_t *keys, const uint32_t *vals, size_t size, size_t *offsets,
                          uint32_t *keys_out, uint32_t *vals_out, uint32_t factor, size_t partitions)
 {
@@ -105,10 +113,69 @@ static void partition_wc(const uint32_t *keys, const uint32_t *vals, size_t size
             }                                                                                    \
         }                                                                                        \
     } while (0)
-    for (; i + 16 <= size; i += 16) {
-        const __m512i k = _mm512_loadu_si512((const void *)(keys + i));
-        _mm512_store_si512((void *)part, mulhi32(_mm512_mullo_epi32(k, f), n));
-        for (int l = 0; l != 16; ++l) HJO_PUT(part[l], keys[i + l], vals[i + l]);
+    if (g_vector_scatter) {
+        /* Vector main loop, the shape of the reference's (phj.cpp:1099-1160): 16 partition ids per vector; lanes that
+         * hit the same partition are serialised (the reference writes lane ids and reads them back, phj.cpp:1099-1102;
+         * AVX-512CD has vpconflictd: a lane is ready when no EARLIER pending lane shares its partition, which also keeps
+         * the sort stable); the ready lanes gather their line slots, scatter key and payload into the write-combining
+         * lines and bump the slots with one more scatter; a line whose last slot was just filled leaves with
+         * non-temporal stores (phj.cpp:1124-1160).  slot16[p] = slot of the partition's next tuple inside its line. */
+        uint32_t *slot16 = (uint32_t *)aligned_alloc(64, ((partitions + 15) & ~(size_t)15) * sizeof(uint32_t));
+        for (size_t p = 0; p != partitions; ++p) slot16[p] = (uint32_t)((offsets[p] + shift) & 15);
+        const __m512i fifteen = _mm512_set1_epi32(15), one = _mm512_set1_epi32(1);
+        for (; i + 16 <= size; i += 16) {
+            const __m512i k = _mm512_loadu_si512((const void *)(keys + i));
+            const __m512i v = _mm512_loadu_si512((const void *)(vals + i));
+            const __m512i p = mulhi32(_mm512_mullo_epi32(k, f), n);
+            __mmask16 pending = 0xFFFF;
+            do {
+                /* conflict bits of lane l: earlier lanes with the same partition; only pending ones still block it */
+                const __m512i conf = _mm512_and_epi32(_mm512_conflict_epi32(p), _mm512_set1_epi32((int)pending));
+                const __mmask16 ready = _mm512_mask_cmpeq_epi32_mask(pending, conf, _mm512_setzero_si512());
+                const __m512i slot = _mm512_mask_i32gather_epi32(_mm512_setzero_si512(), ready, p, slot16, 4);
+                const __m512i at = _mm512_add_epi32(_mm512_slli_epi32(p, 4), slot);
+                _mm512_mask_i32scatter_epi32(bk, ready, at, k, 4);
+                _mm512_mask_i32scatter_epi32(bv, ready, at, v, 4);
+                _mm512_mask_i32scatter_epi32(slot16, ready, p, _mm512_and_epi32(_mm512_add_epi32(slot, one), fifteen), 4);
+                __mmask16 full = _mm512_mask_cmpeq_epi32_mask(ready, slot, fifteen);
+                if (full) {
+                    _mm512_store_si512((void *)part, p);
+                    while (full) {
+                        const int l = __builtin_ctz(full);
+                        full &= (__mmask16)(full - 1);
+                        const size_t p_ = part[l];
+                        /* tuples of this partition so far: the line's last slot belongs to position offsets[p] + 15 - first... */
+                        const size_t o_ = offsets[p_] + (size_t)(15 - ((offsets[p_] + shift) & 15));   /* position of slot 15 */
+                        const ptrdiff_t base_ = (ptrdiff_t)o_ - 15;      /* may lie before keys_out: masked */
+                        const __m512i lk_ = _mm512_load_si512((const void *)(bk + p_ * 16));
+                        const __m512i lv_ = _mm512_load_si512((const void *)(bv + p_ * 16));
+                        if (first[p_] == 0) {
+                            _mm512_stream_si512((__m512i *)(keys_out + base_), lk_);
+                            _mm512_stream_si512((__m512i *)(vals_out + base_), lv_);
+                        } else {
+                            const __mmask16 m_ = (__mmask16)(0xFFFFu << first[p_]);
+                            _mm512_mask_storeu_epi32(keys_out + base_, m_, lk_);
+                            _mm512_mask_storeu_epi32(vals_out + base_, m_, lv_);
+                            first[p_] = 0;
+                        }
+                        offsets[p_] = o_ + 1;                            /* the next line starts here */
+                    }
+                }
+                pending &= (__mmask16)~ready;
+            } while (pending);
+        }
+        /* `offsets` was advanced line by line only: add what sits in the open lines */
+        for (size_t p = 0; p != partitions; ++p) {
+            const size_t s0 = (offsets[p] + shift) & 15;
+            offsets[p] += (size_t)((slot16[p] - s0) & 15);
+        }
+        free(slot16);
+    } else {
+        for (; i + 16 <= size; i += 16) {
+            const __m512i k = _mm512_loadu_si512((const void *)(keys + i));
+            _mm512_store_si512((void *)part, mulhi32(_mm512_mullo_epi32(k, f), n));
+            for (int l = 0; l != 16; ++l) HJO_PUT(part[l], keys[i + l], vals[i + l]);
+        }
     }
     for (; i != size; ++i)
         HJO_PUT((uint32_t)(((uint64_t)(uint32_t)(keys[i] * factor) * partitions) >> 32), keys[i], vals[i]);
@@ -218,4 +285,5 @@ void hjo_phj_probe_avx512(const uint32_t *keys, const uint32_t *vals, size_t siz
 
 #else  /* built without AVX-512: the scalar restatement is all there is */
 int hjo_avx512_compiled(void) { return 0; }
+void hjo_avx512_vector_scatter(int on) { (void)on; }
 #endif

@@ -118,9 +118,10 @@ def simd_available():
 
 
 def set_simd(on):
-    """Selects the AVX-512 operator forms (the timed CPU baseline) or the scalar definitions
-    (default); returns what is in effect.  Results are identical either way."""
-    return bool(lib().hjo_set_simd(1 if on else 0))
+    """Selects the AVX-512 operator forms (the timed CPU baseline; 2 = with the partition's conflict-serialised
+    vector scatter, the reference's shape) or the scalar definitions (default); returns what is in effect
+    (0 where the CPU has no AVX-512).  Results are identical either way."""
+    return int(lib().hjo_set_simd(int(on)))
 
 
 def set_unique(on):

@@ -413,3 +413,33 @@ def test_batched_probe_side_partitioning(hj, batch_tuples):
         hj.set_option("batch_tuples", 0)
     for c in (rk, rv, sk_all, sv_all):
         c.free()
+
+
+def test_options_and_communicator_argument_errors(hj):
+    """hjgpu_set_option / hjgpu_comm_*: unknown names, malformed values and impossible worlds are status codes
+    (the reference asserts), and a refused option leaves the context as it was."""
+    import hash_join_codes_knl_amd as H
+    for name, value in (("no_such_option", "1"), ("unique", "yes"), ("join_cfg", "123,4,5"), ("join_cfg", "x"),
+                        ("placement", "0"), ("placement", "99"), ("range_tiles", "-3"), ("scatter_cfg", "0,4")):
+        with pytest.raises(H.HjGpuError) as e:
+            hj.set_option(name, value)
+        assert e.value.status == H.api.EINVAL
+    hj.set_option("join_cfg", "512,13,2")
+    ik = np.arange(1, 50_001, dtype=np.uint32)
+    rk, rv = hj.column(ik), hj.column(ik)
+    assert hj.phj(rk, rv, len(ik), rk, rv, len(ik)) == numpy_join(ik, ik, ik, ik)
+    with pytest.raises(H.HjGpuError):
+        H.HjComm.local(2, [0, 99], H.TRANSPORT_LOOPBACK)          # no such device
+    with pytest.raises(H.HjGpuError):
+        H.HjComm.local(2, [0, 0], H.TRANSPORT_RCCL)               # RCCL: one rank per device
+    with H.HjComm.local(2, [0, 0], H.TRANSPORT_LOOPBACK) as comm:
+        shards = [(rk, rv, len(ik), rk, rv, len(ik)), (None, None, len(ik) + 1, rk, rv, len(ik))]
+        with pytest.raises(H.HjGpuError) as e:
+            comm.phj_multi(shards, 0)                                  # |R| differs between the ranks
+        assert e.value.status == H.api.EINVAL
+        with pytest.raises(H.HjGpuError):
+            comm.phj_multi(shards[:1] + [(None, None, len(ik), rk, rv, len(ik))], 5)    # root outside the world
+        with pytest.raises(H.HjGpuError):
+            comm.set_option("no_such_option", 1)
+    for c in (rk, rv):
+        c.free()

@@ -19,15 +19,17 @@ FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDE
                   if not os.path.basename(p).startswith("rand32"))
 
 
-@pytest.fixture(params=["scalar", "avx512"], autouse=True)
+@pytest.fixture(params=["scalar", "avx512", "avx512_vector_scatter"], autouse=True)
 def operator_forms(request, oracle):
-    """Every test of this module runs twice: with the scalar definitions (the oracle proper) and
-    with the AVX-512 forms of histogram / partition / probe that bench.py times as the CPU
-    baseline.  Both must reproduce the reference's outputs bit for bit."""
-    if request.param == "avx512":
+    """Every test of this module runs three times: with the scalar definitions (the oracle proper), with the
+    AVX-512 forms of histogram / partition / probe that bench.py times as the CPU baseline, and with the
+    partition's conflict-serialised vector scatter (the reference's shape, phj.cpp:1099-1160).  All must
+    reproduce the reference's outputs bit for bit."""
+    if request.param != "scalar":
         if not oracle.simd_available():
             pytest.skip("no AVX-512 on this CPU")
-        assert oracle.set_simd(True)
+        want = 2 if request.param == "avx512_vector_scatter" else 1
+        assert oracle.set_simd(want) == want
     yield request.param
     oracle.set_simd(False)
 
