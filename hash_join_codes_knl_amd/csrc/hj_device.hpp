@@ -21,6 +21,14 @@ __device__ __forceinline__ uint32_t hj_part2(uint32_t key, uint32_t f1, uint32_t
 
 __device__ __forceinline__ int hj_lane() { return threadIdx.x & 63; }
 
+// 16-byte non-temporal load (global_load_dwordx4 ... nt): for streams that are read exactly once
+__device__ __forceinline__ uint4 hj_load_nt(const uint4 *p)
+{
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    const v4u_t t = __builtin_nontemporal_load(reinterpret_cast<const v4u_t *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
 // Workgroup barrier that orders LDS traffic only.  HIP's __syncthreads() also drains
 // the vector-memory counter (s_waitcnt vmcnt(0)), which turns every global load issued
 // before it into an exposed round trip; kernels that keep loads (or stores) in flight

@@ -167,3 +167,34 @@ def test_unique_mode_with_duplicate_heavy_build_sides(hj, oracle):
         assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == numpy_join(ik, iv, ok, ov)
         for c in (rk, rv, sk, sv):
             c.free()
+
+
+def test_full_size_64m_1g_equals_the_cpu_oracle(hj, oracle):
+    """The headline workload checked against the ORACLE itself, not only against aggregates the library computed:
+    the device-generated 64 M x 1 G relations are copied to the host and joined by oracle/hj_oracle.c's restatement of
+    run_hj (all usable threads, AVX-512 operators where present); PHJ, CPRA and NPJ on the GPU must return the same
+    four aggregates.  (bench.py's cpu_baseline leg makes the same comparison in every driver run.)"""
+    inner, outer = 64_000_000, 1_000_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(17, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    hik, hiv, hok, hov = ik.download(), iv.download(), ok.download(), ov.download()
+    threads = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            threads = min(threads, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    oracle.set_simd(1)
+    try:
+        want = oracle.phj(hik, hiv, hok, hov, threads=threads)
+    finally:
+        oracle.set_simd(0)
+    del hik, hiv, hok, hov
+    assert want[0] == outer
+    assert hj.phj(ik, iv, inner, ok, ov, outer) == want
+    assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=8)) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    for c in (ik, iv, ok, ov):
+        c.free()
