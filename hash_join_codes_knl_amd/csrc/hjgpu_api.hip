@@ -235,10 +235,16 @@ void choose_fanout(const HjTuning &tune, size_t inner, const hjgpu_phj_params *p
         if (parts <= 640) { f1 = (uint32_t)parts; f2 = 1; }
         else {
             // pass 1: the power of two nearest to sqrt(parts) (H(key, f, 2^k) is a shift: one multiply
-            // less per key in K4 and K6); measured flat between 96 x 192 and 192 x 97 at 64M x 1G
+            // less per key in K4 and K6) ...
             f1 = 2;
             while ((double)f1 * f1 * 2.0 < parts) f1 <<= 1;          // f1 ~ sqrt(parts) within a factor sqrt(2)
             if (f1 > 256) f1 = 256;
+            // ... but as soon as pass 2 still keeps >= 64 partitions, pass 1 takes 192: its cost is flat while the
+            // whole-line carry fits beside a 16 K-tuple tile (F <= 209), and every partition less in pass 2 means
+            // longer runs per tile, i.e. fewer < 16-tuple tails written into partial lines.  64 M x 1 G, one process:
+            // 128 x 144 8.64 ms (2.98 + 3.20), 160 x 116 8.59, 192 x 96 8.55 (3.00 + 3.07), 208 x 89 8.59,
+            // 256 x 72 8.71 (3.21 + 3.00: 12 K-tuple tiles in pass 1), 96 x 192 8.74, 64 x 288 8.96
+            if (parts >= 192.0 * 64.0) f1 = 192;
             f2 = (uint32_t)ceil(parts / f1);
             while (f2 > HJGPU_MAX_FANOUT) { f1 <<= 1; f2 = (uint32_t)ceil(parts / f1); }
             while ((u64)f1 * f2 > HJGPU_MAX_PARTS) --f2;
