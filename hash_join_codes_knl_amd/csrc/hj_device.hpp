@@ -44,13 +44,27 @@ __device__ __forceinline__ void hj_barrier_lds()
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T x)
 {
-    const int lane = hj_lane();
+    if constexpr (sizeof(T) == 4) {
+        // DPP: four row_shr steps inside the rows of 16 lanes (lanes without a source read 0), then the row totals
+        // travel with row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) - six VALU instructions instead
+        // of six ds_bpermute round trips through the LDS crossbar (K6 scans its bins once per tile)
+        uint32_t v = (uint32_t)x;
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);      // row_shr:1
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);      // row_shr:2
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);      // row_shr:4
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);      // row_shr:8
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+        return (T)v;
+    } else {
+        const int lane = hj_lane();
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        T y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
+        for (int d = 1; d < 64; d <<= 1) {
+            T y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        return x;
     }
-    return x;
 }
 
 template <typename T>
