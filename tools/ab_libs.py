@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """A/B timing of two (or more) builds of libhjgpu.so INSIDE ONE PROCESS, interleaved, same relations:
 usage: python tools/ab_libs.py <a.so> <b.so> ... [--rounds R --reps K --inner N --outer N --algo phj]
-(variants: tools/build_variant.py).  Every join is checked against the analytic aggregates."""
+(variants: tools/build_variant.py).  Every join is checked against the analytic aggregates.
+--sequential: K6's time depends on WHICH allocation holds its output (placement), so contexts that live
+side by side compare their workspaces' luck as much as their kernels.  In this mode only one measured context
+exists at a time: it is created (placement=1: the first allocation), timed and destroyed, round after round - the
+allocator hands every context the blocks the previous one freed, so all builds write into the same memory."""
 import argparse
 import ctypes
 import os
@@ -20,22 +24,35 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--algo", default="phj")
     ap.add_argument("--no-check", action="store_true", help="timing experiments with deliberately wrong variants")
+    ap.add_argument("--sequential", action="store_true", help="one measured context at a time, same allocations for all")
     a = ap.parse_args()
     import hash_join_codes_knl_amd as H
     from hash_join_codes_knl_amd import api
-    ctxs = []
-    for path in a.libs:
+    def make(path):
         os.environ["HJGPU_LIBRARY"] = os.path.abspath(path)
         api._lib = None                      # the next context binds (and keeps) this build
-        ctxs.append(H.HjGpu(0))
-    hj = ctxs[0]
+        return H.HjGpu(0)
+    ctxs = [make(a.libs[0])] if a.sequential else [make(path) for path in a.libs]
+    hj = ctxs[0]                             # owns the relations
     ik, iv, ok, ov = hj.column(a.inner), hj.column(a.inner), hj.column(a.outer), hj.column(a.outer)
     hj.generate(1, a.inner, a.outer, 0, a.outer, 0x2545F491, 0x9E3779B1, ik, iv, ok, ov)
     sums = hj.column_sums(ok, a.outer, 0x9E3779B1, 0x2545F491)
     want = (a.outer, sums[0], sums[1], sums[2])
     phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join", "ms_build"]
     data = {p: {ph: [] for ph in phases} for p in a.libs}
-    for rnd in range(a.rounds):
+    for rnd in range(a.rounds if a.sequential else 0):
+        for path in a.libs:
+            c = make(path)
+            c.set_option("placement", "1")
+            for rep in range(a.reps + 1):
+                got = getattr(c, a.algo)(ik, iv, a.inner, ok, ov, a.outer)
+                assert a.no_check or got == want, (path, got, want)
+                st = c.stats()
+                if rep > 0:                  # the first join allocates the workspace
+                    for ph in phases:
+                        data[path][ph].append(st[ph])
+            c.close()
+    for rnd in range(0 if a.sequential else a.rounds):
         for path, c in zip(a.libs, ctxs):
             for _ in range(a.reps):
                 got = getattr(c, a.algo)(ik, iv, a.inner, ok, ov, a.outer)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds another libhjgpu.so next to the product's for A/B timing IN ONE PROCESS (tools/ab_libs.py): boxes and
 even processes differ by up to 10 % in K6's pass 1, so only interleaved runs of two libraries in one process compare.
-usage: python tools/build_variant.py <name> [<git-rev>]     (rev omitted: the working tree)
+usage: python tools/build_variant.py <name> [<git-rev>] [-DMACRO=value ...]     (rev omitted: the working tree)
 -> hash_join_codes_knl_amd/lib/variants/<name>.so"""
 import os
 import subprocess
@@ -15,7 +15,9 @@ from hash_join_codes_knl_amd import build as B
 
 def main():
     name = sys.argv[1]
-    rev = sys.argv[2] if len(sys.argv) > 2 else None
+    defines = [a for a in sys.argv[2:] if a.startswith("-D")]
+    rest = [a for a in sys.argv[2:] if not a.startswith("-D")]
+    rev = rest[0] if rest else None
     out_dir = os.path.join(B.LIB, "variants")
     os.makedirs(out_dir, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -40,7 +42,7 @@ def main():
                 continue
             o = os.path.join(tmp, f + ".o")
             subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-O3", "-std=c++20", "-fPIC", "-w",
-                                   "-DHJGPU_KERNEL_HASH=\"%s\"" % name, "-c", s, "-o", o])
+                                   "-DHJGPU_KERNEL_HASH=\"%s\"" % name] + defines + ["-c", s, "-o", o])
             objs.append(o)
         so = os.path.join(out_dir, name + ".so")
         subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"])
