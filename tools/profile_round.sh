@@ -25,5 +25,10 @@ cd $root &&
 python3 tools/collect_traffic.py && cp gpurun_out/traffic.json gpurun_out/${tag}_traffic.json &&
 python3 tools/collect_traffic.py --algo npj && cp gpurun_out/traffic.json gpurun_out/${tag}_npj_traffic.json &&
 python3 tools/collect_traffic.py --algo cpra && cp gpurun_out/traffic.json gpurun_out/${tag}_cpra_traffic.json &&
+# the bench line attaches profiles/<round>_traffic.json (and refuses it when the kernel hash differs): this run's files
+round=${tag:0:3} &&
+cp gpurun_out/${tag}_traffic.json profiles/${round}_traffic.json &&
+cp gpurun_out/${tag}_npj_traffic.json profiles/${round}_npj_traffic.json &&
+cp gpurun_out/${tag}_cpra_traffic.json profiles/${round}_cpra_traffic.json &&
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "profile_round done rc=$?"
