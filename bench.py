@@ -90,6 +90,9 @@ def usable_cpus():
 def connect_ranks(dist, H, local_rank, rank, world):
     """Control plane -> data plane: rank 0 draws the ncclUniqueId (hjgpu_comm_get_id), the gloo group carries it to
     every rank, each rank joins the library's communicator (hjgpu_comm_create_rank = ncclCommInitRank)."""
+    # one node by contract: RCCL's bootstrap sockets need no interface beyond loopback (the box's hostname or its
+    # outward interfaces may not resolve / route); an explicit NCCL_SOCKET_IFNAME of the caller wins
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     box = [H.HjComm.new_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return H.HjComm.rank(local_rank, world, rank, box[0])

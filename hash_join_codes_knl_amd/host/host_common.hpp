@@ -144,6 +144,7 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
         fprintf(stderr, "HJGPU_ROWS: materialised rows come from one GPU; running on device %d only\n", devices[0]);
     if (devices.size() > 1 && !rows_wanted) {
         hjgpu_comm *comm = nullptr;
+        setenv("NCCL_SOCKET_IFNAME", "lo", 0);     // all ranks live in this process: RCCL's bootstrap needs loopback only
         int rc = hjgpu_comm_create_local((int)devices.size(), devices.data(), transport, &comm);
         if (rc != HJGPU_OK) { fprintf(stderr, "hjgpu_comm_create_local(%zu ranks): %s\n", devices.size(), hjgpu_status_string(rc)); return rc; }
         hjgpu_ctx *ctx0 = hjgpu_comm_ctx(comm, 0);
