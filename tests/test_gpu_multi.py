@@ -213,6 +213,63 @@ def test_unique_flag_and_host_columns_through_the_multi_gpu_entry_points(worlds,
         assert got == want, algorithm
 
 
+def test_error_paths_of_the_multi_gpu_entry_points(worlds, oracle):
+    """Errors come back as status codes with a text (hjgpu_comm_last_error), never as a crash, and leave the
+    communicator usable: the reference asserts and aborts, the C-ABI must not."""
+    lib = H.api.load_library()
+    comm = worlds(3)
+    ik, iv, ok, ov = relations(oracle, "unique", seed=8)
+    want = numpy_join(ik, iv, ok, ov)
+    shards, cols = replicated_shards(comm, ik, iv, ok, ov, 1)
+    for root in (-1, 3, 99):
+        with pytest.raises(H.HjGpuError) as e:
+            comm.phj_multi(shards, root)
+        assert e.value.status == H.api.EINVAL and "root" in str(e.value)
+    # the root's build columns are missing (they live on rank 1, the call names rank 0)
+    with pytest.raises(H.HjGpuError) as e:
+        comm.phj_multi(shards, 0)
+    assert e.value.status == H.api.EINVAL and "build columns" in str(e.value)
+    # |R| differs between the ranks
+    bad = [tuple(x) for x in shards]
+    bad[2] = bad[2][:2] + (len(ik) - 1,) + bad[2][3:]
+    with pytest.raises(H.HjGpuError) as e:
+        comm.npj_multi(bad, 1)
+    assert e.value.status == H.api.EINVAL and "same size" in str(e.value)
+    # options
+    for name, value in (("no_such_option", 1), ("max_message_bytes", 8)):
+        with pytest.raises(H.HjGpuError) as e:
+            comm.set_option(name, value)
+        assert e.value.status == H.api.EINVAL
+    assert lib.hjgpu_comm_set_option(comm.handle, b"ring_broadcast", b"yes") == H.api.EINVAL
+    # CPRA: a null column with a non-zero length, too many slices
+    cshards, ccols = chunked_shards(comm, ik, iv, ok, ov)
+    broken = [tuple(x) for x in cshards]
+    broken[1] = (None,) + broken[1][1:]
+    with pytest.raises(H.HjGpuError) as e:
+        comm.cpra_multi(broken)
+    assert e.value.status == H.api.EINVAL and "null column" in str(e.value)
+    with pytest.raises(H.HjGpuError) as e:
+        comm.cpra_multi(cshards, None, 5000)
+    assert e.value.status == H.api.EINVAL and "slices" in str(e.value)
+    # null handles
+    assert lib.hjgpu_phj_multi(None, None, 0, None, None, None) == H.api.EINVAL
+    assert lib.hjgpu_cpra_multi(None, None, None, 0, None, None) == H.api.EINVAL
+    assert lib.hjgpu_comm_barrier(None) == H.api.EINVAL
+    # communicators that cannot be made
+    for nranks, devices, transport in ((0, [], H.TRANSPORT_LOOPBACK), (2, [0, 7777], H.TRANSPORT_LOOPBACK),
+                                      (2, [0, 0], H.TRANSPORT_RCCL), (1, [0], 42)):
+        with pytest.raises(H.HjGpuError) as e:
+            H.HjComm.local(nranks, devices, transport)
+        assert e.value.status == H.api.EINVAL, (nranks, devices, transport)
+    with pytest.raises(H.HjGpuError):
+        H.HjComm.rank(0, 2, 2, H.HjComm.new_id())                   # rank outside the world
+    # ... and the communicator still joins
+    assert comm.phj_multi(shards, 1)[0] == want
+    assert comm.cpra_multi(cshards)[0] == want
+    for c in cols + ccols:
+        c.free()
+
+
 def test_rccl_from_cpp_at_world_size_one(worlds, oracle):
     """The same entry points through RcclTransport: ncclCommInitAll, ncclAllGather, grouped ncclSend / ncclRecv
     (to self), ncclAllReduce - one rank is all a one-GPU box can offer; more ranks are the driver's 8-GPU run."""
