@@ -110,8 +110,10 @@ int ensure(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
 // tools/alloc_luck.py, profiles/r02_alloc_luck.txt, r02_shift_sweep.txt), and a plain streaming fill of the buffer shows
 // the same split - 1.47 to 1.99 ms per 8.5 GB - and predicts it (tools/ubench_placement.hip, profiles/r02_placement.txt).
 // So a large twin is chosen among up to `placement` candidate allocations (all held until the choice is made, so that
-// every candidate is different memory) by that fill: the first one that fills at >= 5.3 TB/s is taken, else the
-// fastest.  This runs when the workspace grows (hjgpu_reserve / first join), never inside a timed join afterwards.
+// every candidate is different memory) by that fill: the first one that fills at >= 5.5 TB/s is taken, else the
+// fastest.  Over fresh processes (tools/placement_dist.sh, profiles/r02_placement_dist.txt) pass 1 then takes
+// 2.98-3.04 ms with 12 candidates, 2.96-3.14 with 6, 3.0-3.5 with the first allocation.
+// This runs when the workspace grows (hjgpu_reserve / first join), never inside a timed join afterwards.
 int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return HJGPU_OK;
@@ -138,7 +140,7 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
             if (t < ms[n]) ms[n] = t;
         }
         if (best < 0 || ms[n] < ms[best]) best = n;
-        if ((double)want / (ms[n] * 1e-3) >= 5.3e12) { ++n; break; }
+        if ((double)want / (ms[n] * 1e-3) >= 5.5e12) { ++n; break; }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (best < 0) return fail(ctx, HJGPU_ENOMEM, "hipMalloc(workspace)");

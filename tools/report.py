@@ -10,10 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROWS = [
-    ("PHJ 64 M x 1 G (headline)", []),
-    ("PHJ 64 M x 1 G, rows materialised", ["--materialize"]),
-    ("CPRA 64 M x 1 G, 8 chunks", ["--algo", "cpra"]),
-    ("NPJ 64 M x 1 G", ["--algo", "npj", "--steps", "5"]),
+    ("PHJ 64 M x 1 G (headline)", None),          # one run: also the materialised, CPRA and NPJ rows (bench.py's extras)
     ("PHJ Zipf(1.0) probe side", ["--zipf", "1.0"]),
     ("PHJ Zipf(1.5) probe side", ["--zipf", "1.5"]),
     ("PHJ Zipf(2.0) probe side", ["--zipf", "2.0"]),
@@ -23,15 +20,25 @@ ROWS = [
     ("PHJ 100 K x 1 G (one pass)", ["--inner", "100000", "--outer", "1000000000"]),
     ("PHJ 1 M x 1 G (one pass)", ["--inner", "1000000", "--outer", "1000000000"]),
     ("PHJ 8 M x 1 G (two passes)", ["--inner", "8000000", "--outer", "1000000000"]),
+    ("PHJ 200 M x 1 G (two table fills per partition)", ["--inner", "200000000", "--outer", "1000000000", "--steps", "5"]),
     ("PHJ 128 M x 2.2 G (16 K-slot tables)", ["--inner", "128000000", "--outer", "2200000000", "--steps", "5"]),
+    ("CPRA 128 M x 2 G, 8 chunks (one GPU's share of configs[4] after the exchange)",
+     ["--algo", "cpra", "--inner", "128000000", "--outer", "2000000000", "--steps", "5"]),
 ]
+
+
+def row(name, ms, outer, ok, fan, ph, join_ms):
+    print("| %s | %.2f | %.1f | %s | %s | %.2f | %.2f | %.2f | %.2f | %.2f |" % (
+        name, ms, outer / ms / 1e6, ok, fan, ph.get("ms_histogram", 0), ph.get("ms_plan", 0), ph.get("ms_scatter1", 0),
+        ph.get("ms_scatter2", 0), join_ms), flush=True)
 
 
 def main():
     print("| Workload | ms / step | Gtuples/s | checksum | fan-out | hist | plan | scatter 1 | scatter 2 | join |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for name, extra in ROWS:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--cpu-outer", "0"] + extra
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--cpu-outer", "0"]
+        cmd += ["--no-secondary"] + extra if extra is not None else []
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if p.returncode != 0 or not lines:
@@ -39,13 +46,17 @@ def main():
             continue
         b = json.loads(lines[-1])
         ph = b["phase_ms"]
-        mat = b.get("materialized")
-        ms = mat["ms_total"] if mat else b["ms_per_step"]
-        rate = b["config"]["outer_tuples_per_gpu"] / ms / 1e6
-        ok = (mat["rows_checksum_ok"] if mat else b["checksum_ok"])
-        print("| %s | %.2f | %.1f | %s | %s | %.2f | %.2f | %.2f | %.2f | %.2f |" % (
-            name, ms, rate, ok, "x".join(str(f) for f in b["config"]["fanout"]), ph["ms_histogram"], ph["ms_plan"],
-            ph["ms_scatter1"], ph["ms_scatter2"], (mat["ms_join"] if mat else ph["ms_join"]) + ph["ms_build"]), flush=True)
+        outer = b["config"]["outer_tuples_per_gpu"]
+        fan = "x".join(str(f) for f in b["config"]["fanout"])
+        row(name, b["ms_per_step"], outer, b["checksum_ok"], fan, ph, ph["ms_join"] + ph["ms_build"])
+        if extra is None:
+            m, sec = b["materialized"], b["secondary"]
+            row("PHJ 64 M x 1 G, rows materialised", m["ms_total"], outer, m["rows_checksum_ok"], fan, ph,
+                m["ms_join"] + m["ms_close_gaps"])
+            c = sec["cpra"]
+            row("CPRA 64 M x 1 G, 8 chunks", c["ms_per_step"], outer, c["checksum_ok"], fan, c["phase_ms"], c["phase_ms"]["ms_join"])
+            n = sec["npj"]
+            row("NPJ 64 M x 1 G (build + probe)", n["ms_per_step"], outer, n["checksum_ok"], "-", {}, n["ms_build"] + n["ms_probe"])
 
 
 if __name__ == "__main__":
