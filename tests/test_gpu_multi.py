@@ -213,6 +213,63 @@ def test_unique_flag_and_host_columns_through_the_multi_gpu_entry_points(worlds,
         assert got == want, algorithm
 
 
+def _multi_cases():
+    # HJ_FUZZ_SEED / HJ_FUZZ_CASES as in test_gpu_fuzz.py: a longer one-off sweep with other draws
+    import os
+    rng = np.random.default_rng(int(os.environ.get("HJ_FUZZ_SEED", "20261004")))
+    out = []
+    for i in range(int(os.environ.get("HJ_FUZZ_CASES", "12"))):
+        out.append(dict(seed=int(rng.integers(1 << 30)), world=int(rng.choice([2, 3, 5, 8])),
+                        inner=int(rng.choice([1, 97, 5_000, 120_000])), outer=int(rng.choice([1, 300, 40_000, 700_000])),
+                        dups=int(rng.choice([1, 1, 3, 40])), selectivity=float(rng.choice([1.0, 0.6, 0.0])),
+                        slices=int(rng.integers(1, 8)), piece=int(rng.choice([64, 1024, 1 << 20, 1 << 30])),
+                        unique=bool(rng.integers(4) == 0), ring=bool(rng.integers(3) == 0)))
+    return out
+
+
+@pytest.mark.parametrize("case", _multi_cases(), ids=lambda c: "w%d-s%d" % (c["world"], c["seed"] % 100000))
+def test_random_multi_gpu_joins_match_numpy(worlds, oracle, case):
+    """Randomised differential test of the three multi-GPU entry points over loopback: world size, root, ragged
+    (also empty) shards and chunks cut at unaligned positions, slice count, message piece size, replication scheme,
+    duplicates, non-matching probe keys, _UNIQUE - every result against the numpy definition of the join."""
+    rng = np.random.default_rng(case["seed"])
+    inner, outer, world = case["inner"], case["outer"], case["world"]
+    distinct = max(1, inner // case["dups"])
+    base = np.unique(rng.integers(1, 2**32, size=distinct, dtype=np.uint64).astype(np.uint32))
+    ik = base[rng.integers(0, len(base), size=inner)]
+    ok = base[rng.integers(0, len(base), size=outer)]
+    miss = rng.random(outer) > case["selectivity"]
+    ok = np.where(miss, rng.integers(1, 2**32, size=outer, dtype=np.uint64).astype(np.uint32), ok).astype(np.uint32)
+    iv = rng.integers(0, 2**32, size=inner, dtype=np.uint64).astype(np.uint32)
+    ov = rng.integers(0, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)
+    want = oracle.join_definition_unique(ik, iv, ok, ov) if case["unique"] else numpy_join(ik, iv, ok, ov)[:3]
+
+    def random_cuts(n):
+        edges = sorted(int(e) for e in rng.integers(0, n + 1, size=world - 1))
+        edges = [0] + edges + [n]
+        return list(zip(edges[:-1], edges[1:]))
+
+    comm = worlds(world)
+    pp = H.PhjParams(flags=H.FLAG_UNIQUE) if case["unique"] else None
+    npp = H.NpjParams(flags=H.FLAG_UNIQUE) if case["unique"] else None
+    comm.set_option("max_message_bytes", case["piece"])
+    comm.set_option("ring_broadcast", int(case["ring"]))
+    try:
+        shards, cols = chunked_shards(comm, ik, iv, ok, ov, random_cuts(inner), random_cuts(outer))
+        assert comm.cpra_multi(shards, pp, case["slices"])[0][:3] == want, "cpra"
+        for c in cols:
+            c.free()
+        root = int(rng.integers(world))
+        shards, cols = replicated_shards(comm, ik, iv, ok, ov, root, random_cuts(outer))
+        assert comm.phj_multi(shards, root, pp)[0][:3] == want, "phj"
+        assert comm.npj_multi(shards, root, npp)[0][:3] == want, "npj"
+        for c in cols:
+            c.free()
+    finally:
+        comm.set_option("max_message_bytes", 1 << 30)
+        comm.set_option("ring_broadcast", 0)
+
+
 def test_error_paths_of_the_multi_gpu_entry_points(worlds, oracle):
     """Errors come back as status codes with a text (hjgpu_comm_last_error), never as a crash, and leave the
     communicator usable: the reference asserts and aborts, the C-ABI must not."""
