@@ -54,6 +54,7 @@ struct HjTuning {
     bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
     int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
+    int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned

@@ -149,6 +149,15 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     return HJGPU_OK;
 }
 
+// K6 occupies a CU completely (one 1024-thread workgroup with ~155 KiB of LDS that lives until the pass ends): a kernel
+// that arrives during a pass - RCCL's, on the multi-GPU path - finds no CU until the pass is over.  "reserve_cus" keeps
+// some CUs out of K6's grid (work is claimed from a ticket counter, so any grid size finishes the pass).
+inline int scatter_cus(const hjgpu_ctx *ctx)
+{
+    const int n = ctx->cus - ctx->tune.reserve_cus;
+    return n < 1 ? 1 : n;
+}
+
 inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) & 3); }
 
 // Carves the meta buffer; must match between sizing and use.
@@ -538,7 +547,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 sa.range_begin = b * pl.batch_ranges;
                 sa.range_count = std::min(pl.batch_ranges, geom[r].ranges_per_chunk - sa.range_begin);
                 sa.in_packed = 0; sa.out_packed = 1;
-                CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
+                CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
                 // pass 2 of the batch: the batch buffer -> the relation's final, line-aligned partitions
                 memset(&sa, 0, sizeof(sa));
                 sa.kin = tbuf; sa.vin = nullptr; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
@@ -548,7 +557,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 sa.ranged = 0; sa.work_counter = m.btickets + 2 * b + 1; sa.geom = geom[r]; sa.range_base = nullptr;
                 sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = 1u;
                 sa.in_packed = 1; sa.out_packed = 1;
-                CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
+                CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
             }
             record(ctx, ev[2], stream);         // both passes interleaved: reported as pass 1, pass 2 = 0
             record(ctx, ev[3], stream);
@@ -567,7 +576,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
             sa.ranged = 1; sa.work_counter = m.tickets + 16 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
             sa.in_packed = 0; sa.out_packed = 1;
-            CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
+            CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
         }
         record(ctx, ev[2], stream);
         // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
@@ -580,7 +589,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
             sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
             sa.in_packed = 1; sa.out_packed = 1;
-            CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
+            CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
         }
         record(ctx, ev[3], stream);
         return HJGPU_OK;
@@ -1004,7 +1013,7 @@ int hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
         sa.ranged = 1; sa.work_counter = m.tickets + 16; sa.geom = geom; sa.range_base = m.range_base[0];
         sa.in_packed = 0; sa.out_packed = 0;
-        CHK(hj_launch_scatter(sa, ctx->tune, ctx->cus, stream));
+        CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
                                hipMemcpyDeviceToDevice, stream));

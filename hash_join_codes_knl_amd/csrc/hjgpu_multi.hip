@@ -71,6 +71,7 @@ struct hjgpu_comm {
     std::unique_ptr<Transport> transport;
     bool ring_broadcast = false;
     size_t max_message_bytes = (size_t)1 << 30;
+    int reserve_cus = -1;                    // -1: 16 with RCCL and more than one rank, else 0 (option "reserve_cus")
     char err[512];
 };
 
@@ -367,6 +368,24 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     CHKM(ensure(c, r, r.d_off, 2 * (G + 1) * sizeof(u64)));
     CHKM(ensure(c, r, r.d_cnt, (G + G * G) * sizeof(u64)));
     CHKM(ensure(c, r, r.d_res, 8 * sizeof(u64)));
+    return HJGPU_OK;
+}
+
+// RCCL's kernels need CUs WHILE the probe side is being partitioned (the build side arrives then; CPRA: slice i is on
+// the links while slice i+1 is partitioned).  K6's workgroups fill a CU's LDS and live until their pass ends, so a
+// kernel that arrives in the middle of a pass would wait for its end: the ranks' K6 grids leave some CUs free.
+// That is free: K6 runs at the memory system's rate, not the CUs' - 64 M x 1 G on one GPU, ms per pass with
+// 0 / 8 / 16 / 32 CUs left out: 3.01 / 3.03 / 3.03 / 3.13 and 3.04 / 3.03 / 3.03 / 3.06 (profiles/r02_reserve_sweep.txt).
+int apply_reserve(hjgpu_comm *c)
+{
+    const bool rccl = c->transport && strcmp(c->transport->name(), "rccl") == 0;
+    const int n = c->reserve_cus >= 0 ? c->reserve_cus : (rccl && c->nranks > 1 ? 16 : 0);
+    char v[16];
+    snprintf(v, sizeof(v), "%d", n);
+    for (Rank &r : c->ranks) {
+        if (r.join && hjgpu_set_option(r.join, "reserve_cus", v) != HJGPU_OK) return cfail(c, HJGPU_EINVAL, "reserve_cus");
+        if (r.part && hjgpu_set_option(r.part, "reserve_cus", v) != HJGPU_OK) return cfail(c, HJGPU_EINVAL, "reserve_cus");
+    }
     return HJGPU_OK;
 }
 
@@ -797,6 +816,7 @@ int hjgpu_comm_create_local(int nranks, const int *devices, int transport, hjgpu
             if (r != ncclSuccess) { fprintf(stderr, "hjgpu: ncclCommInitAll: %s\n", ncclGetErrorString(r)); rc = HJGPU_ERCCL; }
         } else rc = HJGPU_EINVAL;
     }
+    if (rc == HJGPU_OK) rc = apply_reserve(c);
     if (rc != HJGPU_OK) { hjgpu_comm_destroy(c); return rc; }
     *out = c;
     return HJGPU_OK;
@@ -834,6 +854,7 @@ int hjgpu_comm_create_rank(int device, int nranks, int rank, const hjgpu_comm_id
             if (r != ncclSuccess) { fprintf(stderr, "hjgpu: ncclCommInitRank: %s\n", ncclGetErrorString(r)); rc = HJGPU_ERCCL; }
         }
     }
+    if (rc == HJGPU_OK) rc = apply_reserve(c);
     if (rc != HJGPU_OK) { hjgpu_comm_destroy(c); return rc; }
     *out = c;
     return HJGPU_OK;
@@ -863,6 +884,11 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
     const long long x = strtoll(value, &end, 10);
     if (end == value || *end) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: malformed value");
     if (strcmp(name, "ring_broadcast") == 0) { c->ring_broadcast = x != 0; return HJGPU_OK; }
+    if (strcmp(name, "reserve_cus") == 0) {
+        if (x < 0 || x > 128) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: reserve_cus outside 0..128");
+        c->reserve_cus = (int)x;
+        return apply_reserve(c);
+    }
     if (strcmp(name, "max_message_bytes") == 0) {
         if (x < 16) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: max_message_bytes below 16");
         c->max_message_bytes = (size_t)x;

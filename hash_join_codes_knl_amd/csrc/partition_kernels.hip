@@ -1129,7 +1129,7 @@ static int launch_scatter_t(const ScatterArgs &a, bool want_prof, int cus, hipSt
     int per_cu = (int)(HJ_LDS_LIMIT / (lds + 512));
     if (per_cu > 2048 / BLOCK) per_cu = 2048 / BLOCK;
     if (per_cu < 1) per_cu = 1;
-    const int grid = cus * per_cu;
+    const int grid = cus * per_cu;              // `cus` is what the caller wants occupied (option "reserve_cus")
     ScatterArgs b = a;
     // pass-2 tiles are claimed in order, so all workgroups sit inside the same one or two pass-1
     // partitions, whose output region stays in the Infinity Cache (contiguous ownership instead:
@@ -1223,6 +1223,13 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
         t->placement = (int)x;
         return true;
     }
+    if (is("reserve_cus")) {
+        char *end = nullptr;
+        const long x = strtol(value, &end, 10);
+        if (end == value || *end || x < 0 || x > 128) return false;
+        t->reserve_cus = (int)x;
+        return true;
+    }
     if (is("batch_tuples")) {
         char *end = nullptr;
         const long long x = strtoll(value, &end, 10);
@@ -1258,7 +1265,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "range_tiles", "batch_tuples", "placement", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

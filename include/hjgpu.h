@@ -342,7 +342,8 @@ int  hjgpu_comm_size(const hjgpu_comm *comm, int *nranks, int *nlocal, int *firs
 /* the join context of a local rank: its device memory (hjgpu_malloc), generator, options, per-phase stats */
 hjgpu_ctx *hjgpu_comm_ctx(hjgpu_comm *comm, int local_rank);
 /* option "ring_broadcast" (0 / 1): replicate the build side with one ncclBroadcast instead of scatter +
- * all-gather; "max_message_bytes" (n): split larger point-to-point messages into pieces */
+ * all-gather; "max_message_bytes" (n): split larger point-to-point messages into pieces; "reserve_cus" (n): CUs
+ * that the ranks' partitioning kernels leave free for RCCL's kernels (default 16 with RCCL and > 1 rank, else 0: free, K6 is not CU-bound) */
 int  hjgpu_comm_set_option(hjgpu_comm *comm, const char *name, const char *value);
 /* every local rank's streams drained, then a collective over all ranks */
 int  hjgpu_comm_barrier(hjgpu_comm *comm);

@@ -420,7 +420,8 @@ def test_options_and_communicator_argument_errors(hj):
     (the reference asserts), and a refused option leaves the context as it was."""
     import hash_join_codes_knl_amd as H
     for name, value in (("no_such_option", "1"), ("unique", "yes"), ("join_cfg", "123,4,5"), ("join_cfg", "x"),
-                        ("placement", "0"), ("placement", "99"), ("range_tiles", "-3"), ("scatter_cfg", "0,4")):
+                        ("placement", "0"), ("placement", "99"), ("range_tiles", "-3"), ("scatter_cfg", "0,4"),
+                        ("reserve_cus", "-1"), ("reserve_cus", "500")):
         with pytest.raises(H.HjGpuError) as e:
             hj.set_option(name, value)
         assert e.value.status == H.api.EINVAL
@@ -428,6 +429,14 @@ def test_options_and_communicator_argument_errors(hj):
     ik = np.arange(1, 50_001, dtype=np.uint32)
     rk, rv = hj.column(ik), hj.column(ik)
     assert hj.phj(rk, rv, len(ik), rk, rv, len(ik)) == numpy_join(ik, ik, ik, ik)
+    # K6 grids that leave CUs free (what the multi-GPU path sets so that RCCL's kernels find room): work is claimed
+    # from ticket counters, so any grid finishes the passes - down to a single workgroup
+    cus = hj.device_info()["compute_units"]
+    for reserve in (16, min(128, cus - 1)):
+        hj.set_option("reserve_cus", reserve)
+        assert hj.phj(rk, rv, len(ik), rk, rv, len(ik), H.PhjParams(fanout1=24, fanout2=8)) == numpy_join(ik, ik, ik, ik)
+        assert hj.cpra(rk, rv, len(ik), rk, rv, len(ik), H.PhjParams(chunks=3)) == numpy_join(ik, ik, ik, ik)
+    hj.set_option("reserve_cus", 0)
     with pytest.raises(H.HjGpuError):
         H.HjComm.local(2, [0, 99], H.TRANSPORT_LOOPBACK)          # no such device
     with pytest.raises(H.HjGpuError):
@@ -441,5 +450,11 @@ def test_options_and_communicator_argument_errors(hj):
             comm.phj_multi(shards[:1] + [(None, None, len(ik), rk, rv, len(ik))], 5)    # root outside the world
         with pytest.raises(H.HjGpuError):
             comm.set_option("no_such_option", 1)
+        with pytest.raises(H.HjGpuError):
+            comm.set_option("reserve_cus", 129)
+        comm.set_option("reserve_cus", 4)                          # applied to every rank's contexts
+        shards = [(rk, rv, len(ik), rk, rv, len(ik)), (None, None, len(ik), rk, rv, len(ik))]
+        want = numpy_join(ik, ik, np.concatenate([ik, ik]), np.concatenate([ik, ik]))
+        assert comm.phj_multi(shards, 0)[0] == want
     for c in (rk, rv):
         c.free()
