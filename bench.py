@@ -59,6 +59,8 @@ def parse(argv=None):
                     help="at --gpus 1: go through the multi-GPU entry points with a one-rank RCCL communicator")
     ap.add_argument("--ring-broadcast", action="store_true",
                     help="multi-GPU: replicate the build side with one ncclBroadcast instead of scatter + all-gather")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="multi-GPU: CUs the partitioning kernels leave to RCCL's kernels (-1 = the library's default: 16 with > 1 rank)")
     ap.add_argument("--exchange-slices", type=int, default=4,
                     help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap)")
     return ap.parse_args(argv)
@@ -250,6 +252,8 @@ def main():
         comm = connect_ranks(dist, H, local_rank, rank, max(world, 1))             # data plane: RCCL from C++
         if args.ring_broadcast:
             comm.set_option("ring_broadcast", 1)
+        if args.reserve_cus >= 0:
+            comm.set_option("reserve_cus", args.reserve_cus)
         hj = comm.ctx[0]
     else:
         hj = H.HjGpu(local_rank)
