@@ -63,6 +63,11 @@ def parse(argv=None):
                     help="multi-GPU: CUs the partitioning kernels leave to RCCL's kernels (-1 = the library's default: 16 with > 1 rank)")
     ap.add_argument("--exchange-slices", type=int, default=4,
                     help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap)")
+    ap.add_argument("--comm-timeout-ms", type=int, default=120_000,
+                    help="multi-GPU: deadline of every host-side wait inside the library (hjgpu_comm option timeout_ms); when it "
+                         "expires the communicator is aborted (ncclCommAbort) and this process exits with status 3")
+    ap.add_argument("--preflight-bytes", type=int, default=256 << 20,
+                    help="multi-GPU: bytes per peer of the link-bandwidth preflight before the timed region (0 = skip it)")
     return ap.parse_args(argv)
 
 
@@ -98,6 +103,29 @@ def connect_ranks(dist, H, local_rank, rank, world):
     box = [H.HjComm.new_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return H.HjComm.rank(local_rank, world, rank, box[0])
+
+
+def gather_objects(dist, obj):
+    """every rank's `obj` on every rank, over the gloo control plane (None without one)"""
+    if dist is None:
+        return [obj]
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, obj)
+    return box
+
+
+def spread(values):
+    values = [float(v) for v in values]
+    return {"min": round(min(values), 4), "max": round(max(values), 4), "mean": round(sum(values) / len(values), 4)}
+
+
+def die_of_comm_error(rank, ex, where):
+    """A multi-GPU call failed (deadline expired -> communicator aborted, RCCL error, wrong preflight data): say so and
+    leave with a FRESH exit - no re-exec, no teardown that could wait for a dead peer."""
+    sys.stderr.write(json.dumps({"bench_error": "rank %d, %s: %s" % (rank, where, ex)}) + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    os._exit(3)
 
 
 def max_over_ranks(dist, torch, seconds):
@@ -249,7 +277,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=max(world, 1))      # control plane only
-        comm = connect_ranks(dist, H, local_rank, rank, max(world, 1))             # data plane: RCCL from C++
+        try:
+            comm = connect_ranks(dist, H, local_rank, rank, max(world, 1))         # data plane: RCCL from C++
+        except H.HjGpuError as ex:
+            die_of_comm_error(rank, ex, "creating the communicator")
+        comm.set_option("timeout_ms", args.comm_timeout_ms)
         if args.ring_broadcast:
             comm.set_option("ring_broadcast", 1)
         if args.reserve_cus >= 0:
@@ -323,8 +355,21 @@ def main():
               "ms_build", "ms_close_gaps", "ms_inner_wait"]
     per_step = {p: [] for p in phases}
     multi_steps = []
-    for _ in range(args.warmup):
-        step()
+    preflight = None
+    if multi:
+        # before anything is timed: every collective the joins use, verified word for word, and the point-to-point
+        # rate to every peer ("measure link bandwidth first"); a wrong byte or a rank that never
+        # arrives ends the run here, with a message, instead of hanging the timed region
+        try:
+            if args.preflight_bytes > 0:
+                preflight = comm.preflight(args.preflight_bytes)
+            for _ in range(args.warmup):
+                step()
+        except H.HjGpuError as ex:
+            die_of_comm_error(rank, ex, "preflight / warm-up")
+    else:
+        for _ in range(args.warmup):
+            step()
     barrier()
     # empirical streaming-read ceiling of this box: a plain 16-byte-load sweep of the
     # 4 GB probe-key column (nothing computed), outside the timed region
@@ -336,7 +381,12 @@ def main():
     results_ok = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        try:
+            step()
+        except H.HjGpuError as ex:
+            if multi:
+                die_of_comm_error(rank, ex, "timed step")
+            raise
         if multi:
             ms = last["multi"]
             multi_steps.append(ms)
@@ -426,12 +476,42 @@ def main():
     }
     if multi:
         k = len(multi_steps)
-        out["exchange"] = {  # rank 0's view, averaged over the timed steps
-            "ms": round(sum(m["ms_exchange"] for m in multi_steps) / k, 4),
-            "ms_partition": round(sum(m["ms_partition"] for m in multi_steps) / k, 4),
-            "ms_joins_waited_for_it": round(sum(m["ms_exchange_wait"] for m in multi_steps) / k, 4),
-            "MB_sent": round(sum(m["bytes_sent"] for m in multi_steps) / k / 1e6, 1),
-            "local_join_calls": jps, "ms_wall_inside_library": round(sum(m["ms_wall"] for m in multi_steps) / k, 4)}
+        mine = {  # this rank's view, averaged over the timed steps
+            "rank": rank,
+            "ms": sum(m["ms_exchange"] for m in multi_steps) / k,
+            "ms_partition": sum(m["ms_partition"] for m in multi_steps) / k,
+            "ms_joins_waited_for_it": sum(m["ms_exchange_wait"] for m in multi_steps) / k,
+            "MB_sent": sum(m["bytes_sent"] for m in multi_steps) / k / 1e6,
+            "ms_wall_inside_library": sum(m["ms_wall"] for m in multi_steps) / k,
+            "ms_join_kernel": avg["ms_join"], "ms_scatter": avg["ms_scatter1"] + avg["ms_scatter2"],
+            "ms_histogram": avg["ms_histogram"],
+            "rccl": comm.info(), "preflight": preflight}
+        every = gather_objects(dist, mine)
+        keys = ["ms", "ms_partition", "ms_joins_waited_for_it", "MB_sent", "ms_wall_inside_library", "ms_join_kernel",
+                "ms_scatter", "ms_histogram"]
+        out["exchange"] = {k2: round(mine[k2], 4) for k2 in keys}           # rank 0's view ...
+        out["exchange"]["local_join_calls_measured"] = jps
+        out["exchange"]["all_ranks"] = {k2: spread([e[k2] for e in every]) for k2 in keys}     # ... and min / max / mean over ALL ranks
+        # what RCCL itself says the world is (ncclGetVersion, ncclCommCount, ncclCommUserRank of every rank's
+        # communicator): proof that N ranks talked over RCCL and not N replicas next to each other
+        infos = [e["rccl"] for e in every]
+        out["rccl"] = {"transport": infos[0]["transport"], "version": infos[0]["rccl_version"],
+                       "nranks_by_ncclCommCount": sorted({i["rccl_nranks"] for i in infos}),
+                       "ranks_by_ncclCommUserRank": sorted(i["rccl_rank"] for i in infos),
+                       "devices_by_ncclCommCuDevice": [i["rccl_device"] for i in infos],
+                       "timeout_ms": infos[0]["timeout_ms"], "aborted": sorted({i["aborted"] for i in infos})}
+        if preflight:
+            out["exchange"]["preflight"] = {
+                "collectives_verified": all(e["preflight"] and e["preflight"]["ok_all_gather"] and e["preflight"]["ok_all_to_all"]
+                                            and e["preflight"]["ok_all_reduce"] for e in every),
+                "bytes_per_peer": preflight["link_bytes"],
+                # link_GBs[src][dst]: GB/s of `bytes_per_peer` from src to dst while every rank sends to its peer at the
+                # same distance (all pairs' own xGMI links at once)
+                "link_GBs": [e["preflight"]["link_GBs"] for e in every],
+                "all_to_all_GBs_sent_per_rank": [round(e["preflight"]["all_to_all_GBs"], 2) for e in every],
+                "ms_first_collectives_1MB": {"all_gather": round(preflight["ms_all_gather"], 3),
+                                             "all_to_all_v": round(preflight["ms_all_to_all"], 3),
+                                             "all_reduce": round(preflight["ms_all_reduce"], 3)}}
 
     # ---- the other BASELINE configurations, same process, N = 1 ---------------------------------------------------
     extras = (not multi and rank == 0 and not args.no_secondary and args.algo == "phj" and args.zipf <= 0
@@ -500,7 +580,7 @@ def main():
                                "join_phase_rw_frac": round((8 * n_tuples + 12 * j) / (tj * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "rows_checksum_ok": bool(ok_rows)}
         del jk, jo, ji
-    if rank == 0 and not multi and args.cpu_outer > 0:
+    if rank == 0 and args.cpu_outer > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(hj, args, args.algo)
         except Exception as ex:          # the baseline is reported, never required

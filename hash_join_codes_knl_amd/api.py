@@ -22,6 +22,7 @@ FLAG_UNIQUE = 1
 EXPORTS = [
     "hjgpu_kernel_hash", "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
     "hjgpu_get_device_info", "hjgpu_set_option", "hjgpu_reserve", "hjgpu_get_stats",
+    "hjgpu_get_async_status", "hjgpu_accumulate_async_status", "hjgpu_set_async_output", "hjgpu_output_capacity",
     "hjgpu_malloc", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
     "hjgpu_host_alloc", "hjgpu_host_free",
     "hjgpu_histogram", "hjgpu_partition", "hjgpu_partition_async", "hjgpu_join_partitions",
@@ -31,7 +32,9 @@ EXPORTS = [
     "hjgpu_phj_build", "hjgpu_phj_probe", "hjgpu_phj_probe_async",
     "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
     "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
+    "hjgpu_comm_get_info", "hjgpu_comm_preflight",
     "hjgpu_phj_multi", "hjgpu_npj_multi", "hjgpu_cpra_multi", "hjgpu_join_host_multi",
+    "hjgpu_phj_multi_rows", "hjgpu_npj_multi_rows", "hjgpu_cpra_multi_rows", "hjgpu_join_host_rows_multi",
     "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_generate_select", "hjgpu_column_sums", "hjgpu_stream_read_ms",
 ]
 
@@ -70,7 +73,7 @@ class Stats(C.Structure):
                 ("ms_scatter1", C.c_float), ("ms_scatter2", C.c_float), ("ms_join", C.c_float),
                 ("ms_build", C.c_float), ("ms_close_gaps", C.c_float),
                 ("ms_inner_wait", C.c_float), ("ms_upload", C.c_float), ("ms_download", C.c_float),
-                ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("batches", C.c_uint32), ("buckets", C.c_uint64)]
+                ("ms_reserve", C.c_float), ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("batches", C.c_uint32), ("buckets", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -85,7 +88,8 @@ class Shard(C.Structure):
 class MultiStats(C.Structure):
     _fields_ = [("ms_wall", C.c_float), ("ms_exchange", C.c_float), ("ms_partition", C.c_float),
                 ("ms_exchange_wait", C.c_float), ("joins", C.c_uint32), ("reserved", C.c_uint32),
-                ("tuples_joined", C.c_uint64), ("bytes_sent", C.c_uint64), ("join", Stats)]
+                ("tuples_joined", C.c_uint64), ("bytes_sent", C.c_uint64), ("ms_upload", C.c_float),
+                ("ms_overlap", C.c_float), ("join", Stats)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("join", "reserved")}
@@ -95,6 +99,35 @@ class MultiStats(C.Structure):
 
 class CommId(C.Structure):
     _fields_ = [("bytes", C.c_char * 128)]
+
+
+class CommInfo(C.Structure):
+    """hjgpu_comm_info: the transport's own view of the world (ncclCommCount / ncclCommUserRank / ncclGetVersion)."""
+    _fields_ = [("nranks", C.c_int), ("nlocal", C.c_int), ("first_rank", C.c_int), ("transport", C.c_char * 16),
+                ("rccl_version", C.c_int), ("rccl_nranks", C.c_int), ("rccl_rank", C.c_int), ("rccl_device", C.c_int),
+                ("timeout_ms", C.c_int), ("aborted", C.c_int)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["transport"] = d["transport"].decode()
+        return d
+
+
+class Preflight(C.Structure):
+    _fields_ = [("nranks", C.c_uint32), ("rank", C.c_uint32), ("ok_all_gather", C.c_uint32), ("ok_all_to_all", C.c_uint32),
+                ("ok_all_reduce", C.c_uint32), ("ms_all_gather", C.c_float), ("ms_all_to_all", C.c_float),
+                ("ms_all_reduce", C.c_float), ("link_bytes", C.c_uint64), ("link_GBs", C.c_float * 64),
+                ("all_to_all_GBs", C.c_float)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "link_GBs"}
+        d["link_GBs"] = [round(float(x), 2) for x in self.link_GBs[:self.nranks]]
+        return d
+
+
+class ShardRows(C.Structure):
+    """hjgpu_shard_rows: one rank's result columns and, after the call, its number of dense rows."""
+    _fields_ = [("out", Output), ("rows", C.c_uint64)]
 
 
 class DeviceInfo(C.Structure):
@@ -149,6 +182,10 @@ def load_library(build_if_missing=True):
     L.hjgpu_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.hjgpu_reserve.argtypes = [vp, sz, sz]
     L.hjgpu_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.hjgpu_get_async_status.argtypes = [vp, vp]
+    L.hjgpu_accumulate_async_status.argtypes = [vp, vp, vp]
+    L.hjgpu_set_async_output.argtypes = [vp, C.POINTER(Output)]
+    L.hjgpu_output_capacity.argtypes = [vp, C.c_int, sz, sz, sz, C.POINTER(sz)]
     L.hjgpu_malloc.argtypes = [vp, C.POINTER(vp), sz]
     L.hjgpu_free.argtypes = [vp, vp]
     L.hjgpu_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -171,6 +208,13 @@ def load_library(build_if_missing=True):
     L.hjgpu_comm_ctx.argtypes = [vp, C.c_int]
     L.hjgpu_comm_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.hjgpu_comm_barrier.argtypes = [vp]
+    L.hjgpu_comm_get_info.argtypes = [vp, C.POINTER(CommInfo)]
+    L.hjgpu_comm_preflight.argtypes = [vp, sz, C.POINTER(Preflight)]
+    L.hjgpu_phj_multi_rows.argtypes = [vp, C.POINTER(Shard), C.POINTER(ShardRows), C.c_int, C.POINTER(PhjParams), C.POINTER(Result), C.POINTER(MultiStats)]
+    L.hjgpu_npj_multi_rows.argtypes = [vp, C.POINTER(Shard), C.POINTER(ShardRows), C.c_int, C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(MultiStats)]
+    L.hjgpu_cpra_multi_rows.argtypes = [vp, C.POINTER(Shard), C.POINTER(ShardRows), C.POINTER(PhjParams), C.c_int, C.POINTER(Result), C.POINTER(MultiStats)]
+    L.hjgpu_join_host_rows_multi.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams), C.POINTER(NpjParams),
+                                             C.POINTER(HostRows), C.POINTER(Result), C.POINTER(MultiStats)]
     L.hjgpu_phj_multi.argtypes = [vp, C.POINTER(Shard), C.c_int, C.POINTER(PhjParams), C.POINTER(Result), C.POINTER(MultiStats)]
     L.hjgpu_npj_multi.argtypes = [vp, C.POINTER(Shard), C.c_int, C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(MultiStats)]
     L.hjgpu_cpra_multi.argtypes = [vp, C.POINTER(Shard), C.POINTER(PhjParams), C.c_int, C.POINTER(Result), C.POINTER(MultiStats)]
@@ -308,6 +352,24 @@ class HjGpu:
 
     def synchronize(self, stream=None):
         self._check(self.lib.hjgpu_synchronize(self.handle, stream))
+
+    def get_async_status(self, stream=None):
+        """hjgpu_get_async_status: raises what the blocking form of the last *_async join would have raised
+        (HJGPU_EZEROKEY, HJGPU_EOVERFLOW) after waiting for `stream`."""
+        self._check(self.lib.hjgpu_get_async_status(self.handle, stream))
+
+    def accumulate_async_status(self, d_flags, stream=None):
+        self._check(self.lib.hjgpu_accumulate_async_status(self.handle, self._ptr(d_flags), stream))
+
+    def set_async_output(self, out):
+        """hjgpu_set_async_output: the next *_async join of this context materialises into out = (keys, outer_vals,
+        inner_vals, capacity, block_size); None withdraws it."""
+        self._check(self.lib.hjgpu_set_async_output(self.handle, self._out(out)))
+
+    def output_capacity(self, algorithm, outer, rows, block_size=0):
+        cap = C.c_size_t()
+        self._check(self.lib.hjgpu_output_capacity(self.handle, algorithm, outer, rows, block_size, C.byref(cap)))
+        return cap.value
 
     @staticmethod
     def _ptr(x):
@@ -509,14 +571,19 @@ class HjComm:
         self.nranks, self.nlocal, self.first_rank = n.value, l.value, f.value
         self.ctx = [HjGpu(_borrowed=self.lib.hjgpu_comm_ctx(self.handle, i)) for i in range(self.nlocal)]
 
+    @staticmethod
+    def _create_error(lib, st):
+        # the communicator that could not be made is gone: its text is kept per thread (hjgpu_comm_last_error(NULL))
+        return HjGpuError(st, "%s: %s" % (lib.hjgpu_status_string(st).decode(), lib.hjgpu_comm_last_error(None).decode()))
+
     @classmethod
     def local(cls, nranks, devices=None, transport=TRANSPORT_RCCL):
         lib = load_library()
         h = C.c_void_p()
-        devs = (C.c_int * nranks)(*devices) if devices is not None else None
+        devs = (C.c_int * max(nranks, 1))(*devices) if devices is not None else None
         st = lib.hjgpu_comm_create_local(nranks, devs, transport, C.byref(h))
         if st != OK:
-            raise HjGpuError(st, lib.hjgpu_status_string(st).decode())
+            raise cls._create_error(lib, st)
         return cls(h)
 
     @staticmethod
@@ -525,7 +592,7 @@ class HjComm:
         cid = CommId()
         st = lib.hjgpu_comm_get_id(C.byref(cid))
         if st != OK:
-            raise HjGpuError(st, lib.hjgpu_status_string(st).decode())
+            raise HjComm._create_error(lib, st)
         return bytes(bytearray(C.string_at(C.addressof(cid), 128)))
 
     @classmethod
@@ -536,7 +603,7 @@ class HjComm:
         C.memmove(C.addressof(cid), comm_id, 128)
         st = lib.hjgpu_comm_create_rank(device, nranks, rank, C.byref(cid), C.byref(h))
         if st != OK:
-            raise HjGpuError(st, lib.hjgpu_status_string(st).decode())
+            raise cls._create_error(lib, st)
         return cls(h)
 
     def close(self):
@@ -561,6 +628,18 @@ class HjComm:
     def barrier(self):
         self._check(self.lib.hjgpu_comm_barrier(self.handle))
 
+    def info(self):
+        """hjgpu_comm_get_info: transport, RCCL version, ncclCommCount / ncclCommUserRank of local rank 0, timeout, aborted."""
+        i = CommInfo()
+        self._check(self.lib.hjgpu_comm_get_info(self.handle, C.byref(i)))
+        return i.as_dict()
+
+    def preflight(self, link_bytes=256 << 20):
+        """hjgpu_comm_preflight: checksum-verified collectives + point-to-point rates (GB/s per peer)."""
+        p = Preflight()
+        self._check(self.lib.hjgpu_comm_preflight(self.handle, link_bytes, C.byref(p)))
+        return p.as_dict()
+
     def _shards(self, shards):
         """shards: one (rk, rv, inner, sk, sv, outer) per local rank; columns are DeviceColumns / pointers / None."""
         assert len(shards) == self.nlocal
@@ -583,6 +662,55 @@ class HjComm:
 
     def cpra_multi(self, shards, params=None, slices=0):
         return self._run(self.lib.hjgpu_cpra_multi, shards, C.byref(params) if params is not None else None, slices)
+
+    # ---- materialised rows: outs = one (keys, outer_vals, inner_vals, capacity, block_size) per local rank --------
+    def _rows(self, outs):
+        assert len(outs) == self.nlocal
+        arr = (ShardRows * self.nlocal)()
+        for i, (k, o, v, cap, bs) in enumerate(outs):
+            p = HjGpu._ptr
+            arr[i].out = Output(p(k), p(o), p(v), cap, bs)
+        return arr
+
+    def _run_rows(self, fn, shards, outs, *mid):
+        """returns (result, stats, rows per local rank); on HJGPU_EOVERFLOW the exception carries .result and .rows
+        (what every rank needs)"""
+        r, s = Result(), MultiStats()
+        rows = self._rows(outs)
+        st = fn(self.handle, self._shards(shards), rows, *mid, C.byref(r), C.byref(s))
+        counts = [int(rows[i].rows) for i in range(self.nlocal)]
+        if st != OK:
+            e = HjGpuError(st, "%s: %s" % (self.lib.hjgpu_status_string(st).decode(),
+                                           self.lib.hjgpu_comm_last_error(self.handle).decode()))
+            e.result, e.rows = r.as_tuple(), counts
+            raise e
+        return r.as_tuple(), s.as_dict(), counts
+
+    def phj_multi_rows(self, shards, outs, root=0, params=None):
+        return self._run_rows(self.lib.hjgpu_phj_multi_rows, shards, outs, root, C.byref(params) if params is not None else None)
+
+    def npj_multi_rows(self, shards, outs, root=0, params=None):
+        return self._run_rows(self.lib.hjgpu_npj_multi_rows, shards, outs, root, C.byref(params) if params is not None else None)
+
+    def cpra_multi_rows(self, shards, outs, params=None, slices=0):
+        return self._run_rows(self.lib.hjgpu_cpra_multi_rows, shards, outs, C.byref(params) if params is not None else None, slices)
+
+    def join_host_rows_multi(self, algorithm, ik, iv, ok, ov, capacity, phj_params=None, npj_params=None):
+        """hjgpu_join_host_rows_multi: (result, stats, (keys, outer_vals, inner_vals)) with the columns cut to count rows"""
+        ik, iv, ok, ov = (np.ascontiguousarray(c, np.uint32) for c in (ik, iv, ok, ov))
+        cols = [np.empty(max(capacity, 1), np.uint32) for _ in range(3)]
+        rows = HostRows(cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data, capacity)
+        r, s = Result(), MultiStats()
+        st = self.lib.hjgpu_join_host_rows_multi(
+            self.handle, algorithm, ik.ctypes.data, iv.ctypes.data, ik.size, ok.ctypes.data, ov.ctypes.data, ok.size,
+            C.byref(phj_params) if phj_params is not None else None,
+            C.byref(npj_params) if npj_params is not None else None, C.byref(rows), C.byref(r), C.byref(s))
+        if st != OK:
+            e = HjGpuError(st, "%s: %s" % (self.lib.hjgpu_status_string(st).decode(),
+                                           self.lib.hjgpu_comm_last_error(self.handle).decode()))
+            e.result = r.as_tuple()
+            raise e
+        return r.as_tuple(), s.as_dict(), tuple(c[:r.count].copy() for c in cols)
 
     def join_host_multi(self, algorithm, ik, iv, ok, ov, phj_params=None, npj_params=None):
         ik, iv, ok, ov = (np.ascontiguousarray(c, np.uint32) for c in (ik, iv, ok, ov))

@@ -28,8 +28,9 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libhjgpu)")
 
 
+# the kernels AND the plan that launches them (fan-out defaults, grid geometry, placement, reserve_cus live in hjgpu_api.hip)
 KERNEL_HASH_FILES = ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip", "hj_device.hpp",
-                     "hj_emit.hpp", "hj_internal.hpp"]
+                     "hj_emit.hpp", "hj_internal.hpp", "hjgpu_api.hip"]
 
 
 def kernel_hash():
@@ -73,9 +74,10 @@ def build_library(force=False, verbose=True):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(obj)
-    # RCCL (multi-GPU joins, csrc/hjgpu_multi.hip) is linked by soname: a process that has already loaded
-    # torch's copy of librccl.so.1 keeps using that one
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+    # RCCL (multi-GPU joins, csrc/hjgpu_multi.hip) is NOT linked: the first communicator that asks for the RCCL
+    # transport binds librccl.so.1 with dlopen (the copy already in the process - torch ships one - else the
+    # system's), so single-GPU users, the C-ABI tests and hosts on a box without RCCL load the library without it
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", so] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -16,18 +16,24 @@
 
 #define HJ_NO_CURSOR (~0ull)
 
+// The cursor is addressed as LDS (address space 3), not through a generic pointer: with a generic `volatile u64 *`
+// the compiler emitted flat_load / flat_store with `s_waitcnt vmcnt(0)` around every emit - FLAT operations count on
+// the vector-memory counter, so each emit first waited for EVERY outstanding global load and store of the wave
+// (rounds 1-2: the materialising join ran at 0.56-0.59 of the peak on read + written bytes for that reason).
+typedef __attribute__((address_space(3))) u64 hj_lds_u64;
+
 struct Emitter {
     uint32_t *ok, *oov, *oiv;
     u64 block_size, block_limit;
     u64 *block_counter;
     uint32_t *overflow;
-    volatile u64 *cursor;          // this wave's cursor, in LDS
+    volatile hj_lds_u64 *cursor;   // this wave's cursor, in LDS (ds_read_b64 / ds_write_b64)
 
     __device__ __forceinline__ void init(uint32_t *k, uint32_t *ov, uint32_t *iv, u64 bs, u64 bl,
                                          u64 *bc, uint32_t *ovf, u64 *lds_cursor)
     {
         ok = k; oov = ov; oiv = iv; block_size = bs; block_limit = bl;
-        block_counter = bc; overflow = ovf; cursor = lds_cursor;
+        block_counter = bc; overflow = ovf; cursor = (volatile hj_lds_u64 *)lds_cursor;
     }
 
     // Called by the lanes that have a match (any subset of the wave).
@@ -63,5 +69,36 @@ struct Emitter {
         ok[pos] = key;
         oov[pos] = outer_val;
         oiv[pos] = inner_val;
+    }
+
+    // Four rows per lane in one go: called by a (sub)set of lanes that ALL have exactly one match for each of the four
+    // keys of their probe vector (the common case with unique build keys and selectivity 1: every vector of the
+    // stream).  Lane `rank` writes rows [o + 4 rank, o + 4 rank + 4) of the wave's run: one 16-byte store per column
+    // and lane - a column leaves the wave as one 1 KiB piece per instruction instead of four 256-byte pieces -, one
+    // cursor update and one ballot per 256 rows instead of four (npj.cpp:292-317 stages 256 entries and streams them
+    // out the same way).  Returns false (uniformly, nothing written) when the run does not fit the wave's current
+    // block: the caller then emits key by key, and that path claims the next block.
+    // The stores are only 4-byte aligned when the cursor is not a multiple of 4 (after key-by-key emits): gfx950
+    // executes dword-aligned global_store_dwordx4 (unaligned access mode), the type below tells the compiler so.
+    typedef uint32_t row4_t __attribute__((ext_vector_type(4), aligned(4)));
+    __device__ __forceinline__ bool emit4(const uint32_t (&key)[4], const uint32_t (&outer_val)[4],
+                                          const uint32_t (&inner_val)[4])
+    {
+        const u64 m = __ballot(1);
+        const uint32_t n = 4u * (uint32_t)__popcll(m);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const u64 o = *cursor;
+        if (o == HJ_NO_CURSOR) return false;
+        const u64 room = (o & ~(block_size - 1)) + block_size - o;
+        if (n >= room) return false;
+        const u64 pos = o + 4u * rank;
+        if (rank == 0) *cursor = o + n;
+        row4_t k4 = {key[0], key[1], key[2], key[3]};
+        row4_t o4 = {outer_val[0], outer_val[1], outer_val[2], outer_val[3]};
+        row4_t i4 = {inner_val[0], inner_val[1], inner_val[2], inner_val[3]};
+        *reinterpret_cast<row4_t *>(ok + pos) = k4;
+        *reinterpret_cast<row4_t *>(oov + pos) = o4;
+        *reinterpret_cast<row4_t *>(oiv + pos) = i4;
+        return true;
     }
 };

@@ -40,6 +40,8 @@ struct JoinConfig {
 // 16 K-slot tables (128 KiB of LDS, one 1024-thread workgroup per CU): half the partitions for the same build
 // side.  Chosen when the 8 K-slot tables would need more than HJGPU_MAX_PARTS partitions (|R| > ~114 M).
 const JoinConfig &hj_join_config_big();
+// is this geometry among the built instances of join_kernel (with a _UNIQUE instance, if asked for)?
+bool hj_join_config_built(const JoinConfig &c, bool unique);
 
 // Tuning / test switches of ONE context.  They are read from the environment once, in hjgpu_create
 // (HJGPU_<NAME>), and can be set per context with hjgpu_set_option; nothing on a launch path looks at
@@ -53,6 +55,7 @@ struct HjTuning {
     bool force_chained = false;     // "force_chained": chained fallback tables everywhere (tests)
     bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
+    bool emit_vec = true;           // "emit_vec": materialised rows leave as 16-byte stores (4 rows per lane) where every lane matched
     int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
@@ -141,6 +144,7 @@ struct JoinArgs {
     const uint32_t *sentinel;
     uint32_t force_chained;              // tests: skip the cuckoo fast path (option "force_chained")
     uint32_t unique;                     // _UNIQUE (npj.cpp:288-290): a probe key reports its first match only
+    uint32_t emit_vec;                   // materialised rows: four rows per lane and store where every lane matched (option "emit_vec")
 };
 
 struct PlanArgs {

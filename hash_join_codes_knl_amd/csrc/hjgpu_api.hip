@@ -60,6 +60,12 @@ struct hjgpu_ctx {
     size_t prepared_inner = 0, prepared_max_outer = 0;
     unsigned char prepared_plan[96];
     HjTuning tune;          // tuning / test switches: environment at hjgpu_create, hjgpu_set_option afterwards
+    // hjgpu_set_async_output: the next *_async join of this context materialises into these columns (one-shot)
+    hjgpu_output pending_out;
+    bool has_pending_out = false;
+    bool last_had_output = false;   // hjgpu_get_async_status: the last enqueued join wrote result columns
+    hipStream_t aux = nullptr;      // private non-blocking stream: placement probes of the workspace allocator
+    float ms_reserve = 0;           // wall clock of the workspace growth so far (allocations + placement probes)
 };
 
 namespace {
@@ -124,18 +130,26 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     void *cand[16];
     float ms[16];
     int n = 0, best = -1;
+    // the probes run on the context's own non-blocking stream: nothing is issued on the legacy NULL stream (which
+    // would synchronise every blocking stream of the process, and is not legal while another stream captures)
+    if (!ctx->aux) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(ctx, hipEventCreate(&e0));
-    HIPCHK(ctx, hipEventCreate(&e1));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(ctx, HJGPU_EHIP, "hipEventCreate"); }
+    // candidates are held side by side (so that each is different memory): never more than HALF of what is free when
+    // the search starts, so that other allocators of the process (several contexts / loopback ranks on one device,
+    // torch's caching allocator) keep room
+    size_t free0 = 0, total0 = 0;
+    if (hipMemGetInfo(&free0, &total0) != hipSuccess) free0 = 0;
+    const size_t budget = free0 / 2;
     for (; n < tries; ++n) {
-        size_t free_b = 0, total_b = 0;
-        if (n && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < want + ((size_t)2 << 30))) break;   // no room for another candidate
+        if (n && (size_t)(n + 1) * want > budget) break;                     // no room for another candidate
         if (hipMalloc(&cand[n], want) != hipSuccess) { (void)hipGetLastError(); break; }
         ms[n] = 1e30f;
         for (int rep = 0; rep < 2; ++rep) {                                  // the first touch of fresh memory is slower
             float t = 1e30f;
-            if (hipEventRecord(e0, 0) == hipSuccess && hj_launch_fill_probe(cand[n], want, 0) == HJGPU_OK &&
-                hipEventRecord(e1, 0) == hipSuccess && hipEventSynchronize(e1) == hipSuccess)
+            if (hipEventRecord(e0, ctx->aux) == hipSuccess && hj_launch_fill_probe(cand[n], want, ctx->aux) == HJGPU_OK &&
+                hipEventRecord(e1, ctx->aux) == hipSuccess && hipEventSynchronize(e1) == hipSuccess)
                 (void)hipEventElapsedTime(&t, e0, e1);
             if (t < ms[n]) ms[n] = t;
         }
@@ -148,6 +162,27 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     b.p = cand[best]; b.cap = want;
     return HJGPU_OK;
 }
+
+// Wall clock of workspace growth (hjgpu_stats.ms_reserve): the placement search holds and fills up to 12 candidate
+// blocks of the probe side's pass-1 twin; it happens at hjgpu_reserve / the first join of a size, never in a timed join
+// afterwards, and its cost is reported instead of being invisible.
+struct ReserveClock {
+    hjgpu_ctx *ctx;
+    size_t before;
+    std::chrono::steady_clock::time_point t0;
+    static size_t held(const hjgpu_ctx *c)
+    {
+        size_t n = c->meta.cap + c->table.cap + c->state.cap;
+        for (const DevBuf &b : c->tmp) n += b.cap;
+        return n;
+    }
+    explicit ReserveClock(hjgpu_ctx *c) : ctx(c), before(held(c)), t0(std::chrono::steady_clock::now()) {}
+    ~ReserveClock()
+    {
+        if (held(ctx) != before)
+            ctx->ms_reserve += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
 
 // K6 occupies a CU completely (one 1024-thread workgroup with ~155 KiB of LDS that lives until the pass ends): a kernel
 // that arrives during a pass - RCCL's, on the multi-GPU path - finds no CU until the pass is over.  "reserve_cus" keeps
@@ -388,9 +423,13 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
                 uint32_t chunks, PhjPlan *pl)
 {
     ctx->prepared = false;               // the workspace is about to be re-planned (hjgpu_phj_build sets it again)
+    ReserveClock clock(ctx);
     pl->C = chunks;
     pl->unique = ctx->tune.unique || (prm && (prm->flags & HJGPU_FLAG_UNIQUE));
     choose_fanout(ctx->tune, inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
+    if (pl->unique && !hj_join_config_built(hj_join_config_of(ctx->tune, pl->big_tables), true))
+        return fail(ctx, HJGPU_EINVAL, "HJGPU_FLAG_UNIQUE: the join_cfg geometry of this context has no _UNIQUE instance "
+                                       "(built: 512,13,2 / 1024,14,2 / 384,13,3 / 384,13,4)");
     pl->P = pl->F1 * pl->F2;
     if (pl->F1 < 1 || pl->F2 < 1 || pl->F1 > HJGPU_MAX_FANOUT || pl->F2 > HJGPU_MAX_FANOUT ||
         pl->P < 2 || pl->P > HJGPU_MAX_PARTS)
@@ -676,6 +715,7 @@ bool npj_unique(const hjgpu_ctx *ctx, const hjgpu_npj_params *prm)
 int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_t *buckets,
                 uint32_t *factor)
 {
+    ReserveClock clock(ctx);
     double load = (prm && prm->load > 0) ? prm->load : 0.25;
     if (load > 0.99) return fail(ctx, HJGPU_EINVAL, "load factor must be <= 0.99");
     size_t b = (size_t)((double)inner / load);             // npj.cpp:947
@@ -743,6 +783,21 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
     return HJGPU_OK;
 }
 
+// hjgpu_accumulate_async_status: the two flags of the last join -> two running uint64 counters
+__global__ void accumulate_flags_kernel(const DevState *__restrict__ st, u64 *__restrict__ flags)
+{
+    if (threadIdx.x == 0) { if (st->zero_key) flags[0] += 1; if (st->overflow) flags[1] += 1; }
+}
+
+// the one-shot output of hjgpu_set_async_output
+const hjgpu_output *take_async_output(hjgpu_ctx *ctx, const hjgpu_output *given)
+{
+    if (given) return given;
+    if (!ctx->has_pending_out) return nullptr;
+    ctx->has_pending_out = false;
+    return &ctx->pending_out;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -761,6 +816,7 @@ const char *hjgpu_status_string(int s)
     case HJGPU_EZEROKEY: return "key 0 is reserved by NPJ";
     case HJGPU_EOVERFLOW: return "output capacity exceeded";
     case HJGPU_ENODEVICE: return "no GPU device";
+    case HJGPU_ERCCL: return "RCCL / communicator error";
     default: return "unknown status";
     }
 }
@@ -812,6 +868,7 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
                      &ctx->final_offsets};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     delete ctx;
     return HJGPU_OK;
 }
@@ -823,11 +880,11 @@ int hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value)
     if (!ctx || !name || !value) return HJGPU_EINVAL;
     HjTuning t = ctx->tune;
     if (!hj_tuning_set(&t, name, value)) return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: unknown option or malformed value");
-    // the join kernels exist in a fixed set of geometries
-    const JoinConfig &j = t.join;
-    const bool built = (j.block == 512 && j.log2slots == 13 && (j.batch == 1 || j.batch == 2 || j.batch == 4)) ||
-                       (j.block == 1024 && j.log2slots == 14 && j.batch == 2) || (j.block == 256 && j.log2slots == 12 && j.batch == 2);
-    if (!built) return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: join_cfg names a geometry that is not built");
+    // the join kernels exist in a fixed set of geometries, _UNIQUE instances in some of them
+    if (!hj_join_config_built(t.join, false))
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: join_cfg names a geometry that is not built");
+    if (t.unique && !hj_join_config_built(t.join, true))
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: this join_cfg geometry has no _UNIQUE instance (built: 512,13,2 / 1024,14,2 / 384,13,3 / 384,13,4)");
     ctx->tune = t;
     ctx->prepared = false;                   // a prepared build side was planned under the old options
     return HJGPU_OK;
@@ -871,9 +928,11 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
     hjgpu_stats r = ctx->stats;
     r.ms_total = span(EV_BEGIN, EV_GAPS);
     r.ms_inner_wait = 0;
+    r.ms_reserve = ctx->ms_reserve;
     if (ctx->last_algo == 2) {                 // hjgpu_column_sums: one kernel
         memset(&r, 0, sizeof(r));
         r.ms_total = span(EV_BEGIN, EV_GAPS);
+        r.ms_reserve = ctx->ms_reserve;
         *s = r;
         return HJGPU_OK;
     }
@@ -892,6 +951,56 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
     }
     r.ms_close_gaps = span(EV_JOIN, EV_GAPS);
     *s = r;
+    return HJGPU_OK;
+}
+
+int hjgpu_get_async_status(hjgpu_ctx *ctx, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (!ctx->state.p) return HJGPU_OK;                  // nothing was ever enqueued
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevState h;
+    HIPCHK(ctx, hipMemcpyAsync(&h, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    if (h.zero_key) return fail(ctx, HJGPU_EZEROKEY, "NPJ: a build key is 0, the empty-bucket sentinel");
+    if (h.overflow) return fail(ctx, HJGPU_EOVERFLOW, "materialised output exceeded its capacity");
+    if (ctx->last_had_output && h.dense != h.result.count && (h.result.count != 0 || h.dense != 0))
+        return fail(ctx, HJGPU_EHIP, "internal: dense length != match count after close_gaps");
+    return HJGPU_OK;
+}
+
+int hjgpu_accumulate_async_status(hjgpu_ctx *ctx, uint64_t *d_flags, void *stream_)
+{
+    if (!ctx || !d_flags) return HJGPU_EINVAL;
+    if (!ctx->state.p) return HJGPU_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(accumulate_flags_kernel, dim3(1), dim3(64), 0, stream,
+                       reinterpret_cast<const DevState *>(ctx->state.p), reinterpret_cast<u64 *>(d_flags));
+    HIPCHK(ctx, hipGetLastError());
+    return HJGPU_OK;
+}
+
+int hjgpu_set_async_output(hjgpu_ctx *ctx, const hjgpu_output *out)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    ctx->has_pending_out = false;
+    if (!out || !out->d_keys) return HJGPU_OK;
+    if (!out->d_outer_vals || !out->d_inner_vals) return fail(ctx, HJGPU_EINVAL, "output columns");
+    ctx->pending_out = *out;
+    ctx->has_pending_out = true;
+    return HJGPU_OK;
+}
+
+int hjgpu_output_capacity(hjgpu_ctx *ctx, int algorithm, size_t outer_tuples, size_t rows, size_t block_size, size_t *capacity)
+{
+    if (!ctx || !capacity || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
+    const size_t bs = block_size ? block_size : 65536;
+    if (bs < 256 || (bs & (bs - 1))) return fail(ctx, HJGPU_EINVAL, "block_size must be a power of two >= 256");
+    const size_t workers = algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, outer_tuples) * 4
+                                          : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true));
+    *capacity = (rows / bs + 1 + workers) * bs;
     return HJGPU_OK;
 }
 
@@ -1158,8 +1267,11 @@ int hjgpu_npj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     size_t buckets; uint32_t factor;
+    CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
     CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
-    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, nullptr, stream, npj_unique(ctx, prm)));
+    const hjgpu_output *out = take_async_output(ctx, nullptr);
+    ctx->last_had_output = out && out->d_keys;
+    CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream, npj_unique(ctx, prm)));
     if (d_result)
         HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
     return HJGPU_OK;
@@ -1175,7 +1287,9 @@ int hjgpu_npj(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inn
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     size_t buckets; uint32_t factor;
+    CHK(refuse_capture(ctx, stream));
     CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
+    ctx->last_had_output = out && out->d_keys;
     CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream, npj_unique(ctx, prm)));
     return finish_blocking(ctx, result, out, stream);
 }
@@ -1280,6 +1394,9 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     if (chunks < 1 || chunks > 8) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 8]");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
+    if (!blocking) out = take_async_output(ctx, out);
+    ctx->last_had_output = out && out->d_keys;
     if (broadcast_applies(ctx->tune, inner, outer, chunks, prm)) {
         CHK(broadcast_enqueue(ctx, rk, rv, inner, sk, sv, outer, prm, out, stream, (hipEvent_t)inner_ready));
     } else {
@@ -1325,6 +1442,7 @@ int hjgpu_phj_build(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PhjPlan pl;
+    CHK(refuse_capture(ctx, stream));
     CHK(phj_prepare(ctx, inner, max_outer, prm, 1, &pl));        // workspace and plan for the largest batch
     CHK(phj_enqueue(ctx, pl, rk, rv, inner, nullptr, nullptr, 0, nullptr, stream, nullptr, PHJ_BUILD_ONLY));
     memcpy(ctx->prepared_plan, &pl, sizeof(pl));
@@ -1348,6 +1466,8 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PhjPlan pl;
     memcpy(&pl, ctx->prepared_plan, sizeof(pl));
+    if (!blocking) out = take_async_output(ctx, out);
+    ctx->last_had_output = out && out->d_keys;
     // the build columns themselves are not read again: their partitions live in the workspace
     CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, sk, sv, outer, out, stream, nullptr, PHJ_PROBE_ONLY));
     if (d_result)

@@ -12,14 +12,23 @@
 // reductions.  RcclTransport calls RCCL (xGMI); LoopbackTransport moves the same messages with hipMemcpyAsync
 // between the ranks' buffers, so the whole orchestration runs at any world size on ONE GPU (tests).
 // This file only uses the public C-ABI of the single-GPU library (hjgpu_partition_async, hjgpu_phj_build, ...).
+//
+// Barrier discipline.  The reference's workers meet at pthread barriers (cpra2.cpp:1834-1840, phj.cpp:1715-1770); a
+// worker that never arrives hangs the program.  Here every host-side wait (sync_all, the counts the host needs in
+// the middle of a CPRA step) honours the communicator's deadline (option "timeout_ms"): the streams are polled, RCCL
+// is asked for asynchronous errors, and when the deadline passes the communicator is aborted (ncclCommAbort) and the
+// call returns HJGPU_ERCCL with the rank and stream that did not finish - never a hang.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/hjgpu.h"
@@ -29,6 +38,62 @@ typedef unsigned long long u64;
 namespace {
 
 const uint32_t TOP_LEVEL_FACTOR = 0x2C1B3C6Du;        // odd multiplier of the exchange-level partitioning
+
+// ---- RCCL, bound on first use ---------------------------------------------------------------------------------
+// libhjgpu.so does not link librccl: single-GPU users (and the C-ABI tests, and hosts on a box without RCCL) load the
+// library without it.  The first communicator that asks for the RCCL transport binds librccl.so.1 - the copy that is
+// already in the process if there is one (torch ships its own), else the system's.
+struct Rccl {
+    void *lib = nullptr;
+    char why[256] = {0};
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // already in the process
+        for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) {
+            const char *root = getenv("ROCM_PATH");
+            char path[512];
+            snprintf(path, sizeof(path), "%s/lib/librccl.so.1", root && *root ? root : "/opt/rocm");
+            r.lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!r.lib) { snprintf(r.why, sizeof(r.why), "librccl.so.1 cannot be loaded: %s", dlerror()); return; }
+        bool all = true;
+#define BIND(name) do { r.name = reinterpret_cast<decltype(r.name)>(dlsym(r.lib, "nccl" #name)); if (!r.name) { all = false; snprintf(r.why, sizeof(r.why), "librccl lacks nccl" #name); } } while (0)
+        BIND(GetVersion); BIND(GetUniqueId); BIND(CommInitAll); BIND(CommInitRank); BIND(CommDestroy); BIND(CommAbort);
+        BIND(CommGetAsyncError); BIND(CommCount); BIND(CommUserRank); BIND(CommCuDevice); BIND(GroupStart); BIND(GroupEnd);
+        BIND(Send); BIND(Recv); BIND(AllGather); BIND(Broadcast); BIND(AllReduce); BIND(GetErrorString);
+#undef BIND
+        if (!all) r.lib = nullptr;
+    });
+    return r.lib ? &r : nullptr;
+}
+
+// text of the last communicator that could not be created on this thread: hjgpu_comm_last_error(NULL)
+thread_local char g_create_error[512] = "";
 
 struct Buf {
     void *p = nullptr;
@@ -43,22 +108,27 @@ struct Rank {
     hipStream_t main = nullptr;     // local joins
     hipStream_t comm = nullptr;     // exchanges
     hipStream_t prep = nullptr;     // exchange-level partitioning
+    hipStream_t up = nullptr;       // hjgpu_join_host_multi: uploads of this rank's shard
     hipEvent_t ev_ready = nullptr;  // build side replicated (PHJ / NPJ)
     hipEvent_t ev_x0 = nullptr, ev_x1 = nullptr;      // timing of an exchange on `comm`
-    hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr;      // timing of a join's wait for its exchange on `main`
+    std::vector<hipEvent_t> ev_w;                     // [2 * slice]: a slice's join before / after its wait for the exchange
     hipEvent_t ev_part[2] = {nullptr, nullptr};       // send buffers of slot b partitioned
     hipEvent_t ev_xchg[2] = {nullptr, nullptr};       // receive buffers of slot b filled
     hipEvent_t ev_join[2] = {nullptr, nullptr};       // receive buffers of slot b joined (free again)
     hipEvent_t ev_rx = nullptr;                       // build side received (CPRA)
+    hipEvent_t ev_up_s = nullptr, ev_up_r = nullptr;  // host path: probe shard / build columns uploaded
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;      // host path: first kernel of the join started / upload finished (timing)
     hipEvent_t lb_in = nullptr, lb_out = nullptr;     // loopback transport
     Buf rbuf;                       // PHJ / NPJ: replicated build side (keys | payloads)
     Buf send_k[2], send_v[2], recv_k[2], recv_v[2];   // CPRA: probe-side slices, double-buffered
     Buf rsend_k, rsend_v, rrecv_k, rrecv_v;           // CPRA: build side
     Buf d_off;                      // [2][G + 1] u64: partition offsets of slot b
     Buf d_cnt;                      // [G] u64 send counts | [G * G] gathered matrix
-    Buf d_res;                      // [8] u64: accumulated result | last batch
-    Buf scratch;                    // loopback all-reduce staging
-    u64 *h_pin = nullptr;           // pinned host scratch: [2][G + 1] offsets | [G * G] matrix | [8] result | [G] send counts
+    Buf d_res;                      // [12] u64: accumulated result | zero-key flag, overflow flag, 2 spare | last batch
+    Buf scratch;                    // loopback all-reduce staging; preflight buffers
+    Buf shard[4];                   // hjgpu_join_host_multi: this rank's share of ik, iv, ok, ov (kept between calls)
+    Buf rows_col[3];                // hjgpu_join_host_rows_multi: this rank's result columns
+    u64 *h_pin = nullptr;           // pinned host scratch, see hp_*()
 };
 
 struct Transport;
@@ -72,10 +142,22 @@ struct hjgpu_comm {
     bool ring_broadcast = false;
     size_t max_message_bytes = (size_t)1 << 30;
     int reserve_cus = -1;                    // -1: 16 with RCCL and more than one rank, else 0 (option "reserve_cus")
+    int timeout_ms = 0;                      // deadline of every host-side wait; 0 = none (option "timeout_ms")
+    bool broken = false;                     // a deadline expired / RCCL reported an asynchronous error: aborted
+    int stall_rank = -1, stall_ms = 0;       // loopback fault injection (options "stall_rank", "stall_ms")
     char err[512];
+    char why_broken[512];
 };
 
 namespace {
+
+// pinned host scratch of a rank (u64 words)
+inline size_t hp_words(size_t G) { return 2 * (G + 1) + G * G + 8 + G + 8; }
+inline u64 *hp_off(const Rank &r, size_t G, int slot) { (void)G; return r.h_pin + (size_t)slot * (G + 1); }   // [2][G + 1] offsets
+inline u64 *hp_matrix(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1); }                               // [G * G] counts matrix
+inline u64 *hp_result(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1) + G * G; }                       // [8] global result + flags
+inline u64 *hp_cnt(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1) + G * G + 8; }                      // [G] send counts
+inline u64 *hp_local(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1) + G * G + 8 + G; }                // [8] this rank's own result (rows)
 
 int cfail(hjgpu_comm *c, int status, const char *what, const char *detail = nullptr)
 {
@@ -87,11 +169,6 @@ int cfail(hjgpu_comm *c, int status, const char *what, const char *detail = null
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) return cfail((c), HJGPU_EHIP, #call, hipGetErrorString(e_));   \
-    } while (0)
-#define NCCLM(c, call)                                                                       \
-    do {                                                                                     \
-        ncclResult_t r_ = (call);                                                            \
-        if (r_ != ncclSuccess) return cfail((c), HJGPU_ERCCL, #call, ncclGetErrorString(r_)); \
     } while (0)
 #define CHKM(call)                                                                           \
     do {                                                                                     \
@@ -138,6 +215,11 @@ struct Transport {
                              size_t elem_bytes, hipStream_t const *streams) = 0;
     // bufs[l][0..count) = sum over all ranks (uint64, wrap-around)
     virtual int all_reduce_u64(u64 *const *bufs, size_t count, hipStream_t const *streams) = 0;
+    // an error RCCL met asynchronously (a peer died, a link failed): text in `what`, true = there is one
+    virtual bool async_error(char *what, size_t n) { (void)what; (void)n; return false; }
+    // give up: whatever the transport has in flight is cancelled, its resources are released without waiting
+    virtual void abort() {}
+    virtual void info(hjgpu_comm_info *i) { (void)i; }
     size_t replicate_capacity(size_t bytes) const
     {
         const size_t per = ((bytes + c->nranks - 1) / c->nranks + 15) & ~size_t(15);
@@ -146,25 +228,87 @@ struct Transport {
 };
 
 // ---- RCCL over xGMI ---------------------------------------------------------------------------------
+// ncclGroupStart ... ncclGroupEnd: the end is never skipped.  An early return from inside an open group would leave
+// the thread in group mode and every later RCCL call - the ncclCommDestroy of the clean-up included - deferred.
+struct Group {
+    hjgpu_comm *c;
+    Rccl *R;
+    int rc = HJGPU_OK;
+    bool open = false;
+    Group(hjgpu_comm *comm, Rccl *r) : c(comm), R(r)
+    {
+        const ncclResult_t e = R->GroupStart();
+        if (e != ncclSuccess) rc = cfail(c, HJGPU_ERCCL, "ncclGroupStart", R->GetErrorString(e));
+        else open = true;
+    }
+    bool ok() const { return rc == HJGPU_OK; }
+    void nccl(ncclResult_t e, const char *what) { if (e != ncclSuccess && rc == HJGPU_OK) rc = cfail(c, HJGPU_ERCCL, what, R->GetErrorString(e)); }
+    void hip(hipError_t e, const char *what) { if (e != hipSuccess && rc == HJGPU_OK) rc = cfail(c, HJGPU_EHIP, what, hipGetErrorString(e)); }
+    int end()
+    {
+        if (open) {
+            open = false;
+            const ncclResult_t e = R->GroupEnd();
+            if (e != ncclSuccess && rc == HJGPU_OK) rc = cfail(c, HJGPU_ERCCL, "ncclGroupEnd", R->GetErrorString(e));
+        }
+        return rc;
+    }
+    ~Group() { if (open) (void)R->GroupEnd(); }
+};
+
 struct RcclTransport : Transport {
+    Rccl *R;
     std::vector<ncclComm_t> comms;           // one per local rank
-    explicit RcclTransport(hjgpu_comm *comm) : Transport(comm) {}
+    RcclTransport(hjgpu_comm *comm, Rccl *r) : Transport(comm), R(r) {}
     ~RcclTransport() override
     {
         for (size_t l = 0; l < comms.size(); ++l)
-            if (comms[l]) { (void)hipSetDevice(c->ranks[l].device); (void)ncclCommDestroy(comms[l]); }
+            if (comms[l]) {
+                (void)hipSetDevice(c->ranks[l].device);
+                // a communicator that met an error is not waited for
+                if (c->broken) (void)R->CommAbort(comms[l]); else (void)R->CommDestroy(comms[l]);
+            }
     }
     const char *name() const override { return "rccl"; }
 
+    bool async_error(char *what, size_t n) override
+    {
+        for (size_t l = 0; l < comms.size(); ++l) {
+            ncclResult_t e = ncclSuccess;
+            if (comms[l] && R->CommGetAsyncError(comms[l], &e) == ncclSuccess && e != ncclSuccess && e != ncclInProgress) {
+                snprintf(what, n, "RCCL asynchronous error on rank %d: %s", c->ranks[l].global, R->GetErrorString(e));
+                return true;
+            }
+        }
+        return false;
+    }
+
+    void abort() override
+    {
+        for (size_t l = 0; l < comms.size(); ++l)
+            if (comms[l]) { (void)hipSetDevice(c->ranks[l].device); (void)R->CommAbort(comms[l]); comms[l] = nullptr; }
+    }
+
+    void info(hjgpu_comm_info *i) override
+    {
+        int v = 0;
+        if (R->GetVersion(&v) == ncclSuccess) i->rccl_version = v;
+        if (!comms.empty() && comms[0]) {
+            int n = -1, r = -1, d = -1;
+            if (R->CommCount(comms[0], &n) == ncclSuccess) i->rccl_nranks = n;
+            if (R->CommUserRank(comms[0], &r) == ncclSuccess) i->rccl_rank = r;
+            if (R->CommCuDevice(comms[0], &d) == ncclSuccess) i->rccl_device = d;
+        }
+    }
+
     int all_gather(const void *const *send, void *const *recv, size_t bytes, hipStream_t const *streams) override
     {
-        NCCLM(c, ncclGroupStart());
-        for (int l = 0; l < nlocal(); ++l) {
-            HIPM(c, hipSetDevice(c->ranks[l].device));
-            NCCLM(c, ncclAllGather(send[l], recv[l], bytes, ncclUint8, comms[l], streams[l]));
+        Group g(c, R);
+        for (int l = 0; l < nlocal() && g.ok(); ++l) {
+            g.hip(hipSetDevice(c->ranks[l].device), "hipSetDevice");
+            if (g.ok()) g.nccl(R->AllGather(send[l], recv[l], bytes, ncclUint8, comms[l], streams[l]), "ncclAllGather");
         }
-        NCCLM(c, ncclGroupEnd());
-        return HJGPU_OK;
+        return g.end();
     }
 
     int replicate(void *const *bufs, size_t bytes, int root, bool ring, hipStream_t const *streams) override
@@ -173,38 +317,38 @@ struct RcclTransport : Transport {
         if (G == 1) return HJGPU_OK;
         if (ring || bytes < (size_t)G * 4096) {
             // one ring broadcast: bound by ONE xGMI link (512 MB of build side at ~60 GB/s per direction = 8.5 ms)
-            NCCLM(c, ncclGroupStart());
-            for (int l = 0; l < nlocal(); ++l) {
-                HIPM(c, hipSetDevice(c->ranks[l].device));
-                NCCLM(c, ncclBroadcast(bufs[l], bufs[l], bytes, ncclUint8, root, comms[l], streams[l]));
+            Group g(c, R);
+            for (int l = 0; l < nlocal() && g.ok(); ++l) {
+                g.hip(hipSetDevice(c->ranks[l].device), "hipSetDevice");
+                if (g.ok()) g.nccl(R->Broadcast(bufs[l], bufs[l], bytes, ncclUint8, root, comms[l], streams[l]), "ncclBroadcast");
             }
-            NCCLM(c, ncclGroupEnd());
-            return HJGPU_OK;
+            return g.end();
         }
         // xGMI is point to point (7 links per GPU, every pair directly connected): the root sends a DIFFERENT
         // 1/G slice to every peer over its own link, then everybody exchanges slices - all links of all GPUs
         // carry data, 2 x ~1/(G-1) of the single-link time
         const size_t per = replicate_capacity(bytes) / G;
-        NCCLM(c, ncclGroupStart());
-        for (int l = 0; l < nlocal(); ++l) {
-            const int g = c->ranks[l].global;
-            HIPM(c, hipSetDevice(c->ranks[l].device));
-            char *b = static_cast<char *>(bufs[l]);
-            if (g == root) {
-                for (int p = 0; p < G; ++p)
-                    if (p != root) NCCLM(c, ncclSend(b + (size_t)p * per, per, ncclUint8, p, comms[l], streams[l]));
-            } else NCCLM(c, ncclRecv(b + (size_t)g * per, per, ncclUint8, root, comms[l], streams[l]));
+        {
+            Group g(c, R);
+            for (int l = 0; l < nlocal() && g.ok(); ++l) {
+                const int me = c->ranks[l].global;
+                g.hip(hipSetDevice(c->ranks[l].device), "hipSetDevice");
+                char *b = static_cast<char *>(bufs[l]);
+                if (me == root) {
+                    for (int p = 0; p < G && g.ok(); ++p)
+                        if (p != root) g.nccl(R->Send(b + (size_t)p * per, per, ncclUint8, p, comms[l], streams[l]), "ncclSend");
+                } else if (g.ok()) g.nccl(R->Recv(b + (size_t)me * per, per, ncclUint8, root, comms[l], streams[l]), "ncclRecv");
+            }
+            CHKM(g.end());
         }
-        NCCLM(c, ncclGroupEnd());
-        NCCLM(c, ncclGroupStart());
-        for (int l = 0; l < nlocal(); ++l) {
-            const int g = c->ranks[l].global;
-            HIPM(c, hipSetDevice(c->ranks[l].device));
+        Group g(c, R);
+        for (int l = 0; l < nlocal() && g.ok(); ++l) {
+            const int me = c->ranks[l].global;
+            g.hip(hipSetDevice(c->ranks[l].device), "hipSetDevice");
             char *b = static_cast<char *>(bufs[l]);
-            NCCLM(c, ncclAllGather(b + (size_t)g * per, b, per, ncclUint8, comms[l], streams[l]));     // in place
+            if (g.ok()) g.nccl(R->AllGather(b + (size_t)me * per, b, per, ncclUint8, comms[l], streams[l]), "ncclAllGather");   // in place
         }
-        NCCLM(c, ncclGroupEnd());
-        return HJGPU_OK;
+        return g.end();
     }
 
     int all_to_all_v(const void *const *send, const u64 *const *soff, const u64 *const *scnt,
@@ -216,35 +360,33 @@ struct RcclTransport : Transport {
         // message lost half its payload through torch's all_to_all_single on RCCL 2.26 in round 1.
         const int G = c->nranks;
         const u64 piece = c->max_message_bytes / elem_bytes ? c->max_message_bytes / elem_bytes : 1;
-        NCCLM(c, ncclGroupStart());
-        for (int l = 0; l < nlocal(); ++l) {
-            HIPM(c, hipSetDevice(c->ranks[l].device));
-            for (int p = 0; p < G; ++p) {
+        Group g(c, R);
+        for (int l = 0; l < nlocal() && g.ok(); ++l) {
+            g.hip(hipSetDevice(c->ranks[l].device), "hipSetDevice");
+            for (int p = 0; p < G && g.ok(); ++p) {
                 const char *s = static_cast<const char *>(send[l]) + soff[l][p] * elem_bytes;
-                for (u64 at = 0; at < scnt[l][p]; at += piece) {
+                for (u64 at = 0; at < scnt[l][p] && g.ok(); at += piece) {
                     const u64 n = scnt[l][p] - at < piece ? scnt[l][p] - at : piece;
-                    NCCLM(c, ncclSend(s + at * elem_bytes, n * elem_bytes, ncclUint8, p, comms[l], streams[l]));
+                    g.nccl(R->Send(s + at * elem_bytes, n * elem_bytes, ncclUint8, p, comms[l], streams[l]), "ncclSend");
                 }
                 char *r = static_cast<char *>(recv[l]) + roff[l][p] * elem_bytes;
-                for (u64 at = 0; at < rcnt[l][p]; at += piece) {
+                for (u64 at = 0; at < rcnt[l][p] && g.ok(); at += piece) {
                     const u64 n = rcnt[l][p] - at < piece ? rcnt[l][p] - at : piece;
-                    NCCLM(c, ncclRecv(r + at * elem_bytes, n * elem_bytes, ncclUint8, p, comms[l], streams[l]));
+                    g.nccl(R->Recv(r + at * elem_bytes, n * elem_bytes, ncclUint8, p, comms[l], streams[l]), "ncclRecv");
                 }
             }
         }
-        NCCLM(c, ncclGroupEnd());
-        return HJGPU_OK;
+        return g.end();
     }
 
     int all_reduce_u64(u64 *const *bufs, size_t count, hipStream_t const *streams) override
     {
-        NCCLM(c, ncclGroupStart());
-        for (int l = 0; l < nlocal(); ++l) {
-            HIPM(c, hipSetDevice(c->ranks[l].device));
-            NCCLM(c, ncclAllReduce(bufs[l], bufs[l], count, ncclUint64, ncclSum, comms[l], streams[l]));
+        Group g(c, R);
+        for (int l = 0; l < nlocal() && g.ok(); ++l) {
+            g.hip(hipSetDevice(c->ranks[l].device), "hipSetDevice");
+            if (g.ok()) g.nccl(R->AllReduce(bufs[l], bufs[l], count, ncclUint64, ncclSum, comms[l], streams[l]), "ncclAllReduce");
         }
-        NCCLM(c, ncclGroupEnd());
-        return HJGPU_OK;
+        return g.end();
     }
 };
 
@@ -256,6 +398,13 @@ __global__ void sum_rows_kernel(const u64 *__restrict__ rows, u64 *__restrict__ 
     u64 s = 0;
     for (uint32_t r = 0; r < nrows; ++r) s += rows[(u64)r * count + i];
     out[i] = s;
+}
+
+// fault injection: a rank that does not arrive at a collective for `ms` (a host function on its stream: the GPU is
+// idle meanwhile, nothing spins, and the stall ends by itself)
+void stall_host_fn(void *arg)
+{
+    std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)arg));
 }
 
 struct LoopbackTransport : Transport {
@@ -271,6 +420,8 @@ struct LoopbackTransport : Transport {
         const int G = nlocal();
         for (int l = 0; l < G; ++l) {
             HIPM(c, hipSetDevice(c->ranks[l].device));
+            if (l == c->stall_rank && c->stall_ms > 0)
+                HIPM(c, hipLaunchHostFunc(streams[l], stall_host_fn, (void *)(intptr_t)c->stall_ms));
             HIPM(c, hipEventRecord(c->ranks[l].lb_in, streams[l]));
         }
         for (int d = 0; d < G; ++d) {
@@ -355,19 +506,18 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     rc = hjgpu_create(device, &r.part);
     if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_create(partition context)");
     HIPM(c, hipSetDevice(device));
-    HIPM(c, hipStreamCreateWithFlags(&r.main, hipStreamNonBlocking));
-    HIPM(c, hipStreamCreateWithFlags(&r.comm, hipStreamNonBlocking));
-    HIPM(c, hipStreamCreateWithFlags(&r.prep, hipStreamNonBlocking));
-    hipEvent_t *timed[] = {&r.ev_x0, &r.ev_x1, &r.ev_w0, &r.ev_w1};
+    for (hipStream_t *s : {&r.main, &r.comm, &r.prep, &r.up}) HIPM(c, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    hipEvent_t *timed[] = {&r.ev_x0, &r.ev_x1, &r.ev_t0, &r.ev_t1};
     for (hipEvent_t *e : timed) HIPM(c, hipEventCreate(e));
     hipEvent_t *plain[] = {&r.ev_ready, &r.ev_part[0], &r.ev_part[1], &r.ev_xchg[0], &r.ev_xchg[1],
-                           &r.ev_join[0], &r.ev_join[1], &r.ev_rx, &r.lb_in, &r.lb_out};
+                           &r.ev_join[0], &r.ev_join[1], &r.ev_rx, &r.ev_up_s, &r.ev_up_r, &r.lb_in, &r.lb_out};
     for (hipEvent_t *e : plain) HIPM(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     const size_t G = (size_t)c->nranks;
-    HIPM(c, hipHostMalloc(reinterpret_cast<void **>(&r.h_pin), (2 * (G + 1) + G * G + 8 + G) * sizeof(u64), hipHostMallocDefault));
+    HIPM(c, hipHostMalloc(reinterpret_cast<void **>(&r.h_pin), hp_words(G) * sizeof(u64), hipHostMallocDefault));
+    memset(r.h_pin, 0, hp_words(G) * sizeof(u64));
     CHKM(ensure(c, r, r.d_off, 2 * (G + 1) * sizeof(u64)));
     CHKM(ensure(c, r, r.d_cnt, (G + G * G) * sizeof(u64)));
-    CHKM(ensure(c, r, r.d_res, 8 * sizeof(u64)));
+    CHKM(ensure(c, r, r.d_res, 12 * sizeof(u64)));
     return HJGPU_OK;
 }
 
@@ -378,8 +528,8 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
 // 0 / 8 / 16 / 32 CUs left out: 3.01 / 3.03 / 3.03 / 3.13 and 3.04 / 3.03 / 3.03 / 3.06 (profiles/r02_reserve_sweep.txt).
 int apply_reserve(hjgpu_comm *c)
 {
-    const bool rccl = c->transport && strcmp(c->transport->name(), "rccl") == 0;
-    const int n = c->reserve_cus >= 0 ? c->reserve_cus : (rccl && c->nranks > 1 ? 16 : 0);
+    const bool rccl_ = c->transport && strcmp(c->transport->name(), "rccl") == 0;
+    const int n = c->reserve_cus >= 0 ? c->reserve_cus : (rccl_ && c->nranks > 1 ? 16 : 0);
     char v[16];
     snprintf(v, sizeof(v), "%d", n);
     for (Rank &r : c->ranks) {
@@ -395,12 +545,14 @@ void destroy_rank(Rank &r)
     (void)hipDeviceSynchronize();
     Buf *bufs[] = {&r.rbuf, &r.send_k[0], &r.send_k[1], &r.send_v[0], &r.send_v[1], &r.recv_k[0], &r.recv_k[1],
                    &r.recv_v[0], &r.recv_v[1], &r.rsend_k, &r.rsend_v, &r.rrecv_k, &r.rrecv_v, &r.d_off, &r.d_cnt,
-                   &r.d_res, &r.scratch};
+                   &r.d_res, &r.scratch, &r.shard[0], &r.shard[1], &r.shard[2], &r.shard[3], &r.rows_col[0],
+                   &r.rows_col[1], &r.rows_col[2]};
     for (Buf *b : bufs) if (b->p) (void)hipFree(b->p);
-    hipEvent_t evs[] = {r.ev_ready, r.ev_x0, r.ev_x1, r.ev_w0, r.ev_w1, r.ev_part[0], r.ev_part[1], r.ev_xchg[0],
-                        r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.lb_in, r.lb_out};
+    hipEvent_t evs[] = {r.ev_ready, r.ev_x0, r.ev_x1, r.ev_t0, r.ev_t1, r.ev_part[0], r.ev_part[1], r.ev_xchg[0],
+                        r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.ev_up_s, r.ev_up_r, r.lb_in, r.lb_out};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-    for (hipStream_t s : {r.main, r.comm, r.prep}) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : r.ev_w) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t s : {r.main, r.comm, r.prep, r.up}) if (s) (void)hipStreamDestroy(s);
     if (r.h_pin) (void)hipHostFree(r.h_pin);
     if (r.join) (void)hjgpu_destroy(r.join);
     if (r.part) (void)hjgpu_destroy(r.part);
@@ -421,15 +573,86 @@ std::vector<hipStream_t> streams_of(hjgpu_comm *c, hipStream_t Rank::*which)
     return s;
 }
 
-int sync_all(hjgpu_comm *c)
+// ---- host-side waits with a deadline ------------------------------------------------------------------------
+// The communicator gives up: whatever RCCL has in flight is cancelled (ncclCommAbort), every later call fails fast.
+int give_up(hjgpu_comm *c, const char *why)
 {
-    for (Rank &r : c->ranks) {
-        HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipStreamSynchronize(r.prep));
-        HIPM(c, hipStreamSynchronize(r.comm));
-        HIPM(c, hipStreamSynchronize(r.main));
+    snprintf(c->why_broken, sizeof(c->why_broken), "%s", why);
+    if (c->transport) c->transport->abort();
+    c->broken = true;
+    return cfail(c, HJGPU_ERCCL, c->why_broken);
+}
+
+int refuse_broken(hjgpu_comm *c)
+{
+    if (c && c->broken) return cfail(c, HJGPU_ERCCL, "the communicator was aborted", c->why_broken);
+    return HJGPU_OK;
+}
+
+struct Waited { int local; hipStream_t stream; const char *name; };
+
+// Blocks until every listed stream has drained.  Without a deadline (timeout_ms = 0) that is hipStreamSynchronize;
+// with one the streams are polled, RCCL is asked for asynchronous errors, and at the deadline the communicator is
+// aborted: the call returns HJGPU_ERCCL naming the rank and stream that did not finish.
+int wait_for(hjgpu_comm *c, const std::vector<Waited> &ws)
+{
+    char text[400];
+    if (c->timeout_ms <= 0) {
+        for (const Waited &w : ws) {
+            HIPM(c, hipSetDevice(c->ranks[(size_t)w.local].device));
+            HIPM(c, hipStreamSynchronize(w.stream));
+        }
+        if (c->transport && c->transport->async_error(text, sizeof(text))) return give_up(c, text);
+        return HJGPU_OK;
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(c->timeout_ms);
+    std::vector<bool> done(ws.size(), false);
+    size_t left = ws.size();
+    unsigned spins = 0;
+    while (left) {
+        for (size_t i = 0; i < ws.size(); ++i) {
+            if (done[i]) continue;
+            HIPM(c, hipSetDevice(c->ranks[(size_t)ws[i].local].device));
+            const hipError_t e = hipStreamQuery(ws[i].stream);
+            if (e == hipSuccess) { done[i] = true; --left; }
+            else if (e != hipErrorNotReady) return cfail(c, HJGPU_EHIP, "hipStreamQuery", hipGetErrorString(e));
+            else (void)hipGetLastError();
+        }
+        if (!left) break;
+        if (c->transport && c->transport->async_error(text, sizeof(text))) return give_up(c, text);
+        if (std::chrono::steady_clock::now() > deadline) {
+            for (size_t i = 0; i < ws.size(); ++i)
+                if (!done[i]) {
+                    snprintf(text, sizeof(text), "deadline of %d ms expired: the %s stream of rank %d did not finish (transport %s, %d ranks); "
+                                                 "communicator aborted", c->timeout_ms, ws[i].name, c->ranks[(size_t)ws[i].local].global,
+                             c->transport ? c->transport->name() : "?", c->nranks);
+                    break;
+                }
+            return give_up(c, text);
+        }
+        // the first polls spin (a step is a few milliseconds), later ones sleep
+        if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        else std::this_thread::yield();
     }
     return HJGPU_OK;
+}
+
+int wait_stream(hjgpu_comm *c, int local, hipStream_t s, const char *name)
+{
+    return wait_for(c, std::vector<Waited>{{local, s, name}});
+}
+
+int sync_all(hjgpu_comm *c)
+{
+    std::vector<Waited> ws;
+    for (int l = 0; l < (int)c->ranks.size(); ++l) {
+        Rank &r = c->ranks[(size_t)l];
+        ws.push_back({l, r.up, "upload"});
+        ws.push_back({l, r.prep, "partitioning"});
+        ws.push_back({l, r.comm, "exchange"});
+        ws.push_back({l, r.main, "join"});
+    }
+    return wait_for(c, ws);
 }
 
 void add_stats(hjgpu_stats *acc, const hjgpu_stats &s)
@@ -437,7 +660,7 @@ void add_stats(hjgpu_stats *acc, const hjgpu_stats &s)
     acc->ms_total += s.ms_total; acc->ms_histogram += s.ms_histogram; acc->ms_plan += s.ms_plan;
     acc->ms_scatter1 += s.ms_scatter1; acc->ms_scatter2 += s.ms_scatter2; acc->ms_join += s.ms_join;
     acc->ms_build += s.ms_build; acc->ms_close_gaps += s.ms_close_gaps; acc->ms_inner_wait += s.ms_inner_wait;
-    acc->fanout1 = s.fanout1; acc->fanout2 = s.fanout2; acc->buckets = s.buckets;
+    acc->fanout1 = s.fanout1; acc->fanout2 = s.fanout2; acc->buckets = s.buckets; acc->ms_reserve = s.ms_reserve;
 }
 
 float elapsed(hipEvent_t a, hipEvent_t b)
@@ -446,33 +669,59 @@ float elapsed(hipEvent_t a, hipEvent_t b)
     return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f;
 }
 
-// global sum of the ranks' running results (d_res[0..3]) -> host, on the join streams
+// Global sum of the ranks' running results and status flags (d_res[0..5]) -> host, on the join streams.  The flags
+// travel with the aggregates, so EVERY rank learns that SOME rank met a zero build key (npj.cpp:196-210: such a
+// tuple is not in the table) or overflowed its result columns, and every rank returns the same status.
+// Before the reduction every rank's own result (its rows, for materialised joins) goes to hp_local().
 int reduce_results(hjgpu_comm *c, hjgpu_result *result)
 {
-    std::vector<u64 *> res;
-    for (Rank &r : c->ranks) res.push_back(static_cast<u64 *>(r.d_res.p));
-    const std::vector<hipStream_t> mains = streams_of(c, &Rank::main);
-    CHKM(c->transport->all_reduce_u64(res.data(), 4, mains.data()));
     const size_t G = (size_t)c->nranks;
+    std::vector<u64 *> res;
+    for (Rank &r : c->ranks) {
+        res.push_back(static_cast<u64 *>(r.d_res.p));
+        HIPM(c, hipSetDevice(r.device));
+        HIPM(c, hipMemcpyAsync(hp_local(r, G), r.d_res.p, 6 * sizeof(u64), hipMemcpyDeviceToHost, r.main));
+    }
+    const std::vector<hipStream_t> mains = streams_of(c, &Rank::main);
+    CHKM(c->transport->all_reduce_u64(res.data(), 6, mains.data()));
     for (Rank &r : c->ranks) {
         HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipMemcpyAsync(r.h_pin + 2 * (G + 1) + G * G, r.d_res.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, r.main));
+        HIPM(c, hipMemcpyAsync(hp_result(r, G), r.d_res.p, 6 * sizeof(u64), hipMemcpyDeviceToHost, r.main));
     }
     CHKM(sync_all(c));
-    const u64 *h = c->ranks[0].h_pin + 2 * (G + 1) + G * G;
+    const u64 *h = hp_result(c->ranks[0], G);
     if (result) { result->count = h[0]; result->sum_keys = h[1]; result->sum_outer_vals = h[2]; result->sum_inner_vals = h[3]; }
+    if (h[4]) return cfail(c, HJGPU_EZEROKEY, "NPJ: a build key is 0, the empty-bucket sentinel (npj.cpp:583): that tuple is not in the table");
+    if (h[5]) return cfail(c, HJGPU_EOVERFLOW, "materialised output exceeded the capacity of some rank's result columns (rows needed per rank: hjgpu_shard_rows.rows)");
+    return HJGPU_OK;
+}
+
+int check_rows(hjgpu_comm *c, const hjgpu_shard_rows *rows)
+{
+    if (!rows) return HJGPU_OK;
+    for (size_t l = 0; l < c->ranks.size(); ++l) {
+        const hjgpu_output &o = rows[l].out;
+        if (!o.d_keys || !o.d_outer_vals || !o.d_inner_vals) return cfail(c, HJGPU_EINVAL, "null result column in a rank's hjgpu_shard_rows");
+        const size_t bs = o.block_size ? o.block_size : 65536;
+        if (bs < 256 || (bs & (bs - 1)) || o.capacity < bs) return cfail(c, HJGPU_EINVAL, "result columns: block_size must be a power of two >= 256 and capacity at least one block");
+    }
     return HJGPU_OK;
 }
 
 // ---- PHJ / NPJ: replicated build side, sharded probe side ---------------------------------------------
-int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, int root,
+// `inner_ready[l]` (optional): an event after which rank l's columns are valid (hjgpu_join_host_multi's uploads) -
+// the probe shard's for every rank, the build columns' as well on the root.
+int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, hjgpu_shard_rows *rows, int root,
                     const hjgpu_phj_params *pp, const hjgpu_npj_params *np, hjgpu_result *result,
-                    hjgpu_multi_stats *stats)
+                    hjgpu_multi_stats *stats, bool from_host = false)
 {
     if (!c || !shards) return HJGPU_EINVAL;
+    CHKM(refuse_broken(c));
     if (root < 0 || root >= c->nranks) return cfail(c, HJGPU_EINVAL, "root is not a rank of this communicator");
+    CHKM(check_rows(c, rows));
     const auto t0 = std::chrono::steady_clock::now();
     const int L = (int)c->ranks.size();
+    const size_t G = (size_t)c->nranks;
     const size_t inner = shards[0].inner;
     for (int l = 0; l < L; ++l) {
         if (shards[l].inner != inner) return cfail(c, HJGPU_EINVAL, "the build side has the same size on every rank");
@@ -489,8 +738,12 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, int
         CHKM(ensure(c, r, r.rbuf, c->transport->replicate_capacity(bytes)));
         bufs.push_back(r.rbuf.p);
         HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipMemsetAsync(r.d_res.p, 0, 8 * sizeof(u64), r.main));
+        HIPM(c, hipMemsetAsync(r.d_res.p, 0, 12 * sizeof(u64), r.main));
         HIPM(c, hipEventRecord(r.ev_x0, r.comm));
+        if (from_host) {
+            HIPM(c, hipStreamWaitEvent(r.main, r.ev_up_s, 0));       // the probe shard is in HBM
+            if (r.global == root) HIPM(c, hipStreamWaitEvent(r.comm, r.ev_up_r, 0));
+        }
         if (r.global == root && inner) {
             uint32_t *b = static_cast<uint32_t *>(r.rbuf.p);
             HIPM(c, hipMemcpyAsync(b, shards[l].d_inner_keys, inner * sizeof(uint32_t), hipMemcpyDeviceToDevice, r.comm));
@@ -505,7 +758,10 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, int
         HIPM(c, hipEventRecord(r.ev_x1, r.comm));
         HIPM(c, hipEventRecord(r.ev_ready, r.comm));
         const uint32_t *rk = static_cast<const uint32_t *>(r.rbuf.p), *rv = rk + stride;
-        hjgpu_result *d_res = static_cast<hjgpu_result *>(r.d_res.p);
+        u64 *acc = static_cast<u64 *>(r.d_res.p);
+        hjgpu_result *d_res = reinterpret_cast<hjgpu_result *>(acc);
+        if (from_host) HIPM(c, hipEventRecord(r.ev_t0, r.main));    // the join starts here: before the upload has ended?
+        if (rows) JOINM(c, r.join, hjgpu_set_async_output(r.join, &rows[l].out));
         if (algorithm == 1) {
             // the probe shard is histogrammed and partitioned while the build side is still arriving
             JOINM(c, r.join, hjgpu_phj_overlapped_async(r.join, rk, rv, inner, shards[l].d_outer_keys, shards[l].d_outer_vals,
@@ -515,8 +771,12 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, int
             JOINM(c, r.join, hjgpu_npj_async(r.join, rk, rv, inner, shards[l].d_outer_keys, shards[l].d_outer_vals,
                                              shards[l].outer, np, d_res, r.main));
         }
+        // a zero build key / an overflowing result column on ANY rank fails the call on EVERY rank
+        JOINM(c, r.join, hjgpu_accumulate_async_status(r.join, reinterpret_cast<uint64_t *>(acc + 4), r.main));
     }
-    CHKM(reduce_results(c, result));
+    const int status = reduce_results(c, result);
+    if (status != HJGPU_OK && status != HJGPU_EZEROKEY && status != HJGPU_EOVERFLOW) return status;
+    if (rows) for (int l = 0; l < L; ++l) rows[l].rows = hp_local(c->ranks[l], G)[0];
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         Rank &r = c->ranks[0];
@@ -532,7 +792,7 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, int
             stats->bytes_sent = c->ring_broadcast ? (u64)bytes : (u64)(r.global == root ? 2 : 1) * (c->nranks - 1) * per;
         stats->ms_wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    return HJGPU_OK;
+    return status;
 }
 
 // ---- CPRA: both sides chunked, co-partitioned by an all-to-all-v -------------------------------------------
@@ -558,6 +818,7 @@ struct CpraStep {
     std::vector<u64> recv_total;
     hjgpu_multi_stats *stats;
     bool exchange_in_flight = false;                          // local rank 0's ev_x0 / ev_x1 hold an unread exchange
+    bool from_host = false;                                   // the inputs are being uploaded (hjgpu_join_host_multi)
     float exchange_ms = 0;
     CpraStep(hjgpu_comm *comm, hjgpu_multi_stats *st)
         : c(comm), L((int)comm->ranks.size()), G(comm->nranks), soff(L, std::vector<u64>(G)), scnt(L, std::vector<u64>(G)),
@@ -576,7 +837,8 @@ struct CpraStep {
     // local partition with fan-out G (cpra2.cpp:1757-1827 on the rank's own chunk) -> counts to every rank
     // (cpra2.cpp:1834-1840) -> all-to-all-v of keys and payloads (the gather of cpra2.cpp:1891-1904 / 1946-1959).
     // `slot`: which offsets / events; the call returns with the transfers enqueued.
-    int exchange(const std::vector<Slice> &in, int which, int slot)
+    // `ready`: which upload event of the rank the partitioning waits for (host path), or nullptr.
+    int exchange(const std::vector<Slice> &in, int which, int slot, hipEvent_t Rank::*ready = nullptr)
     {
         const size_t Gs = (size_t)G;
         for (int l = 0; l < L; ++l) {
@@ -585,8 +847,9 @@ struct CpraStep {
             CHKM(ensure(c, r, *b.sk, (in[l].n + 4) * sizeof(uint32_t)));
             CHKM(ensure(c, r, *b.sv, (in[l].n + 4) * sizeof(uint32_t)));
             u64 *d_off = static_cast<u64 *>(r.d_off.p) + (size_t)slot * (Gs + 1);
-            u64 *h_off = r.h_pin + (size_t)slot * (Gs + 1);
+            u64 *h_off = hp_off(r, Gs, slot);
             HIPM(c, hipSetDevice(r.device));
+            if (ready) HIPM(c, hipStreamWaitEvent(r.prep, r.*ready, 0));
             if (in[l].n)
                 JOINM(c, r.part, hjgpu_partition_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)G,
                                                        static_cast<uint32_t *>(b.sk->p), static_cast<uint32_t *>(b.sv->p),
@@ -598,9 +861,8 @@ struct CpraStep {
         // the host needs the counts: how much every peer gets decides the receive buffers
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
-            HIPM(c, hipSetDevice(r.device));
-            HIPM(c, hipStreamSynchronize(r.prep));
-            const u64 *h_off = r.h_pin + (size_t)slot * (Gs + 1);
+            CHKM(wait_stream(c, l, r.prep, "partitioning"));
+            const u64 *h_off = hp_off(r, Gs, slot);
             for (int p = 0; p < G; ++p) { soff[l][p] = h_off[p]; scnt[l][p] = h_off[p + 1] - h_off[p]; }
             if (l == 0 && stats) {
                 hjgpu_stats ps;
@@ -615,7 +877,7 @@ struct CpraStep {
             Rank &r = c->ranks[l];
             u64 *d_cnt = static_cast<u64 *>(r.d_cnt.p);
             HIPM(c, hipSetDevice(r.device));
-            u64 *h_cnt = r.h_pin + 2 * (Gs + 1) + Gs * Gs + 8;         // pinned: the copy is a DMA that runs later
+            u64 *h_cnt = hp_cnt(r, Gs);                             // pinned: the copy is a DMA that runs later
             memcpy(h_cnt, scnt[l].data(), Gs * sizeof(u64));
             HIPM(c, hipMemcpyAsync(d_cnt, h_cnt, Gs * sizeof(u64), hipMemcpyHostToDevice, r.comm));
             csend.push_back(d_cnt); crecv.push_back(d_cnt + Gs);
@@ -625,7 +887,7 @@ struct CpraStep {
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
             HIPM(c, hipSetDevice(r.device));
-            HIPM(c, hipMemcpyAsync(r.h_pin + 2 * (Gs + 1), static_cast<u64 *>(r.d_cnt.p) + Gs, Gs * Gs * sizeof(u64),
+            HIPM(c, hipMemcpyAsync(hp_matrix(r, Gs), static_cast<u64 *>(r.d_cnt.p) + Gs, Gs * Gs * sizeof(u64),
                                    hipMemcpyDeviceToHost, r.comm));
         }
         std::vector<const void *> ks, vs;
@@ -634,10 +896,10 @@ struct CpraStep {
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
             ExchangeBufs b = bufs_of(r, which);
+            CHKM(wait_stream(c, l, r.comm, "exchange"));            // also: the previous exchange has left the links
             HIPM(c, hipSetDevice(r.device));
-            HIPM(c, hipStreamSynchronize(r.comm));                  // also: the previous exchange has left the links
             if (l == 0) note_exchange();
-            const u64 *matrix = r.h_pin + 2 * (Gs + 1);             // matrix[src][dst]
+            const u64 *matrix = hp_matrix(r, Gs);                   // matrix[src][dst]
             u64 at = 0;
             for (int p = 0; p < G; ++p) { rcnt[l][p] = matrix[(size_t)p * Gs + r.global]; roff[l][p] = at; at += rcnt[l][p]; }
             recv_total[l] = at;
@@ -664,15 +926,18 @@ struct CpraStep {
     }
 };
 
-int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, const hjgpu_phj_params *prm, int slices,
-              hjgpu_result *result, hjgpu_multi_stats *stats)
+int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, const hjgpu_phj_params *prm, int slices,
+              hjgpu_result *result, hjgpu_multi_stats *stats, bool from_host = false)
 {
     if (!c || !shards) return HJGPU_EINVAL;
+    CHKM(refuse_broken(c));
     if (slices <= 0) slices = 4;
     if (slices > 4096) return cfail(c, HJGPU_EINVAL, "at most 4096 slices");
+    CHKM(check_rows(c, rows));
     const auto t0 = std::chrono::steady_clock::now();
     if (stats) memset(stats, 0, sizeof(*stats));
     const int L = (int)c->ranks.size();
+    const size_t G = (size_t)c->nranks;
     for (int l = 0; l < L; ++l) {
         const hjgpu_shard &s = shards[l];
         if ((s.inner && (!s.d_inner_keys || !s.d_inner_vals)) || (s.outer && (!s.d_outer_keys || !s.d_outer_vals)))
@@ -681,12 +946,18 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, const hjgpu_phj_params *
     CpraStep step(c, stats);
     for (Rank &r : c->ranks) {
         HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipMemsetAsync(r.d_res.p, 0, 8 * sizeof(u64), r.main));
+        HIPM(c, hipMemsetAsync(r.d_res.p, 0, 12 * sizeof(u64), r.main));
+        // timing events of the slices' waits, one pair per slice, read after the step (nobody waits in between)
+        while (r.ev_w.size() < 2 * (size_t)slices) {
+            hipEvent_t e = nullptr;
+            HIPM(c, hipEventCreate(&e));
+            r.ev_w.push_back(e);
+        }
     }
     // ---- build side: partition the own chunk -> exchange -> prepared once for all probe slices ---------
     std::vector<Slice> in(L);
     for (int l = 0; l < L; ++l) in[l] = {shards[l].d_inner_keys, shards[l].d_inner_vals, shards[l].inner};
-    CHKM(step.exchange(in, 0, 0));
+    CHKM(step.exchange(in, 0, 0, from_host ? &Rank::ev_up_r : nullptr));
     const std::vector<u64> inner_recv = step.recv_total;
     std::vector<size_t> max_outer(L);
     for (int l = 0; l < L; ++l) {
@@ -697,50 +968,76 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, const hjgpu_phj_params *
         max_outer[l] = (per * 3 / 2 > ((size_t)1 << 20) ? per * 3 / 2 : ((size_t)1 << 20)) & ~size_t(15);
         HIPM(c, hipSetDevice(r.device));
         HIPM(c, hipStreamWaitEvent(r.main, r.ev_rx, 0));
+        if (from_host && l == 0) HIPM(c, hipEventRecord(r.ev_t0, r.main));
         if (inner_recv[l])
             JOINM(c, r.join, hjgpu_phj_build(r.join, static_cast<const uint32_t *>(r.rrecv_k.p), static_cast<const uint32_t *>(r.rrecv_v.p),
                                              (size_t)inner_recv[l], max_outer[l], prm, r.main));
     }
-    if (stats && inner_recv[0]) {
-        // the build's phase times are read before the first probe re-records the context's events
-        hjgpu_stats js;
-        if (hjgpu_get_stats(c->ranks[0].join, &js) == HJGPU_OK) { add_stats(&stats->join, js); stats->joins += 1; stats->tuples_joined += inner_recv[0]; }
-    }
+    // Phase times of local rank 0's joins: the BUILD and the LAST probe batch are measured (stats->joins /
+    // tuples_joined describe exactly those).  The context's events are re-recorded by every call, so reading a
+    // slice's times means waiting for that slice - which would hold the single driving host thread until join(i-1)
+    // has finished before partition(i+1) can be enqueued, i.e. the pipeline would be measured out of shape.
+    // The build's times are read when the host blocks anyway (the first probe slice's partition counts).
+    bool build_stats_pending = stats && inner_recv[0];
     // ---- probe side in slices: partition(i+1) | exchange(i) | join(i-1) ----------------------------------
     // R join S = union_i (R join S_i): the slice results add up (add_result_kernel).
-    auto join_slice = [&](int slot, const std::vector<u64> &got) -> int {
-        u64 measured = 0;
+    // Materialised rows: a slice's rows follow the rows of the slices before it in the rank's result columns; where
+    // they start is known on the host once the previous join has finished (its count), which is long before this
+    // slice has arrived.
+    std::vector<u64> used(L, 0);                 // rows in the rank's result columns so far
+    std::vector<bool> row_pending(L, false);     // hp_local()[0] will hold the rank's running count
+    u64 measured = 0;
+    auto join_slice = [&](int i, int slot, const std::vector<u64> &got) -> int {
+        measured = 0;
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
             HIPM(c, hipSetDevice(r.device));
-            if (l == 0) HIPM(c, hipEventRecord(r.ev_w0, r.main));
+            HIPM(c, hipEventRecord(r.ev_w[2 * (size_t)i], r.main));
             HIPM(c, hipStreamWaitEvent(r.main, r.ev_xchg[slot], 0));
-            if (l == 0) HIPM(c, hipEventRecord(r.ev_w1, r.main));
+            HIPM(c, hipEventRecord(r.ev_w[2 * (size_t)i + 1], r.main));
             const uint32_t *sk = static_cast<const uint32_t *>(r.recv_k[slot].p), *sv = static_cast<const uint32_t *>(r.recv_v[slot].p);
             u64 *acc = static_cast<u64 *>(r.d_res.p);
             if (inner_recv[l])
                 for (u64 b = 0; b < got[l]; b += max_outer[l]) {
                     const size_t m = got[l] - b < max_outer[l] ? (size_t)(got[l] - b) : max_outer[l];
-                    JOINM(c, r.join, hjgpu_phj_probe_async(r.join, sk + b, sv + b, m, reinterpret_cast<hjgpu_result *>(acc + 4), r.main));
-                    hipLaunchKernelGGL(add_result_kernel, dim3(1), dim3(64), 0, r.main, acc, acc + 4);
+                    if (rows) {
+                        if (row_pending[l]) {                       // the rows so far: the previous batch's running count
+                            CHKM(wait_stream(c, l, r.main, "join"));
+                            used[l] = hp_local(r, G)[0];
+                            row_pending[l] = false;
+                        }
+                        const hjgpu_output &o = rows[l].out;
+                        const size_t bs = o.block_size ? o.block_size : 65536;
+                        hjgpu_output piece = o;
+                        piece.block_size = bs;
+                        if (used[l] + bs <= o.capacity) {
+                            piece.d_keys = o.d_keys + used[l]; piece.d_outer_vals = o.d_outer_vals + used[l]; piece.d_inner_vals = o.d_inner_vals + used[l];
+                            piece.capacity = (o.capacity - used[l]) / bs * bs;
+                        } else {
+                            // no block left: the batch writes into the last block (its rows are lost) and raises the
+                            // overflow flag through a capacity of exactly one block that it cannot fit... unless it is empty
+                            const size_t at = o.capacity - bs;
+                            piece.d_keys = o.d_keys + at; piece.d_outer_vals = o.d_outer_vals + at; piece.d_inner_vals = o.d_inner_vals + at;
+                            piece.capacity = bs;
+                        }
+                        JOINM(c, r.join, hjgpu_set_async_output(r.join, &piece));
+                    }
+                    JOINM(c, r.join, hjgpu_phj_probe_async(r.join, sk + b, sv + b, m, reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
+                    hipLaunchKernelGGL(add_result_kernel, dim3(1), dim3(64), 0, r.main, acc, acc + 8);
                     HIPM(c, hipGetLastError());
+                    if (rows) {
+                        JOINM(c, r.join, hjgpu_accumulate_async_status(r.join, reinterpret_cast<uint64_t *>(acc + 4), r.main));
+                        HIPM(c, hipMemcpyAsync(hp_local(r, G), acc, sizeof(u64), hipMemcpyDeviceToHost, r.main));
+                        row_pending[l] = true;
+                    }
                     if (l == 0) measured = m;                        // the context's events describe its LAST batch
                 }
             HIPM(c, hipEventRecord(r.ev_join[slot], r.main));
         }
-        if (stats) {
-            // read after every rank's work is enqueued (a single host thread must not wait in between)
-            Rank &r = c->ranks[0];
-            HIPM(c, hipSetDevice(r.device));
-            hjgpu_stats js;
-            if (measured && hjgpu_get_stats(r.join, &js) == HJGPU_OK) { add_stats(&stats->join, js); stats->joins += 1; stats->tuples_joined += measured; }
-            HIPM(c, hipEventSynchronize(r.ev_w1));
-            stats->ms_exchange_wait += elapsed(r.ev_w0, r.ev_w1);
-        }
         return HJGPU_OK;
     };
     std::vector<u64> pending;
-    int pending_slot = -1;
+    int pending_slice = -1;
     for (int i = 0; i < slices; ++i) {
         const int slot = i & 1;
         for (int l = 0; l < L; ++l) {
@@ -748,31 +1045,67 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, const hjgpu_phj_params *
             range_of(shards[l].outer, 16, (size_t)i, (size_t)slices, &b, &e);
             in[l] = {shards[l].outer ? shards[l].d_outer_keys + b : nullptr, shards[l].outer ? shards[l].d_outer_vals + b : nullptr, e - b};
         }
-        CHKM(step.exchange(in, 1 + slot, slot));
-        if (pending_slot >= 0) CHKM(join_slice(pending_slot, pending));
+        CHKM(step.exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr));
+        if (build_stats_pending && i == 0) {
+            // the host has just waited for this slice's partition counts and the counts gather; the build was enqueued
+            // before both and is (nearly always) done: reading its events costs the pipeline nothing
+            hjgpu_stats js;
+            if (hjgpu_get_stats(c->ranks[0].join, &js) == HJGPU_OK) { add_stats(&stats->join, js); stats->joins += 1; stats->tuples_joined += inner_recv[0]; }
+            build_stats_pending = false;
+        }
+        if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending));
         pending = step.recv_total;
-        pending_slot = slot;
+        pending_slice = i;
     }
-    CHKM(join_slice(pending_slot, pending));
-    CHKM(reduce_results(c, result));
+    CHKM(join_slice(pending_slice, pending_slice & 1, pending));
+    const int status = reduce_results(c, result);
+    if (status != HJGPU_OK && status != HJGPU_EOVERFLOW) return status;
+    if (rows) for (int l = 0; l < L; ++l) rows[l].rows = hp_local(c->ranks[l], G)[0];
     step.note_exchange();
     if (stats) {
+        Rank &r = c->ranks[0];
+        HIPM(c, hipSetDevice(r.device));
+        hjgpu_stats js;
+        if (measured && hjgpu_get_stats(r.join, &js) == HJGPU_OK) { add_stats(&stats->join, js); stats->joins += 1; stats->tuples_joined += measured; }
+        for (int i = 0; i < slices; ++i) stats->ms_exchange_wait += elapsed(r.ev_w[2 * (size_t)i], r.ev_w[2 * (size_t)i + 1]);
         stats->ms_exchange = step.exchange_ms;
         stats->ms_wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    return HJGPU_OK;
+    return status;
 }
 
 int new_comm(int nranks, hjgpu_comm **out, hjgpu_comm **c)
 {
+    g_create_error[0] = 0;
     if (!out) return HJGPU_EINVAL;
     *out = nullptr;
-    if (nranks < 1 || nranks > 1024) return HJGPU_EINVAL;
+    if (nranks < 1 || nranks > 1024) { snprintf(g_create_error, sizeof(g_create_error), "a communicator has 1 to 1024 ranks"); return HJGPU_EINVAL; }
     *c = new hjgpu_comm();
     (*c)->err[0] = 0;
+    (*c)->why_broken[0] = 0;
     (*c)->nranks = nranks;
+    const char *t = getenv("HJGPU_COMM_TIMEOUT_MS");       // read once per communicator, like the contexts' HJGPU_<OPTION>
+    if (t && *t) { const long v = strtol(t, nullptr, 10); if (v > 0 && v < (1L << 30)) (*c)->timeout_ms = (int)v; }
     return HJGPU_OK;
 }
+
+// a communicator that cannot be made: its text survives it (hjgpu_comm_last_error(NULL) on this thread)
+int fail_create(hjgpu_comm *c, int rc, const char *what = nullptr)
+{
+    if (what) snprintf(g_create_error, sizeof(g_create_error), "%s", what);
+    else if (c && c->err[0]) snprintf(g_create_error, sizeof(g_create_error), "%s", c->err);
+    else snprintf(g_create_error, sizeof(g_create_error), "%s", hjgpu_status_string(rc));
+    if (c) hjgpu_comm_destroy(c);
+    return rc;
+}
+
+// ---- preflight ----------------------------------------------------------------------------------------------
+__global__ void pattern_kernel(u64 *__restrict__ p, u64 n, u64 seed)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        p[i] = (seed + i) * 0x9E3779B97F4A7C15ull + (seed << 17);
+}
+inline u64 pattern_at(u64 seed, u64 i) { return (seed + i) * 0x9E3779B97F4A7C15ull + (seed << 17); }
 
 }  // namespace
 
@@ -782,6 +1115,8 @@ extern "C" {
 int hjgpu_comm_destroy(hjgpu_comm *c)
 {
     if (!c) return HJGPU_OK;
+    // RCCL first when the communicator gave up: its kernels may still sit on the streams, waiting for a peer
+    if (c->broken) c->transport.reset();
     for (Rank &r : c->ranks) { (void)hipSetDevice(r.device); (void)hipDeviceSynchronize(); }
     c->transport.reset();                    // communicators before the streams they used
     for (Rank &r : c->ranks) destroy_rank(r);
@@ -794,30 +1129,32 @@ int hjgpu_comm_create_local(int nranks, const int *devices, int transport, hjgpu
     hjgpu_comm *c = nullptr;
     CHKM(new_comm(nranks, out, &c));
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete c; return HJGPU_ENODEVICE; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail_create(c, HJGPU_ENODEVICE, "no GPU device visible");
     c->first = 0;
     c->ranks.resize((size_t)nranks);
     int rc = HJGPU_OK;
     std::vector<int> devs;
     for (int i = 0; i < nranks && rc == HJGPU_OK; ++i) {
         const int d = devices ? devices[i] : (transport == HJGPU_TRANSPORT_LOOPBACK ? i % ndev : i);
-        if (d < 0 || d >= ndev) { rc = HJGPU_EINVAL; break; }
-        for (int q : devs) if (q == d && transport == HJGPU_TRANSPORT_RCCL) rc = HJGPU_EINVAL;   // RCCL: one rank per device
+        if (d < 0 || d >= ndev) { rc = cfail(c, HJGPU_EINVAL, "a rank names a device that is not visible"); break; }
+        for (int q : devs) if (q == d && transport == HJGPU_TRANSPORT_RCCL) rc = cfail(c, HJGPU_EINVAL, "RCCL: one rank per device");
         devs.push_back(d);
         if (rc == HJGPU_OK) rc = init_rank(c, c->ranks[(size_t)i], d, i);
     }
     if (rc == HJGPU_OK) {
         if (transport == HJGPU_TRANSPORT_LOOPBACK) c->transport.reset(new LoopbackTransport(c));
         else if (transport == HJGPU_TRANSPORT_RCCL) {
-            RcclTransport *t = new RcclTransport(c);
+            Rccl *R = rccl();
+            if (!R) return fail_create(c, HJGPU_ERCCL, "RCCL transport: librccl.so.1 cannot be loaded (or lacks a symbol)");
+            RcclTransport *t = new RcclTransport(c, R);
             c->transport.reset(t);
             t->comms.assign((size_t)nranks, nullptr);
-            const ncclResult_t r = ncclCommInitAll(t->comms.data(), nranks, devs.data());
-            if (r != ncclSuccess) { fprintf(stderr, "hjgpu: ncclCommInitAll: %s\n", ncclGetErrorString(r)); rc = HJGPU_ERCCL; }
-        } else rc = HJGPU_EINVAL;
+            const ncclResult_t r = R->CommInitAll(t->comms.data(), nranks, devs.data());
+            if (r != ncclSuccess) rc = cfail(c, HJGPU_ERCCL, "ncclCommInitAll", R->GetErrorString(r));
+        } else rc = cfail(c, HJGPU_EINVAL, "unknown transport");
     }
     if (rc == HJGPU_OK) rc = apply_reserve(c);
-    if (rc != HJGPU_OK) { hjgpu_comm_destroy(c); return rc; }
+    if (rc != HJGPU_OK) return fail_create(c, rc);
     *out = c;
     return HJGPU_OK;
 }
@@ -827,8 +1164,11 @@ int hjgpu_comm_get_id(hjgpu_comm_id *id)
     static_assert(sizeof(ncclUniqueId) <= sizeof(hjgpu_comm_id), "hjgpu_comm_id too small for ncclUniqueId");
     if (!id) return HJGPU_EINVAL;
     memset(id, 0, sizeof(*id));
+    Rccl *R = rccl();
+    if (!R) { snprintf(g_create_error, sizeof(g_create_error), "librccl.so.1 cannot be loaded"); return HJGPU_ERCCL; }
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess) return HJGPU_ERCCL;
+    const ncclResult_t r = R->GetUniqueId(&u);
+    if (r != ncclSuccess) { snprintf(g_create_error, sizeof(g_create_error), "ncclGetUniqueId: %s", R->GetErrorString(r)); return HJGPU_ERCCL; }
     memcpy(id->bytes, &u, sizeof(u));
     return HJGPU_OK;
 }
@@ -837,30 +1177,32 @@ int hjgpu_comm_create_rank(int device, int nranks, int rank, const hjgpu_comm_id
 {
     hjgpu_comm *c = nullptr;
     CHKM(new_comm(nranks, out, &c));
-    if (!id || rank < 0 || rank >= nranks) { delete c; return HJGPU_EINVAL; }
-    if (device < 0 && hipGetDevice(&device) != hipSuccess) { delete c; return HJGPU_ENODEVICE; }
+    if (!id || rank < 0 || rank >= nranks) return fail_create(c, HJGPU_EINVAL, "hjgpu_comm_create_rank: null id or rank outside the world");
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail_create(c, HJGPU_ENODEVICE, "no current device");
     c->first = rank;
     c->ranks.resize(1);
     int rc = init_rank(c, c->ranks[0], device, rank);
     if (rc == HJGPU_OK) {
-        RcclTransport *t = new RcclTransport(c);
+        Rccl *R = rccl();
+        if (!R) return fail_create(c, HJGPU_ERCCL, "RCCL transport: librccl.so.1 cannot be loaded (or lacks a symbol)");
+        RcclTransport *t = new RcclTransport(c, R);
         c->transport.reset(t);
         t->comms.assign(1, nullptr);
         ncclUniqueId u;
         memcpy(&u, id->bytes, sizeof(u));
-        if (hipSetDevice(device) != hipSuccess) rc = HJGPU_EHIP;
+        if (hipSetDevice(device) != hipSuccess) rc = cfail(c, HJGPU_EHIP, "hipSetDevice");
         else {
-            const ncclResult_t r = ncclCommInitRank(&t->comms[0], nranks, u, rank);
-            if (r != ncclSuccess) { fprintf(stderr, "hjgpu: ncclCommInitRank: %s\n", ncclGetErrorString(r)); rc = HJGPU_ERCCL; }
+            const ncclResult_t r = R->CommInitRank(&t->comms[0], nranks, u, rank);
+            if (r != ncclSuccess) rc = cfail(c, HJGPU_ERCCL, "ncclCommInitRank", R->GetErrorString(r));
         }
     }
     if (rc == HJGPU_OK) rc = apply_reserve(c);
-    if (rc != HJGPU_OK) { hjgpu_comm_destroy(c); return rc; }
+    if (rc != HJGPU_OK) return fail_create(c, rc);
     *out = c;
     return HJGPU_OK;
 }
 
-const char *hjgpu_comm_last_error(const hjgpu_comm *c) { return c ? c->err : "null communicator"; }
+const char *hjgpu_comm_last_error(const hjgpu_comm *c) { return c ? c->err : g_create_error; }
 
 int hjgpu_comm_size(const hjgpu_comm *c, int *nranks, int *nlocal, int *first_rank)
 {
@@ -868,6 +1210,19 @@ int hjgpu_comm_size(const hjgpu_comm *c, int *nranks, int *nlocal, int *first_ra
     if (nranks) *nranks = c->nranks;
     if (nlocal) *nlocal = (int)c->ranks.size();
     if (first_rank) *first_rank = c->first;
+    return HJGPU_OK;
+}
+
+int hjgpu_comm_get_info(hjgpu_comm *c, hjgpu_comm_info *info)
+{
+    if (!c || !info) return HJGPU_EINVAL;
+    memset(info, 0, sizeof(*info));
+    info->nranks = c->nranks; info->nlocal = (int)c->ranks.size(); info->first_rank = c->first;
+    info->rccl_nranks = info->rccl_rank = info->rccl_device = -1;
+    info->timeout_ms = c->timeout_ms;
+    info->aborted = c->broken ? 1 : 0;
+    snprintf(info->transport, sizeof(info->transport), "%s", c->transport ? c->transport->name() : "none");
+    if (c->transport && !c->broken) c->transport->info(info);
     return HJGPU_OK;
 }
 
@@ -894,12 +1249,28 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
         c->max_message_bytes = (size_t)x;
         return HJGPU_OK;
     }
+    if (strcmp(name, "timeout_ms") == 0) {
+        if (x < 0 || x > (1 << 30)) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: timeout_ms outside 0..2^30");
+        c->timeout_ms = (int)x;
+        return HJGPU_OK;
+    }
+    if (strcmp(name, "stall_rank") == 0) {                  // fault injection, loopback transport only
+        if (!c->transport || strcmp(c->transport->name(), "loopback") != 0) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: stall_rank is a loopback test switch");
+        c->stall_rank = (int)x;
+        return HJGPU_OK;
+    }
+    if (strcmp(name, "stall_ms") == 0) {
+        if (x < 0 || x > 10000) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: stall_ms outside 0..10000");
+        c->stall_ms = (int)x;
+        return HJGPU_OK;
+    }
     return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: unknown option");
 }
 
 int hjgpu_comm_barrier(hjgpu_comm *c)
 {
     if (!c) return HJGPU_EINVAL;
+    CHKM(refuse_broken(c));
     CHKM(sync_all(c));
     std::vector<u64 *> one;
     for (Rank &r : c->ranks) one.push_back(static_cast<u64 *>(r.d_cnt.p));
@@ -908,22 +1279,280 @@ int hjgpu_comm_barrier(hjgpu_comm *c)
     return sync_all(c);
 }
 
+// Checksum-verified collectives and point-to-point rates BEFORE a join is trusted to the links (SURVEY section 5:
+// "measure link bandwidth first"): 1 MB through every collective the joins use, verified word for word on the host;
+// then `link_bytes` from every rank to the peer k places on, k = 1 .. G-1 (all ranks at once: every pair's own
+// link), and finally to all peers at once (the all-to-all-v shape of the CPRA exchange).
+int hjgpu_comm_preflight(hjgpu_comm *c, size_t link_bytes, hjgpu_preflight *rep)
+{
+    if (!c || !rep) return HJGPU_EINVAL;
+    CHKM(refuse_broken(c));
+    memset(rep, 0, sizeof(*rep));
+    const int L = (int)c->ranks.size(), G = c->nranks;
+    const size_t Gs = (size_t)G;
+    if (G > (int)(sizeof(rep->link_GBs) / sizeof(rep->link_GBs[0]))) return cfail(c, HJGPU_EINVAL, "preflight reports at most 64 ranks");
+    rep->nranks = (uint32_t)G; rep->rank = (uint32_t)c->ranks[0].global;
+    const size_t W = 131072;                                   // 1 MB of u64 per rank and collective
+    link_bytes = (link_bytes + 15) & ~size_t(15);
+    rep->link_bytes = link_bytes;
+    // scratch per rank: [W] send | [G * W] all-gather | [G * W] all-to-all send | [G * W] all-to-all receive | [W] reduce
+    //                   | link send [link_bytes] | link receive [G * link_bytes]
+    const size_t words = W + 3 * Gs * W + W;
+    std::vector<u64 *> base(L);
+    std::vector<std::vector<u64>> host(L);
+    const std::vector<hipStream_t> comms = streams_of(c, &Rank::comm);
+    for (int l = 0; l < L; ++l) {
+        Rank &r = c->ranks[l];
+        CHKM(ensure(c, r, r.scratch, words * sizeof(u64) + (Gs + 1) * link_bytes + 256));
+        base[l] = static_cast<u64 *>(r.scratch.p);
+        HIPM(c, hipSetDevice(r.device));
+        HIPM(c, hipMemsetAsync(base[l], 0, words * sizeof(u64), r.comm));
+        hipLaunchKernelGGL(pattern_kernel, dim3(64), dim3(256), 0, r.comm, base[l], (u64)W, (u64)(1000 + r.global));                       // all-gather
+        hipLaunchKernelGGL(pattern_kernel, dim3(256), dim3(256), 0, r.comm, base[l] + W + Gs * W, (u64)(Gs * W), (u64)(5000 + r.global));   // all-to-all
+        hipLaunchKernelGGL(pattern_kernel, dim3(64), dim3(256), 0, r.comm, base[l] + W + 3 * Gs * W, (u64)W, (u64)(9000 + r.global));       // all-reduce
+        HIPM(c, hipGetLastError());
+        host[l].resize(words);
+    }
+    auto timed = [&](float *ms, auto enqueue) -> int {
+        Rank &r0 = c->ranks[0];
+        HIPM(c, hipSetDevice(r0.device));
+        HIPM(c, hipEventRecord(r0.ev_x0, r0.comm));
+        CHKM(enqueue());
+        HIPM(c, hipSetDevice(r0.device));
+        HIPM(c, hipEventRecord(r0.ev_x1, r0.comm));
+        CHKM(sync_all(c));
+        HIPM(c, hipSetDevice(r0.device));
+        *ms = elapsed(r0.ev_x0, r0.ev_x1);
+        return HJGPU_OK;
+    };
+    // ---- all-gather
+    {
+        std::vector<const void *> s; std::vector<void *> d;
+        for (int l = 0; l < L; ++l) { s.push_back(base[l]); d.push_back(base[l] + W); }
+        CHKM(timed(&rep->ms_all_gather, [&] { return c->transport->all_gather(s.data(), d.data(), W * sizeof(u64), comms.data()); }));
+    }
+    // ---- all-to-all-v: rank s sends W - 37 * s - 11 * d words to rank d (different for every pair)
+    std::vector<std::vector<u64>> soff(L, std::vector<u64>(Gs)), scnt = soff, roff = soff, rcnt = soff;
+    auto a2a_count = [&](int s, int d) -> u64 { return (u64)W - 37ull * (u64)s - 11ull * (u64)d; };
+    {
+        std::vector<const void *> s; std::vector<void *> d;
+        std::vector<const u64 *> so, sc, ro, rc;
+        for (int l = 0; l < L; ++l) {
+            const int me = c->ranks[l].global;
+            for (int p = 0; p < G; ++p) {
+                soff[l][p] = (u64)p * W; scnt[l][p] = a2a_count(me, p);
+                roff[l][p] = (u64)p * W; rcnt[l][p] = a2a_count(p, me);
+            }
+            s.push_back(base[l] + W + Gs * W); d.push_back(base[l] + W + 2 * Gs * W);
+            so.push_back(soff[l].data()); sc.push_back(scnt[l].data()); ro.push_back(roff[l].data()); rc.push_back(rcnt[l].data());
+        }
+        CHKM(timed(&rep->ms_all_to_all, [&] { return c->transport->all_to_all_v(s.data(), so.data(), sc.data(), d.data(), ro.data(), rc.data(), sizeof(u64), comms.data()); }));
+    }
+    // ---- all-reduce
+    {
+        std::vector<u64 *> b;
+        for (int l = 0; l < L; ++l) b.push_back(base[l] + W + 3 * Gs * W);
+        CHKM(timed(&rep->ms_all_reduce, [&] { return c->transport->all_reduce_u64(b.data(), W, comms.data()); }));
+    }
+    // ---- verify on the host
+    for (int l = 0; l < L; ++l) {
+        Rank &r = c->ranks[l];
+        HIPM(c, hipSetDevice(r.device));
+        HIPM(c, hipMemcpyAsync(host[l].data(), base[l], words * sizeof(u64), hipMemcpyDeviceToHost, r.comm));
+    }
+    CHKM(sync_all(c));
+    bool ok_g = true, ok_a = true, ok_r = true;
+    for (int l = 0; l < L; ++l) {
+        const int me = c->ranks[l].global;
+        const u64 *h = host[l].data();
+        for (int p = 0; p < G && ok_g; ++p)
+            for (size_t i = 0; i < W; ++i) if (h[W + (size_t)p * W + i] != pattern_at(1000 + (u64)p, i)) { ok_g = false; break; }
+        for (int p = 0; p < G && ok_a; ++p) {
+            const u64 n = a2a_count(p, me);
+            // rank p filled its send buffer [G * W] with pattern(5000 + p); what it sends to me starts at word me * W
+            for (u64 i = 0; i < n; ++i) if (h[W + 2 * Gs * W + (size_t)p * W + i] != pattern_at(5000 + (u64)p, (u64)me * W + i)) { ok_a = false; break; }
+            if (n < W && h[W + 2 * Gs * W + (size_t)p * W + n] != 0) ok_a = false;          // nothing beyond the message
+        }
+        for (size_t i = 0; i < W && ok_r; ++i) {
+            u64 want = 0;
+            for (int p = 0; p < G; ++p) want += pattern_at(9000 + (u64)p, i);
+            if (h[W + 3 * Gs * W + i] != want) ok_r = false;
+        }
+    }
+    rep->ok_all_gather = ok_g; rep->ok_all_to_all = ok_a; rep->ok_all_reduce = ok_r;
+    // ---- point-to-point rates: shift by k (every rank sends to the peer k places on), then all peers at once
+    if (link_bytes && G > 1) {
+        std::vector<const void *> s; std::vector<void *> d;
+        std::vector<const u64 *> so, sc, ro, rc;
+        for (int l = 0; l < L; ++l) {
+            char *lb = reinterpret_cast<char *>(base[l] + words);
+            s.push_back(lb); d.push_back(lb + link_bytes);
+            so.push_back(soff[l].data()); sc.push_back(scnt[l].data()); ro.push_back(roff[l].data()); rc.push_back(rcnt[l].data());
+        }
+        for (int k = 1; k <= G; ++k) {                       // k == G: all peers at once
+            for (int l = 0; l < L; ++l) {
+                const int me = c->ranks[l].global;
+                for (int p = 0; p < G; ++p) {
+                    const bool to = k < G ? p == (me + k) % G : p != me, from = k < G ? p == (me - k + G) % G : p != me;
+                    soff[l][p] = 0; scnt[l][p] = to ? link_bytes : 0;
+                    roff[l][p] = (u64)p * link_bytes; rcnt[l][p] = from ? link_bytes : 0;
+                }
+            }
+            float ms = 0;
+            for (int rep_i = 0; rep_i < 2; ++rep_i)           // the first message over a link sets the connection up
+                CHKM(timed(&ms, [&] { return c->transport->all_to_all_v(s.data(), so.data(), sc.data(), d.data(), ro.data(), rc.data(), 1, comms.data()); }));
+            const float gbs = ms > 0 ? (float)((double)link_bytes / (ms * 1e-3) / 1e9) : 0.f;
+            if (k < G) rep->link_GBs[(c->ranks[0].global + k) % G] = gbs;
+            else rep->all_to_all_GBs = gbs * (float)(G - 1);       // sent to all peers together, per rank
+        }
+    }
+    if (!(ok_g && ok_a && ok_r)) {
+        char text[200];
+        snprintf(text, sizeof(text), "preflight: corrupted collective (all-gather %s, all-to-all-v %s, all-reduce %s) over %s",
+                 ok_g ? "ok" : "BAD", ok_a ? "ok" : "BAD", ok_r ? "ok" : "BAD", c->transport->name());
+        return cfail(c, HJGPU_ERCCL, text);
+    }
+    return HJGPU_OK;
+}
+
 int hjgpu_phj_multi(hjgpu_comm *c, const hjgpu_shard *shards, int root, const hjgpu_phj_params *params,
                     hjgpu_result *result, hjgpu_multi_stats *stats)
 {
-    return replicated_join(c, 1, shards, root, params, nullptr, result, stats);
+    return replicated_join(c, 1, shards, nullptr, root, params, nullptr, result, stats);
 }
 
 int hjgpu_npj_multi(hjgpu_comm *c, const hjgpu_shard *shards, int root, const hjgpu_npj_params *params,
                     hjgpu_result *result, hjgpu_multi_stats *stats)
 {
-    return replicated_join(c, 0, shards, root, nullptr, params, result, stats);
+    return replicated_join(c, 0, shards, nullptr, root, nullptr, params, result, stats);
 }
 
 int hjgpu_cpra_multi(hjgpu_comm *c, const hjgpu_shard *shards, const hjgpu_phj_params *params, int slices,
                      hjgpu_result *result, hjgpu_multi_stats *stats)
 {
-    return cpra_join(c, shards, params, slices, result, stats);
+    return cpra_join(c, shards, nullptr, params, slices, result, stats);
+}
+
+int hjgpu_phj_multi_rows(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, int root,
+                         const hjgpu_phj_params *params, hjgpu_result *result, hjgpu_multi_stats *stats)
+{
+    if (!rows) return cfail(c, HJGPU_EINVAL, "hjgpu_phj_multi_rows: rows is required");
+    return replicated_join(c, 1, shards, rows, root, params, nullptr, result, stats);
+}
+
+int hjgpu_npj_multi_rows(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, int root,
+                         const hjgpu_npj_params *params, hjgpu_result *result, hjgpu_multi_stats *stats)
+{
+    if (!rows) return cfail(c, HJGPU_EINVAL, "hjgpu_npj_multi_rows: rows is required");
+    return replicated_join(c, 0, shards, rows, root, nullptr, params, result, stats);
+}
+
+int hjgpu_cpra_multi_rows(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, const hjgpu_phj_params *params,
+                          int slices, hjgpu_result *result, hjgpu_multi_stats *stats)
+{
+    if (!rows) return cfail(c, HJGPU_EINVAL, "hjgpu_cpra_multi_rows: rows is required");
+    return cpra_join(c, shards, rows, params, slices, result, stats);
+}
+
+// The host columns are cut into the ranks' shares; every rank's share travels on the rank's own upload stream into
+// buffers that the communicator keeps between calls (no hipMalloc / hipFree per call), probe side first, and the
+// joins are enqueued right behind: a rank partitions its probe shard while its (and the root's build) columns are
+// still arriving - the single-GPU host path's pipeline (hjgpu_join_host), per rank.
+static int join_host_multi_impl(hjgpu_comm *c, int algorithm,
+                                const uint32_t *ik, const uint32_t *iv, size_t inner,
+                                const uint32_t *ok, const uint32_t *ov, size_t outer,
+                                const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
+                                const hjgpu_host_rows *host_rows, hjgpu_result *result, hjgpu_multi_stats *stats)
+{
+    if (!c || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
+    CHKM(refuse_broken(c));
+    if ((int)c->ranks.size() != c->nranks) return cfail(c, HJGPU_EINVAL, "hjgpu_join_host_multi needs a local communicator");
+    if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return cfail(c, HJGPU_EINVAL, "null column");
+    if (host_rows && (!result || (host_rows->capacity && (!host_rows->keys || !host_rows->outer_vals || !host_rows->inner_vals))))
+        return cfail(c, HJGPU_EINVAL, "hjgpu_join_host_rows_multi: result and the three result columns are required");
+    const int G = c->nranks;
+    std::vector<hjgpu_shard> shards((size_t)G);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int g = 0; g < G; ++g) {
+        Rank &r = c->ranks[(size_t)g];
+        hjgpu_shard &s = shards[(size_t)g];
+        memset(&s, 0, sizeof(s));
+        size_t sb, se, rb = 0, re = 0;
+        range_of(outer, 16, (size_t)g, (size_t)G, &sb, &se);            // thread_beg / thread_end with T = ranks
+        s.outer = se - sb;
+        if (algorithm == 2) { range_of(inner, 16, (size_t)g, (size_t)G, &rb, &re); s.inner = re - rb; }
+        else { s.inner = inner; if (g == 0) { rb = 0; re = inner; } }
+        const uint32_t *h[4] = {ik + rb, iv + rb, ok + sb, ov + sb};
+        const size_t n[4] = {re - rb, re - rb, s.outer, s.outer};
+        for (int i = 0; i < 4; ++i) CHKM(ensure(c, r, r.shard[i], (n[i] + 4) * sizeof(uint32_t)));
+        HIPM(c, hipSetDevice(r.device));
+        // pinned columns (hjgpu_host_alloc) are DMA'd; the GPUs' uploads run side by side, probe side first
+        for (int i : {2, 3, 0, 1}) {
+            if (n[i]) HIPM(c, hipMemcpyAsync(r.shard[i].p, h[i], n[i] * sizeof(uint32_t), hipMemcpyHostToDevice, r.up));
+            if (i == 3) HIPM(c, hipEventRecord(r.ev_up_s, r.up));
+        }
+        HIPM(c, hipEventRecord(r.ev_up_r, r.up));
+        HIPM(c, hipEventRecord(r.ev_t1, r.up));
+        s.d_outer_keys = static_cast<const uint32_t *>(r.shard[2].p); s.d_outer_vals = static_cast<const uint32_t *>(r.shard[3].p);
+        if (re > rb) { s.d_inner_keys = static_cast<const uint32_t *>(r.shard[0].p); s.d_inner_vals = static_cast<const uint32_t *>(r.shard[1].p); }
+    }
+    std::vector<hjgpu_shard_rows> rows;
+    int rc = HJGPU_OK;
+    if (host_rows) {
+        // result columns per rank: its share of the caller's capacity with a quarter of headroom; a rank that needs
+        // more says how much (rows[l].rows) and the join is run once more with exactly that
+        rows.resize((size_t)G);
+        const size_t bs = host_rows->capacity >= (64u << 20) ? 65536 : 1024;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int g = 0; g < G; ++g) {
+                Rank &r = c->ranks[(size_t)g];
+                const size_t want_rows = attempt ? (size_t)rows[(size_t)g].rows : host_rows->capacity / (size_t)G + host_rows->capacity / (size_t)(4 * G) + 1;
+                size_t cap = 0;
+                JOINM(c, r.join, hjgpu_output_capacity(r.join, algorithm, shards[(size_t)g].outer, want_rows, bs, &cap));
+                for (int i = 0; i < 3; ++i) CHKM(ensure(c, r, r.rows_col[i], cap * sizeof(uint32_t)));
+                hjgpu_output &o = rows[(size_t)g].out;
+                o.d_keys = static_cast<uint32_t *>(r.rows_col[0].p); o.d_outer_vals = static_cast<uint32_t *>(r.rows_col[1].p);
+                o.d_inner_vals = static_cast<uint32_t *>(r.rows_col[2].p);
+                o.capacity = cap; o.block_size = bs;
+            }
+            if (algorithm == 2) rc = cpra_join(c, shards.data(), rows.data(), pp, 0, result, stats, attempt == 0);
+            else rc = replicated_join(c, algorithm, shards.data(), rows.data(), 0, pp, np, result, stats, attempt == 0);
+            if (rc != HJGPU_EOVERFLOW) break;
+        }
+    } else {
+        if (algorithm == 2) rc = cpra_join(c, shards.data(), nullptr, pp, 0, result, stats, true);
+        else rc = replicated_join(c, algorithm, shards.data(), nullptr, 0, pp, np, result, stats, true);
+    }
+    if (rc != HJGPU_OK) { if (!c->broken) (void)sync_all(c); return rc; }
+    if (stats) {
+        // local rank 0: how long its columns took to arrive, and whether its first join kernel started before that
+        Rank &r = c->ranks[0];
+        HIPM(c, hipSetDevice(r.device));
+        stats->ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count() - stats->ms_wall;
+        if (stats->ms_upload < 0) stats->ms_upload = 0;
+        // > 0: the join's first kernel was on the device this long BEFORE the last byte of the upload arrived
+        stats->ms_overlap = elapsed(r.ev_t0, r.ev_t1);
+    }
+    if (host_rows) {
+        if (result->count > host_rows->capacity)
+            return cfail(c, HJGPU_EOVERFLOW, "hjgpu_join_host_rows_multi: the result has more rows than rows->capacity (see result->count)");
+        // concatenation = result: rank g's rows follow the rows of the ranks before it
+        const auto d0 = std::chrono::steady_clock::now();
+        u64 at = 0;
+        for (int g = 0; g < G; ++g) {
+            Rank &r = c->ranks[(size_t)g];
+            const u64 n = rows[(size_t)g].rows;
+            uint32_t *hcol[3] = {host_rows->keys, host_rows->outer_vals, host_rows->inner_vals};
+            HIPM(c, hipSetDevice(r.device));
+            for (int i = 0; i < 3 && n; ++i)
+                HIPM(c, hipMemcpyAsync(hcol[i] + at, r.rows_col[i].p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, r.up));
+            at += n;
+        }
+        CHKM(sync_all(c));
+        if (at != result->count) return cfail(c, HJGPU_EHIP, "internal: the ranks' rows do not add up to the global count");
+        if (stats) stats->join.ms_download = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - d0).count();
+    }
+    return HJGPU_OK;
 }
 
 int hjgpu_join_host_multi(hjgpu_comm *c, int algorithm,
@@ -932,50 +1561,18 @@ int hjgpu_join_host_multi(hjgpu_comm *c, int algorithm,
                           const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
                           hjgpu_result *result, hjgpu_multi_stats *stats)
 {
-    if (!c || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
-    if ((int)c->ranks.size() != c->nranks) return cfail(c, HJGPU_EINVAL, "hjgpu_join_host_multi needs a local communicator");
-    if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return cfail(c, HJGPU_EINVAL, "null column");
-    const int G = c->nranks;
-    std::vector<hjgpu_shard> shards((size_t)G);
-    std::vector<void *> owned;
-    int rc = HJGPU_OK;
-    auto upload = [&](Rank &r, const uint32_t *h, size_t n, const uint32_t **d) {
-        *d = nullptr;
-        if (rc != HJGPU_OK) return;
-        void *p = nullptr;
-        if (hipSetDevice(r.device) != hipSuccess || hipMalloc(&p, (n + 4) * sizeof(uint32_t)) != hipSuccess) { rc = cfail(c, HJGPU_ENOMEM, "hipMalloc(shard)"); return; }
-        owned.push_back(p);
-        // pinned columns (hjgpu_host_alloc) are DMA'd; the GPUs' uploads then run side by side
-        if (n && hipMemcpyAsync(p, h, n * sizeof(uint32_t), hipMemcpyHostToDevice, r.prep) != hipSuccess) { rc = cfail(c, HJGPU_EHIP, "hipMemcpyAsync(shard)"); return; }
-        *d = static_cast<const uint32_t *>(p);
-    };
-    for (int g = 0; g < G; ++g) {
-        Rank &r = c->ranks[(size_t)g];
-        hjgpu_shard &s = shards[(size_t)g];
-        memset(&s, 0, sizeof(s));
-        size_t b, e;
-        range_of(outer, 16, (size_t)g, (size_t)G, &b, &e);            // thread_beg / thread_end with T = ranks
-        s.outer = e - b;
-        upload(r, ok + b, s.outer, &s.d_outer_keys);
-        upload(r, ov + b, s.outer, &s.d_outer_vals);
-        if (algorithm == 2) {
-            range_of(inner, 16, (size_t)g, (size_t)G, &b, &e);
-            s.inner = e - b;
-            upload(r, ik + b, s.inner, &s.d_inner_keys);
-            upload(r, iv + b, s.inner, &s.d_inner_vals);
-        } else {
-            s.inner = inner;
-            if (g == 0) { upload(r, ik, inner, &s.d_inner_keys); upload(r, iv, inner, &s.d_inner_vals); }
-        }
-    }
-    if (rc == HJGPU_OK) rc = sync_all(c);
-    if (rc == HJGPU_OK) {
-        if (algorithm == 2) rc = cpra_join(c, shards.data(), pp, 0, result, stats);
-        else rc = replicated_join(c, algorithm, shards.data(), 0, pp, np, result, stats);
-    }
-    (void)sync_all(c);
-    for (void *p : owned) (void)hipFree(p);
-    return rc;
+    return join_host_multi_impl(c, algorithm, ik, iv, inner, ok, ov, outer, pp, np, nullptr, result, stats);
+}
+
+int hjgpu_join_host_rows_multi(hjgpu_comm *c, int algorithm,
+                               const uint32_t *ik, const uint32_t *iv, size_t inner,
+                               const uint32_t *ok, const uint32_t *ov, size_t outer,
+                               const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
+                               const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_multi_stats *stats)
+{
+    if (!c) return HJGPU_EINVAL;
+    if (!rows) return cfail(c, HJGPU_EINVAL, "hjgpu_join_host_rows_multi: rows is required");
+    return join_host_multi_impl(c, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result, stats);
 }
 
 }  // extern "C"

@@ -42,8 +42,24 @@
 // a build partition that takes several table fills keeps one bit per probe row of the work item in LDS
 // (`matched`), so that a row reported by an earlier fill is skipped by the later ones (such partitions
 // are then planned as ONE fill group: all fills of a probe slice stay with one workgroup).
+// Waves per SIMD the geometry runs at: workgroups per CU (LDS: one table + ~10 KiB each in 160 KiB; threads: 2048
+// per CU) x waves per workgroup / 4 SIMDs.  It is the second argument of __launch_bounds__ (HIP: minimum waves per
+// execution unit), i.e. the register budget: 512 / waves VGPRs per lane.  The probe stream's loads live in VGPRs, so
+// a geometry with fewer waves and more vectors per lane keeps more bytes in flight per CU.
+constexpr int hj_join_wgs_per_cu(int block, int log2slots)
+{
+    const int by_lds = (160 * 1024) / ((1 << log2slots) * 8 + 1024 + 9 * 1024), by_threads = 2048 / block;
+    const int n = by_lds < by_threads ? by_lds : by_threads;
+    return n < 1 ? 1 : n;
+}
+constexpr int hj_join_waves_per_simd(int block, int log2slots)
+{
+    const int w = hj_join_wgs_per_cu(block, log2slots) * (block / 64) / 4;
+    return w < 1 ? 1 : w;
+}
+
 template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE>
-__global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
+__global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) void join_kernel(JoinArgs a)
 {
     constexpr uint32_t SLOTS = 1u << LOG2SLOTS;
     constexpr uint32_t MASK = SLOTS - 1;
@@ -204,6 +220,8 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
         }
         u64 sk_ = 0, so_ = 0, si_ = 0;
         uint32_t n = 0;
+        bool one_each = true;                        // every key of this lane's vector has exactly one match
+        uint32_t inner[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
@@ -215,11 +233,21 @@ __global__ __launch_bounds__(BLOCK, 4) void join_kernel(JoinArgs a)
             so_ += (u64)val[j] * m;
             si_ += (h1 ? (uint32_t)(t1[j] >> 32) : 0u);
             si_ += (h2 ? (uint32_t)(t2[j] >> 32) : 0u);
-            if (a.ok) {
-                // one emit for "this key matched" (with unique build keys that is every lane of the wave:
-                // 64 rows, the cursor moves in whole lines), a second one only for a key found in BOTH slots
-                if (h1 | h2) em.emit(key[j], val[j], (uint32_t)((h1 ? t1[j] : t2[j]) >> 32));
-                if (h1 & h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
+            one_each = one_each && (h1 != h2);
+            inner[j] = (uint32_t)((h1 ? t1[j] : t2[j]) >> 32);
+        }
+        if (a.ok) {
+            // the wave's whole vector step as ONE run of 4 rows per lane (see Emitter::emit4) when every lane found
+            // exactly one partner per key; otherwise key by key: one emit for "this key matched" (64 rows with
+            // unique build keys), a second one only for a key found in BOTH slots
+            if (!(a.emit_vec && __all(one_each) && em.emit4(key, val, inner))) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
+                    const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]) && !(UNIQUE && h1);
+                    if (h1 | h2) em.emit(key[j], val[j], inner[j]);
+                    if (h1 & h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
+                }
             }
         }
         acc_n += n; acc_k += sk_; acc_o += so_; acc_i += si_;
@@ -478,10 +506,7 @@ const JoinConfig &hj_join_config_big()
 static int join_wgs_per_cu(const JoinConfig &c)
 {
     // + 9 KiB: the UNIQUE instances' `matched` bits; the same grid for both keeps hj_join_workers one number
-    int by_lds = (160 * 1024) / (c.slots() * 8 + 1024 + 9 * 1024);
-    int by_threads = 2048 / c.block;
-    int n = by_lds < by_threads ? by_lds : by_threads;
-    return n < 1 ? 1 : n;
+    return hj_join_wgs_per_cu(c.block, c.log2slots);
 }
 
 static int join_grid(int cus, const JoinConfig &c) { return cus * join_wgs_per_cu(c); }
@@ -498,6 +523,19 @@ int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
     }
 
+// The geometries that are built (option "join_cfg"): {block, log2slots, batch, a UNIQUE instance exists}.
+static const struct { int block, log2slots, batch; bool unique; } JOIN_BUILT[] = {
+    {512, 13, 2, true}, {512, 13, 1, false}, {512, 13, 3, false}, {512, 13, 4, false}, {1024, 14, 2, true},
+    {256, 12, 2, false}, {384, 13, 3, true}, {384, 13, 4, true}, {256, 13, 4, false}, {256, 13, 8, false},
+};
+
+bool hj_join_config_built(const JoinConfig &c, bool unique)
+{
+    for (const auto &g : JOIN_BUILT)
+        if (g.block == c.block && g.log2slots == c.log2slots && g.batch == c.batch && (!unique || g.unique)) return true;
+    return false;
+}
+
 int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t stream)
 {
     if ((a.P < 2 && !a.broadcast) || a.P < 1 || a.chunks == 0) return HJGPU_EINVAL;
@@ -505,12 +543,20 @@ int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t st
     JoinArgs b = a;
     b.force_chained = t.force_chained ? 1u : 0u;       // tests: exercise the fallback table everywhere
     b.unique = (a.unique || t.unique) ? 1u : 0u;
+    b.emit_vec = t.emit_vec ? 1u : 0u;
     JOIN_CASE(512, 13, 2, false)
     JOIN_CASE(512, 13, 2, true)
     JOIN_CASE(512, 13, 1, false)
+    JOIN_CASE(512, 13, 3, false)
     JOIN_CASE(512, 13, 4, false)
     JOIN_CASE(1024, 14, 2, false)
     JOIN_CASE(1024, 14, 2, true)
     JOIN_CASE(256, 12, 2, false)
+    JOIN_CASE(384, 13, 3, false)
+    JOIN_CASE(384, 13, 3, true)
+    JOIN_CASE(384, 13, 4, false)
+    JOIN_CASE(384, 13, 4, true)
+    JOIN_CASE(256, 13, 4, false)
+    JOIN_CASE(256, 13, 8, false)
     return HJGPU_EINVAL;
 }

@@ -1216,6 +1216,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("force_chained")) return parse_flag(value, &t->force_chained);
     if (is("scatter_prof")) return parse_flag(value, &t->scatter_prof);
     if (is("unique")) return parse_flag(value, &t->unique);
+    if (is("emit_vec")) return parse_flag(value, &t->emit_vec);
     if (is("placement")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1265,13 +1266,14 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "emit_vec", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);
         for (const char *c = n; *c && at + 1 < sizeof(env); ++c) env[at++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
         env[at] = 0;
         const char *v = getenv(env);
-        if (v && *v) (void)hj_tuning_set(t, n, v);
+        if (v && *v && !hj_tuning_set(t, n, v))
+            fprintf(stderr, "hjgpu: ignoring malformed %s=%s\n", env, v);      // once per context creation, never on a launch path
     }
 }

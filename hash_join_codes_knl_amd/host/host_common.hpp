@@ -100,6 +100,31 @@ inline bool load_relations(const Args &a, Relations &r)
            read_column(column_path("ov", a.outer), a.outer, r.ov);
 }
 
+// HJGPU_ROWS: the result columns that arrived on the host must add up to the aggregates the device computed;
+// HJGPU_ROWS=<prefix> (anything but "1") also writes them as raw uint32 files <prefix>jk_<J>.txt, jo_, ji_.
+inline int report_rows(const char *rows_env, uint32_t *const rows_col[3], const hjgpu_result *res, double ms_download)
+{
+    uint64_t sums[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+        for (size_t j = 0; j < res->count; ++j) sums[i] += rows_col[i][j];
+    const bool same = sums[0] == res->sum_keys && sums[1] == res->sum_outer_vals && sums[2] == res->sum_inner_vals;
+    const double down = ms_download * 1e-3;
+    fprintf(stderr, "result rows on the host: %llu x 12 bytes in %.4f s (%.1f GB/s), column sums %s\n",
+            (unsigned long long)res->count, down, down > 0 ? 12.0 * res->count / down / 1e9 : 0.0, same ? "match" : "DIFFER");
+    if (!same) return HJGPU_EHIP;
+    if (strcmp(rows_env, "1") != 0) {
+        const char *name[3] = {"jk", "jo", "ji"};
+        for (int i = 0; i < 3; ++i) {
+            const std::string path = std::string(rows_env) + name[i] + "_" + std::to_string(res->count) + ".txt";
+            FILE *f = fopen(path.c_str(), "wb");
+            const size_t put = f && res->count ? fwrite(rows_col[i], sizeof(uint32_t), res->count, f) : 0;
+            if (f) fclose(f);
+            if (!f || put != res->count) { fprintf(stderr, "cannot write %s\n", path.c_str()); return -2; }
+        }
+    }
+    return HJGPU_OK;
+}
+
 // Loads the four column files, runs one join on the GPU and prints the extended report on stderr;
 // the reference's own stdout line is printed by each main in its own format.
 // Exit codes of the mains: 2 = input files, 1 = no GPU / join failed.
@@ -140,13 +165,20 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
     }
     const char *rows_req = getenv("HJGPU_ROWS");
     const bool rows_wanted = rows_req && *rows_req && strcmp(rows_req, "0") != 0;
-    if (devices.size() > 1 && rows_wanted)
-        fprintf(stderr, "HJGPU_ROWS: materialised rows come from one GPU; running on device %d only\n", devices[0]);
-    if (devices.size() > 1 && !rows_wanted) {
+    if (devices.size() > 1) {
+        // said once, on stderr: the reference's #threads is not what decides the workers here
+        fprintf(stderr, "%zu GPUs visible: the join runs on all of them (%s); HJGPU_DEVICES=<id> keeps it on one\n", devices.size(),
+                algorithm == 2 ? "both sides chunked over the GPUs, #threads is not used" : "build side replicated, probe side sharded");
         hjgpu_comm *comm = nullptr;
         setenv("NCCL_SOCKET_IFNAME", "lo", 0);     // all ranks live in this process: RCCL's bootstrap needs loopback only
         int rc = hjgpu_comm_create_local((int)devices.size(), devices.data(), transport, &comm);
-        if (rc != HJGPU_OK) { fprintf(stderr, "hjgpu_comm_create_local(%zu ranks): %s\n", devices.size(), hjgpu_status_string(rc)); return rc; }
+        if (rc != HJGPU_OK) {
+            fprintf(stderr, "hjgpu_comm_create_local(%zu ranks): %s (%s)\n", devices.size(), hjgpu_status_string(rc), hjgpu_comm_last_error(nullptr));
+            return rc;
+        }
+        // a GPU that never arrives at an exchange ends the program with a message instead of hanging it (the reference's
+        // pthread barriers would wait forever): 5 minutes unless HJGPU_COMM_TIMEOUT_MS says otherwise
+        if (!getenv("HJGPU_COMM_TIMEOUT_MS")) (void)hjgpu_comm_set_option(comm, "timeout_ms", "300000");
         hjgpu_ctx *ctx0 = hjgpu_comm_ctx(comm, 0);
         {
             PinnedRelations r;
@@ -158,11 +190,32 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
             }
             hjgpu_multi_stats ms;
             memset(&ms, 0, sizeof(ms));
-            if (rc == HJGPU_OK) {
+            uint32_t *rows_col[3] = {nullptr, nullptr, nullptr};
+            if (rc == HJGPU_OK && !rows_wanted) {
                 rc = hjgpu_join_host_multi(comm, algorithm, r.col[0], r.col[1], a.inner, r.col[2], r.col[3], a.outer,
                                            nullptr, nullptr, res, &ms);
                 if (rc != HJGPU_OK) fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_comm_last_error(comm));
+            } else if (rc == HJGPU_OK) {
+                // HJGPU_ROWS: every GPU materialises its share, the shares land back to back in three host columns
+                // (the reference's join_keys / join_outer_vals / join_inner_vals, npj.cpp:997-1000); sized for 1.05 x the
+                // expected matches, a larger result reports its size and is run again with columns of that size
+                size_t cap = (size_t)((double)(a.outer > a.inner ? a.outer : a.inner) * 1.05) + 1;
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
+                        rc = hjgpu_host_alloc(ctx0, (void **)&rows_col[i], cap * sizeof(uint32_t));
+                    if (rc != HJGPU_OK) { fprintf(stderr, "host allocation failed: %s\n", hjgpu_last_error(ctx0)); break; }
+                    hjgpu_host_rows rows = {rows_col[0], rows_col[1], rows_col[2], cap};
+                    rc = hjgpu_join_host_rows_multi(comm, algorithm, r.col[0], r.col[1], a.inner, r.col[2], r.col[3], a.outer,
+                                                    nullptr, nullptr, &rows, res, &ms);
+                    if (rc != HJGPU_EOVERFLOW || attempt == 1) break;
+                    for (int i = 0; i < 3; ++i) { hjgpu_host_free(ctx0, rows_col[i]); rows_col[i] = nullptr; }
+                    cap = res->count;
+                    rc = HJGPU_OK;
+                }
+                if (rc != HJGPU_OK) fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_comm_last_error(comm));
+                if (rc == HJGPU_OK) rc = report_rows(rows_req, rows_col, res, ms.join.ms_download);
             }
+            for (uint32_t *c : rows_col) if (c) hjgpu_host_free(ctx0, c);
             if (rc == HJGPU_OK) {
                 *st = ms.join;
                 st->ms_total = ms.ms_wall;                 // the step as the host saw it: exchange + local joins
@@ -173,9 +226,11 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
                         (unsigned long long)res->count, (unsigned long long)res->sum_keys,
                         (unsigned long long)res->sum_outer_vals, (unsigned long long)res->sum_inner_vals);
                 fprintf(stderr, "step %.4f s: %.2f Gtuples/s probe-side; rank 0: exchange %.4f s (%.1f MB sent), partitioning %.4f s, "
-                                "%u local joins %.4f s, waited %.4f s for exchanges\n",
+                                "%u measured local joins %.4f s, waited %.4f s for exchanges; its first join kernel ran %.4f s before its "
+                                "upload had ended\n",
                         ms.ms_wall * 1e-3, ms.ms_wall > 0 ? a.outer / (ms.ms_wall * 1e-3) / 1e9 : 0.0, ms.ms_exchange * 1e-3,
-                        ms.bytes_sent / 1e6, ms.ms_partition * 1e-3, ms.joins, ms.join.ms_total * 1e-3, ms.ms_exchange_wait * 1e-3);
+                        ms.bytes_sent / 1e6, ms.ms_partition * 1e-3, ms.joins, ms.join.ms_total * 1e-3, ms.ms_exchange_wait * 1e-3,
+                        ms.ms_overlap * 1e-3);
             }
         }   // pinned columns are released before the communicator (they belong to its rank-0 context)
         hjgpu_comm_destroy(comm);
@@ -231,28 +286,7 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
             }
             if (rc != HJGPU_OK)
                 fprintf(stderr, "join failed: %s (%s)\n", hjgpu_status_string(rc), hjgpu_last_error(ctx));
-            if (rc == HJGPU_OK) {
-                // the columns that arrived must add up to the aggregates the device computed
-                uint64_t sums[3] = {0, 0, 0};
-                for (int i = 0; i < 3; ++i)
-                    for (size_t j = 0; j < res->count; ++j) sums[i] += rows_col[i][j];
-                const bool same = sums[0] == res->sum_keys && sums[1] == res->sum_outer_vals && sums[2] == res->sum_inner_vals;
-                const double down = st->ms_download * 1e-3;
-                fprintf(stderr, "result rows on the host: %llu x 12 bytes in %.4f s (%.1f GB/s), column sums %s\n",
-                        (unsigned long long)res->count, down, down > 0 ? 12.0 * res->count / down / 1e9 : 0.0,
-                        same ? "match" : "DIFFER");
-                if (!same) rc = HJGPU_EHIP;
-                if (same && strcmp(rows_env, "1") != 0) {
-                    const char *name[3] = {"jk", "jo", "ji"};
-                    for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) {
-                        const std::string path = std::string(rows_env) + name[i] + "_" + std::to_string(res->count) + ".txt";
-                        FILE *f = fopen(path.c_str(), "wb");
-                        const size_t put = f && res->count ? fwrite(rows_col[i], sizeof(uint32_t), res->count, f) : 0;
-                        if (f) fclose(f);
-                        if (!f || put != res->count) { fprintf(stderr, "cannot write %s\n", path.c_str()); rc = -2; }
-                    }
-                }
-            }
+            if (rc == HJGPU_OK) rc = report_rows(rows_env, rows_col, res, st->ms_download);
         }
         for (uint32_t *c : rows_col) if (c) hjgpu_host_free(ctx, c);
         hjgpu_device_info info;

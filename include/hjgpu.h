@@ -111,6 +111,10 @@ typedef struct {
     float    ms_upload;        /* hjgpu_join_host: host columns -> HBM (wall clock, pipelined
                                   with the probe side's partitioning for PHJ / CPRA)         */
     float    ms_download;      /* hjgpu_join_host_rows: result columns -> host (wall clock)  */
+    float    ms_reserve;       /* wall clock this context has spent growing its workspace so far (hjgpu_reserve / the
+                                  first join of a size): allocations plus the placement search for the probe side's
+                                  pass-1 twin (option "placement": up to 12 candidate blocks held and filled twice);
+                                  never inside a timed join once the workspace is reserved                   */
     uint32_t fanout1, fanout2; /* what was used                                              */
     uint32_t batches;          /* PHJ: batches the probe side was partitioned in (both passes of a batch
                                   back to back, its intermediate copy kept in the Infinity Cache; their
@@ -252,6 +256,27 @@ int  hjgpu_cpra_async(hjgpu_ctx *ctx,
                       const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
                       const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
                       const hjgpu_phj_params *params, hjgpu_result *d_result, void *stream);
+/* Status of an enqueue-only join.  The blocking forms report HJGPU_EZEROKEY (a build key of 0 met by NPJ: the
+ * reference's empty-bucket sentinel, npj.cpp:196-210, 583, 867 - such a tuple is not in the table) and
+ * HJGPU_EOVERFLOW (the reference's assert(o <= block_limit), npj.cpp:245); an *_async join cannot, so its caller asks:
+ *   hjgpu_get_async_status        waits for `stream` and returns what the blocking form of the LAST join enqueued on this
+ *                                 context would have returned (HJGPU_OK / HJGPU_EZEROKEY / HJGPU_EOVERFLOW);
+ *   hjgpu_accumulate_async_status enqueue-only: d_flags[0] += 1 if that join met a zero build key, d_flags[1] += 1 if
+ *                                 its materialised output overflowed (two uint64 in device memory: the multi-GPU joins
+ *                                 all-reduce them with the four aggregates, so every rank returns the same status). */
+int  hjgpu_get_async_status(hjgpu_ctx *ctx, void *stream);
+int  hjgpu_accumulate_async_status(hjgpu_ctx *ctx, uint64_t *d_flags, void *stream);
+/* Materialised rows from an enqueue-only join: the NEXT *_async join enqueued on this context (hjgpu_npj_async,
+ * hjgpu_phj_async, hjgpu_phj_overlapped_async, hjgpu_cpra_async, hjgpu_phj_probe_async) writes its rows into `out`
+ * exactly as the blocking form does (block protocol + close_gaps; the dense prefix [0, d_result->count) holds the
+ * result once `stream` has passed the join).  One-shot; out == NULL withdraws it.  Overflow: see above. */
+int  hjgpu_set_async_output(hjgpu_ctx *ctx, const hjgpu_output *out);
+/* Capacity (in rows, a multiple of block_size) of result columns that are guaranteed to hold `rows` result rows
+ * of a join of this context: rows rounded up to whole blocks plus one open block per worker (the reference sizes its
+ * output the same way: 1.05 J + 2 T blocks, npj.cpp:997-1000).  algorithm: 0 npj (needs outer_tuples), 1 phj, 2 cpra;
+ * block_size 0 = 65536. */
+int  hjgpu_output_capacity(hjgpu_ctx *ctx, int algorithm, size_t outer_tuples, size_t rows, size_t block_size,
+                           size_t *capacity);
 
 /* ---- PHJ with the build side prepared once and probed by any number of batches -------------------
  * R join S = union over batches S_i of R join S_i, so a probe side that arrives in pieces (slices of a
@@ -336,6 +361,8 @@ int  hjgpu_comm_create_local(int nranks, const int *devices, int transport, hjgp
 int  hjgpu_comm_get_id(hjgpu_comm_id *id);
 int  hjgpu_comm_create_rank(int device, int nranks, int rank, const hjgpu_comm_id *id, hjgpu_comm **comm);
 int  hjgpu_comm_destroy(hjgpu_comm *comm);
+/* comm == NULL: why the last hjgpu_comm_create_* / hjgpu_comm_get_id of THIS thread failed (the communicator that could
+ * not be made no longer exists; RCCL's own text, e.g. of ncclCommInitRank, is kept here) */
 const char *hjgpu_comm_last_error(const hjgpu_comm *comm);
 /* world size, local ranks of this process, global rank of local rank 0 */
 int  hjgpu_comm_size(const hjgpu_comm *comm, int *nranks, int *nlocal, int *first_rank);
@@ -343,8 +370,43 @@ int  hjgpu_comm_size(const hjgpu_comm *comm, int *nranks, int *nlocal, int *firs
 hjgpu_ctx *hjgpu_comm_ctx(hjgpu_comm *comm, int local_rank);
 /* option "ring_broadcast" (0 / 1): replicate the build side with one ncclBroadcast instead of scatter +
  * all-gather; "max_message_bytes" (n): split larger point-to-point messages into pieces; "reserve_cus" (n): CUs
- * that the ranks' partitioning kernels leave free for RCCL's kernels (default 16 with RCCL and > 1 rank, else 0: free, K6 is not CU-bound) */
+ * that the ranks' partitioning kernels leave free for RCCL's kernels (default 16 with RCCL and > 1 rank, else 0: free, K6 is not CU-bound);
+ * "timeout_ms" (n, 0 = none; HJGPU_COMM_TIMEOUT_MS presets it): deadline of every host-side wait of the multi-GPU
+ * calls.  The reference's workers meet at pthread barriers (cpra2.cpp:1834-1840, phj.cpp:1715-1770) and a worker
+ * that never arrives hangs the program; here the streams are polled, RCCL is asked for asynchronous errors
+ * (ncclCommGetAsyncError), and at the deadline the communicator is aborted (ncclCommAbort): the call returns
+ * HJGPU_ERCCL naming the rank and stream that did not finish, every later call on the communicator fails fast, and
+ * the process can exit.  "stall_rank" (k) / "stall_ms" (n): fault injection for tests, loopback transport only - rank
+ * k arrives n ms late at every collective. */
 int  hjgpu_comm_set_option(hjgpu_comm *comm, const char *name, const char *value);
+/* What the communicator really is: the transport's own view of the world (ncclCommCount / ncclCommUserRank /
+ * ncclCommCuDevice of local rank 0, ncclGetVersion), so that a result line can prove that N ranks talked over RCCL. */
+typedef struct {
+    int  nranks, nlocal, first_rank;
+    char transport[16];        /* "rccl" | "loopback"                                          */
+    int  rccl_version;         /* ncclGetVersion, e.g. 22707; 0 without RCCL                   */
+    int  rccl_nranks;          /* ncclCommCount of local rank 0's communicator; -1 without     */
+    int  rccl_rank;            /* ncclCommUserRank                                             */
+    int  rccl_device;          /* ncclCommCuDevice                                             */
+    int  timeout_ms;           /* option "timeout_ms"                                          */
+    int  aborted;              /* 1: a deadline expired or RCCL reported an asynchronous error */
+} hjgpu_comm_info;
+int  hjgpu_comm_get_info(hjgpu_comm *comm, hjgpu_comm_info *info);
+/* Preflight ("measure link bandwidth first"): 1 MB through every collective the joins use
+ * (all-gather, all-to-all-v with a different count for every pair, all-reduce), each verified word for word on the
+ * host; then `link_bytes` from every rank to the peer k places on, for k = 1 .. G-1 (all ranks at once, every
+ * pair's own xGMI link), and to all peers at once (the CPRA exchange's shape).  Local rank 0's view.
+ * Returns HJGPU_ERCCL when a collective delivered wrong data (ok_* say which). */
+typedef struct {
+    uint32_t nranks, rank;
+    uint32_t ok_all_gather, ok_all_to_all, ok_all_reduce;
+    float    ms_all_gather, ms_all_to_all, ms_all_reduce;      /* 1 MB per rank, includes RCCL's lazy set-up */
+    uint64_t link_bytes;
+    float    link_GBs[64];     /* [peer]: link_bytes sent to `peer` while every other rank sends to ITS peer at the same
+                                  distance (second of two rounds); 0 for the rank itself                      */
+    float    all_to_all_GBs;   /* bytes this rank SENDS per second when every rank sends link_bytes to every peer at once */
+} hjgpu_preflight;
+int  hjgpu_comm_preflight(hjgpu_comm *comm, size_t link_bytes, hjgpu_preflight *report);
 /* every local rank's streams drained, then a collective over all ranks */
 int  hjgpu_comm_barrier(hjgpu_comm *comm);
 
@@ -363,11 +425,18 @@ typedef struct {
     float    ms_exchange;        /* local rank 0: device time of its exchanges (replication / all-to-all-v)  */
     float    ms_partition;       /* local rank 0: exchange-level partitioning (CPRA)                         */
     float    ms_exchange_wait;   /* local rank 0: stream time its joins spent waiting for an exchange        */
-    uint32_t joins;              /* local rank 0: local join calls of this step (build + probes)             */
+    uint32_t joins;              /* local rank 0: local join calls whose phase times are in `join`           */
     uint32_t reserved;
     uint64_t tuples_joined;      /* local rank 0: tuples those joins read                                    */
     uint64_t bytes_sent;         /* local rank 0: bytes sent to OTHER ranks                                  */
-    hjgpu_stats join;            /* local rank 0: phase times of those joins, summed                         */
+    float    ms_upload;          /* hjgpu_join_host_multi: wall clock of the call outside the join step itself (cutting the
+                                    columns, enqueueing every rank's uploads); 0 for device-resident shards     */
+    float    ms_overlap;         /* hjgpu_join_host_multi, local rank 0: how long BEFORE the last byte of its upload
+                                    arrived its first join kernel was already on the device (> 0: the partitioning
+                                    of the probe shard overlaps the upload, as in hjgpu_join_host)              */
+    hjgpu_stats join;            /* local rank 0: phase times of the MEASURED joins, summed: PHJ / NPJ the one local
+                                    join; CPRA the build and the last probe batch (`joins`, `tuples_joined` count
+                                    exactly those) - reading every slice's times would hold the host thread back  */
 } hjgpu_multi_stats;
 
 /* shards: one entry per LOCAL rank, in rank order */
@@ -377,6 +446,23 @@ int  hjgpu_npj_multi(hjgpu_comm *comm, const hjgpu_shard *shards, int root, cons
                      hjgpu_result *result, hjgpu_multi_stats *stats);
 int  hjgpu_cpra_multi(hjgpu_comm *comm, const hjgpu_shard *shards, const hjgpu_phj_params *params,
                       int slices /* 0 = 4 */, hjgpu_result *result, hjgpu_multi_stats *stats);
+/* Materialised rows (the reference's join_keys / join_outer_vals / join_inner_vals, which every worker writes:
+ * npj.cpp:882-915, cpra2.cpp:1965-1982) through the multi-GPU joins: every rank materialises ITS share of the result
+ * into its own three device columns (block protocol + close_gaps; CPRA: slice after slice, each behind the rows of
+ * the slices before it) and reports how many dense rows it holds; the concatenation of the ranks' rows is the result
+ * (SURVEY.md 8e).  `rows`: one entry per LOCAL rank.  When some rank's columns are too small EVERY rank returns
+ * HJGPU_EOVERFLOW (the flags are all-reduced with the aggregates), result->count is the global row count and
+ * rows[l].rows what rank l needs: size the columns with hjgpu_output_capacity and call again. */
+typedef struct {
+    hjgpu_output out;            /* this rank's result columns (device memory of the rank's device)         */
+    uint64_t     rows;           /* OUT: rows [0, rows) of them hold the rank's share of the result          */
+} hjgpu_shard_rows;
+int  hjgpu_phj_multi_rows(hjgpu_comm *comm, const hjgpu_shard *shards, hjgpu_shard_rows *rows, int root,
+                          const hjgpu_phj_params *params, hjgpu_result *result, hjgpu_multi_stats *stats);
+int  hjgpu_npj_multi_rows(hjgpu_comm *comm, const hjgpu_shard *shards, hjgpu_shard_rows *rows, int root,
+                          const hjgpu_npj_params *params, hjgpu_result *result, hjgpu_multi_stats *stats);
+int  hjgpu_cpra_multi_rows(hjgpu_comm *comm, const hjgpu_shard *shards, hjgpu_shard_rows *rows,
+                           const hjgpu_phj_params *params, int slices, hjgpu_result *result, hjgpu_multi_stats *stats);
 /* As hjgpu_join_host on all ranks of a LOCAL communicator (what ./npj ./phj ./cpra call when several GPUs are
  * visible): the host columns are cut into the ranks' shares (thread_beg / thread_end, T = ranks), uploaded, joined.
  * algorithm: 0 npj, 1 phj (build side uploaded to rank 0 and replicated from there), 2 cpra (both sides chunked). */
@@ -385,6 +471,15 @@ int  hjgpu_join_host_multi(hjgpu_comm *comm, int algorithm,
                            const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
                            const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
                            hjgpu_result *result, hjgpu_multi_stats *stats);
+/* hjgpu_join_host_rows on all ranks of a local communicator: every rank materialises its share, the shares are copied
+ * back to back into the caller's three host columns (rank 0's rows first).  HJGPU_EOVERFLOW with result->count set
+ * when the result has more rows than rows->capacity.  (A rank whose own device columns turn out too small is run a
+ * second time with exactly the size it reported: not the caller's concern.) */
+int  hjgpu_join_host_rows_multi(hjgpu_comm *comm, int algorithm,
+                                const uint32_t *inner_keys, const uint32_t *inner_vals, size_t inner,
+                                const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
+                                const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
+                                const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_multi_stats *stats);
 
 /* ---- data generator (write.cpp / generate_data_for_join, cpra2.cpp:1578-1696):
  * statistical contract only — non-zero build keys, unique when outer_total >= inner_total

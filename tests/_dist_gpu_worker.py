@@ -16,7 +16,7 @@ def main():
     torch.cuda.init()
     import torch.distributed as dist
     import hash_join_codes_knl_amd as H
-    from hash_join_codes_knl_amd import distributed as D
+    import torch_orchestration as D
     from helpers import numpy_join
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", sys.argv[1])

@@ -45,7 +45,8 @@ def test_struct_layouts_match_header(tmp_path):
     pairs = [("hjgpu_result", H.Result), ("hjgpu_phj_params", H.PhjParams), ("hjgpu_npj_params", H.NpjParams),
              ("hjgpu_output", H.Output), ("hjgpu_stats", H.Stats), ("hjgpu_host_rows", api.HostRows),
              ("hjgpu_device_info", api.DeviceInfo), ("hjgpu_shard", api.Shard), ("hjgpu_multi_stats", api.MultiStats),
-             ("hjgpu_comm_id", api.CommId)]
+             ("hjgpu_comm_id", api.CommId), ("hjgpu_comm_info", api.CommInfo), ("hjgpu_preflight", api.Preflight),
+             ("hjgpu_shard_rows", api.ShardRows)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hjgpu.h"', 'int main(void){']
     for cname, cls in pairs:
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
@@ -62,7 +63,25 @@ def test_struct_layouts_match_header(tmp_path):
         got = [int(x) for x in line.split()[1:]]
         want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert got == want, (cname, got, want)
-    assert C.sizeof(H.Stats) == 64 and C.sizeof(api.HostRows) == 32
+    assert C.sizeof(H.Stats) == 72 and C.sizeof(api.HostRows) == 32
+
+
+def test_library_does_not_link_rccl():
+    """RCCL is bound with dlopen by the first RCCL communicator: loading libhjgpu.so (single-GPU users, these tests,
+    hosts on a box without RCCL) must not need it."""
+    import subprocess
+    from hash_join_codes_knl_amd import build as B
+    needed = subprocess.check_output(["readelf", "-d", B.lib_path()], text=True)
+    assert "librccl" not in needed, needed
+
+
+def test_comm_create_errors_keep_their_text():
+    """A communicator that cannot be made no longer exists: its text is kept per thread, hjgpu_comm_last_error(NULL)."""
+    lib = H.load_library()
+    h = C.c_void_p()
+    st = lib.hjgpu_comm_create_local(0, None, H.api.TRANSPORT_LOOPBACK, C.byref(h))
+    assert st == H.api.EINVAL and not h.value
+    assert b"1 to 1024 ranks" in lib.hjgpu_comm_last_error(None)
 
 
 def test_product_package_never_uses_the_oracle():

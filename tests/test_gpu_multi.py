@@ -9,8 +9,10 @@ independent numpy definition of the join."""
 import numpy as np
 import pytest
 
+import time
+
 import hash_join_codes_knl_amd as H
-from helpers import numpy_join
+from helpers import materialised_rows, numpy_join, sort_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -94,8 +96,7 @@ def test_replicated_build_joins_over_loopback(worlds, oracle, world, kind):
         assert got == want, (world, kind, root)
         assert st["joins"] == 1 and st["ms_wall"] > 0
         assert comm.phj_multi(shards, root, H.PhjParams(fanout1=16, fanout2=3))[0] == want
-        if not (ik == 0).any():
-            assert comm.npj_multi(shards, root)[0] == want
+        assert comm.npj_multi(shards, root)[0] == want
         for c in cols:
             c.free()
 
@@ -387,3 +388,221 @@ def test_full_size_property_two_ranks_64m_by_200m_each(worlds):
     assert list(got) == expect
     for c in cols + [rk, rv]:
         c.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: deadlines, status flags across ranks, materialised rows, preflight
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo", ["phj", "cpra"])
+def test_a_stalled_rank_returns_an_error_within_the_deadline(oracle, algo):
+    """Fault injection (loopback option "stall_rank"): rank 1 arrives 2.5 s late at a collective while the communicator's
+    deadline is 300 ms.  The call must come back with HJGPU_ERCCL naming the rank instead of hanging (the reference's
+    pthread barriers, cpra2.cpp:1834-1840 / phj.cpp:1715-1770, would wait forever); the communicator is aborted,
+    later calls fail fast, destroying it works."""
+    ik, iv, ok, ov = relations(oracle, "unique", seed=5)
+    comm = H.HjComm.local(3, [0, 0, 0], H.TRANSPORT_LOOPBACK)
+    try:
+        if algo == "phj":
+            shards, cols = replicated_shards(comm, ik, iv, ok, ov, 0)
+            run = lambda: comm.phj_multi(shards, 0)
+        else:
+            shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+            run = lambda: comm.cpra_multi(shards, None, 2)
+        assert run()[0] == numpy_join(ik, iv, ok, ov)            # healthy first
+        comm.set_option("timeout_ms", 300)
+        assert comm.info()["timeout_ms"] == 300 and comm.info()["aborted"] == 0
+        assert run()[0] == numpy_join(ik, iv, ok, ov)            # polling waits give the same result
+        comm.set_option("stall_ms", 2500)
+        comm.set_option("stall_rank", 1)
+        t0 = time.perf_counter()
+        with pytest.raises(H.HjGpuError) as e:
+            run()
+        dt = time.perf_counter() - t0
+        assert e.value.status == H.api.ERCCL and "deadline of 300 ms" in str(e.value), str(e.value)
+        assert dt < 1.5, "the call took %.2f s: it waited for the stalled rank" % dt
+        assert comm.info()["aborted"] == 1
+        t0 = time.perf_counter()
+        with pytest.raises(H.HjGpuError) as e:
+            run()
+        assert e.value.status == H.api.ERCCL and "aborted" in str(e.value) and time.perf_counter() - t0 < 0.2
+        with pytest.raises(H.HjGpuError):
+            comm.barrier()
+    finally:
+        comm.close()                                             # waits for the stall to end, no longer
+        for c in cols:
+            c.free()
+
+
+def test_stall_options_are_loopback_test_switches(worlds):
+    rccl = worlds(1, H.TRANSPORT_RCCL)
+    with pytest.raises(H.HjGpuError) as e:
+        rccl.set_option("stall_rank", 0)
+    assert e.value.status == H.api.EINVAL
+    info = rccl.info()
+    assert info["transport"] == "rccl" and info["rccl_version"] >= 20000 and info["rccl_nranks"] == 1 and info["rccl_rank"] == 0
+    lb = worlds(3)
+    assert lb.info()["transport"] == "loopback" and lb.info()["rccl_nranks"] == -1 and lb.info()["nranks"] == 3
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_a_zero_build_key_fails_loudly_on_every_rank(worlds, hj, oracle, world):
+    """NPJ's empty-bucket sentinel is key 0 (npj.cpp:196-210, 583, 867): a build tuple with key 0 is not in the table.
+    The blocking hjgpu_npj says HJGPU_EZEROKEY; the enqueue-only form cannot, so the multi-GPU NPJ reduces the flag with
+    the aggregates - every rank returns the error - and single-GPU callers ask hjgpu_get_async_status."""
+    ik, iv, ok, ov = relations(oracle, "unique", seed=13)
+    ik = ik.copy()
+    ik[1234] = 0
+    comm = worlds(world) if world > 1 else worlds(1, H.TRANSPORT_RCCL)
+    for root in sorted({0, world - 1}):
+        shards, cols = replicated_shards(comm, ik, iv, ok, ov, root)
+        with pytest.raises(H.HjGpuError) as e:
+            comm.npj_multi(shards, root)
+        assert e.value.status == H.api.EZEROKEY, str(e.value)
+        assert comm.phj_multi(shards, root)[0] == numpy_join(ik, iv, ok, ov)      # key 0 is legal in PHJ (phj.cpp:1886-1897)
+        for c in cols:
+            c.free()
+    # single GPU, enqueue-only form
+    rk, rv, sk, sv = (hj.column(x) for x in (ik, iv, ok, ov))
+    d_res = hj.column(4, np.uint64)
+    hj.npj_async(rk, rv, len(ik), sk, sv, len(ok), None, d_res)
+    with pytest.raises(H.HjGpuError) as e:
+        hj.get_async_status()
+    assert e.value.status == H.api.EZEROKEY
+    hj.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, d_res)
+    hj.get_async_status()                                        # fine
+    assert tuple(int(x) for x in d_res.download()) == numpy_join(ik, iv, ok, ov)
+    for c in (rk, rv, sk, sv, d_res):
+        c.free()
+
+
+def test_async_joins_materialise_and_report_overflow(hj, oracle):
+    """hjgpu_set_async_output + hjgpu_get_async_status: the enqueue-only forms write rows like the blocking ones."""
+    ik, iv, ok, ov = relations(oracle, "dups", seed=2)
+    want = numpy_join(ik, iv, ok, ov)
+    wk, wo, wi = materialised_rows(ik, iv, ok, ov)
+    rk, rv, sk, sv = (hj.column(x) for x in (ik, iv, ok, ov))
+    d_res = hj.column(4, np.uint64)
+    for algorithm, fn in ((1, hj.phj_async), (2, hj.cpra_async), (0, hj.npj_async)):
+        cap = hj.output_capacity(algorithm, len(ok), want[0], 1024)
+        jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+        hj.set_async_output((jk, jo, ji, cap, 1024))
+        fn(rk, rv, len(ik), sk, sv, len(ok), None, d_res)
+        hj.get_async_status()
+        assert tuple(int(x) for x in d_res.download()) == want
+        gk, go, gi = sort_rows(jk.download(want[0]), jo.download(want[0]), ji.download(want[0]))
+        assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi)
+        # one-shot: the next join aggregates only
+        fn(rk, rv, len(ik), sk, sv, len(ok), None, d_res)
+        hj.get_async_status()
+        # too small: overflow is reported, the count is still right
+        hj.set_async_output((jk, jo, ji, 2048, 1024))
+        fn(rk, rv, len(ik), sk, sv, len(ok), None, d_res)
+        with pytest.raises(H.HjGpuError) as e:
+            hj.get_async_status()
+        assert e.value.status == H.api.EOVERFLOW and int(d_res.download()[0]) == want[0]
+        for c in (jk, jo, ji):
+            c.free()
+    for c in (rk, rv, sk, sv, d_res):
+        c.free()
+
+
+def _rank_outputs(comm, rows_per_rank, block=1024, algorithm=1, outer=0):
+    outs, cols = [], []
+    for g in range(comm.nlocal):
+        cap = comm.ctx[g].output_capacity(algorithm, outer, rows_per_rank[g], block)
+        c = [comm.ctx[g].column(cap) for _ in range(3)]
+        cols += c
+        outs.append((c[0], c[1], c[2], cap, block))
+    return outs, cols
+
+
+def _gather_rows(outs, counts):
+    parts = [[o[i].download(n) for o, n in zip(outs, counts)] for i in range(3)]
+    return sort_rows(*(np.concatenate(p) if p else np.zeros(0, np.uint32) for p in parts))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("kind", ["unique", "dups", "half"])
+def test_materialised_rows_through_the_multi_gpu_entry_points(worlds, oracle, world, kind):
+    """Every rank writes its share of the result rows (npj.cpp:882-915, cpra2.cpp:1965-1982); the concatenation of the
+    ranks' dense prefixes is the join, row for row (sorted) against numpy.  First call with columns that are too small
+    on purpose: HJGPU_EOVERFLOW on every rank, the needed rows per rank reported; second call with exactly those."""
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, kind, seed=30 + world)
+    want = numpy_join(ik, iv, ok, ov)
+    wk, wo, wi = materialised_rows(ik, iv, ok, ov)
+    for name in ("phj", "npj", "cpra"):
+        if name == "cpra":
+            shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+            run = lambda outs: comm.cpra_multi_rows(shards, outs, None, 3)
+        else:
+            shards, cols = replicated_shards(comm, ik, iv, ok, ov, world - 1)
+            fn = comm.phj_multi_rows if name == "phj" else comm.npj_multi_rows
+            run = lambda outs: fn(shards, outs, world - 1)
+        algorithm = {"npj": 0, "phj": 1, "cpra": 2}[name]
+        small, scols = [], []
+        for g in range(world):
+            c = [comm.ctx[g].column(2048) for _ in range(3)]
+            scols += c
+            small.append((c[0], c[1], c[2], 2048, 1024))
+        with pytest.raises(H.HjGpuError) as e:
+            run(small)
+        assert e.value.status == H.api.EOVERFLOW and e.value.result == want, (name, str(e.value))
+        assert sum(e.value.rows) == want[0], (name, e.value.rows)
+        outs, ocols = _rank_outputs(comm, e.value.rows, 1024, algorithm, max(s[5] for s in shards))
+        got, st, counts = run(outs)
+        assert got == want and counts == e.value.rows, (name, counts, e.value.rows)
+        gk, go, gi = _gather_rows(outs, counts)
+        assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi), name
+        for c in cols + scols + ocols:
+            c.free()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_unique_rows_and_host_rows_through_the_multi_gpu_entry_points(worlds, oracle, world):
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, "dups", seed=3)
+    want_u = oracle.join_definition_unique(ik, iv, ok, ov)
+    pay = {}
+    for k, v in zip(ik.tolist(), iv.tolist()):
+        pay.setdefault(k, set()).add(v)
+    shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+    outs, ocols = _rank_outputs(comm, [want_u[0]] * world, 1024, 2)
+    got, st, counts = comm.cpra_multi_rows(shards, outs, H.PhjParams(flags=H.FLAG_UNIQUE), 2)
+    assert got[:3] == want_u and sum(counts) == want_u[0]
+    gk, go, gi = _gather_rows(outs, counts)
+    # one row per probe tuple with a partner; the inner payload is ONE of the key's build payloads
+    matched = np.isin(ok, ik)
+    ek, eo = ok[matched], ov[matched]
+    idx = np.lexsort((eo, ek))
+    assert np.array_equal(gk, ek[idx]) and np.array_equal(np.sort(go), np.sort(eo))
+    assert all(int(i) in pay[int(k)] for k, i in zip(gk[:2000], gi[:2000]))
+    for c in cols + ocols:
+        c.free()
+    # hjgpu_join_host_rows_multi: host columns in, host rows out; a capacity below the result is HJGPU_EOVERFLOW
+    want = numpy_join(ik, iv, ok, ov)
+    wk, wo, wi = materialised_rows(ik, iv, ok, ov)
+    for algorithm in (0, 1, 2):
+        got, st, (jk, jo, ji) = comm.join_host_rows_multi(algorithm, ik, iv, ok, ov, want[0] + 5)
+        assert got == want, algorithm
+        gk, go, gi = sort_rows(jk, jo, ji)
+        assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi), algorithm
+    with pytest.raises(H.HjGpuError) as e:
+        comm.join_host_rows_multi(1, ik, iv, ok, ov, want[0] - 1)
+    assert e.value.status == H.api.EOVERFLOW and e.value.result[0] == want[0]
+    # the aggregate-only host call reports its pipeline: the join's first kernel was enqueued behind the probe shard's
+    # upload, not behind the whole upload (ms_overlap is measured between device events, any sign is legal here)
+    got, st = comm.join_host_multi(1, ik, iv, ok, ov)
+    assert got == want and "ms_overlap" in st and st["ms_upload"] >= 0
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_preflight_verifies_the_collectives_and_measures_the_links(worlds, world):
+    comm = worlds(world) if world > 1 else worlds(1, H.TRANSPORT_RCCL)
+    rep = comm.preflight(8 << 20)
+    assert rep["ok_all_gather"] == rep["ok_all_to_all"] == rep["ok_all_reduce"] == 1 and rep["nranks"] == world
+    assert len(rep["link_GBs"]) == world and rep["link_GBs"][rep["rank"]] == 0
+    if world > 1:
+        assert all(x > 0 for i, x in enumerate(rep["link_GBs"]) if i != rep["rank"]) and rep["all_to_all_GBs"] > 0
+    # and the communicator still joins
+    assert comm.info()["aborted"] == 0

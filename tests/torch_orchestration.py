@@ -1,4 +1,11 @@
-"""Multi-GPU orchestration of the joins: one process per GPU, torch.distributed
+"""TEST INFRASTRUCTURE (retired from the product package in round 3): round 1's orchestration of the multi-GPU joins
+over a caller-owned torch.distributed group.  The product's orchestration is C++ (csrc/hjgpu_multi.hip: hjgpu_phj_multi,
+hjgpu_npj_multi, hjgpu_cpra_multi, RCCL called from the library); this second, independent implementation stays as a
+cross-check of the host logic - ownership, split sizes, slicing, reductions - that runs WITHOUT a GPU: over gloo at
+world 2 / 3 with the CPU oracle injected (test_distributed_gloo.py), and once on the GPU box over RCCL at world 1
+(test_gpu_distributed.py).  Nothing in hash_join_codes_knl_amd/, bench.py or the hosts imports it.
+
+Multi-GPU orchestration of the joins: one process per GPU, torch.distributed
 (backend "nccl" = RCCL over xGMI on MI355X nodes).
 
 This is the distributed counterpart of the reference's thread orchestration:
