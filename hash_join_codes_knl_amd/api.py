@@ -30,6 +30,7 @@ EXPORTS = [
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
     "hjgpu_phj_build", "hjgpu_phj_probe", "hjgpu_phj_probe_async",
+    "hjgpu_partition_packed_async", "hjgpu_phj_build_prepartitioned", "hjgpu_phj_probe_prepartitioned_async",
     "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
     "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
     "hjgpu_comm_get_info", "hjgpu_comm_preflight",
@@ -123,6 +124,12 @@ class Preflight(C.Structure):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "link_GBs"}
         d["link_GBs"] = [round(float(x), 2) for x in self.link_GBs[:self.nranks]]
         return d
+
+
+class PrePartitioned(C.Structure):
+    """hjgpu_prepartitioned: a relation that arrives pass-1-partitioned in `chunks` pieces (multi-GPU CPRA receiver)."""
+    _fields_ = [("factor1", C.c_uint32), ("fanout1_total", C.c_uint32), ("first_partition", C.c_uint32),
+                ("fanout1", C.c_uint32), ("chunks", C.c_uint32), ("reserved", C.c_uint32), ("chunk_offsets", C.c_uint64 * 9)]
 
 
 class ShardRows(C.Structure):
@@ -236,6 +243,9 @@ def load_library(build_if_missing=True):
     L.hjgpu_phj_build.argtypes = [vp, vp, vp, sz, sz, C.POINTER(PhjParams), vp]
     L.hjgpu_phj_probe.argtypes = [vp, vp, vp, sz, C.POINTER(Result), C.POINTER(Output), vp]
     L.hjgpu_phj_probe_async.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.hjgpu_partition_packed_async.argtypes = [vp, vp, vp, sz, u32, u32, vp, vp, vp]
+    L.hjgpu_phj_build_prepartitioned.argtypes = [vp, vp, C.POINTER(PrePartitioned), sz, C.POINTER(PhjParams), vp]
+    L.hjgpu_phj_probe_prepartitioned_async.argtypes = [vp, vp, C.POINTER(PrePartitioned), vp, vp]
     L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
                                   C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Stats)]
     L.hjgpu_join_host_rows.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
@@ -447,6 +457,26 @@ class HjGpu:
     def phj_probe_async(self, sk, sv, outer, d_result, stream=None):
         self._check(self.lib.hjgpu_phj_probe_async(self.handle, self._ptr(sk), self._ptr(sv), outer,
                                                    self._ptr(d_result), stream))
+
+    # relations that arrive pass-1-partitioned (the receiving side of the multi-GPU CPRA)
+    def partition_packed_async(self, d_keys, d_vals, n, factor, fanout, d_tuples_out, d_offsets, stream=None):
+        self._check(self.lib.hjgpu_partition_packed_async(self.handle, self._ptr(d_keys), self._ptr(d_vals), n, factor, fanout,
+                                                          self._ptr(d_tuples_out), self._ptr(d_offsets), stream))
+
+    @staticmethod
+    def prepartitioned(factor1, fanout1_total, first_partition, fanout1, chunk_offsets):
+        lay = PrePartitioned(factor1, fanout1_total, first_partition, fanout1, len(chunk_offsets) - 1, 0)
+        for i in range(9):
+            lay.chunk_offsets[i] = int(chunk_offsets[min(i, len(chunk_offsets) - 1)])
+        return lay
+
+    def phj_build_prepartitioned(self, d_tuples, layout, max_outer, params=None, stream=None):
+        self._check(self.lib.hjgpu_phj_build_prepartitioned(self.handle, self._ptr(d_tuples), C.byref(layout), max_outer,
+                                                            C.byref(params) if params is not None else None, stream))
+
+    def phj_probe_prepartitioned_async(self, d_tuples, layout, d_result, stream=None):
+        self._check(self.lib.hjgpu_phj_probe_prepartitioned_async(self.handle, self._ptr(d_tuples), C.byref(layout),
+                                                                  self._ptr(d_result), stream))
 
     def _join_async(self, fn, params, rk, rv, inner, sk, sv, outer, d_result, stream):
         self._check(fn(self.handle, self._ptr(rk), self._ptr(rv), inner, self._ptr(sk),

@@ -66,9 +66,15 @@ struct Emitter {
             next = base + (n - room);
         }
         if (rank == 0) *cursor = next;
+#if defined(HJ_EXP_NOSTORE)          // tools/build_variant.py experiments (timing only, wrong rows): never defined in the product build
+        (void)pos;
+#elif defined(HJ_EXP_ONECOL)
+        ok[pos] = key;
+#else
         ok[pos] = key;
         oov[pos] = outer_val;
         oiv[pos] = inner_val;
+#endif
     }
 
     // Four rows per lane in one go: called by a (sub)set of lanes that ALL have exactly one match for each of the four
@@ -96,9 +102,19 @@ struct Emitter {
         row4_t k4 = {key[0], key[1], key[2], key[3]};
         row4_t o4 = {outer_val[0], outer_val[1], outer_val[2], outer_val[3]};
         row4_t i4 = {inner_val[0], inner_val[1], inner_val[2], inner_val[3]};
+#if defined(HJ_EXP_NOSTORE)
+        (void)k4; (void)o4; (void)i4; (void)pos;
+#elif defined(HJ_EXP_ONECOL)
+        *reinterpret_cast<row4_t *>(ok + pos) = k4;
+#elif defined(HJ_EXP_NTSTORE)
+        __builtin_nontemporal_store(k4, reinterpret_cast<row4_t *>(ok + pos));
+        __builtin_nontemporal_store(o4, reinterpret_cast<row4_t *>(oov + pos));
+        __builtin_nontemporal_store(i4, reinterpret_cast<row4_t *>(oiv + pos));
+#else
         *reinterpret_cast<row4_t *>(ok + pos) = k4;
         *reinterpret_cast<row4_t *>(oov + pos) = o4;
         *reinterpret_cast<row4_t *>(oiv + pos) = i4;
+#endif
         return true;
     }
 };

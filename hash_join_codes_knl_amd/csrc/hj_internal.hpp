@@ -56,6 +56,7 @@ struct HjTuning {
     bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
     bool emit_vec = true;           // "emit_vec": materialised rows leave as 16-byte stores (4 rows per lane) where every lane matched
+    bool emit_pipe = true;          // "emit_pipe": materialising joins run the instances with the hand-pipelined probe stream
     int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
@@ -127,6 +128,9 @@ struct JoinArgs {
     const uint32_t *item_part;           // [items] partition of work item w
     uint32_t P, chunks;
     uint32_t f1, F1, f2, F2;             // the passes that produced the partitions
+    uint32_t p1_base;                    // pre-partitioned relations: the partitions are pass-1 partitions [p1_base, ...) of F1 (then
+                                         // F1 = the exchange's total fan-out; the local partition of a key is
+                                         // (H(key, f1, F1) - p1_base) * F2 + H(key, f2, F2))
     uint32_t tf0, tf1;                   // table hash / step multipliers
     uint32_t s_align;                    // (address of sk / 4) % 4
     hjgpu_result *result;                // device, accumulated atomically
@@ -174,6 +178,14 @@ struct PlanArgs {
     uint32_t unique;          // _UNIQUE joins: all table fills of a probe slice stay with ONE work item (see join_kernel)
 };
 
+// A relation that arrives pass-1-partitioned in pieces (the multi-GPU CPRA's receiving side): piece c = rows
+// [b[c], b[c + 1]) of one packed array, c < chunks <= 8 (one piece per source rank).
+struct HjChunks {
+    u64 b[9];
+    uint32_t chunks;
+};
+int hj_launch_hist_packed(const u64 *tuples, const HjChunks &ch, uint32_t f1, uint32_t F1tot, uint32_t p1_base,
+                          uint32_t F1, uint32_t f2, uint32_t F2, u64 *counts, int cus, hipStream_t stream);
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
                     u64 *counts, uint32_t *range_counts, uint32_t *work_counter /* [chunks], zeroed */,

@@ -58,7 +58,7 @@ struct hjgpu_ctx {
     // another entry point uses the workspace
     bool prepared = false;
     size_t prepared_inner = 0, prepared_max_outer = 0;
-    unsigned char prepared_plan[96];
+    unsigned char prepared_plan[128];
     HjTuning tune;          // tuning / test switches: environment at hjgpu_create, hjgpu_set_option afterwards
     // hjgpu_set_async_output: the next *_async join of this context materialises into these columns (one-shot)
     hjgpu_output pending_out;
@@ -415,18 +415,29 @@ struct PhjPlan {
     uint32_t batch_tile_cap; // tiles per range the batch buffers are sized for
     size_t tdesc_b_cap;      // pass-2 tile descriptors per batch
     size_t batch_bytes;      // one batch buffer (packed tuples)
+    // pre-partitioned relations (hjgpu_phj_build_prepartitioned): pass 1 was the exchange-level partitioning of the
+    // multi-GPU CPRA; F1 = this rank's share k of its fan-out pre_F1tot, partitions [pre_base, pre_base + k)
+    uint32_t pre;            // 1: the relations arrive pass-1-partitioned
+    uint32_t pre_f1, pre_F1tot, pre_base;
 };
 static_assert(sizeof(PhjPlan) <= sizeof(hjgpu_ctx::prepared_plan), "prepared_plan too small");
+// the pieces a pre-partitioned relation arrives in (one per source rank)
+struct PrePieces {
+    const u64 *tuples[2] = {nullptr, nullptr};      // [0] build side, [1] probe side (packed: payload << 32 | key)
+    HjChunks ch[2];
+};
 enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
 
 int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm,
-                uint32_t chunks, PhjPlan *pl)
+                uint32_t chunks, PhjPlan *pl, bool pre = false, int big_override = -1)
 {
     ctx->prepared = false;               // the workspace is about to be re-planned (hjgpu_phj_build sets it again)
     ReserveClock clock(ctx);
     pl->C = chunks;
+    pl->pre = pre ? 1u : 0u; pl->pre_f1 = 1; pl->pre_F1tot = 1; pl->pre_base = 0;
     pl->unique = ctx->tune.unique || (prm && (prm->flags & HJGPU_FLAG_UNIQUE));
     choose_fanout(ctx->tune, inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
+    if (big_override >= 0) pl->big_tables = big_override != 0;
     if (pl->unique && !hj_join_config_built(hj_join_config_of(ctx->tune, pl->big_tables), true))
         return fail(ctx, HJGPU_EINVAL, "HJGPU_FLAG_UNIQUE: the join_cfg geometry of this context has no _UNIQUE instance "
                                        "(built: 512,13,2 / 1024,14,2 / 384,13,3 / 384,13,4)");
@@ -444,8 +455,10 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     // packed (payload << 32 | key) twins: tmp[0] / tmp[2] = pass-1 output of R / S,
     // tmp[4] / tmp[6] = pass-2 output
     const size_t rb = (inner + 4) * sizeof(u64), sb = (outer + 4) * sizeof(u64);
-    CHK(ensure(ctx, ctx->tmp[0], rb));
-    CHK(ensure_placed(ctx, ctx->tmp[2], sb));
+    if (!pre) {                          // pre-partitioned relations are read where the caller has them: no pass-1 twins
+        CHK(ensure(ctx, ctx->tmp[0], rb));
+        CHK(ensure_placed(ctx, ctx->tmp[2], sb));
+    }
     if (pl->F2 > 1) {
         // the final layout starts every partition on a 128-byte line: < 16 tuples of padding each
         const size_t pad = (size_t)pl->C * pl->P * HJ_LINE_TUPLES * sizeof(u64);
@@ -494,9 +507,10 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *rk, const uint32_t *rv, size_t inner,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
                 const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr,
-                PhjMode mode = PHJ_WHOLE)
+                PhjMode mode = PHJ_WHOLE, const PrePieces *pre = nullptr)
 {
     CHK(refuse_capture(ctx, stream));
+    if ((pre != nullptr) != (pl.pre != 0)) return fail(ctx, HJGPU_EINVAL, "internal: plan and relations disagree about pre-partitioning");
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2, pl.batch_cap, pl.tdesc_b_cap);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
@@ -519,9 +533,15 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     }
     if (mode != PHJ_BUILD_ONLY) HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
 
-    const Pass1Geom geom[2] = {make_geom(ctx->tune, rk, inner, pl.C, pl.F1, true), make_geom(ctx->tune, sk, outer, pl.C, pl.F1, true)};
+    Pass1Geom geom[2] = {make_geom(ctx->tune, rk, inner, pl.C, pl.F1, true), make_geom(ctx->tune, sk, outer, pl.C, pl.F1, true)};
+    if (pre)
+        for (int r = 0; r < 2; ++r) {
+            if (!pre->tuples[r]) continue;
+            for (uint32_t c = 0; c < 9; ++c) geom[r].b[c] = c <= pl.C ? pre->ch[r].b[c] : pre->ch[r].b[pl.C];
+            geom[r].align = 0;
+        }
     for (int r = 0; r < 2; ++r)
-        if ((size_t)geom[r].ranges_per_chunk * pl.C > pl.ranges)
+        if (!pre && (size_t)geom[r].ranges_per_chunk * pl.C > pl.ranges)
             return fail(ctx, HJGPU_EINVAL, "internal: the relation needs more pass-1 ranges than the plan's tables hold");
     const uint32_t *in_k[2] = {rk, sk}, *in_v[2] = {rv, sv};
     const size_t nn[2] = {inner, outer};
@@ -539,10 +559,12 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     const bool pad2 = pl.F2 > 1 && !ctx->tune.dense2;
     pa.pad2 = pad2 ? 1u : 0u;
     pa.n[0] = inner; pa.n[1] = outer;
+    // pre-partitioned pieces sit at absolute rows [b[0], b[C]) of the caller's array
+    if (pre) for (int r = 0; r < 2; ++r) if (pre->tuples[r]) pa.n[r] = pre->ch[r].b[pl.C];
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
     pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
-    pa.in_align[0] = align_of(rk); pa.in_align[1] = align_of(sk);
+    pa.in_align[0] = pre ? 0u : align_of(rk); pa.in_align[1] = pre ? 0u : align_of(sk);
     pa.tile1 = (uint32_t)hj_scatter_tile(ctx->tune, 1, pl.F1, true); pa.tile2 = (uint32_t)hj_scatter_tile(ctx->tune, 2, pl.F2, true);
     pa.slice = HJ_JOIN_SLICE;
     pa.cap = (uint32_t)hj_join_config_of(ctx->tune, pl.big_tables).cap();
@@ -550,6 +572,31 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     uint32_t batches_used = 0;
     // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
     auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
+        if (pre) {
+            // The relation arrives pass-1-partitioned (multi-GPU CPRA: the exchange-level partitioning of the senders'
+            // chunks was pass 1, cpra2.cpp:1757-1827): K4p counts per (piece, final partition), K5 lays pass 2 out,
+            // K6 pass 2 reads the pieces where they are.  16 + 8 bytes per tuple less than partitioning from scratch.
+            if (nn[r]) CHK(hj_launch_hist_packed(pre->tuples[r], pre->ch[r], pl.pre_f1, pl.pre_F1tot, pl.pre_base, pl.F1,
+                                                 pl.f2, pl.F2, m.counts[r], ctx->cus, stream));
+            record(ctx, ev[0], stream);
+            pa.mask = plan_mask;
+            CHK(hj_launch_plan(pa, stream));
+            record(ctx, ev[1], stream);
+            record(ctx, ev[2], stream);
+            if (nn[r]) {
+                ScatterArgs sa;
+                memset(&sa, 0, sizeof(sa));
+                sa.kin = reinterpret_cast<const uint32_t *>(pre->tuples[r]); sa.vin = nullptr; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
+                sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
+                sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
+                sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
+                sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
+                sa.in_packed = 1; sa.out_packed = 1;
+                CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
+            }
+            record(ctx, ev[3], stream);
+            return HJGPU_OK;
+        }
         // K4: one read of the key column gives the histograms of both passes
         if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
                                        m.range_counts[r], m.tickets + 8 * r, ctx->cus, stream));
@@ -662,6 +709,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         // line-aligned two-pass layout: the chunks' pass-2 tiles wrote every final partition as ONE region
         ja.P = pl.P; ja.chunks = pad2 ? 1u : pl.C;
         ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2;
+        if (pre) { ja.f1 = pl.pre_f1; ja.F1 = pl.pre_F1tot; ja.p1_base = pl.pre_base; }   // the empty sentinel of a partition
         ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
         ja.s_align = 0;
         ja.packed = 1;
@@ -1486,6 +1534,138 @@ int hjgpu_phj_probe_async(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv
                           hjgpu_result *d_result, void *stream)
 {
     return phj_probe_prepared(ctx, sk, sv, outer, nullptr, d_result, nullptr, stream, false);
+}
+
+// ---- relations that arrive pass-1-partitioned (the receiving side of the multi-GPU CPRA) --------------------
+int hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                                 uint32_t factor, uint32_t fanout, uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_)
+{
+    if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
+    if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
+        return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 1024] and factor odd");
+    if (n && !d_tuples_out) return fail(ctx, HJGPU_EINVAL, "null output array");
+    if ((uintptr_t)d_tuples_out & 127) return fail(ctx, HJGPU_EALIGN, "the packed output must be 128-byte aligned (whole-line writes)");
+    CHK(check_columns(ctx, d_keys, d_vals, n));
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(refuse_capture(ctx, stream));
+    const Pass1Geom geom = make_geom(ctx->tune, d_keys, n, 1, fanout, true);
+    MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
+    ctx->prepared = false;                 // the workspace is re-planned below
+    CHK(ensure(ctx, ctx->meta, sz.total_bytes));
+    MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
+    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
+    ctx->last_algo = 2;                    // hjgpu_get_stats().ms_total = the whole operator
+    record(ctx, EV_BEGIN, stream);
+    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
+    if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets, ctx->cus, stream));
+    PlanArgs pa;
+    for (int r = 0; r < 2; ++r) {
+        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
+        pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
+        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
+    }
+    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = 0;
+    pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
+    for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
+    pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
+    pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
+    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 1u;
+    CHK(hj_launch_plan(pa, stream));
+    if (n) {
+        CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1, geom.ranges_per_chunk, fanout, stream));
+        ScatterArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.kin = d_keys; sa.vin = d_vals; sa.kout = reinterpret_cast<uint32_t *>(d_tuples_out); sa.vout = nullptr;
+        sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
+        sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
+        sa.ranged = 1; sa.work_counter = m.tickets + 16; sa.geom = geom; sa.range_base = m.range_base[0];
+        sa.in_packed = 0; sa.out_packed = 1;
+        CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    record(ctx, EV_GAPS, stream);
+    return HJGPU_OK;
+}
+
+static int check_layout(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, HjChunks *ch, size_t *rows)
+{
+    if (!lay) return fail(ctx, HJGPU_EINVAL, "null layout");
+    if (lay->chunks < 1 || lay->chunks > 8) return fail(ctx, HJGPU_EINVAL, "a pre-partitioned relation arrives in 1 to 8 pieces");
+    if (!(lay->factor1 & 1) || lay->fanout1 == 0 || lay->fanout1_total > HJGPU_MAX_FANOUT ||
+        (u64)lay->first_partition + lay->fanout1 > lay->fanout1_total)
+        return fail(ctx, HJGPU_EINVAL, "pre-partitioned layout: odd factor1, fanout1 >= 1, first_partition + fanout1 <= fanout1_total <= 1024");
+    ch->chunks = lay->chunks;
+    for (uint32_t c = 0; c < 9; ++c) {
+        ch->b[c] = lay->chunk_offsets[c <= lay->chunks ? c : lay->chunks];
+        if (c && ch->b[c] < ch->b[c - 1]) return fail(ctx, HJGPU_EINVAL, "pre-partitioned layout: chunk_offsets must not decrease");
+    }
+    *rows = (size_t)(ch->b[lay->chunks] - ch->b[0]);
+    if (*rows && !d_tuples) return fail(ctx, HJGPU_EINVAL, "null tuple array");
+    if ((uintptr_t)d_tuples & 15) return fail(ctx, HJGPU_EALIGN, "packed tuples must be 16-byte aligned");
+    return HJGPU_OK;
+}
+
+int hjgpu_phj_build_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay,
+                                   size_t max_outer, const hjgpu_phj_params *prm, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    PrePieces pre;
+    size_t inner = 0;
+    CHK(check_layout(ctx, d_tuples, lay, &pre.ch[0], &inner));
+    pre.tuples[0] = reinterpret_cast<const u64 *>(d_tuples);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(refuse_capture(ctx, stream));
+    // pass 1 is given (fan-out k = lay->fanout1 on this rank): pass 2 brings the build partitions down to one LDS table.
+    // Always a second pass (F2 >= 2): the final partitions are then ONE line-aligned region each, whatever the number of pieces.
+    hjgpu_phj_params p2;
+    memset(&p2, 0, sizeof(p2));
+    if (prm) p2 = *prm;
+    const uint32_t k = lay->fanout1;
+    bool big = false;
+    double parts = ceil((double)inner / (ctx->tune.join.cap() * 0.85));
+    if (parts > HJGPU_MAX_PARTS) { big = true; parts = ceil((double)inner / (hj_join_config_big().cap() * 0.85)); }
+    uint32_t F2 = p2.fanout2 ? p2.fanout2 : (uint32_t)std::max(2.0, ceil(parts / k));
+    if (F2 < 2) F2 = 2;
+    if (F2 > HJGPU_MAX_FANOUT) F2 = HJGPU_MAX_FANOUT;
+    while ((u64)k * F2 > HJGPU_MAX_PARTS && F2 > 2) --F2;
+    p2.fanout1 = k; p2.fanout2 = F2;
+    PhjPlan pl;
+    CHK(phj_prepare(ctx, inner, max_outer, &p2, lay->chunks, &pl, true, big ? 1 : 0));
+    pl.pre_f1 = lay->factor1; pl.pre_F1tot = lay->fanout1_total; pl.pre_base = lay->first_partition;
+    if (pl.f2 == pl.pre_f1) return fail(ctx, HJGPU_EINVAL, "factor2 must differ from the exchange-level factor1 (same factor: the second pass would not split)");
+    CHK(phj_enqueue(ctx, pl, nullptr, nullptr, inner, nullptr, nullptr, 0, nullptr, stream, nullptr, PHJ_BUILD_ONLY, &pre));
+    memcpy(ctx->prepared_plan, &pl, sizeof(pl));
+    ctx->prepared_inner = inner; ctx->prepared_max_outer = max_outer;
+    ctx->prepared = true;
+    return HJGPU_OK;
+}
+
+int hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay,
+                                         hjgpu_result *d_result, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (!ctx->prepared) return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe_prepartitioned_async: no prepared build side, or another entry point has used the workspace since");
+    PhjPlan pl;
+    memcpy(&pl, ctx->prepared_plan, sizeof(pl));
+    if (!pl.pre) return fail(ctx, HJGPU_EINVAL, "the prepared build side was not pre-partitioned (hjgpu_phj_build_prepartitioned)");
+    PrePieces pre;
+    size_t outer = 0;
+    CHK(check_layout(ctx, d_tuples, lay, &pre.ch[1], &outer));
+    if (lay->chunks != pl.C || lay->factor1 != pl.pre_f1 || lay->fanout1_total != pl.pre_F1tot ||
+        lay->first_partition != pl.pre_base || lay->fanout1 != pl.F1)
+        return fail(ctx, HJGPU_EINVAL, "the probe batch's layout differs from the prepared build side's (pieces, factor1, fan-outs, first partition)");
+    if (outer > ctx->prepared_max_outer) return fail(ctx, HJGPU_EINVAL, "batch larger than the max_outer given to hjgpu_phj_build_prepartitioned");
+    pre.tuples[1] = reinterpret_cast<const u64 *>(d_tuples);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const hjgpu_output *out = take_async_output(ctx, nullptr);
+    ctx->last_had_output = out && out->d_keys;
+    CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, nullptr, nullptr, outer, out, stream, nullptr, PHJ_PROBE_ONLY, &pre));
+    if (d_result)
+        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+    return HJGPU_OK;
 }
 
 int hjgpu_cpra(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,

@@ -122,10 +122,11 @@ struct Rank {
     Buf rbuf;                       // PHJ / NPJ: replicated build side (keys | payloads)
     Buf send_k[2], send_v[2], recv_k[2], recv_v[2];   // CPRA: probe-side slices, double-buffered
     Buf rsend_k, rsend_v, rrecv_k, rrecv_v;           // CPRA: build side
-    Buf d_off;                      // [2][G + 1] u64: partition offsets of slot b
+    Buf d_off;                      // [2][OFF_WORDS] u64: partition offsets of slot b
     Buf d_cnt;                      // [G] u64 send counts | [G * G] gathered matrix
     Buf d_res;                      // [12] u64: accumulated result | zero-key flag, overflow flag, 2 spare | last batch
-    Buf scratch;                    // loopback all-reduce staging; preflight buffers
+    Buf scratch;                    // loopback all-reduce staging
+    Buf pre;                        // preflight buffers (their own: the loopback all-reduce stages in `scratch`)
     Buf shard[4];                   // hjgpu_join_host_multi: this rank's share of ik, iv, ok, ov (kept between calls)
     Buf rows_col[3];                // hjgpu_join_host_rows_multi: this rank's result columns
     u64 *h_pin = nullptr;           // pinned host scratch, see hp_*()
@@ -145,6 +146,7 @@ struct hjgpu_comm {
     int timeout_ms = 0;                      // deadline of every host-side wait; 0 = none (option "timeout_ms")
     bool broken = false;                     // a deadline expired / RCCL reported an asynchronous error: aborted
     int stall_rank = -1, stall_ms = 0;       // loopback fault injection (options "stall_rank", "stall_ms")
+    bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
     char err[512];
     char why_broken[512];
 };
@@ -152,12 +154,13 @@ struct hjgpu_comm {
 namespace {
 
 // pinned host scratch of a rank (u64 words)
-inline size_t hp_words(size_t G) { return 2 * (G + 1) + G * G + 8 + G + 8; }
-inline u64 *hp_off(const Rank &r, size_t G, int slot) { (void)G; return r.h_pin + (size_t)slot * (G + 1); }   // [2][G + 1] offsets
-inline u64 *hp_matrix(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1); }                               // [G * G] counts matrix
-inline u64 *hp_result(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1) + G * G; }                       // [8] global result + flags
-inline u64 *hp_cnt(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1) + G * G + 8; }                      // [G] send counts
-inline u64 *hp_local(const Rank &r, size_t G) { return r.h_pin + 2 * (G + 1) + G * G + 8 + G; }                // [8] this rank's own result (rows)
+constexpr size_t OFF_WORDS = 1040;           // partition offsets of one slot: fan-out <= 1024 (+ 1), or G + 1
+inline size_t hp_words(size_t G) { return 2 * OFF_WORDS + G * G + 8 + G + 8; }
+inline u64 *hp_off(const Rank &r, size_t G, int slot) { (void)G; return r.h_pin + (size_t)slot * OFF_WORDS; }  // [2][fan-out + 1] offsets
+inline u64 *hp_matrix(const Rank &r, size_t G) { (void)G; return r.h_pin + 2 * OFF_WORDS; }                    // [G * G] counts matrix
+inline u64 *hp_result(const Rank &r, size_t G) { return r.h_pin + 2 * OFF_WORDS + G * G; }                     // [8] global result + flags
+inline u64 *hp_cnt(const Rank &r, size_t G) { return r.h_pin + 2 * OFF_WORDS + G * G + 8; }                    // [G] send counts
+inline u64 *hp_local(const Rank &r, size_t G) { return r.h_pin + 2 * OFF_WORDS + G * G + 8 + G; }              // [8] this rank's own result (rows)
 
 int cfail(hjgpu_comm *c, int status, const char *what, const char *detail = nullptr)
 {
@@ -515,7 +518,7 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     const size_t G = (size_t)c->nranks;
     HIPM(c, hipHostMalloc(reinterpret_cast<void **>(&r.h_pin), hp_words(G) * sizeof(u64), hipHostMallocDefault));
     memset(r.h_pin, 0, hp_words(G) * sizeof(u64));
-    CHKM(ensure(c, r, r.d_off, 2 * (G + 1) * sizeof(u64)));
+    CHKM(ensure(c, r, r.d_off, 2 * OFF_WORDS * sizeof(u64)));
     CHKM(ensure(c, r, r.d_cnt, (G + G * G) * sizeof(u64)));
     CHKM(ensure(c, r, r.d_res, 12 * sizeof(u64)));
     return HJGPU_OK;
@@ -545,7 +548,7 @@ void destroy_rank(Rank &r)
     (void)hipDeviceSynchronize();
     Buf *bufs[] = {&r.rbuf, &r.send_k[0], &r.send_k[1], &r.send_v[0], &r.send_v[1], &r.recv_k[0], &r.recv_k[1],
                    &r.recv_v[0], &r.recv_v[1], &r.rsend_k, &r.rsend_v, &r.rrecv_k, &r.rrecv_v, &r.d_off, &r.d_cnt,
-                   &r.d_res, &r.scratch, &r.shard[0], &r.shard[1], &r.shard[2], &r.shard[3], &r.rows_col[0],
+                   &r.d_res, &r.scratch, &r.pre, &r.shard[0], &r.shard[1], &r.shard[2], &r.shard[3], &r.rows_col[0],
                    &r.rows_col[1], &r.rows_col[2]};
     for (Buf *b : bufs) if (b->p) (void)hipFree(b->p);
     hipEvent_t evs[] = {r.ev_ready, r.ev_x0, r.ev_x1, r.ev_t0, r.ev_t1, r.ev_part[0], r.ev_part[1], r.ev_xchg[0],
@@ -817,12 +820,20 @@ struct CpraStep {
     std::vector<std::vector<u64>> soff, scnt, roff, rcnt;    // [local rank][peer]
     std::vector<u64> recv_total;
     hjgpu_multi_stats *stats;
+    // the pieces of what local rank l received in the LAST exchange: piece p (from rank p) = rows [pieces[l][p], pieces[l][p + 1])
+    std::vector<std::vector<u64>> pieces;
     bool exchange_in_flight = false;                          // local rank 0's ev_x0 / ev_x1 hold an unread exchange
     bool from_host = false;                                   // the inputs are being uploaded (hjgpu_join_host_multi)
     float exchange_ms = 0;
+    // One-level plan (1 <= G <= 8): the exchange-level partitioning has fan-out G * k and packed output - it IS pass 1 of
+    // the join (the reference's own-chunk partitioning is the join's partitioning, cpra2.cpp:1757-1827; ownership
+    // 1868-1872): rank g owns partitions [g k, (g + 1) k), the receiver runs pass 2 + build / probe on the pieces as
+    // they arrived (hjgpu_phj_build_prepartitioned).  k = 0: round 2's two-level plan (fan-out G, complete local PHJ).
+    uint32_t k = 0;
+    uint32_t fanout() const { return k ? (uint32_t)G * k : (uint32_t)G; }
     CpraStep(hjgpu_comm *comm, hjgpu_multi_stats *st)
         : c(comm), L((int)comm->ranks.size()), G(comm->nranks), soff(L, std::vector<u64>(G)), scnt(L, std::vector<u64>(G)),
-          roff(L, std::vector<u64>(G)), rcnt(L, std::vector<u64>(G)), recv_total(L), stats(st) {}
+          roff(L, std::vector<u64>(G)), rcnt(L, std::vector<u64>(G)), recv_total(L), stats(st), pieces(L, std::vector<u64>(G + 1)) {}
 
     // call when local rank 0's exchange stream is known to be idle
     void note_exchange()
@@ -841,21 +852,26 @@ struct CpraStep {
     int exchange(const std::vector<Slice> &in, int which, int slot, hipEvent_t Rank::*ready = nullptr)
     {
         const size_t Gs = (size_t)G;
+        const size_t F = fanout();                                  // partitions of the exchange-level pass
+        const size_t tuple_bytes = k ? sizeof(u64) : sizeof(uint32_t);
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
             ExchangeBufs b = bufs_of(r, which);
-            CHKM(ensure(c, r, *b.sk, (in[l].n + 4) * sizeof(uint32_t)));
-            CHKM(ensure(c, r, *b.sv, (in[l].n + 4) * sizeof(uint32_t)));
-            u64 *d_off = static_cast<u64 *>(r.d_off.p) + (size_t)slot * (Gs + 1);
+            CHKM(ensure(c, r, *b.sk, (in[l].n + 16) * tuple_bytes));
+            if (!k) CHKM(ensure(c, r, *b.sv, (in[l].n + 4) * sizeof(uint32_t)));
+            u64 *d_off = static_cast<u64 *>(r.d_off.p) + (size_t)slot * OFF_WORDS;
             u64 *h_off = hp_off(r, Gs, slot);
             HIPM(c, hipSetDevice(r.device));
             if (ready) HIPM(c, hipStreamWaitEvent(r.prep, r.*ready, 0));
-            if (in[l].n)
+            if (in[l].n && k)
+                JOINM(c, r.part, hjgpu_partition_packed_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)F,
+                                                              static_cast<uint64_t *>(b.sk->p), reinterpret_cast<uint64_t *>(d_off), r.prep));
+            else if (in[l].n)
                 JOINM(c, r.part, hjgpu_partition_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)G,
                                                        static_cast<uint32_t *>(b.sk->p), static_cast<uint32_t *>(b.sv->p),
                                                        reinterpret_cast<uint64_t *>(d_off), r.prep));
-            else HIPM(c, hipMemsetAsync(d_off, 0, (Gs + 1) * sizeof(u64), r.prep));
-            HIPM(c, hipMemcpyAsync(h_off, d_off, (Gs + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
+            else HIPM(c, hipMemsetAsync(d_off, 0, (F + 1) * sizeof(u64), r.prep));
+            HIPM(c, hipMemcpyAsync(h_off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
             HIPM(c, hipEventRecord(r.ev_part[slot], r.prep));
         }
         // the host needs the counts: how much every peer gets decides the receive buffers
@@ -863,7 +879,8 @@ struct CpraStep {
             Rank &r = c->ranks[l];
             CHKM(wait_stream(c, l, r.prep, "partitioning"));
             const u64 *h_off = hp_off(r, Gs, slot);
-            for (int p = 0; p < G; ++p) { soff[l][p] = h_off[p]; scnt[l][p] = h_off[p + 1] - h_off[p]; }
+            const size_t per = k ? k : 1;                           // partitions per destination rank
+            for (int p = 0; p < G; ++p) { soff[l][p] = h_off[(size_t)p * per]; scnt[l][p] = h_off[(size_t)(p + 1) * per] - h_off[(size_t)p * per]; }
             if (l == 0 && stats) {
                 hjgpu_stats ps;
                 if (in[l].n && hjgpu_get_stats(r.part, &ps) == HJGPU_OK) stats->ms_partition += ps.ms_total;
@@ -903,10 +920,12 @@ struct CpraStep {
             u64 at = 0;
             for (int p = 0; p < G; ++p) { rcnt[l][p] = matrix[(size_t)p * Gs + r.global]; roff[l][p] = at; at += rcnt[l][p]; }
             recv_total[l] = at;
+            for (int p = 0; p < G; ++p) pieces[l][p] = roff[l][p];
+            pieces[l][G] = at;
             // a quarter of headroom: the next slices rarely need a new allocation (hipFree waits for the device)
-            if ((at + 4) * sizeof(uint32_t) > b.rk->cap) {
-                CHKM(ensure(c, r, *b.rk, (at + at / 4 + 4) * sizeof(uint32_t)));
-                CHKM(ensure(c, r, *b.rv, (at + at / 4 + 4) * sizeof(uint32_t)));
+            if ((at + 16) * tuple_bytes > b.rk->cap) {
+                CHKM(ensure(c, r, *b.rk, (at + at / 4 + 16) * tuple_bytes));
+                if (!k) CHKM(ensure(c, r, *b.rv, (at + at / 4 + 4) * sizeof(uint32_t)));
             }
             ks.push_back(b.sk->p); vs.push_back(b.sv->p); kr.push_back(b.rk->p); vr.push_back(b.rv->p);
             so.push_back(soff[l].data()); sc.push_back(scnt[l].data()); ro.push_back(roff[l].data()); rc.push_back(rcnt[l].data());
@@ -914,8 +933,9 @@ struct CpraStep {
             if (which) HIPM(c, hipStreamWaitEvent(r.comm, r.ev_join[slot], 0));   // the slot's previous slice has been joined
             if (l == 0) HIPM(c, hipEventRecord(r.ev_x0, r.comm));
         }
-        CHKM(c->transport->all_to_all_v(ks.data(), so.data(), sc.data(), kr.data(), ro.data(), rc.data(), sizeof(uint32_t), comms.data()));
-        CHKM(c->transport->all_to_all_v(vs.data(), so.data(), sc.data(), vr.data(), ro.data(), rc.data(), sizeof(uint32_t), comms.data()));
+        // packed tuples: keys and payloads travel together, ONE all-to-all-v per slice
+        CHKM(c->transport->all_to_all_v(ks.data(), so.data(), sc.data(), kr.data(), ro.data(), rc.data(), tuple_bytes, comms.data()));
+        if (!k) CHKM(c->transport->all_to_all_v(vs.data(), so.data(), sc.data(), vr.data(), ro.data(), rc.data(), sizeof(uint32_t), comms.data()));
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
             HIPM(c, hipSetDevice(r.device));
@@ -944,6 +964,20 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             return cfail(c, HJGPU_EINVAL, "null column in a shard");
     }
     CpraStep step(c, stats);
+    // one-level plan while the receiver can take one piece per source rank (<= 8 pieces): fan-out G * k with G * k <= 192,
+    // the widest pass 1 whose whole-line carry still fits beside a 16 K-tuple tile
+    if (c->nranks <= 8 && !c->cpra_two_level) step.k = (uint32_t)(192 / c->nranks);
+    const uint32_t K = step.k;
+    // the layout of what local rank l received (pieces = one per source rank), rows [lo, hi) of it
+    auto layout_of = [&](int l, const std::vector<u64> &pieces, u64 lo, u64 hi) {
+        hjgpu_prepartitioned lay;
+        memset(&lay, 0, sizeof(lay));
+        lay.factor1 = TOP_LEVEL_FACTOR; lay.fanout1_total = (uint32_t)c->nranks * K; lay.fanout1 = K;
+        lay.first_partition = (uint32_t)c->ranks[l].global * K; lay.chunks = (uint32_t)c->nranks;
+        for (int p = 0; p <= c->nranks; ++p) { const u64 x = pieces[(size_t)p]; lay.chunk_offsets[p] = x < lo ? lo : (x > hi ? hi : x); }
+        for (int p = c->nranks + 1; p < 9; ++p) lay.chunk_offsets[p] = lay.chunk_offsets[c->nranks];
+        return lay;
+    };
     for (Rank &r : c->ranks) {
         HIPM(c, hipSetDevice(r.device));
         HIPM(c, hipMemsetAsync(r.d_res.p, 0, 12 * sizeof(u64), r.main));
@@ -959,6 +993,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     for (int l = 0; l < L; ++l) in[l] = {shards[l].d_inner_keys, shards[l].d_inner_vals, shards[l].inner};
     CHKM(step.exchange(in, 0, 0, from_host ? &Rank::ev_up_r : nullptr));
     const std::vector<u64> inner_recv = step.recv_total;
+    const std::vector<std::vector<u64>> inner_pieces = step.pieces;
     std::vector<size_t> max_outer(L);
     for (int l = 0; l < L; ++l) {
         Rank &r = c->ranks[l];
@@ -969,7 +1004,10 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         HIPM(c, hipSetDevice(r.device));
         HIPM(c, hipStreamWaitEvent(r.main, r.ev_rx, 0));
         if (from_host && l == 0) HIPM(c, hipEventRecord(r.ev_t0, r.main));
-        if (inner_recv[l])
+        if (inner_recv[l] && K) {
+            const hjgpu_prepartitioned lay = layout_of(l, inner_pieces[l], 0, inner_recv[l]);
+            JOINM(c, r.join, hjgpu_phj_build_prepartitioned(r.join, static_cast<const uint64_t *>(r.rrecv_k.p), &lay, max_outer[l], prm, r.main));
+        } else if (inner_recv[l])
             JOINM(c, r.join, hjgpu_phj_build(r.join, static_cast<const uint32_t *>(r.rrecv_k.p), static_cast<const uint32_t *>(r.rrecv_v.p),
                                              (size_t)inner_recv[l], max_outer[l], prm, r.main));
     }
@@ -987,7 +1025,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     std::vector<u64> used(L, 0);                 // rows in the rank's result columns so far
     std::vector<bool> row_pending(L, false);     // hp_local()[0] will hold the rank's running count
     u64 measured = 0;
-    auto join_slice = [&](int i, int slot, const std::vector<u64> &got) -> int {
+    auto join_slice = [&](int i, int slot, const std::vector<u64> &got, const std::vector<std::vector<u64>> &got_pieces) -> int {
         measured = 0;
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
@@ -1022,6 +1060,12 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                         }
                         JOINM(c, r.join, hjgpu_set_async_output(r.join, &piece));
                     }
+                    if (K) {
+                        // a batch = rows [b, b + m) of what arrived: a contiguous piece of the pieces (still sorted by partition)
+                        const hjgpu_prepartitioned lay = layout_of(l, got_pieces[l], b, b + m);
+                        JOINM(c, r.join, hjgpu_phj_probe_prepartitioned_async(r.join, static_cast<const uint64_t *>(r.recv_k[slot].p), &lay,
+                                                                              reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
+                    } else
                     JOINM(c, r.join, hjgpu_phj_probe_async(r.join, sk + b, sv + b, m, reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
                     hipLaunchKernelGGL(add_result_kernel, dim3(1), dim3(64), 0, r.main, acc, acc + 8);
                     HIPM(c, hipGetLastError());
@@ -1037,6 +1081,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         return HJGPU_OK;
     };
     std::vector<u64> pending;
+    std::vector<std::vector<u64>> pending_pieces;
     int pending_slice = -1;
     for (int i = 0; i < slices; ++i) {
         const int slot = i & 1;
@@ -1053,11 +1098,12 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             if (hjgpu_get_stats(c->ranks[0].join, &js) == HJGPU_OK) { add_stats(&stats->join, js); stats->joins += 1; stats->tuples_joined += inner_recv[0]; }
             build_stats_pending = false;
         }
-        if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending));
+        if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces));
         pending = step.recv_total;
+        pending_pieces = step.pieces;
         pending_slice = i;
     }
-    CHKM(join_slice(pending_slice, pending_slice & 1, pending));
+    CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces));
     const int status = reduce_results(c, result);
     if (status != HJGPU_OK && status != HJGPU_EOVERFLOW) return status;
     if (rows) for (int l = 0; l < L; ++l) rows[l].rows = hp_local(c->ranks[l], G)[0];
@@ -1249,6 +1295,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
         c->max_message_bytes = (size_t)x;
         return HJGPU_OK;
     }
+    if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
     if (strcmp(name, "timeout_ms") == 0) {
         if (x < 0 || x > (1 << 30)) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: timeout_ms outside 0..2^30");
         c->timeout_ms = (int)x;
@@ -1303,8 +1350,8 @@ int hjgpu_comm_preflight(hjgpu_comm *c, size_t link_bytes, hjgpu_preflight *rep)
     const std::vector<hipStream_t> comms = streams_of(c, &Rank::comm);
     for (int l = 0; l < L; ++l) {
         Rank &r = c->ranks[l];
-        CHKM(ensure(c, r, r.scratch, words * sizeof(u64) + (Gs + 1) * link_bytes + 256));
-        base[l] = static_cast<u64 *>(r.scratch.p);
+        CHKM(ensure(c, r, r.pre, words * sizeof(u64) + (Gs + 1) * link_bytes + 256));
+        base[l] = static_cast<u64 *>(r.pre.p);
         HIPM(c, hipSetDevice(r.device));
         HIPM(c, hipMemsetAsync(base[l], 0, words * sizeof(u64), r.comm));
         hipLaunchKernelGGL(pattern_kernel, dim3(64), dim3(256), 0, r.comm, base[l], (u64)W, (u64)(1000 + r.global));                       // all-gather

@@ -58,9 +58,20 @@ constexpr int hj_join_waves_per_simd(int block, int log2slots)
     return w < 1 ? 1 : w;
 }
 
-template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE>
+// PIPE: the materialising instances' probe stream is software-pipelined by hand.  gfx950 counts loads and stores on
+// ONE in-order counter (vmcnt), so in the plain loop - loads of step n+1 issued after the stores of step n - waiting
+// for the next vectors also waits for the acknowledgement of every row store before them: a step costs load latency
+// PLUS store latency, per wave, with 4 waves per SIMD to hide it (profiles/r03_ab_emit.txt: 1.9 ms without the
+// stores, 4.4 ms with them, for 12 GB that a fill writes in 1.9 ms).  Here the loads of step n+1 are issued BEFORE step
+// n is probed and stored, and the wait for them names how many younger operations may stay in flight (the stores).
+// The compiler cannot express that (its waitcnt pass must assume the path without stores), so the loads are inline
+// assembly and the waits are placed by hand: `vmcnt(2 + 3)` after a step that left by emit4 (three stores), `vmcnt(2)`
+// otherwise - the two loads of the FOLLOWING step are always younger.  A wait that names too few younger operations
+// only waits longer; everything is drained before the registers are given back.
+template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) void join_kernel(JoinArgs a)
 {
+    static_assert(!PIPE || PACKED, "the pipelined probe stream reads packed tuples");
     constexpr uint32_t SLOTS = 1u << LOG2SLOTS;
     constexpr uint32_t MASK = SLOTS - 1;
     constexpr uint32_t CAP = SLOTS / 2;
@@ -95,6 +106,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     u64 acc_n = 0, acc_k = 0, acc_o = 0, acc_i = 0;
     uint32_t empty = 0;
     uint32_t q = 0;
+    bool step_stored3 = false;                   // PIPE: the last probe step left through emit4, i.e. issued three row stores (uniform)
 
     // ---- visit rows [fill_beg, fill_end) of the chunk-concatenated build partition q ----
     // rows below `from_row` were already inserted (from the prefetch registers)
@@ -162,6 +174,61 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     // ---- stream the S rows [gb, ge): BATCH key + BATCH payload vectors in flight per lane ----
     // `row0`: index of row gb among the probe rows of this work item (UNIQUE's `matched` bits)
     auto for_each_probe_vector = [&](u64 gb, u64 ge, u64 row0, auto probe4) {
+        if constexpr (PIPE) {
+            typedef uint32_t v4_t __attribute__((ext_vector_type(4)));
+            const u64 first = gb & ~3ull, stride = (u64)BLOCK * 4;
+            const u64 g_last = (ge - 1) & ~3ull;                     // last vector that overlaps the slice (ge > gb)
+            v4_t ak, av, bk, bv;
+            // the two 16-byte loads of the four tuples at base + 4 tid (clamped into the slice: every lane always loads)
+            auto issue = [&](v4_t &k, v4_t &v, u64 base) {
+                u64 g = base + (u64)tid * 4;
+                g = g < g_last ? g : g_last;
+                const uint4 *p = sk4 + (g >> 1);
+                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                             : "=&v"(k), "=&v"(v) : "v"(p) : "memory");
+            };
+            // k, v were requested one step ago; since then: that step's stores, then the two loads of the next step
+            auto arrive = [&](v4_t &k, v4_t &v) {
+                if (step_stored3) asm volatile("s_waitcnt vmcnt(5)" : "+v"(k), "+v"(v) : : "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" : "+v"(k), "+v"(v) : : "memory");
+            };
+            auto step = [&](const v4_t &k, const v4_t &v, u64 base) {
+                step_stored3 = false;
+                const u64 g = base + (u64)tid * 4;
+                const uint32_t key[4] = {k.x, k.z, v.x, v.z};
+                const uint32_t val[4] = {k.y, k.w, v.y, v.w};
+                bool valid[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) valid[j] = (g + j >= gb) && (g + j < ge);
+                if (UNIQUE && dedup) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t row = (uint32_t)(row0 + (g + j - gb));
+                        if (valid[j]) valid[j] = !((matched[row >> 5] >> (row & 31)) & 1u);
+                    }
+                    const uint32_t hits = probe4(key, val, valid);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t row = (uint32_t)(row0 + (g + j - gb));
+                        if ((hits >> j) & 1u) atomicOr(&matched[row >> 5], 1u << (row & 31));
+                    }
+                } else (void)probe4(key, val, valid);
+            };
+            step_stored3 = false;
+            issue(ak, av, first);
+            for (u64 base = first; base < ge; base += 2 * stride) {          // uniform trip count: every wave issues every load
+                issue(bk, bv, base + stride);
+                arrive(ak, av);
+                step(ak, av, base);
+                issue(ak, av, base + 2 * stride);
+                arrive(bk, bv);
+                if (base + stride < ge) step(bk, bv, base + stride);
+                else step_stored3 = false;
+            }
+            // nothing of this loop may still be on its way when the registers are reused
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ak), "+v"(av), "+v"(bk), "+v"(bv) : : "memory");
+            return;
+        }
         for (u64 g0 = (gb & ~3ull) + (u64)tid * 4; g0 < ge; g0 += (u64)BLOCK * 4 * BATCH) {
             uint4 kk[BATCH], vv[BATCH];
 #pragma unroll
@@ -240,7 +307,9 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
             // the wave's whole vector step as ONE run of 4 rows per lane (see Emitter::emit4) when every lane found
             // exactly one partner per key; otherwise key by key: one emit for "this key matched" (64 rows with
             // unique build keys), a second one only for a key found in BOTH slots
-            if (!(a.emit_vec && __all(one_each) && em.emit4(key, val, inner))) {
+            const bool by4 = a.emit_vec && __all(one_each) && em.emit4(key, val, inner);
+            if (PIPE && by4) step_stored3 = true;
+            if (!by4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
@@ -367,8 +436,10 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
         // build key equals, found once by broadcast_meta_kernel
         if (a.broadcast) empty = hj_uniform(*a.sentinel);
         else {
+            // (pre-partitioned relations: p1_base shifts the pass-1 partition; values of other ranks' partitions wrap to
+            // numbers far above P and never equal q)
             empty = 0;
-            while (hj_part2(empty, a.f1, a.F1, a.f2, a.F2) == q) ++empty;
+            while ((hj_hash(empty, a.f1, a.F1) - a.p1_base) * a.F2 + hj_hash(empty, a.f2, a.F2) == q) ++empty;
         }
         const u64 EMPTY64 = (u64)empty;
         if (UNIQUE) {
@@ -516,6 +587,12 @@ int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
     return join_grid(cus, c) * (c.block / 64);
 }
 
+// the materialising instances with the hand-pipelined probe stream (option "emit_pipe", on by default)
+#define JOIN_CASE_PIPE(B, L, U, UNQ)                                                              \
+    if (c.block == B && c.log2slots == L && c.batch == U && (b.unique != 0) == UNQ && b.packed && b.ok && t.emit_pipe) {      \
+        hipLaunchKernelGGL((join_kernel<B, L, U, true, UNQ, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);          \
+        return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
+    }
 #define JOIN_CASE(B, L, U, UNQ)                                                                   \
     if (c.block == B && c.log2slots == L && c.batch == U && (b.unique != 0) == UNQ) {             \
         if (b.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true, UNQ>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
@@ -544,6 +621,10 @@ int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t st
     b.force_chained = t.force_chained ? 1u : 0u;       // tests: exercise the fallback table everywhere
     b.unique = (a.unique || t.unique) ? 1u : 0u;
     b.emit_vec = t.emit_vec ? 1u : 0u;
+    // (no _UNIQUE instances: at the 128-register cap they spill ~25 VGPRs, and a spilled in-flight register of the
+    // hand-placed loads would be stored before its data has arrived; tools/kernel_resources.py must show spill v0 here)
+    JOIN_CASE_PIPE(512, 13, 2, false)
+    JOIN_CASE_PIPE(1024, 14, 2, false)
     JOIN_CASE(512, 13, 2, false)
     JOIN_CASE(512, 13, 2, true)
     JOIN_CASE(512, 13, 1, false)

@@ -223,6 +223,78 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
 }
 
 // --------------------------------------------------------------------------
+// K4p: fused histogram of PRE-PARTITIONED packed tuples.  The receiving side of the multi-GPU CPRA gets its share of
+// a relation pass-1-partitioned already - the exchange-level partitioning of the senders' own chunks IS pass 1
+// (cpra2.cpp:1757-1827; ownership 1868-1872) - as `chunks` pieces (one per source rank), each holding this rank's
+// pass-1 partitions [p1_base, p1_base + F1) in order.  What pass 2 and the join still need are the counts per
+// (chunk, final partition): bin = (H(key, f1, F1tot) - p1_base) * F2 + H(key, f2, F2), one read of the tuples.
+// grid = (workgroups per chunk, chunks); counts[chunk][F1 * F2] must be zeroed by the caller.
+// --------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hist_packed_kernel(const u64 *__restrict__ tuples, HjChunks ch,
+                                                            uint32_t f1, uint32_t F1tot, uint32_t p1_base, uint32_t F1,
+                                                            uint32_t f2, uint32_t F2, u64 *__restrict__ counts)
+{
+    extern __shared__ uint32_t lds_hist[];              // [F1 * F2]
+    const uint32_t P = F1 * F2;
+    const uint32_t chunk = blockIdx.y;
+    u64 cb = 0, ce = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q == (int)chunk) { cb = ch.b[q]; ce = ch.b[q + 1]; }
+    counts += (u64)chunk * P;
+    for (uint32_t i = threadIdx.x; i < P; i += BLOCK) lds_hist[i] = 0;
+    __syncthreads();
+    const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(tuples);     // two tuples per 16 bytes
+    constexpr int U = 4;                                // vectors per lane in flight
+    const u64 first = cb & ~1ull;                       // the 16-byte vector that holds the chunk's first tuple
+    const u64 step = (u64)BLOCK * 2 * U;
+    auto add = [&](uint32_t key) {
+        const uint32_t p1 = hj_hash(key, f1, F1tot) - p1_base;
+        const uint32_t bin = p1 * F2 + hj_hash(key, f2, F2);
+        if (p1 < F1) atomicAdd(&lds_hist[bin], 1u);     // a tuple of another rank's partitions cannot be here; never index outside
+    };
+    for (u64 base = first + (u64)blockIdx.x * step; base < ce; base += (u64)gridDim.x * step) {
+        uint4 v[U];
+        const bool whole = base >= cb && base + step <= ce;                     // uniform: no per-tuple predicates
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u64 g = base + ((u64)u * BLOCK + threadIdx.x) * 2;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (whole || g < ce) v[u] = hj_load_nt(t4 + (g >> 1));              // read once
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u64 g = base + ((u64)u * BLOCK + threadIdx.x) * 2;
+            if (whole || (g >= cb && g < ce)) add(v[u].x);
+            if (whole || (g + 1 >= cb && g + 1 < ce)) add(v[u].z);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < P; i += BLOCK) {
+        const uint32_t c = lds_hist[i];
+        if (c) atomicAdd(&counts[i], (u64)c);
+    }
+}
+
+int hj_launch_hist_packed(const u64 *tuples, const HjChunks &ch, uint32_t f1, uint32_t F1tot, uint32_t p1_base,
+                          uint32_t F1, uint32_t f2, uint32_t F2, u64 *counts, int cus, hipStream_t stream)
+{
+    constexpr int BLOCK = 1024;
+    const uint32_t P = F1 * F2;
+    const size_t lds = (size_t)P * sizeof(uint32_t);
+    if (ch.chunks == 0 || ch.chunks > 8 || P == 0 || lds > 140 * 1024 || p1_base + F1 > F1tot) return HJGPU_EINVAL;
+    static HjPerDeviceOnce once;
+    if (hj_allow_dynamic_lds(reinterpret_cast<const void *>(&hist_packed_kernel<BLOCK>), 140 * 1024, &once) != HJGPU_OK)
+        return HJGPU_EHIP;
+    const uint32_t per_cu = (lds > 72 * 1024) ? 1 : 2;
+    uint32_t gx = ((uint32_t)cus * per_cu + ch.chunks - 1) / ch.chunks;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(hist_packed_kernel<BLOCK>, dim3(gx, ch.chunks), dim3(BLOCK), lds, stream, tuples, ch, f1, F1tot,
+                       p1_base, F1, f2, F2, counts);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+// --------------------------------------------------------------------------
 // K5b: per-range write bases of pass 1.  One workgroup per (chunk, partition):
 // base[range][p] = off1[chunk][p] + sum of the counts of earlier ranges of the chunk.
 // --------------------------------------------------------------------------
@@ -1217,6 +1289,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("scatter_prof")) return parse_flag(value, &t->scatter_prof);
     if (is("unique")) return parse_flag(value, &t->unique);
     if (is("emit_vec")) return parse_flag(value, &t->emit_vec);
+    if (is("emit_pipe")) return parse_flag(value, &t->emit_pipe);
     if (is("placement")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1266,7 +1339,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "emit_vec", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "emit_vec", "emit_pipe", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

@@ -298,6 +298,40 @@ int  hjgpu_phj_probe_async(hjgpu_ctx *ctx,
                            const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
                            hjgpu_result *d_result, void *stream);
 
+/* ---- PHJ over relations that ARRIVE pass-1-partitioned: the receiving side of the multi-GPU CPRA ---------------------
+ * In the reference every worker partitions its own chunk and the owner of a partition gathers that partition's slice
+ * from every chunk (cpra2.cpp:1757-1827 own-chunk passes, 1868-1872 ownership, 1891-1959 gather): the own-chunk
+ * partitioning IS the join's partitioning.  Across GPUs the same holds when the exchange-level partitioning is pass 1:
+ *   sender    hjgpu_partition_packed_async: own chunk -> packed tuples (payload << 32 | key, 8 bytes) partitioned with
+ *             fan-out G * k, H(key, factor, G * k); rank g owns partitions [g * k, (g + 1) * k): ONE contiguous message
+ *             per destination (keys and payloads travel together: one all-to-all-v instead of two);
+ *   receiver  gets `chunks` pieces (one per source rank), each holding its k partitions in order, and runs pass 2 +
+ *             build / probe only: hjgpu_phj_build_prepartitioned prepares the received build side once (fused histogram
+ *             over the pieces, pass 2 into line-aligned final partitions), hjgpu_phj_probe_prepartitioned_async joins
+ *             one received probe batch against it (results add up over the batches).
+ * 16 bytes per tuple less HBM traffic on the receiver than partitioning the received tuples from scratch.
+ * d_tuples_out of the sender must be 128-byte aligned; d_offsets: fanout + 1 uint64 (rows).  The receiver's pieces are
+ * rows [chunk_offsets[c], chunk_offsets[c + 1]) of ONE array (contiguous, e.g. a receive buffer); a batch that is
+ * too large for max_outer is passed in several calls, each a contiguous row range cut at any row (a piece of a
+ * piece is still sorted by partition): pieces that do not take part have chunk_offsets[c] == chunk_offsets[c + 1]. */
+typedef struct {
+    uint32_t factor1;           /* the exchange-level pass: p1 = H(key, factor1, fanout1_total)                  */
+    uint32_t fanout1_total;     /* G * k, <= 1024                                                                */
+    uint32_t first_partition;   /* this rank owns pass-1 partitions [first_partition, first_partition + fanout1) */
+    uint32_t fanout1;           /* k                                                                             */
+    uint32_t chunks;            /* pieces (source ranks), 1..8                                                   */
+    uint32_t reserved;
+    uint64_t chunk_offsets[9];  /* rows; non-decreasing; entries beyond [chunks] are ignored                      */
+} hjgpu_prepartitioned;
+int  hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                                  uint32_t factor, uint32_t fanout, uint64_t *d_tuples_out, uint64_t *d_offsets,
+                                  void *stream);
+int  hjgpu_phj_build_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *layout,
+                                    size_t max_outer, const hjgpu_phj_params *params /* fanout2, factor2, table factors, flags */,
+                                    void *stream);
+int  hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *layout,
+                                          hjgpu_result *d_result, void *stream);
+
 /* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
  * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates.
  * The upload runs on its own stream: probe side first, build side behind it; PHJ / CPRA

@@ -378,7 +378,9 @@ def test_full_size_property_two_ranks_64m_by_200m_each(worlds):
         shards.append((c[0], c[1], inner // 2, c[2], c[3], outer // 2))
     got, st = comm.cpra_multi(shards, None, 4)
     assert list(got) == expect
-    assert st["joins"] == 5 and st["tuples_joined"] > 0 and st["ms_exchange"] > 0
+    # measured local joins of rank 0: the build and the last probe batch (reading every slice's phase times would hold
+    # the host thread back: include/hjgpu.h, hjgpu_multi_stats.join)
+    assert st["joins"] == 2 and st["tuples_joined"] > 0 and st["ms_exchange"] > 0 and st["join"]["ms_join"] > 0
     # replicated build: the whole build side on rank 0
     ctx = comm.ctx[0]
     rk, rv = ctx.column(inner), ctx.column(inner)

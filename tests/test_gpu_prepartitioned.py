@@ -1,0 +1,105 @@
+"""GPU tests of PHJ over relations that ARRIVE pass-1-partitioned (hjgpu_partition_packed_async,
+hjgpu_phj_build_prepartitioned, hjgpu_phj_probe_prepartitioned_async): the receiving side of the multi-GPU CPRA, where
+the exchange-level partitioning of every sender's own chunk IS pass 1 (cpra2.cpp:1757-1827, ownership 1868-1872, gather
+1891-1959).  Here ONE GPU plays every sender and every receiver in turn; the host moves the "messages"."""
+import numpy as np
+import pytest
+
+import hash_join_codes_knl_amd as H
+from helpers import mulhi_hash, numpy_join
+
+pytestmark = pytest.mark.gpu
+FACTOR1 = 0x2C1B3C6D
+
+
+def bounds(n, parts, alignment=16):
+    part = (n // parts) & ~(alignment - 1)
+    return [(part * t, n if t + 1 == parts else part * (t + 1)) for t in range(parts)]
+
+
+def send(hj, keys, vals, chunks, fanout):
+    """every sender partitions its own chunk: [(packed tuples, offsets[fanout + 1])] per chunk"""
+    out = []
+    for b, e in bounds(len(keys), chunks):
+        n = e - b
+        dk, dv = hj.column(np.concatenate([keys[b:e], np.zeros(1, np.uint32)])), hj.column(np.concatenate([vals[b:e], np.zeros(1, np.uint32)]))
+        dt, do = hj.column(n + 16, np.uint64), hj.column(fanout + 1, np.uint64)
+        hj.partition_packed_async(dk, dv, n, FACTOR1, fanout, dt, do)
+        hj.synchronize()
+        t, o = dt.download(n), do.download()
+        # the operator's contract: partition p of the chunk = rows [o[p], o[p + 1]), every tuple in its partition
+        assert o[0] == 0 and o[-1] == n and np.all(np.diff(o.astype(np.int64)) >= 0)
+        p = mulhi_hash((t & np.uint64(0xFFFFFFFF)).astype(np.uint32), FACTOR1, fanout)
+        assert np.array_equal(p, np.repeat(np.arange(fanout), np.diff(o.astype(np.int64))))
+        assert np.array_equal(np.sort(t), np.sort((vals[b:e].astype(np.uint64) << np.uint64(32)) | keys[b:e].astype(np.uint64)))
+        out.append((t, o.astype(np.int64)))
+        for c in (dk, dv, dt, do):
+            c.free()
+    return out
+
+
+def received(sent, g, k):
+    """what rank g gets: from every chunk its partitions [g k, (g + 1) k), back to back; chunk offsets"""
+    pieces = [t[o[g * k]:o[(g + 1) * k]] for t, o in sent]
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in pieces])])
+    return (np.concatenate(pieces) if pieces else np.zeros(0, np.uint64)), offs
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 3, 8])
+@pytest.mark.parametrize("kind", ["unique", "dups", "half", "tiny"])
+def test_prepartitioned_relations_join_like_the_whole_relations(hj, oracle, ranks, kind):
+    ik, iv, ok, ov = {"unique": lambda: oracle.generate(300_007, 61_003, seed=ranks),
+                      "dups": lambda: oracle.generate(40_000, 250_000, seed=ranks),
+                      "half": lambda: oracle.generate(200_000, 90_000, selectivity=0.5, seed=ranks),
+                      "tiny": lambda: oracle.generate(37, 5, seed=ranks)}[kind]()
+    want = numpy_join(ik, iv, ok, ov)
+    k = max(1, 192 // ranks)
+    fanout = ranks * k
+    sent_r, sent_s = send(hj, ik, iv, ranks, fanout), send(hj, ok, ov, ranks, fanout)
+    total = [0, 0, 0, 0]
+    d_res = hj.column(4, np.uint64)
+    for g in range(ranks):
+        tr, offr = received(sent_r, g, k)
+        ts, offs = received(sent_s, g, k)
+        dr, ds = hj.column(np.concatenate([tr, np.zeros(2, np.uint64)]), np.uint64), hj.column(np.concatenate([ts, np.zeros(2, np.uint64)]), np.uint64)
+        max_outer = max(len(ts), 1 << 16)
+        hj.phj_build_prepartitioned(dr, hj.prepartitioned(FACTOR1, fanout, g * k, k, offr), max_outer)
+        # the probe side in two batches cut at an arbitrary row (a piece of a piece is still sorted by partition)
+        cut = (len(ts) * 3) // 7
+        for lo, hi in ((0, cut), (cut, len(ts))):
+            lay = hj.prepartitioned(FACTOR1, fanout, g * k, k, np.clip(offs, lo, hi))
+            hj.phj_probe_prepartitioned_async(ds, lay, d_res)
+            hj.get_async_status()
+            total = [(a + int(b)) & ((1 << 64) - 1) for a, b in zip(total, d_res.download())]
+        dr.free(); ds.free()
+    d_res.free()
+    assert tuple(total) == want, (ranks, kind)
+
+
+def test_prepartitioned_layout_errors(hj, oracle):
+    ik, iv, ok, ov = oracle.generate(5_000, 1_000, seed=1)
+    sent = send(hj, ik, iv, 2, 8)
+    t, offs = received(sent, 0, 4)
+    d = hj.column(np.concatenate([t, np.zeros(2, np.uint64)]), np.uint64)
+    d_res = hj.column(4, np.uint64)
+    for bad in (hj.prepartitioned(FACTOR1 + 1, 8, 0, 4, offs),            # even factor
+                hj.prepartitioned(FACTOR1, 8, 6, 4, offs),                # partitions beyond the fan-out
+                hj.prepartitioned(FACTOR1, 8, 0, 4, offs[::-1])):         # offsets decrease
+        with pytest.raises(H.HjGpuError) as e:
+            hj.phj_build_prepartitioned(d, bad, 1 << 16)
+        assert e.value.status == H.api.EINVAL
+    hj.phj_build_prepartitioned(d, hj.prepartitioned(FACTOR1, 8, 0, 4, offs), 1 << 16)
+    with pytest.raises(H.HjGpuError) as e:                                # another layout than the prepared build side's
+        hj.phj_probe_prepartitioned_async(d, hj.prepartitioned(FACTOR1, 8, 4, 4, offs), d_res)
+    assert e.value.status == H.api.EINVAL and "layout" in str(e.value)
+    with pytest.raises(H.HjGpuError) as e:                                # batch beyond max_outer
+        hj.phj_probe_prepartitioned_async(d, hj.prepartitioned(FACTOR1, 8, 0, 4, [0, 1 << 20, 1 << 21]), d_res)
+    assert e.value.status == H.api.EINVAL
+    # a plain prepared build side is not a pre-partitioned one
+    rk, rv = hj.column(ik), hj.column(iv)
+    hj.phj_build(rk, rv, len(ik), 1 << 16)
+    with pytest.raises(H.HjGpuError) as e:
+        hj.phj_probe_prepartitioned_async(d, hj.prepartitioned(FACTOR1, 8, 0, 4, offs), d_res)
+    assert e.value.status == H.api.EINVAL
+    for c in (d, d_res, rk, rv):
+        c.free()

@@ -35,8 +35,9 @@ def main():
         out = (jk, jo, ji, cap, block)
     agg = {c: [] for c in a.cfgs}
     total = {c: [] for c in a.cfgs}
-    rows = {(c, e): [] for c in a.cfgs for e in (0, 1)}
-    gaps = {(c, e): [] for c in a.cfgs for e in (0, 1)}
+    modes = [(0, 0), (1, 0), (0, 1), (1, 1)]              # (emit_vec, emit_pipe)
+    rows = {(c, e): [] for c in a.cfgs for e in modes}
+    gaps = {(c, e): [] for c in a.cfgs for e in modes}
     for rnd in range(a.rounds + 1):
         for c in a.cfgs:
             hj.set_option("join_cfg", c)
@@ -47,14 +48,17 @@ def main():
                     agg[c].append(st["ms_join"])
                     total[c].append(st["ms_total"])
             if out:
-                for e in (0, 1):
-                    hj.set_option("emit_vec", e)
+                for e in modes:
+                    hj.set_option("emit_vec", e[0])
+                    hj.set_option("emit_pipe", e[1])
                     assert hj.phj(ik, iv, inner, ok, ov, outer, out=out) == want, (c, e)
                     st = hj.stats()
+                    assert hj.column_sums(jk, outer, 1, 1)[0] == want[1], (c, e)      # the rows themselves (resets the stats)
                     if rnd:
                         rows[(c, e)].append(st["ms_join"])
                         gaps[(c, e)].append(st["ms_close_gaps"])
                 hj.set_option("emit_vec", 1)
+                hj.set_option("emit_pipe", 1)
     if out:
         assert hj.column_sums(jk, outer, 1, 1)[0] == want[1]
     rw = 8 * (inner + outer) + 12 * outer
@@ -63,11 +67,11 @@ def main():
             c, statistics.median(agg[c]), min(agg[c]), 8 * (inner + outer) / (statistics.median(agg[c]) * 1e-3) / 8e12,
             statistics.median(total[c]))
         if out:
-            for e in (0, 1):
+            for e in modes:
                 m = statistics.median(rows[(c, e)])
                 g = statistics.median(gaps[(c, e)])
-                line += " | rows emit_vec=%d: join med %.3f min %.3f + gaps %.3f (r+w %.3f of 8 TB/s)" % (
-                    e, m, min(rows[(c, e)]), g, rw / ((m + g) * 1e-3) / 8e12)
+                line += "\n    rows emit_vec=%d emit_pipe=%d: join med %.3f min %.3f + gaps %.3f (r+w %.3f of 8 TB/s)" % (
+                    e[0], e[1], m, min(rows[(c, e)]), g, rw / ((m + g) * 1e-3) / 8e12)
         print(line, flush=True)
 
 

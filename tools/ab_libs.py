@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--algo", default="phj")
     ap.add_argument("--no-check", action="store_true", help="timing experiments with deliberately wrong variants")
     ap.add_argument("--sequential", action="store_true", help="one measured context at a time, same allocations for all")
+    ap.add_argument("--rows", action="store_true", help="materialise the result (three columns shared by all builds)")
     a = ap.parse_args()
     import hash_join_codes_knl_amd as H
     from hash_join_codes_knl_amd import api
@@ -38,14 +39,19 @@ def main():
     hj.generate(1, a.inner, a.outer, 0, a.outer, 0x2545F491, 0x9E3779B1, ik, iv, ok, ov)
     sums = hj.column_sums(ok, a.outer, 0x9E3779B1, 0x2545F491)
     want = (a.outer, sums[0], sums[1], sums[2])
-    phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join", "ms_build"]
+    phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join", "ms_build", "ms_close_gaps"]
+    kw = {}
+    if a.rows:
+        block = 16384
+        cap = ((a.outer + block - 1) // block + 4096 + 8) * block
+        kw["out"] = (hj.column(cap), hj.column(cap), hj.column(cap), cap, block)
     data = {p: {ph: [] for ph in phases} for p in a.libs}
     for rnd in range(a.rounds if a.sequential else 0):
         for path in a.libs:
             c = make(path)
             c.set_option("placement", "1")
             for rep in range(a.reps + 1):
-                got = getattr(c, a.algo)(ik, iv, a.inner, ok, ov, a.outer)
+                got = getattr(c, a.algo)(ik, iv, a.inner, ok, ov, a.outer, **kw)
                 assert a.no_check or got == want, (path, got, want)
                 st = c.stats()
                 if rep > 0:                  # the first join allocates the workspace
@@ -55,7 +61,7 @@ def main():
     for rnd in range(0 if a.sequential else a.rounds):
         for path, c in zip(a.libs, ctxs):
             for _ in range(a.reps):
-                got = getattr(c, a.algo)(ik, iv, a.inner, ok, ov, a.outer)
+                got = getattr(c, a.algo)(ik, iv, a.inner, ok, ov, a.outer, **kw)
                 assert a.no_check or got == want, (path, got, want)
                 st = c.stats()
                 if rnd > 0 or a.rounds == 1:

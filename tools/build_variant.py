@@ -45,7 +45,7 @@ def main():
                                    "-DHJGPU_KERNEL_HASH=\"%s\"" % name] + defines + ["-c", s, "-o", o])
             objs.append(o)
         so = os.path.join(out_dir, name + ".so")
-        subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", so] + objs + ["-L/opt/rocm/lib", "-lrccl"])
+        subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", so] + objs + ["-ldl"])
         print("built", so)
 
 
