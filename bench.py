@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 INNER_FACTOR, OUTER_FACTOR = 0x2545F491, 0x9E3779B1
 # PMC traffic of the kernels (tools/collect_traffic.py): THIS file, and only while its kernel hash is the
 # running library's (hjgpu_kernel_hash) and it was taken on the workload being run
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 MASK64 = (1 << 64) - 1
 
 
@@ -557,8 +557,12 @@ def main():
         out["secondary"] = sec
         # rows (key, outer payload, inner payload) written through the block
         # protocol, compacted by close_gaps; priced against read + written bytes.
-        block = 16384
-        cap = ((outer + block - 1) // block + 4096 + 8) * block
+        # block size of the output protocol (npj.cpp:244-246 claims 65 536-row blocks per thread): a free parameter of
+        # hjgpu_output.  Every wave leaves one partly filled block for close_gaps to compact, so smaller blocks mean
+        # less to move (profiles/r03_ab_emit.txt: 65536 -> 0.60 ms of close_gaps, 16384 -> 0.21, 4096 -> 0.12; at 1024
+        # the claims themselves cost 8 ms)
+        block = 4096
+        cap = ((outer + block - 1) // block + 8192 + 8) * block
         jk, jo, ji = (torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(3))
         mt = {"ms_join": [], "ms_close_gaps": [], "ms_total": []}
         for _ in range(3):
@@ -578,7 +582,7 @@ def main():
                                "gtuples_per_s": round(outer / min(mt["ms_total"]) / 1e6, 2),
                                "join_phase_rw_GBs": round((8 * n_tuples + 12 * j) / (tj * 1e-3) / 1e9, 1),
                                "join_phase_rw_frac": round((8 * n_tuples + 12 * j) / (tj * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "rows_checksum_ok": bool(ok_rows)}
+                               "block_size": block, "rows_checksum_ok": bool(ok_rows)}
         del jk, jo, ji
     if rank == 0 and args.cpu_outer > 0:
         try:

@@ -55,8 +55,7 @@ struct HjTuning {
     bool force_chained = false;     // "force_chained": chained fallback tables everywhere (tests)
     bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
-    bool emit_vec = true;           // "emit_vec": materialised rows leave as 16-byte stores (4 rows per lane) where every lane matched
-    bool emit_pipe = true;          // "emit_pipe": materialising joins run the instances with the hand-pipelined probe stream
+    bool merged_plan = true;        // "merged_plan": whole joins on resident columns plan both relations with one set of K5 launches
     int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
@@ -148,7 +147,6 @@ struct JoinArgs {
     const uint32_t *sentinel;
     uint32_t force_chained;              // tests: skip the cuckoo fast path (option "force_chained")
     uint32_t unique;                     // _UNIQUE (npj.cpp:288-290): a probe key reports its first match only
-    uint32_t emit_vec;                   // materialised rows: four rows per lane and store where every lane matched (option "emit_vec")
 };
 
 struct PlanArgs {

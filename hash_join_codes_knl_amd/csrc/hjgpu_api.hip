@@ -440,7 +440,7 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     if (big_override >= 0) pl->big_tables = big_override != 0;
     if (pl->unique && !hj_join_config_built(hj_join_config_of(ctx->tune, pl->big_tables), true))
         return fail(ctx, HJGPU_EINVAL, "HJGPU_FLAG_UNIQUE: the join_cfg geometry of this context has no _UNIQUE instance "
-                                       "(built: 512,13,2 / 1024,14,2 / 384,13,3 / 384,13,4)");
+                                       "(built: 512,13,2 / 1024,14,2)");
     pl->P = pl->F1 * pl->F2;
     if (pl->F1 < 1 || pl->F2 < 1 || pl->F1 > HJGPU_MAX_FANOUT || pl->F2 > HJGPU_MAX_FANOUT ||
         pl->P < 2 || pl->P > HJGPU_MAX_PARTS)
@@ -570,6 +570,40 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.cap = (uint32_t)hj_join_config_of(ctx->tune, pl.big_tables).cap();
 
     uint32_t batches_used = 0;
+    // the stages of one relation's partitioning
+    auto k4 = [&](int r) -> int {          // one read of the key column gives the histograms of both passes
+        if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
+                                       m.range_counts[r], m.tickets + 8 * r, ctx->cus, stream));
+        return HJGPU_OK;
+    };
+    auto k5b = [&](int r) -> int {
+        if (nn[r]) CHK(hj_launch_range_base(m.range_counts[r], m.off1[r], m.range_base[r], pl.C,
+                                            geom[r].ranges_per_chunk, pl.F1, stream));
+        return HJGPU_OK;
+    };
+    auto pass1 = [&](int r) -> int {       // K6 pass 1: caller's columns -> tmp[0..3]
+        if (!nn[r]) return HJGPU_OK;
+        ScatterArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
+        sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
+        sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
+        sa.ranged = 1; sa.work_counter = m.tickets + 16 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
+        sa.in_packed = 0; sa.out_packed = 1;
+        return hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream);
+    };
+    auto pass2 = [&](int r) -> int {       // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
+        if (!nn[r] || pl.F2 <= 1) return HJGPU_OK;
+        ScatterArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
+        sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
+        sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
+        sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
+        sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
+        sa.in_packed = 1; sa.out_packed = 1;
+        return hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream);
+    };
     // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
     auto partition_relation = [&](int r, uint32_t plan_mask, const int ev[4]) -> int {
         if (pre) {
@@ -597,9 +631,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             record(ctx, ev[3], stream);
             return HJGPU_OK;
         }
-        // K4: one read of the key column gives the histograms of both passes
-        if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
-                                       m.range_counts[r], m.tickets + 8 * r, ctx->cus, stream));
+        CHK(k4(r));
         record(ctx, ev[0], stream);
         // K5 (+ the join's work items once both histograms exist), K5b
         pa.mask = plan_mask;
@@ -650,43 +682,41 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             batches_used = batches;
             return HJGPU_OK;
         }
-        if (nn[r]) CHK(hj_launch_range_base(m.range_counts[r], m.off1[r], m.range_base[r], pl.C,
-                                            geom[r].ranges_per_chunk, pl.F1, stream));
+        CHK(k5b(r));
         record(ctx, ev[1], stream);
-        // K6 pass 1: caller's columns -> tmp[0..3]
-        if (nn[r]) {
-            ScatterArgs sa;
-            memset(&sa, 0, sizeof(sa));
-            sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
-            sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
-            sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
-            sa.ranged = 1; sa.work_counter = m.tickets + 16 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
-            sa.in_packed = 0; sa.out_packed = 1;
-            CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
-        }
+        CHK(pass1(r));
         record(ctx, ev[2], stream);
-        // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
-        if (nn[r] && pl.F2 > 1) {
-            ScatterArgs sa;
-            memset(&sa, 0, sizeof(sa));
-            sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
-            sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
-            sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
-            sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
-            sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
-            sa.in_packed = 1; sa.out_packed = 1;
-            CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
-        }
+        CHK(pass2(r));
         record(ctx, ev[3], stream);
         return HJGPU_OK;
     };
     const int ev_s[4] = {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2};
     const int ev_r[4] = {EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2};
-    if (mode != PHJ_BUILD_ONLY) CHK(partition_relation(1, 2u, ev_s));       // probe side first
-    else for (int e : ev_s) record(ctx, e, stream);
+    // Both relations are there from the start (hjgpu_phj / hjgpu_cpra on resident columns: nothing to wait for): their
+    // stages run side by side - K4 of R and S, then ONE set of K5 launches that plans both relations and the join's work
+    // items (the plan kernels are single-workgroup, latency-bound: two sets cost twice the latency, 0.15 ms per step),
+    // then pass 1 of both, then pass 2 of both.  The phase events are recorded at the stage boundaries, so
+    // hjgpu_get_stats keeps its meaning (histogram / plan / pass 1 / pass 2 of R and S together).
+    const bool merged = mode == PHJ_WHOLE && !inner_ready && !pre && !pl.batch_ranges && ctx->tune.merged_plan;
+    if (merged) {
+        CHK(k4(0)); CHK(k4(1));
+        record(ctx, EV_S_HIST, stream);
+        pa.mask = 7u;
+        CHK(hj_launch_plan(pa, stream));
+        CHK(k5b(0)); CHK(k5b(1));
+        record(ctx, EV_S_PLAN, stream);
+        CHK(pass1(0)); CHK(pass1(1));
+        record(ctx, EV_S_SC1, stream);
+        CHK(pass2(0)); CHK(pass2(1));
+        record(ctx, EV_S_SC2, stream);
+        record(ctx, EV_WAITED, stream);
+        for (int e : ev_r) record(ctx, e, stream);
+    }
+    if (!merged && mode != PHJ_BUILD_ONLY) CHK(partition_relation(1, 2u, ev_s));       // probe side first
+    else if (!merged) for (int e : ev_s) record(ctx, e, stream);
     if (inner_ready) HIPCHK(ctx, hipStreamWaitEvent(stream, inner_ready, 0));
-    record(ctx, EV_WAITED, stream);
-    if (mode == PHJ_WHOLE) CHK(partition_relation(0, 1u | 4u, ev_r));       // build side + join work items
+    if (!merged) record(ctx, EV_WAITED, stream);
+    if (!merged && mode == PHJ_WHOLE) CHK(partition_relation(0, 1u | 4u, ev_r));       // build side + join work items
     if (mode == PHJ_BUILD_ONLY) CHK(partition_relation(0, 1u, ev_r));       // build side; work items come with a probe
     if (mode == PHJ_PROBE_ONLY) {
         // the build side was partitioned by hjgpu_phj_build: only the work items are missing
@@ -932,7 +962,7 @@ int hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value)
     if (!hj_join_config_built(t.join, false))
         return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: join_cfg names a geometry that is not built");
     if (t.unique && !hj_join_config_built(t.join, true))
-        return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: this join_cfg geometry has no _UNIQUE instance (built: 512,13,2 / 1024,14,2 / 384,13,3 / 384,13,4)");
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: this join_cfg geometry has no _UNIQUE instance (built: 512,13,2 / 1024,14,2)");
     ctx->tune = t;
     ctx->prepared = false;                   // a prepared build side was planned under the old options
     return HJGPU_OK;

@@ -44,8 +44,10 @@
 // are then planned as ONE fill group: all fills of a probe slice stay with one workgroup).
 // Waves per SIMD the geometry runs at: workgroups per CU (LDS: one table + ~10 KiB each in 160 KiB; threads: 2048
 // per CU) x waves per workgroup / 4 SIMDs.  It is the second argument of __launch_bounds__ (HIP: minimum waves per
-// execution unit), i.e. the register budget: 512 / waves VGPRs per lane.  The probe stream's loads live in VGPRs, so
-// a geometry with fewer waves and more vectors per lane keeps more bytes in flight per CU.
+// execution unit), i.e. the register budget: 512 / waves VGPRs per lane.  More bytes in flight per lane at the price
+// of fewer waves does NOT pay here (round 3, profiles/r03_ab_emit.txt: 384 threads x 4 vectors at 3 waves per SIMD
+// 3.15 ms, 256 x 8 at 2 waves 2.74 ms, against 1.58 ms for 512 x 2 at 4 waves): K7+K8 is bound by instruction issue
+// and LDS latency, which only resident waves hide, not by the probe stream's bytes in flight.
 constexpr int hj_join_wgs_per_cu(int block, int log2slots)
 {
     const int by_lds = (160 * 1024) / ((1 << log2slots) * 8 + 1024 + 9 * 1024), by_threads = 2048 / block;
@@ -58,20 +60,9 @@ constexpr int hj_join_waves_per_simd(int block, int log2slots)
     return w < 1 ? 1 : w;
 }
 
-// PIPE: the materialising instances' probe stream is software-pipelined by hand.  gfx950 counts loads and stores on
-// ONE in-order counter (vmcnt), so in the plain loop - loads of step n+1 issued after the stores of step n - waiting
-// for the next vectors also waits for the acknowledgement of every row store before them: a step costs load latency
-// PLUS store latency, per wave, with 4 waves per SIMD to hide it (profiles/r03_ab_emit.txt: 1.9 ms without the
-// stores, 4.4 ms with them, for 12 GB that a fill writes in 1.9 ms).  Here the loads of step n+1 are issued BEFORE step
-// n is probed and stored, and the wait for them names how many younger operations may stay in flight (the stores).
-// The compiler cannot express that (its waitcnt pass must assume the path without stores), so the loads are inline
-// assembly and the waits are placed by hand: `vmcnt(2 + 3)` after a step that left by emit4 (three stores), `vmcnt(2)`
-// otherwise - the two loads of the FOLLOWING step are always younger.  A wait that names too few younger operations
-// only waits longer; everything is drained before the registers are given back.
-template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE, bool PIPE = false>
+template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE>
 __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) void join_kernel(JoinArgs a)
 {
-    static_assert(!PIPE || PACKED, "the pipelined probe stream reads packed tuples");
     constexpr uint32_t SLOTS = 1u << LOG2SLOTS;
     constexpr uint32_t MASK = SLOTS - 1;
     constexpr uint32_t CAP = SLOTS / 2;
@@ -106,7 +97,6 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     u64 acc_n = 0, acc_k = 0, acc_o = 0, acc_i = 0;
     uint32_t empty = 0;
     uint32_t q = 0;
-    bool step_stored3 = false;                   // PIPE: the last probe step left through emit4, i.e. issued three row stores (uniform)
 
     // ---- visit rows [fill_beg, fill_end) of the chunk-concatenated build partition q ----
     // rows below `from_row` were already inserted (from the prefetch registers)
@@ -174,61 +164,6 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     // ---- stream the S rows [gb, ge): BATCH key + BATCH payload vectors in flight per lane ----
     // `row0`: index of row gb among the probe rows of this work item (UNIQUE's `matched` bits)
     auto for_each_probe_vector = [&](u64 gb, u64 ge, u64 row0, auto probe4) {
-        if constexpr (PIPE) {
-            typedef uint32_t v4_t __attribute__((ext_vector_type(4)));
-            const u64 first = gb & ~3ull, stride = (u64)BLOCK * 4;
-            const u64 g_last = (ge - 1) & ~3ull;                     // last vector that overlaps the slice (ge > gb)
-            v4_t ak, av, bk, bv;
-            // the two 16-byte loads of the four tuples at base + 4 tid (clamped into the slice: every lane always loads)
-            auto issue = [&](v4_t &k, v4_t &v, u64 base) {
-                u64 g = base + (u64)tid * 4;
-                g = g < g_last ? g : g_last;
-                const uint4 *p = sk4 + (g >> 1);
-                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
-                             : "=&v"(k), "=&v"(v) : "v"(p) : "memory");
-            };
-            // k, v were requested one step ago; since then: that step's stores, then the two loads of the next step
-            auto arrive = [&](v4_t &k, v4_t &v) {
-                if (step_stored3) asm volatile("s_waitcnt vmcnt(5)" : "+v"(k), "+v"(v) : : "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" : "+v"(k), "+v"(v) : : "memory");
-            };
-            auto step = [&](const v4_t &k, const v4_t &v, u64 base) {
-                step_stored3 = false;
-                const u64 g = base + (u64)tid * 4;
-                const uint32_t key[4] = {k.x, k.z, v.x, v.z};
-                const uint32_t val[4] = {k.y, k.w, v.y, v.w};
-                bool valid[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) valid[j] = (g + j >= gb) && (g + j < ge);
-                if (UNIQUE && dedup) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t row = (uint32_t)(row0 + (g + j - gb));
-                        if (valid[j]) valid[j] = !((matched[row >> 5] >> (row & 31)) & 1u);
-                    }
-                    const uint32_t hits = probe4(key, val, valid);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t row = (uint32_t)(row0 + (g + j - gb));
-                        if ((hits >> j) & 1u) atomicOr(&matched[row >> 5], 1u << (row & 31));
-                    }
-                } else (void)probe4(key, val, valid);
-            };
-            step_stored3 = false;
-            issue(ak, av, first);
-            for (u64 base = first; base < ge; base += 2 * stride) {          // uniform trip count: every wave issues every load
-                issue(bk, bv, base + stride);
-                arrive(ak, av);
-                step(ak, av, base);
-                issue(ak, av, base + 2 * stride);
-                arrive(bk, bv);
-                if (base + stride < ge) step(bk, bv, base + stride);
-                else step_stored3 = false;
-            }
-            // nothing of this loop may still be on its way when the registers are reused
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ak), "+v"(av), "+v"(bk), "+v"(bv) : : "memory");
-            return;
-        }
         for (u64 g0 = (gb & ~3ull) + (u64)tid * 4; g0 < ge; g0 += (u64)BLOCK * 4 * BATCH) {
             uint4 kk[BATCH], vv[BATCH];
 #pragma unroll
@@ -287,8 +222,6 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
         }
         u64 sk_ = 0, so_ = 0, si_ = 0;
         uint32_t n = 0;
-        bool one_each = true;                        // every key of this lane's vector has exactly one match
-        uint32_t inner[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
@@ -300,23 +233,11 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
             so_ += (u64)val[j] * m;
             si_ += (h1 ? (uint32_t)(t1[j] >> 32) : 0u);
             si_ += (h2 ? (uint32_t)(t2[j] >> 32) : 0u);
-            one_each = one_each && (h1 != h2);
-            inner[j] = (uint32_t)((h1 ? t1[j] : t2[j]) >> 32);
-        }
-        if (a.ok) {
-            // the wave's whole vector step as ONE run of 4 rows per lane (see Emitter::emit4) when every lane found
-            // exactly one partner per key; otherwise key by key: one emit for "this key matched" (64 rows with
-            // unique build keys), a second one only for a key found in BOTH slots
-            const bool by4 = a.emit_vec && __all(one_each) && em.emit4(key, val, inner);
-            if (PIPE && by4) step_stored3 = true;
-            if (!by4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
-                    const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]) && !(UNIQUE && h1);
-                    if (h1 | h2) em.emit(key[j], val[j], inner[j]);
-                    if (h1 & h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
-                }
+            if (a.ok) {
+                // one emit for "this key matched" (with unique build keys that is every lane of the wave:
+                // 64 rows, the cursor moves in whole lines), a second one only for a key found in BOTH slots
+                if (h1 | h2) em.emit(key[j], val[j], (uint32_t)((h1 ? t1[j] : t2[j]) >> 32));
+                if (h1 & h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
             }
         }
         acc_n += n; acc_k += sk_; acc_o += so_; acc_i += si_;
@@ -587,12 +508,6 @@ int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
     return join_grid(cus, c) * (c.block / 64);
 }
 
-// the materialising instances with the hand-pipelined probe stream (option "emit_pipe", on by default)
-#define JOIN_CASE_PIPE(B, L, U, UNQ)                                                              \
-    if (c.block == B && c.log2slots == L && c.batch == U && (b.unique != 0) == UNQ && b.packed && b.ok && t.emit_pipe) {      \
-        hipLaunchKernelGGL((join_kernel<B, L, U, true, UNQ, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);          \
-        return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
-    }
 #define JOIN_CASE(B, L, U, UNQ)                                                                   \
     if (c.block == B && c.log2slots == L && c.batch == U && (b.unique != 0) == UNQ) {             \
         if (b.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true, UNQ>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
@@ -602,8 +517,7 @@ int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
 
 // The geometries that are built (option "join_cfg"): {block, log2slots, batch, a UNIQUE instance exists}.
 static const struct { int block, log2slots, batch; bool unique; } JOIN_BUILT[] = {
-    {512, 13, 2, true}, {512, 13, 1, false}, {512, 13, 3, false}, {512, 13, 4, false}, {1024, 14, 2, true},
-    {256, 12, 2, false}, {384, 13, 3, true}, {384, 13, 4, true}, {256, 13, 4, false}, {256, 13, 8, false},
+    {512, 13, 2, true}, {512, 13, 1, false}, {512, 13, 4, false}, {1024, 14, 2, true}, {256, 12, 2, false},
 };
 
 bool hj_join_config_built(const JoinConfig &c, bool unique)
@@ -620,24 +534,12 @@ int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t st
     JoinArgs b = a;
     b.force_chained = t.force_chained ? 1u : 0u;       // tests: exercise the fallback table everywhere
     b.unique = (a.unique || t.unique) ? 1u : 0u;
-    b.emit_vec = t.emit_vec ? 1u : 0u;
-    // (no _UNIQUE instances: at the 128-register cap they spill ~25 VGPRs, and a spilled in-flight register of the
-    // hand-placed loads would be stored before its data has arrived; tools/kernel_resources.py must show spill v0 here)
-    JOIN_CASE_PIPE(512, 13, 2, false)
-    JOIN_CASE_PIPE(1024, 14, 2, false)
     JOIN_CASE(512, 13, 2, false)
     JOIN_CASE(512, 13, 2, true)
     JOIN_CASE(512, 13, 1, false)
-    JOIN_CASE(512, 13, 3, false)
     JOIN_CASE(512, 13, 4, false)
     JOIN_CASE(1024, 14, 2, false)
     JOIN_CASE(1024, 14, 2, true)
     JOIN_CASE(256, 12, 2, false)
-    JOIN_CASE(384, 13, 3, false)
-    JOIN_CASE(384, 13, 3, true)
-    JOIN_CASE(384, 13, 4, false)
-    JOIN_CASE(384, 13, 4, true)
-    JOIN_CASE(256, 13, 4, false)
-    JOIN_CASE(256, 13, 8, false)
     return HJGPU_EINVAL;
 }

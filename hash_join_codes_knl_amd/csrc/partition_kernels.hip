@@ -1288,8 +1288,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("force_chained")) return parse_flag(value, &t->force_chained);
     if (is("scatter_prof")) return parse_flag(value, &t->scatter_prof);
     if (is("unique")) return parse_flag(value, &t->unique);
-    if (is("emit_vec")) return parse_flag(value, &t->emit_vec);
-    if (is("emit_pipe")) return parse_flag(value, &t->emit_pipe);
+    if (is("merged_plan")) return parse_flag(value, &t->merged_plan);
     if (is("placement")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1339,7 +1338,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "emit_vec", "emit_pipe", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

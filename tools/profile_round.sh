@@ -1,9 +1,9 @@
 #!/bin/bash
-# One round's profiling artefacts; run on the GPU box: tools/profile_round.sh <tag>   (e.g. r02)
+# One round's profiling artefacts; run on the GPU box: tools/profile_round.sh <tag>   (e.g. r03)
 # Writes gpurun_out/<tag>_*: rocprofv3 --kernel-trace --stats summaries of the PHJ headline run, NPJ, one-GPU CPRA and
 # the materialising PHJ, and the PMC traffic files (separate FETCH_SIZE / WRITE_SIZE passes, tools/collect_traffic.py).
 # Copy what is to be judged into profiles/.
-tag=${1:-r02}
+tag=${1:-r03}
 root=$GRAFT_REPO_ROOT
 [ -z "$root" ] && root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out
