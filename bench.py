@@ -473,6 +473,9 @@ def main():
         "checksum_ok": checksum_ok,
         "result": {"count": got[0], "sum_keys": got[1], "sum_outer_vals": got[2], "sum_inner_vals": got[3]},
         "device": info["name"], "arch": info["arch"],
+        # wall clock this context spent growing its workspace before the timed region (allocations + the placement search
+        # for the probe side's pass-1 twin: up to 12 candidate blocks of 8.5 GB held and filled twice, hjgpu_stats.ms_reserve)
+        "workspace": {"ms_reserve": round(hj.stats()["ms_reserve"], 1)},
     }
     if multi:
         k = len(multi_steps)

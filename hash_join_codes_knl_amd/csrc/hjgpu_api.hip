@@ -440,7 +440,7 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     if (big_override >= 0) pl->big_tables = big_override != 0;
     if (pl->unique && !hj_join_config_built(hj_join_config_of(ctx->tune, pl->big_tables), true))
         return fail(ctx, HJGPU_EINVAL, "HJGPU_FLAG_UNIQUE: the join_cfg geometry of this context has no _UNIQUE instance "
-                                       "(built: 512,13,2 / 1024,14,2)");
+                                       "(geometries with one: 512,13,2 and 1024,14,2)");
     pl->P = pl->F1 * pl->F2;
     if (pl->F1 < 1 || pl->F2 < 1 || pl->F1 > HJGPU_MAX_FANOUT || pl->F2 > HJGPU_MAX_FANOUT ||
         pl->P < 2 || pl->P > HJGPU_MAX_PARTS)
@@ -962,7 +962,7 @@ int hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value)
     if (!hj_join_config_built(t.join, false))
         return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: join_cfg names a geometry that is not built");
     if (t.unique && !hj_join_config_built(t.join, true))
-        return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: this join_cfg geometry has no _UNIQUE instance (built: 512,13,2 / 1024,14,2)");
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: this join_cfg geometry has no _UNIQUE instance (geometries with one: 512,13,2 and 1024,14,2)");
     ctx->tune = t;
     ctx->prepared = false;                   // a prepared build side was planned under the old options
     return HJGPU_OK;

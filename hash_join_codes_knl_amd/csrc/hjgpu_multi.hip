@@ -116,6 +116,7 @@ struct Rank {
     hipEvent_t ev_xchg[2] = {nullptr, nullptr};       // receive buffers of slot b filled
     hipEvent_t ev_join[2] = {nullptr, nullptr};       // receive buffers of slot b joined (free again)
     hipEvent_t ev_rx = nullptr;                       // build side received (CPRA)
+    hipEvent_t ev_dbg = nullptr;                      // option "debug_serialize"
     hipEvent_t ev_up_s = nullptr, ev_up_r = nullptr;  // host path: probe shard / build columns uploaded
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;      // host path: first kernel of the join started / upload finished (timing)
     hipEvent_t lb_in = nullptr, lb_out = nullptr;     // loopback transport
@@ -146,6 +147,10 @@ struct hjgpu_comm {
     int timeout_ms = 0;                      // deadline of every host-side wait; 0 = none (option "timeout_ms")
     bool broken = false;                     // a deadline expired / RCCL reported an asynchronous error: aborted
     int stall_rank = -1, stall_ms = 0;       // loopback fault injection (options "stall_rank", "stall_ms")
+    bool self_via_rccl = false;              // option "self_via_rccl": a rank's message to itself goes through ncclSend / ncclRecv too (tests:
+                                             // grouped point-to-point RCCL calls run on a one-GPU box that way)
+    int debug_serialize = 0;                 // option "debug_serialize" (diagnostics): bit 0 host waits after every slice's join, bit 1 the
+                                             // partitioning waits for the joins enqueued so far, bit 2 the exchange waits for them
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
     char err[512];
     char why_broken[512];
@@ -363,10 +368,25 @@ struct RcclTransport : Transport {
         // message lost half its payload through torch's all_to_all_single on RCCL 2.26 in round 1.
         const int G = c->nranks;
         const u64 piece = c->max_message_bytes / elem_bytes ? c->max_message_bytes / elem_bytes : 1;
+        // a rank's message to ITSELF (1 / G of every exchange) never touches a link: a device-to-device copy on the same
+        // stream (5 TB/s of read + write) instead of RCCL's self send / receive (measured at world 1: 0.8 TB/s)
+        const bool self_copy = !c->self_via_rccl;
+        for (int l = 0; l < nlocal() && self_copy; ++l) {
+            const int me = c->ranks[l].global;
+            if (scnt[l][me] != rcnt[l][me]) return cfail(c, HJGPU_EINVAL, "all_to_all_v: a rank's counts for itself disagree");
+            if (!scnt[l][me]) continue;
+            HIPM(c, hipSetDevice(c->ranks[l].device));
+            HIPM(c, hipMemcpyAsync(static_cast<char *>(recv[l]) + roff[l][me] * elem_bytes,
+                                   static_cast<const char *>(send[l]) + soff[l][me] * elem_bytes, scnt[l][me] * elem_bytes,
+                                   hipMemcpyDeviceToDevice, streams[l]));
+        }
+        if (G == 1 && self_copy) return HJGPU_OK;
         Group g(c, R);
         for (int l = 0; l < nlocal() && g.ok(); ++l) {
+            const int me = c->ranks[l].global;
             g.hip(hipSetDevice(c->ranks[l].device), "hipSetDevice");
             for (int p = 0; p < G && g.ok(); ++p) {
+                if (p == me && self_copy) continue;
                 const char *s = static_cast<const char *>(send[l]) + soff[l][p] * elem_bytes;
                 for (u64 at = 0; at < scnt[l][p] && g.ok(); at += piece) {
                     const u64 n = scnt[l][p] - at < piece ? scnt[l][p] - at : piece;
@@ -513,7 +533,7 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     hipEvent_t *timed[] = {&r.ev_x0, &r.ev_x1, &r.ev_t0, &r.ev_t1};
     for (hipEvent_t *e : timed) HIPM(c, hipEventCreate(e));
     hipEvent_t *plain[] = {&r.ev_ready, &r.ev_part[0], &r.ev_part[1], &r.ev_xchg[0], &r.ev_xchg[1],
-                           &r.ev_join[0], &r.ev_join[1], &r.ev_rx, &r.ev_up_s, &r.ev_up_r, &r.lb_in, &r.lb_out};
+                           &r.ev_join[0], &r.ev_join[1], &r.ev_rx, &r.ev_dbg, &r.ev_up_s, &r.ev_up_r, &r.lb_in, &r.lb_out};
     for (hipEvent_t *e : plain) HIPM(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     const size_t G = (size_t)c->nranks;
     HIPM(c, hipHostMalloc(reinterpret_cast<void **>(&r.h_pin), hp_words(G) * sizeof(u64), hipHostMallocDefault));
@@ -552,7 +572,7 @@ void destroy_rank(Rank &r)
                    &r.rows_col[1], &r.rows_col[2]};
     for (Buf *b : bufs) if (b->p) (void)hipFree(b->p);
     hipEvent_t evs[] = {r.ev_ready, r.ev_x0, r.ev_x1, r.ev_t0, r.ev_t1, r.ev_part[0], r.ev_part[1], r.ev_xchg[0],
-                        r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.ev_up_s, r.ev_up_r, r.lb_in, r.lb_out};
+                        r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.ev_dbg, r.ev_up_s, r.ev_up_r, r.lb_in, r.lb_out};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r.ev_w) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {r.main, r.comm, r.prep, r.up}) if (s) (void)hipStreamDestroy(s);
@@ -863,6 +883,11 @@ struct CpraStep {
             u64 *h_off = hp_off(r, Gs, slot);
             HIPM(c, hipSetDevice(r.device));
             if (ready) HIPM(c, hipStreamWaitEvent(r.prep, r.*ready, 0));
+            if (c->debug_serialize & 6) {
+                HIPM(c, hipEventRecord(r.ev_dbg, r.main));
+                if (c->debug_serialize & 2) HIPM(c, hipStreamWaitEvent(r.prep, r.ev_dbg, 0));
+                if (c->debug_serialize & 4) HIPM(c, hipStreamWaitEvent(r.comm, r.ev_dbg, 0));
+            }
             if (in[l].n && k)
                 JOINM(c, r.part, hjgpu_partition_packed_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)F,
                                                               static_cast<uint64_t *>(b.sk->p), reinterpret_cast<uint64_t *>(d_off), r.prep));
@@ -923,10 +948,8 @@ struct CpraStep {
             for (int p = 0; p < G; ++p) pieces[l][p] = roff[l][p];
             pieces[l][G] = at;
             // a quarter of headroom: the next slices rarely need a new allocation (hipFree waits for the device)
-            if ((at + 16) * tuple_bytes > b.rk->cap) {
-                CHKM(ensure(c, r, *b.rk, (at + at / 4 + 16) * tuple_bytes));
-                if (!k) CHKM(ensure(c, r, *b.rv, (at + at / 4 + 4) * sizeof(uint32_t)));
-            }
+            if ((at + 16) * tuple_bytes > b.rk->cap) CHKM(ensure(c, r, *b.rk, (at + at / 4 + 16) * tuple_bytes));
+            if (!k && (at + 4) * sizeof(uint32_t) > b.rv->cap) CHKM(ensure(c, r, *b.rv, (at + at / 4 + 4) * sizeof(uint32_t)));
             ks.push_back(b.sk->p); vs.push_back(b.sv->p); kr.push_back(b.rk->p); vr.push_back(b.rv->p);
             so.push_back(soff[l].data()); sc.push_back(scnt[l].data()); ro.push_back(roff[l].data()); rc.push_back(rcnt[l].data());
             HIPM(c, hipStreamWaitEvent(r.comm, r.ev_part[slot], 0));
@@ -1078,6 +1101,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                 }
             HIPM(c, hipEventRecord(r.ev_join[slot], r.main));
         }
+        if (c->debug_serialize & 1) for (int l = 0; l < L; ++l) CHKM(wait_stream(c, l, c->ranks[l].main, "join"));
         return HJGPU_OK;
     };
     std::vector<u64> pending;
@@ -1296,6 +1320,8 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
         return HJGPU_OK;
     }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
+    if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }
+    if (strcmp(name, "self_via_rccl") == 0) { c->self_via_rccl = x != 0; return HJGPU_OK; }
     if (strcmp(name, "timeout_ms") == 0) {
         if (x < 0 || x > (1 << 30)) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: timeout_ms outside 0..2^30");
         c->timeout_ms = (int)x;

@@ -397,7 +397,9 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
             for_each_build_row(fill_beg, fill_end, from_regs, cuckoo_insert);
             __syncthreads();
             // build rows of the NEXT item: issue the loads now, they land during this probe
-            if (fill_beg == 0 && C == 1 && PACKED && d_item[par ^ 1] < total_items) {
+            // (not in the _UNIQUE instances: the 16 prefetch registers are what they would spill to scratch, and no shipped
+            // kernel may use scratch - see the note at hj_launch_join)
+            if (!UNIQUE && fill_beg == 0 && C == 1 && PACKED && d_item[par ^ 1] < total_items) {
                 const u64 nb = d_rb[par ^ 1];
                 pre_rows = min(min(d_rn[par ^ 1], (u64)BLOCK * RB), (u64)CAP);
 #pragma unroll
@@ -516,8 +518,14 @@ int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
     }
 
 // The geometries that are built (option "join_cfg"): {block, log2slots, batch, a UNIQUE instance exists}.
+// NO SHIPPED INSTANCE MAY USE SCRATCH (tests/test_kernel_resources.py reads the compiler's remarks).  Round 3's
+// multi-GPU stress runs (tools/stress_cpra.py) lost a few hundred tuples in ~5 % of the steps while K6's pass-2
+// instance spilled 6 VGPRs and ran next to another stream's kernels, and none in 600 steps once it was free of
+// scratch: a wave's scratch slot is not safe here when kernels of several queues share the CUs.  The _UNIQUE instances
+// therefore run with ONE probe vector per lane and without the build-row prefetch (that is what fits 128 VGPRs), and
+// the geometries that spill (512,13,1 and 512,13,4 without _UNIQUE) are no longer built.
 static const struct { int block, log2slots, batch; bool unique; } JOIN_BUILT[] = {
-    {512, 13, 2, true}, {512, 13, 1, false}, {512, 13, 4, false}, {1024, 14, 2, true}, {256, 12, 2, false},
+    {512, 13, 2, true}, {1024, 14, 2, true}, {256, 12, 2, false},
 };
 
 bool hj_join_config_built(const JoinConfig &c, bool unique)
@@ -527,6 +535,14 @@ bool hj_join_config_built(const JoinConfig &c, bool unique)
     return false;
 }
 
+// the _UNIQUE instance of a geometry: one vector per lane (see above)
+#define JOIN_CASE_UNIQUE(B, L)                                                                    \
+    if (c.block == B && c.log2slots == L && b.unique) {                                           \
+        if (b.packed) hipLaunchKernelGGL((join_kernel<B, L, 1, true, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
+        else hipLaunchKernelGGL((join_kernel<B, L, 1, false, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);          \
+        return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
+    }
+
 int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t stream)
 {
     if ((a.P < 2 && !a.broadcast) || a.P < 1 || a.chunks == 0) return HJGPU_EINVAL;
@@ -534,12 +550,10 @@ int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t st
     JoinArgs b = a;
     b.force_chained = t.force_chained ? 1u : 0u;       // tests: exercise the fallback table everywhere
     b.unique = (a.unique || t.unique) ? 1u : 0u;
+    JOIN_CASE_UNIQUE(512, 13)
+    JOIN_CASE_UNIQUE(1024, 14)
     JOIN_CASE(512, 13, 2, false)
-    JOIN_CASE(512, 13, 2, true)
-    JOIN_CASE(512, 13, 1, false)
-    JOIN_CASE(512, 13, 4, false)
     JOIN_CASE(1024, 14, 2, false)
-    JOIN_CASE(1024, 14, 2, true)
     JOIN_CASE(256, 12, 2, false)
     return HJGPU_EINVAL;
 }

@@ -395,12 +395,17 @@ __device__ __forceinline__ void plan_scan2(u64 &a, u64 &b, u64 &total_a, u64 &to
 // K5, step 1: one workgroup per (chunk, relation).  A chunk's final offsets are its
 // own exclusive scan plus the chunk's first row (known on the host), so the chunks
 // scan in parallel.
+__device__ __forceinline__ void plan_items_body(const PlanArgs &a);
+
 template <bool PAD>
 __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
 {
     __shared__ u64 scratch[PLAN_BLOCK / 64 + 1];
     const uint32_t P = a.F1 * a.F2, C = a.chunks;
     const uint32_t c = blockIdx.x;
+    // grid row 2: the join's work items (K5 step 3) ride along - they depend on the two histograms only, not on the
+    // offsets, and a single-workgroup kernel of their own cost another 29 us of launch-to-launch latency per step
+    if (blockIdx.y == 2) { if (c == 0) plan_items_body(a); return; }
     const int r = blockIdx.y;
     if (!((a.mask >> r) & 1u)) return;
     const u64 *__restrict__ cnt = a.counts[r] + (u64)c * P;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void tile_desc_kernel(PlanArgs a)
 // K5, step 3: the join's work items.  Partition q with both sides non-empty gets slices(q) = ceil(|S_q| / slice)
 // probe slices times groups(q) = min(HJ_JOIN_FILL_GROUPS, ceil(|R_q| / cap)) groups of table fills: a build
 // partition that fits one LDS table (the planned case) is one group.
-__global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
+__device__ __forceinline__ void plan_items_body(const PlanArgs &a)
 {
     const uint32_t P = a.F1 * a.F2;
     const uint32_t C = a.chunks;
@@ -567,6 +572,8 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a)
     if (threadIdx.x == 0) a.slice_prefix[P] = run;
 }
 
+__global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a) { plan_items_body(a); }
+
 // Batch plan (see BatchPlanArgs): one workgroup per batch, thread p = pass-1 partition p (F1 <= 1024).
 __global__ __launch_bounds__(PLAN_BLOCK) void batch_plan_kernel(BatchPlanArgs a)
 {
@@ -611,14 +618,16 @@ int hj_launch_batch_plan(const BatchPlanArgs &a, uint32_t batches, hipStream_t s
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
 {
     if (a.mask & 3u) {
-        if (a.pad2) hipLaunchKernelGGL(plan_offsets_kernel<true>, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL(plan_offsets_kernel<false>, dim3(a.chunks, 2), dim3(PLAN_BLOCK), 0, stream, a);
+        const unsigned rows = (a.mask & 4u) ? 3u : 2u;          // row 2 = the join's work items
+        if ((a.mask & 4u) && ((a.cap & (a.cap - 1)) || a.slice != (uint32_t)HJ_JOIN_SLICE)) return HJGPU_EINVAL;
+        if (a.pad2) hipLaunchKernelGGL(plan_offsets_kernel<true>, dim3(a.chunks, rows), dim3(PLAN_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL(plan_offsets_kernel<false>, dim3(a.chunks, rows), dim3(PLAN_BLOCK), 0, stream, a);
     }
     if (a.mask & 3u) hipLaunchKernelGGL(plan_tiles_kernel, dim3(2), dim3(PLAN_BLOCK), 0, stream, a);
     if ((a.mask & 3u) && (a.tdesc[0] || a.tdesc[1]))
         hipLaunchKernelGGL(tile_desc_kernel, dim3(TDESC_BLOCKS, 2), dim3(PLAN_BLOCK), 0, stream, a);
     if ((a.mask & 4u) && ((a.cap & (a.cap - 1)) || a.slice != (uint32_t)HJ_JOIN_SLICE)) return HJGPU_EINVAL;
-    if (a.mask & 4u) hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);
+    if ((a.mask & 4u) && !(a.mask & 3u)) hipLaunchKernelGGL(plan_items_kernel, dim3(1), dim3(PLAN_BLOCK), 0, stream, a);   // a probe of a prepared build side
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
@@ -743,11 +752,17 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     // A lane-dependent zero the compiler cannot see through: with a provably uniform address LLVM's atomic
     // optimizer aggregates the add over the wave and needs its result at once (s_waitcnt vmcnt(0) +
     // readfirstlane right after the atomic), which stalls wave 0 for the round trip on every tile of pass 2.
-    uint32_t opaque_zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    // It is produced where it is used, every time (volatile): computed once in front of the tile loop, the compiler
+    // kept `work_counter + zero` - and, the same way, `part_start + tid` / `part_end + tid` below - as per-thread 64-bit
+    // addresses across the whole loop, three register pairs that pass 2 at the 128-VGPR cap had to spill to SCRATCH.
+    auto opaque_zero_now = []() -> uint32_t {
+        uint32_t z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        return z;
+    };
     auto take_ticket = [&]() -> uint32_t {                          // uniform; at most once between two deposits
         const uint32_t t = claim[claim_parity];
-        if (tid == 0) { pending_ticket = atomicAdd(a.work_counter + opaque_zero, 1u); pending_slot = claim_parity; }
+        if (tid == 0) { pending_ticket = atomicAdd(a.work_counter + opaque_zero_now(), 1u); pending_slot = claim_parity; }
         claim_parity ^= 1;
         return t;
     };
@@ -988,10 +1003,17 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     // whole lines from the front of the partition, the last (< 16) tuples from its back:
                     // one returning atomic carries both claims (lines | tail tuples << 32)
                     const uint32_t front = cnt[i] & ~(LINE - 1), tail = cnt[i] & (LINE - 1);
-                    dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], ((u64)tail << 32) | (u64)(front / LINE));
-                    pstart[i] = a.part_start[cur.cursor_row + bin];
-                    pend[i] = a.part_end[cur.cursor_row + bin];
-                } else dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], (u64)cnt[i]);
+                    // (the index is laundered per tile: no per-thread address lives across the tile loop, see opaque_zero_now)
+                    uint32_t at = cur.cursor_row + bin;
+                    asm volatile("" : "+v"(at));                    // an index the compiler cannot take apart
+                    dst[i] = atomicAdd(&a.cursors[at], ((u64)tail << 32) | (u64)(front / LINE));
+                    pstart[i] = a.part_start[at];
+                    pend[i] = a.part_end[at];
+                } else {
+                    uint32_t at = cur.cursor_row + bin;
+                    asm volatile("" : "+v"(at));                    // an index the compiler cannot take apart (see opaque_zero_now)
+                    dst[i] = atomicAdd(&a.cursors[at], (u64)cnt[i]);
+                }
             }
         }
         uint32_t biggest = 0;                                           // largest of my bins: count << 10 | bin
@@ -1022,15 +1044,23 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 
         // ---- counting sort inside LDS --------------------------------------------
         if (interior) {                                                // every tuple of the tile is valid
-            // all partition bases are requested before the first is used (one LDS round trip per tile, not 16)
-            uint32_t pbase[VPT * 4];
+            // all partition bases of a group are requested before the first is used (one LDS round trip per group, not one
+            // per tuple).  Pass 2 at 4 vectors per thread takes two groups of 8: with all 16 bases live next to the 16 ranks
+            // and the 32 registers of the next tile's loads the kernel needed 134 VGPRs, i.e. 6 spilled to SCRATCH at the
+            // 128-register cap of a 1024-thread workgroup - and a kernel with scratch must not run next to other streams'
+            // kernels: round 3's multi-GPU stress runs (tools/stress_cpra.py: prep / exchange / join streams of a rank
+            // side by side) lost a few hundred tuples in ~5 % of the steps with the spilling instance and none in 150
+            // steps without scratch.  tests/test_kernel_resources.py keeps every shipped instance free of scratch.
+            constexpr int GROUP = (!RANGED && VPT == 4) ? 8 : VPT * 4;
 #pragma unroll
-            for (int k = 0; k < VPT * 4; ++k) pbase[k] = hist[pr[k] >> 16];
+            for (int k0 = 0; k0 < VPT * 4; k0 += GROUP) {
+                uint32_t pbase[GROUP];
 #pragma unroll
-            for (int j = 0; j < VPT; ++j) {
+                for (int k = 0; k < GROUP; ++k) pbase[k] = hist[pr[k0 + k] >> 16];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t pos = pbase[j * 4 + c] + (pr[j * 4 + c] & 0xFFFFu);
+                for (int k = 0; k < GROUP; ++k) {
+                    const int j = (k0 + k) / 4, c = (k0 + k) % 4;
+                    const uint32_t pos = pbase[k] + (pr[k0 + k] & 0xFFFFu);
                     stage[pos] = (u64)key_of(j, c) | ((u64)val_of(j, c) << 32);
                 }
             }

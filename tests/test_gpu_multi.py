@@ -144,6 +144,11 @@ def test_cpra_co_partitioned_over_loopback(worlds, oracle, world, kind):
         assert got == want, (world, kind, slices)
     assert st["joins"] >= 1 and st["bytes_sent"] > 0 or kind == "tiny"
     assert comm.cpra_multi(shards, H.PhjParams(fanout1=7, fanout2=5), 2)[0] == want
+    comm.set_option("cpra_two_level", 1)          # round 2's plan (exchange with fan-out G, complete local PHJ): what > 8 ranks use
+    try:
+        assert comm.cpra_multi(shards, None, 3)[0] == want
+    finally:
+        comm.set_option("cpra_two_level", 0)
     for c in cols:
         c.free()
 
@@ -341,6 +346,15 @@ def test_rccl_from_cpp_at_world_size_one(worlds, oracle):
     assert comm.phj_multi(shards, 0)[0] == want
     assert comm.npj_multi(shards, 0)[0] == want
     comm.barrier()
+    # a rank's message to itself is a device copy by default; through ncclSend / ncclRecv (grouped point-to-point RCCL
+    # calls, the all-to-all-v of more than one rank) and with round 2's two-level plan the result is the same
+    for option in ("self_via_rccl", "cpra_two_level"):
+        comm.set_option(option, 1)
+        try:
+            assert comm.cpra_multi(shards, None, 3)[0] == want, option
+            assert comm.preflight(1 << 20)["ok_all_to_all"] == 1
+        finally:
+            comm.set_option(option, 0)
     for c in cols:
         c.free()
 

@@ -492,6 +492,16 @@ def test_host_programs_on_several_ranks(hj, oracle, tmp_path):
         assert ("join_tuples=%d sum_keys=%d sum_outer_vals=%d sum_inner_vals=%d" % want) in p.stderr
         lines = p.stdout.strip().splitlines()
         assert float(lines[-1].split("\t")[0]) > 0
+        # HJGPU_ROWS on several ranks (round 3: no longer one device only): every rank materialises its share, the shares
+        # arrive back to back in the host columns and are written as <prefix>jk_<J>.txt ...
+        prefix = "./m3_%s_" % prog
+        p = subprocess.run([os.path.join(lib, prog), "8", "500000", "120000"], cwd=tmp_path, env=dict(env, HJGPU_ROWS=prefix),
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert "3 ranks (loopback)" in p.stderr and "column sums match" in p.stderr
+        got = [np.fromfile(tmp_path / ("m3_%s_%s_%d.txt" % (prog, c, want[0])), dtype="<u4") for c in ("jk", "jo", "ji")]
+        for a, b in zip(sort_rows(*got), materialised_rows(*cols)):
+            assert np.array_equal(a, b)
     # a device the box does not have: reported, exit code 1, no crash
     p = subprocess.run([os.path.join(lib, "phj"), "8", "500000", "120000"], cwd=tmp_path,
                        env=dict(os.environ, HJGPU_DEVICES="0,63"), capture_output=True, text=True)

@@ -1,0 +1,37 @@
+"""CPU test (hipcc cross-compiles without a GPU): NO kernel instance of the library may use scratch memory.
+
+Round 3 found why: the multi-GPU CPRA runs a rank's partitioning, exchange and join streams side by side, and while
+K6's pass-2 instance spilled 6 VGPRs to scratch those runs lost a few hundred tuples in ~5 % of the steps
+(tools/stress_cpra.py; none in 600 steps once the instance was free of scratch; the same kernel alone on the device
+was always right).  A wave's scratch slot is evidently not safe when kernels of several queues share the CUs, so the
+rule is structural: zero scratch bytes per lane in every instance, checked from the compiler's own remarks."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def resources(source):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"),
+                          os.path.join(ROOT, "hash_join_codes_knl_amd", "csrc", source)],
+                         capture_output=True, text=True, check=True).stdout
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r"(.*?)\s+vgpr\s+(\d+)\s+spill v(\d+) s(\d+)\s+scratch (\d+)\s+occ (\d+)", line)
+        if m:
+            rows[m.group(1).strip()] = dict(vgpr=int(m.group(2)), vspill=int(m.group(3)), sspill=int(m.group(4)),
+                                            scratch=int(m.group(5)), occ=int(m.group(6)))
+    return rows
+
+
+@pytest.mark.parametrize("source", ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip", "gen_kernels.hip",
+                                    "hjgpu_api.hip", "hjgpu_multi.hip"])
+def test_no_kernel_instance_uses_scratch(source):
+    rows = resources(source)
+    assert rows, "no kernels found in %s" % source
+    bad = {k: v for k, v in rows.items() if v["scratch"] or v["vspill"]}
+    assert not bad, bad

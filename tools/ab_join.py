@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfgs", nargs="+", default=["512,13,2", "512,13,1", "512,13,4", "256,12,2"])
+    ap.add_argument("--cfgs", nargs="+", default=["512,13,2", "256,12,2"])
     ap.add_argument("--inner", type=int, default=64_000_000)
     ap.add_argument("--outer", type=int, default=1_000_000_000)
     ap.add_argument("--rounds", type=int, default=4)

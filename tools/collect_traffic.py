@@ -42,15 +42,28 @@ def main():
     fetch = run_pass("FETCH_SIZE", extra)
     write = run_pass("WRITE_SIZE", extra)
     res = {}
+    sizes = {"--inner": 64_000_000, "--outer": 1_000_000_000}
+    for i, a in enumerate(extra):
+        if a in sizes and i + 1 < len(extra):
+            sizes[a] = int(extra[i + 1])
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0))
         w, _ = write.get(k, (0.0, 0))
-        res[k] = {"launches_seen": nf, "read_bytes_per_launch": 2.0 * f * 1024.0,
+        raw = f * 1024.0
+        read = 2.0 * raw
+        note = "wide coalesced streams: FETCH_SIZE counts half of them (gfx950), read = 2 * raw"
+        # NPJ walks a table with 64-byte random line reads, which ARE counted at their size; only the column stream of
+        # the kernel (8 bytes per tuple) is tallied at half.  Doubling the whole counter would double the line reads too
+        # (round 2's file said 136 GB per probe launch for 72 GB real): real = raw + the missing half of the stream.
+        stream = {"npj_probe": 8.0 * sizes["--outer"], "npj_build": 8.0 * sizes["--inner"]}
+        for prefix, stream_bytes in stream.items():
+            if k.startswith(prefix):
+                read = raw + stream_bytes / 2.0
+                note = "64-byte line reads counted at their size + a %d-byte column stream counted at half: read = raw + stream / 2" % stream_bytes
+        res[k] = {"launches_seen": nf, "read_bytes_per_launch": read,
                   "written_bytes_per_launch": w * 1024.0,
-                  "hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0,
-                  # uncorrected counter: what applies to 64-byte random line reads (NPJ's table walks), which are
-                  # 64-byte requests and counted at their size; only wide coalesced streams are tallied at half
-                  "fetch_size_bytes_raw": f * 1024.0}
+                  "hbm_bytes_per_launch": read + w * 1024.0,
+                  "fetch_size_bytes_raw": raw, "read_correction": note}
     sys.path.insert(0, ROOT)
     import hash_join_codes_knl_amd as H
     out = {"kernel_hash": H.kernel_hash(),

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Repeats hjgpu_cpra_multi on one communicator and reports every step whose result differs from the analytic
+aggregates (a race in the slice pipeline shows up as an occasional wrong step, not as a wrong final step).
+usage: python tools/stress_cpra.py [--world 1 --transport rccl|loopback --slices 8 --steps 40 --inner N --outer N --option name=value ...]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=1)
+    ap.add_argument("--transport", default="rccl")
+    ap.add_argument("--slices", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--inner", type=int, default=64_000_000)
+    ap.add_argument("--outer", type=int, default=1_000_000_000)
+    ap.add_argument("--unique", action="store_true", help="HJGPU_FLAG_UNIQUE (same result here: the build keys are unique)")
+    ap.add_argument("--option", action="append", default=[])
+    ap.add_argument("--ctx-option", action="append", default=[], help="hjgpu_set_option on every rank's join context")
+    a = ap.parse_args()
+    import torch
+    torch.cuda.init()
+    import hash_join_codes_knl_amd as H
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    comm = H.HjComm.local(a.world, [0] * a.world, H.TRANSPORT_RCCL if a.transport == "rccl" else H.TRANSPORT_LOOPBACK)
+    for o in a.option:
+        n, v = o.split("=")
+        comm.set_option(n, int(v))
+    for o in a.ctx_option:
+        n, v = o.split("=")
+        for ctx in comm.ctx:
+            ctx.set_option(n, v)
+    fi, fo = 0x2545F491, 0x9E3779B1
+    G = a.world
+    cols, shards, expect = [], [], [0, 0, 0, 0]
+    for g in range(G):
+        ctx = comm.ctx[g]
+        ri, ro = a.inner // G, a.outer // G
+        c = [ctx.column(ri), ctx.column(ri), ctx.column(ro), ctx.column(ro)]
+        ctx.generate_range(1, ri * G, ro * G, g * ri, ri, g * ro, ro, fi, fo, *c)
+        sums = ctx.column_sums(c[2], ro, fo, fi)
+        expect = [expect[0] + ro] + [(x + y) & ((1 << 64) - 1) for x, y in zip(expect[1:], sums)]
+        cols += c
+        shards.append((c[0], c[1], ri, c[2], c[3], ro))
+    bad = 0
+    for s in range(a.steps):
+        got, st = comm.cpra_multi(shards, H.PhjParams(flags=H.FLAG_UNIQUE) if a.unique else None, a.slices)
+        if list(got) != expect:
+            bad += 1
+            print("step %d WRONG: count %+d, sums %s" % (s, got[0] - expect[0], ["%+d" % ((x - y + (1 << 63)) % (1 << 64) - (1 << 63)) for x, y in zip(got[1:], expect[1:])]), flush=True)
+    print("%s world %d slices %d options %s: %d of %d steps wrong, last %.2f ms" % (a.transport, G, a.slices, a.option + a.ctx_option + (["unique"] if a.unique else []), bad, a.steps, st["ms_wall"]), flush=True)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()
