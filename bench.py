@@ -539,6 +539,12 @@ def main():
         # configs[1]: NPJ build + probe on one GPU
         ms, ph = time_steps(lambda: hj.npj_async(*a, nprm, d_result.data_ptr(), stream))
         ok_ = [int(x) & MASK64 for x in d_result.tolist()] == expect_local
+        # what the memory system gives for NPJ's access shape: 10^9 independent pseudo-random 64-byte line reads out of a
+        # 2 GiB buffer (the table's size at load 0.25), four lanes per line as in the probe, nothing else computed
+        table_bytes = 2 << 30
+        scratch_t = torch.empty(table_bytes // 4, dtype=torch.int32, device=dev)
+        rl_ms = min(hj.random_line_read_ms(scratch_t.data_ptr(), table_bytes, outer, stream) for _ in range(3))
+        del scratch_t
         sec["npj"] = {"workload": "NPJ |R|=%d join |S|=%d, global line-hashed table, load %.2f (%d buckets)"
                                   % (inner, outer, 0.25, int(ph["buckets"])),
                       "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2),
@@ -547,6 +553,10 @@ def main():
                       # 64-byte line at the memory side: 8 + 64 B "sector-granular"
                       "roofline_probe": roof(16 * outer, ph["ms_join"], 1, stream_read_gbs),
                       "roofline_probe_line_granular": roof(72 * outer, ph["ms_join"], 1, stream_read_gbs),
+                      # the empirical ceiling of that shape on this box: random 64-byte line reads per second
+                      "random_line_read_ceiling": {"ms_per_1e9_lines": round(rl_ms * 1e9 / outer, 3),
+                                                   "Glines_per_s": round(outer / rl_ms / 1e6, 2),
+                                                   "probe_frac_of_it": round(rl_ms / ph["ms_join"], 4)},
                       "roofline_build": roof(8 * inner + 8 * ph["buckets"] + 8 * inner, ph["ms_build"], 1, stream_read_gbs)}
         # one-GPU CPRA: 8 chunks partitioned independently (cpra2.cpp:1757-1827), gathered in place
         cprm = H.PhjParams(chunks=8)

@@ -206,6 +206,38 @@ int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hi
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
+// Random 64-byte line reads (hjgpu_random_line_read_ms): the access shape of the NPJ probe without the join - the four
+// lanes of a quad fetch the four quarters of one pseudo-random line of the buffer with ONE load instruction, four lines
+// in flight per quad.  What it reaches is the memory system's rate for independent 64-byte reads out of a table that
+// does not fit the caches (DRAM row activations, not bytes, are the limit), i.e. the ceiling bench.py prices NPJ against.
+__global__ __launch_bounds__(256) void random_line_read_kernel(const uint4 *__restrict__ in, u64 lines, u64 reads, uint4 *sink)
+{
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    const uint32_t sub = threadIdx.x & 3;
+    const u64 quads = (u64)gridDim.x * 64, quad = (u64)blockIdx.x * 64 + (threadIdx.x >> 2);
+    for (u64 r = quad * 4; r < reads; r += quads * 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // a multiplicative hash of the read's index, as the join's H(key, f, lines)
+            const u64 x = (u64)(uint32_t)((uint32_t)(r + i) * 0x9E3779B1u) ^ ((r + i) >> 32);
+            const u64 line = (u64)(((unsigned __int128)(x & 0xFFFFFFFFull) * lines) >> 32);
+            v[i] = in[4 * line + sub];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc.x ^= v[i].x; acc.y ^= v[i].y; acc.z ^= v[i].z; acc.w ^= v[i].w; }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = acc;      // keeps the loads alive
+}
+
+int hj_launch_random_line_read(const void *p, size_t bytes, size_t reads, void *sink16, int cus, hipStream_t stream)
+{
+    const u64 lines = bytes / 64;
+    if (lines == 0 || reads == 0 || ((uintptr_t)p & 63)) return HJGPU_EINVAL;
+    hipLaunchKernelGGL(random_line_read_kernel, dim3(cus * 8), dim3(256), 0, stream, (const uint4 *)p, lines, (u64)reads, (uint4 *)sink16);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
 // Placement probe (hjgpu_api.hip, ensure_placed): a plain streaming fill of a freshly allocated buffer.  Its rate
 // differs by up to 26 % between allocations of the same size on one MI355X (physical placement; profiles/r02_placement.txt)
 // and predicts how fast K6 pass 1 will write into that buffer.

@@ -2007,4 +2007,20 @@ int hjgpu_stream_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, float 
     return HJGPU_OK;
 }
 
+int hjgpu_random_line_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, size_t reads, float *ms, void *stream_)
+{
+    if (!ctx || !d_ptr || !ms) return HJGPU_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->moves, 64));
+    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
+    record(ctx, EV_BEGIN, stream);
+    CHK(hj_launch_random_line_read(d_ptr, bytes, reads, ctx->moves.p, ctx->cus, stream));
+    record(ctx, EV_GAPS, stream);
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[EV_BEGIN], ctx->ev[EV_GAPS]));
+    ctx->last_algo = 2;
+    return HJGPU_OK;
+}
+
 }  // extern "C"

@@ -154,6 +154,7 @@ struct hjgpu_comm {
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
     char err[512];
     char why_broken[512];
+    std::mutex err_mu;                       // the local ranks' enqueue work runs on one host thread per rank (each_rank)
 };
 
 namespace {
@@ -169,8 +170,27 @@ inline u64 *hp_local(const Rank &r, size_t G) { return r.h_pin + 2 * OFF_WORDS +
 
 int cfail(hjgpu_comm *c, int status, const char *what, const char *detail = nullptr)
 {
-    if (c) snprintf(c->err, sizeof(c->err), detail ? "%s: %s" : "%s", what, detail);
+    if (c) {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        snprintf(c->err, sizeof(c->err), detail ? "%s: %s" : "%s", what, detail);
+    }
     return status;
+}
+
+// The enqueue work of the local ranks - about 25 kernel launches per rank and join - runs on one host thread per rank:
+// issued from a single thread, rank 7 of an 8-GPU host started a millisecond after rank 0 on an 8 ms step (round 2).
+// RCCL's grouped calls stay on the calling thread.  fn(l) returns an HJGPU_* status; the first failure is returned.
+template <typename F>
+int each_rank(int L, F fn)
+{
+    if (L == 1) return fn(0);
+    std::vector<int> rc((size_t)L, HJGPU_OK);
+    std::vector<std::thread> workers;
+    for (int l = 1; l < L; ++l) workers.emplace_back([&rc, &fn, l] { rc[(size_t)l] = fn(l); });
+    rc[0] = fn(0);
+    for (std::thread &t : workers) t.join();
+    for (int l = 0; l < L; ++l) if (rc[(size_t)l] != HJGPU_OK) return rc[(size_t)l];
+    return HJGPU_OK;
 }
 
 #define HIPM(c, call)                                                                        \
@@ -775,7 +795,7 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, hjg
     }
     const std::vector<hipStream_t> comms = streams_of(c, &Rank::comm);
     if (inner) CHKM(c->transport->replicate(bufs.data(), bytes, root, c->ring_broadcast, comms.data()));
-    for (int l = 0; l < L; ++l) {
+    CHKM(each_rank(L, [&](int l) -> int {
         Rank &r = c->ranks[l];
         HIPM(c, hipSetDevice(r.device));
         HIPM(c, hipEventRecord(r.ev_x1, r.comm));
@@ -796,7 +816,8 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, hjg
         }
         // a zero build key / an overflowing result column on ANY rank fails the call on EVERY rank
         JOINM(c, r.join, hjgpu_accumulate_async_status(r.join, reinterpret_cast<uint64_t *>(acc + 4), r.main));
-    }
+        return HJGPU_OK;
+    }));
     const int status = reduce_results(c, result);
     if (status != HJGPU_OK && status != HJGPU_EZEROKEY && status != HJGPU_EOVERFLOW) return status;
     if (rows) for (int l = 0; l < L; ++l) rows[l].rows = hp_local(c->ranks[l], G)[0];
@@ -874,7 +895,7 @@ struct CpraStep {
         const size_t Gs = (size_t)G;
         const size_t F = fanout();                                  // partitions of the exchange-level pass
         const size_t tuple_bytes = k ? sizeof(u64) : sizeof(uint32_t);
-        for (int l = 0; l < L; ++l) {
+        CHKM(each_rank(L, [&](int l) -> int {
             Rank &r = c->ranks[l];
             ExchangeBufs b = bufs_of(r, which);
             CHKM(ensure(c, r, *b.sk, (in[l].n + 16) * tuple_bytes));
@@ -898,7 +919,8 @@ struct CpraStep {
             else HIPM(c, hipMemsetAsync(d_off, 0, (F + 1) * sizeof(u64), r.prep));
             HIPM(c, hipMemcpyAsync(h_off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
             HIPM(c, hipEventRecord(r.ev_part[slot], r.prep));
-        }
+            return HJGPU_OK;
+        }));
         // the host needs the counts: how much every peer gets decides the receive buffers
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
@@ -1046,11 +1068,11 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     // they start is known on the host once the previous join has finished (its count), which is long before this
     // slice has arrived.
     std::vector<u64> used(L, 0);                 // rows in the rank's result columns so far
-    std::vector<bool> row_pending(L, false);     // hp_local()[0] will hold the rank's running count
+    std::vector<char> row_pending(L, 0);         // hp_local()[0] will hold the rank's running count (char: the ranks' threads write their own element)
     u64 measured = 0;
     auto join_slice = [&](int i, int slot, const std::vector<u64> &got, const std::vector<std::vector<u64>> &got_pieces) -> int {
         measured = 0;
-        for (int l = 0; l < L; ++l) {
+        CHKM(each_rank(L, [&](int l) -> int {
             Rank &r = c->ranks[l];
             HIPM(c, hipSetDevice(r.device));
             HIPM(c, hipEventRecord(r.ev_w[2 * (size_t)i], r.main));
@@ -1100,7 +1122,8 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                     if (l == 0) measured = m;                        // the context's events describe its LAST batch
                 }
             HIPM(c, hipEventRecord(r.ev_join[slot], r.main));
-        }
+            return HJGPU_OK;
+        }));
         if (c->debug_serialize & 1) for (int l = 0; l < L; ++l) CHKM(wait_stream(c, l, c->ranks[l].main, "join"));
         return HJGPU_OK;
     };
@@ -1224,6 +1247,14 @@ int hjgpu_comm_create_local(int nranks, const int *devices, int transport, hjgpu
         } else rc = cfail(c, HJGPU_EINVAL, "unknown transport");
     }
     if (rc == HJGPU_OK) rc = apply_reserve(c);
+    // ranks that share a device (loopback tests) share its free memory: their workspaces take the first allocation
+    // instead of holding up to 12 candidates of the probe side's twin side by side (option "placement")
+    for (size_t i = 0; i < devs.size() && rc == HJGPU_OK; ++i) {
+        int sharers = 0;
+        for (int d : devs) sharers += d == devs[i];
+        if (sharers > 1 && (hjgpu_set_option(c->ranks[i].join, "placement", "1") != HJGPU_OK ||
+                            hjgpu_set_option(c->ranks[i].part, "placement", "1") != HJGPU_OK)) rc = cfail(c, HJGPU_EINVAL, "placement");
+    }
     if (rc != HJGPU_OK) return fail_create(c, rc);
     *out = c;
     return HJGPU_OK;

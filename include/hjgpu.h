@@ -570,6 +570,11 @@ int  hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n,
  * of `bytes` (a multiple of 64 KiB is read) at d_ptr: the empirical HBM-read ceiling of this
  * device that bench.py reports next to the kernels' rates. */
 int  hjgpu_stream_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, float *ms, void *stream);
+/* Measurement helper: duration of `reads` independent pseudo-random 64-byte line reads out of the `bytes` at d_ptr
+ * (64-byte aligned), four lanes per line and four lines in flight per quad - the NPJ probe's access shape without the
+ * join (npj.cpp:216-364 gathers one bucket per lane the same way).  The empirical ceiling bench.py prices NPJ against:
+ * out of a table that does not fit the caches the limit is DRAM row activations per second, not bytes. */
+int  hjgpu_random_line_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, size_t reads, float *ms, void *stream);
 
 #ifdef __cplusplus
 }
