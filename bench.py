@@ -66,6 +66,11 @@ def parse(argv=None):
     ap.add_argument("--comm-timeout-ms", type=int, default=120_000,
                     help="multi-GPU: deadline of every host-side wait inside the library (hjgpu_comm option timeout_ms); when it "
                          "expires the communicator is aborted (ncclCommAbort) and this process exits with status 3")
+    ap.add_argument("--rehearse-solo", action="store_true",
+                    help="rehearsal of the N > 1 control flow on a box with ONE GPU: every rank of the torchrun world runs on "
+                         "device 0 with its own one-rank RCCL communicator (no exchange between the processes: RCCL wants one "
+                         "device per rank), so that everything around the data plane - gloo gathers, barriers, per-rank "
+                         "statistics, the N > 1 JSON line - executes with more than one process; its numbers mean nothing")
     ap.add_argument("--preflight-bytes", type=int, default=256 << 20,
                     help="multi-GPU: bytes per peer of the link-bandwidth preflight before the timed region (0 = skip it)")
     return ap.parse_args(argv)
@@ -267,6 +272,8 @@ def main():
 
     import torch
     import hash_join_codes_knl_amd as H
+    if args.rehearse_solo:
+        local_rank = 0                     # every process on the one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -278,7 +285,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=max(world, 1))      # control plane only
         try:
-            comm = connect_ranks(dist, H, local_rank, rank, max(world, 1))         # data plane: RCCL from C++
+            if args.rehearse_solo:
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+                comm = H.HjComm.rank(local_rank, 1, 0, H.HjComm.new_id())          # a world of one per process
+            else:
+                comm = connect_ranks(dist, H, local_rank, rank, max(world, 1))     # data plane: RCCL from C++
         except H.HjGpuError as ex:
             die_of_comm_error(rank, ex, "creating the communicator")
         comm.set_option("timeout_ms", args.comm_timeout_ms)
@@ -302,6 +313,8 @@ def main():
     copart = multi and args.algo == "cpra"
     inner_total = inner * n_gpus if copart else inner
     rk, rv, sk, sv = col(inner), col(inner), col(outer), col(outer)
+    if copart and args.rehearse_solo:
+        sys.exit("--rehearse-solo joins replicated build sides only (every process needs the whole build side)")
     if copart:
         hj.generate_range(1, inner_total, outer_total, rank * inner, inner, rank * outer, outer,
                           INNER_FACTOR, OUTER_FACTOR, rk.data_ptr(), rv.data_ptr(), sk.data_ptr(),
@@ -321,7 +334,7 @@ def main():
     if multi:
         # replicated build: only the root's build columns are read, every step replicates them again (measured,
         # not assumed); co-partitioned: the rank's chunk of both relations
-        root_cols = (rk.data_ptr(), rv.data_ptr()) if (copart or rank == 0) else (None, None)
+        root_cols = (rk.data_ptr(), rv.data_ptr()) if (copart or rank == 0 or args.rehearse_solo) else (None, None)
         shards = [(root_cols[0], root_cols[1], inner, sk.data_ptr(), sv.data_ptr(), outer)]
 
     last = {}
@@ -334,6 +347,8 @@ def main():
                 res, ms = comm.npj_multi(shards, 0, nprm)
             else:
                 res, ms = comm.phj_multi(shards, 0, prm)
+            if args.rehearse_solo:         # the solo communicators know their own shard only: add the ranks' results up
+                res = sum_over_ranks(dist, torch, list(res))
             last["result"], last["multi"] = list(res), ms
             return
         s = torch.cuda.current_stream().cuda_stream
@@ -477,6 +492,8 @@ def main():
         # for the probe side's pass-1 twin: up to 12 candidate blocks of 8.5 GB held and filled twice, hjgpu_stats.ms_reserve)
         "workspace": {"ms_reserve": round(hj.stats()["ms_reserve"], 1)},
     }
+    if args.rehearse_solo:
+        out["rehearsal"] = "--rehearse-solo: %d processes on ONE GPU, each with a one-rank RCCL communicator; the numbers mean nothing" % world
     if multi:
         k = len(multi_steps)
         mine = {  # this rank's view, averaged over the timed steps
