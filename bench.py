@@ -266,6 +266,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "RANK" not in os.environ:
         relaunch_under_torchrun(args)
+    # stdout carries ONE line, the result: whatever libraries print there on the way (RCCL's version banner at
+    # communicator creation goes to stdout) is sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = max(args.gpus, world)
@@ -627,7 +632,8 @@ def main():
                 out["cpu_baseline_config0"] = {"value": None, "unit": "Gtuples/s (probe side)", "cores": 0, "kind": "port",
                                                "sample": "failed: %r" % (ex,)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
     if comm is not None:

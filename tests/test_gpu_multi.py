@@ -609,7 +609,7 @@ def test_unique_rows_and_host_rows_through_the_multi_gpu_entry_points(worlds, or
     # the aggregate-only host call reports its pipeline: the join's first kernel was enqueued behind the probe shard's
     # upload, not behind the whole upload (ms_overlap is measured between device events, any sign is legal here)
     got, st = comm.join_host_multi(1, ik, iv, ok, ov)
-    assert got == want and "ms_overlap" in st and st["ms_upload"] >= 0
+    assert got == want and st["ms_upload"] >= 0 and "ms_overlap" in st
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
@@ -622,3 +622,31 @@ def test_preflight_verifies_the_collectives_and_measures_the_links(worlds, world
         assert all(x > 0 for i, x in enumerate(rep["link_GBs"]) if i != rep["rank"]) and rep["all_to_all_GBs"] > 0
     # and the communicator still joins
     assert comm.info()["aborted"] == 0
+
+
+def test_the_multi_gpu_host_call_joins_while_its_columns_are_still_arriving(worlds):
+    """hjgpu_join_host_multi is hjgpu_join_host's pipeline per rank (SURVEY 8 f3 x e): from page-locked columns every
+    rank's share is DMA'd on the rank's own upload stream, probe side first, and the rank's join is enqueued behind the
+    probe shard's event - so on the root (which also receives the build columns) the first join kernel is on the device
+    BEFORE the last byte of the upload has arrived.  Device event timestamps: ms_overlap > 0."""
+    comm = worlds(3)
+    ctx = comm.ctx[0]
+    inner, outer = 40_000_000, 48_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    d = [ctx.column(inner), ctx.column(inner), ctx.column(outer), ctx.column(outer)]
+    ctx.generate(3, inner, outer, 0, outer, fi, fo, *d)
+    sums = ctx.column_sums(d[2], outer, fo, fi)
+    host = [ctx.host_column(n) for n in (inner, inner, outer, outer)]
+    for h, c in zip(host, d):
+        h.array[:] = c.download()
+        c.free()
+    try:
+        comm.join_host_multi(1, *(h.array for h in host))           # the first call grows the ranks' workspaces
+        got, st = comm.join_host_multi(1, *(h.array for h in host))
+        assert got == (outer, sums[0], sums[1], sums[2])
+        assert st["ms_overlap"] > 0, (st["ms_overlap"], st["ms_upload"], st["ms_wall"])
+        got, st = comm.join_host_multi(2, *(h.array for h in host))
+        assert got == (outer, sums[0], sums[1], sums[2])
+    finally:
+        for h in host:
+            h.free()
