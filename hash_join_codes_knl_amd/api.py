@@ -30,7 +30,7 @@ EXPORTS = [
     "hjgpu_npj", "hjgpu_phj", "hjgpu_cpra",
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
     "hjgpu_phj_build", "hjgpu_phj_probe", "hjgpu_phj_probe_async",
-    "hjgpu_partition_packed_async", "hjgpu_phj_build_prepartitioned", "hjgpu_phj_probe_prepartitioned_async",
+    "hjgpu_partition_packed_async", "hjgpu_partition_packed_own_last_async", "hjgpu_phj_build_prepartitioned", "hjgpu_phj_probe_prepartitioned_async",
     "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
     "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
     "hjgpu_comm_get_info", "hjgpu_comm_preflight",
@@ -88,7 +88,7 @@ class Shard(C.Structure):
 
 class MultiStats(C.Structure):
     _fields_ = [("ms_wall", C.c_float), ("ms_exchange", C.c_float), ("ms_partition", C.c_float),
-                ("ms_exchange_wait", C.c_float), ("joins", C.c_uint32), ("reserved", C.c_uint32),
+                ("ms_exchange_wait", C.c_float), ("joins", C.c_uint32), ("self_copies", C.c_uint32),
                 ("tuples_joined", C.c_uint64), ("bytes_sent", C.c_uint64), ("ms_upload", C.c_float),
                 ("ms_overlap", C.c_float), ("join", Stats)]
 
@@ -245,6 +245,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_phj_probe.argtypes = [vp, vp, vp, sz, C.POINTER(Result), C.POINTER(Output), vp]
     L.hjgpu_phj_probe_async.argtypes = [vp, vp, vp, sz, vp, vp]
     L.hjgpu_partition_packed_async.argtypes = [vp, vp, vp, sz, u32, u32, vp, vp, vp]
+    L.hjgpu_partition_packed_own_last_async.argtypes = [vp, vp, vp, sz, u32, u32, u32, u32, vp, vp, vp]
     L.hjgpu_phj_build_prepartitioned.argtypes = [vp, vp, C.POINTER(PrePartitioned), sz, C.POINTER(PhjParams), vp]
     L.hjgpu_phj_probe_prepartitioned_async.argtypes = [vp, vp, C.POINTER(PrePartitioned), vp, vp]
     L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
@@ -463,6 +464,10 @@ class HjGpu:
     def partition_packed_async(self, d_keys, d_vals, n, factor, fanout, d_tuples_out, d_offsets, stream=None):
         self._check(self.lib.hjgpu_partition_packed_async(self.handle, self._ptr(d_keys), self._ptr(d_vals), n, factor, fanout,
                                                           self._ptr(d_tuples_out), self._ptr(d_offsets), stream))
+
+    def partition_packed_own_last_async(self, d_keys, d_vals, n, factor, fanout, own_first, own_count, d_tuples_out, d_offsets, stream=None):
+        self._check(self.lib.hjgpu_partition_packed_own_last_async(self.handle, self._ptr(d_keys), self._ptr(d_vals), n, factor, fanout,
+                                                                   own_first, own_count, self._ptr(d_tuples_out), self._ptr(d_offsets), stream))
 
     @staticmethod
     def prepartitioned(factor1, fanout1_total, first_partition, fanout1, chunk_offsets):

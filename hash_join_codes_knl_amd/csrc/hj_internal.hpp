@@ -188,8 +188,10 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
                     u64 *counts, uint32_t *range_counts, uint32_t *work_counter /* [chunks], zeroed */,
                     int cus, hipStream_t stream);
+// own_count > 0 (chunks == 1): partitions [own_first, own_first + own_count) are laid out behind all others
 int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
-                         uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream);
+                         uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream,
+                         uint32_t own_first = 0, uint32_t own_count = 0);
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream);
 // Batched partitioning of ONE relation (single chunk): the relation's pass-1 ranges are cut into batches of
 // `ranges_per_batch`; pass 1 of a batch writes into a small REUSED buffer (dense layout starting at 0) and pass 2 of

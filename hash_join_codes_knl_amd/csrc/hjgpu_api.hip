@@ -1567,10 +1567,12 @@ int hjgpu_phj_probe_async(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv
 }
 
 // ---- relations that arrive pass-1-partitioned (the receiving side of the multi-GPU CPRA) --------------------
-int hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                                 uint32_t factor, uint32_t fanout, uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_)
+static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                            uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
+                            uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_)
 {
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
+    if ((u64)own_first + own_count > fanout) return fail(ctx, HJGPU_EINVAL, "own_first + own_count must not exceed fanout");
     if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
         return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 1024] and factor odd");
     if (n && !d_tuples_out) return fail(ctx, HJGPU_EINVAL, "null output array");
@@ -1603,7 +1605,8 @@ int hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const u
     pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 1u;
     CHK(hj_launch_plan(pa, stream));
     if (n) {
-        CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1, geom.ranges_per_chunk, fanout, stream));
+        CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1, geom.ranges_per_chunk, fanout, stream,
+                                 own_first, own_count));
         ScatterArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = reinterpret_cast<uint32_t *>(d_tuples_out); sa.vout = nullptr;
@@ -1616,6 +1619,19 @@ int hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const u
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
     record(ctx, EV_GAPS, stream);
     return HJGPU_OK;
+}
+
+int hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                                 uint32_t factor, uint32_t fanout, uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream)
+{
+    return partition_packed(ctx, d_keys, d_vals, n, factor, fanout, 0, 0, d_tuples_out, d_offsets, stream);
+}
+
+int hjgpu_partition_packed_own_last_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                                          uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
+                                          uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream)
+{
+    return partition_packed(ctx, d_keys, d_vals, n, factor, fanout, own_first, own_count, d_tuples_out, d_offsets, stream);
 }
 
 static int check_layout(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, HjChunks *ch, size_t *rows)
@@ -1832,7 +1848,10 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
         dev_out.d_inner_vals = (uint32_t *)d_rows[2];
         out = &dev_out;
     }
-    hip_ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking), "hipStreamCreate(copy)");
+    // the upload stream in the high-priority queue pool: its copies never share a hardware queue with the join's kernels
+    int least = 0, greatest = 0;
+    hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    hip_ok(hipStreamCreateWithPriority(&copy, hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
     hip_ok(hipStreamCreateWithFlags(&run, hipStreamNonBlocking), "hipStreamCreate(run)");
     hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
     hip_ok(hipEventCreateWithFlags(&s_ready, hipEventDisableTiming), "hipEventCreate");

@@ -123,6 +123,7 @@ struct Rank {
     Buf rbuf;                       // PHJ / NPJ: replicated build side (keys | payloads)
     Buf send_k[2], send_v[2], recv_k[2], recv_v[2];   // CPRA: probe-side slices, double-buffered
     Buf rsend_k, rsend_v, rrecv_k, rrecv_v;           // CPRA: build side
+    u64 want_rows[3] = {0, 0, 0};   // CPRA, exchange in place: rows the send buffer (build side, probe slot 0 / 1) should hold next time
     Buf d_off;                      // [2][OFF_WORDS] u64: partition offsets of slot b
     Buf d_cnt;                      // [G] u64 send counts | [G * G] gathered matrix
     Buf d_res;                      // [12] u64: accumulated result | zero-key flag, overflow flag, 2 spare | last batch
@@ -151,6 +152,8 @@ struct hjgpu_comm {
                                              // grouped point-to-point RCCL calls run on a one-GPU box that way)
     int debug_serialize = 0;                 // option "debug_serialize" (diagnostics): bit 0 host waits after every slice's join, bit 1 the
                                              // partitioning waits for the joins enqueued so far, bit 2 the exchange waits for them
+    bool exchange_in_place = true;           // option "exchange_in_place": a CPRA rank keeps its own partitions where its partitioning wrote
+                                             // them (last) and receives the other ranks' pieces right behind: the message to itself is never copied
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
     char err[512];
     char why_broken[512];
@@ -549,7 +552,17 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     rc = hjgpu_create(device, &r.part);
     if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_create(partition context)");
     HIPM(c, hipSetDevice(device));
-    for (hipStream_t *s : {&r.main, &r.comm, &r.prep, &r.up}) HIPM(c, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    // The runtime maps streams onto a few hardware queues PER PRIORITY (4 by default), and the commands of streams that
+    // share a queue run in the order they were submitted - a wait of one stream holds back whatever another stream
+    // submitted behind it.  With the two contexts' own streams a rank has more than four: the exchange and the upload
+    // streams take the high priority, the exchange-level partitioning the low one, the joins stay normal - three queue
+    // pools.  An exchange never waits behind a join that merely shares its queue (and RCCL's kernels find CUs ahead of
+    // the next persistent grid), a join never behind the upload or the partitioning it is meant to overlap.
+    int least = 0, greatest = 0;
+    HIPM(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPM(c, hipStreamCreateWithFlags(&r.main, hipStreamNonBlocking));
+    HIPM(c, hipStreamCreateWithPriority(&r.prep, hipStreamNonBlocking, least));
+    for (hipStream_t *s : {&r.comm, &r.up}) HIPM(c, hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest));
     hipEvent_t *timed[] = {&r.ev_x0, &r.ev_x1, &r.ev_t0, &r.ev_t1};
     for (hipEvent_t *e : timed) HIPM(c, hipEventCreate(e));
     hipEvent_t *plain[] = {&r.ev_ready, &r.ev_part[0], &r.ev_part[1], &r.ev_xchg[0], &r.ev_xchg[1],
@@ -863,6 +876,10 @@ struct CpraStep {
     hjgpu_multi_stats *stats;
     // the pieces of what local rank l received in the LAST exchange: piece p (from rank p) = rows [pieces[l][p], pieces[l][p + 1])
     std::vector<std::vector<u64>> pieces;
+    // ... of the array `base[l]`, the first of them at row pieces[l][0].  One-level plan, exchange in place: the array is the
+    // rank's SEND buffer - its own partitions were written last (hjgpu_partition_packed_own_last_async), the other ranks'
+    // pieces are received right behind them: piece 0 = the own one, never copied; pieces 1.. = the other ranks in order.
+    std::vector<const void *> base;
     bool exchange_in_flight = false;                          // local rank 0's ev_x0 / ev_x1 hold an unread exchange
     bool from_host = false;                                   // the inputs are being uploaded (hjgpu_join_host_multi)
     float exchange_ms = 0;
@@ -874,7 +891,8 @@ struct CpraStep {
     uint32_t fanout() const { return k ? (uint32_t)G * k : (uint32_t)G; }
     CpraStep(hjgpu_comm *comm, hjgpu_multi_stats *st)
         : c(comm), L((int)comm->ranks.size()), G(comm->nranks), soff(L, std::vector<u64>(G)), scnt(L, std::vector<u64>(G)),
-          roff(L, std::vector<u64>(G)), rcnt(L, std::vector<u64>(G)), recv_total(L), stats(st), pieces(L, std::vector<u64>(G + 1)) {}
+          roff(L, std::vector<u64>(G)), rcnt(L, std::vector<u64>(G)), recv_total(L), stats(st), pieces(L, std::vector<u64>(G + 1)),
+          base(L, nullptr) {}
 
     // call when local rank 0's exchange stream is known to be idle
     void note_exchange()
@@ -895,10 +913,18 @@ struct CpraStep {
         const size_t Gs = (size_t)G;
         const size_t F = fanout();                                  // partitions of the exchange-level pass
         const size_t tuple_bytes = k ? sizeof(u64) : sizeof(uint32_t);
+        const bool own_last = k && c->exchange_in_place && !c->self_via_rccl;
         CHKM(each_rank(L, [&](int l) -> int {
             Rank &r = c->ranks[l];
             ExchangeBufs b = bufs_of(r, which);
-            CHKM(ensure(c, r, *b.sk, (in[l].n + 16) * tuple_bytes));
+            size_t hold = in[l].n;
+            if (own_last) {
+                // room for what the others will send, behind the rank's own output: as much as the last exchange through
+                // this buffer needed, or - first time - the others' shares of a chunk like this one, with an eighth of headroom
+                const u64 guess = (u64)in[l].n + (u64)in[l].n / Gs * (Gs - 1) * 9 / 8 + 4096;
+                hold = (size_t)(r.want_rows[which] > guess ? r.want_rows[which] : guess);
+            }
+            CHKM(ensure(c, r, *b.sk, (hold + 16) * tuple_bytes));
             if (!k) CHKM(ensure(c, r, *b.sv, (in[l].n + 4) * sizeof(uint32_t)));
             u64 *d_off = static_cast<u64 *>(r.d_off.p) + (size_t)slot * OFF_WORDS;
             u64 *h_off = hp_off(r, Gs, slot);
@@ -909,7 +935,13 @@ struct CpraStep {
                 if (c->debug_serialize & 2) HIPM(c, hipStreamWaitEvent(r.prep, r.ev_dbg, 0));
                 if (c->debug_serialize & 4) HIPM(c, hipStreamWaitEvent(r.comm, r.ev_dbg, 0));
             }
-            if (in[l].n && k)
+            // in place: the slot's previous slice has been joined (its own piece lives in this buffer)
+            if (own_last && which) HIPM(c, hipStreamWaitEvent(r.prep, r.ev_join[slot], 0));
+            if (in[l].n && own_last)
+                JOINM(c, r.part, hjgpu_partition_packed_own_last_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)F,
+                                                                       (uint32_t)r.global * k, k, static_cast<uint64_t *>(b.sk->p),
+                                                                       reinterpret_cast<uint64_t *>(d_off), r.prep));
+            else if (in[l].n && k)
                 JOINM(c, r.part, hjgpu_partition_packed_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)F,
                                                               static_cast<uint64_t *>(b.sk->p), reinterpret_cast<uint64_t *>(d_off), r.prep));
             else if (in[l].n)
@@ -928,6 +960,12 @@ struct CpraStep {
             const u64 *h_off = hp_off(r, Gs, slot);
             const size_t per = k ? k : 1;                           // partitions per destination rank
             for (int p = 0; p < G; ++p) { soff[l][p] = h_off[(size_t)p * per]; scnt[l][p] = h_off[(size_t)(p + 1) * per] - h_off[(size_t)p * per]; }
+            if (own_last) {
+                // own partitions last: the others close up, the own ones end the chunk's rows
+                const u64 own = scnt[l][r.global];
+                for (int p = r.global + 1; p < G; ++p) soff[l][p] -= own;
+                soff[l][r.global] = (u64)in[l].n - own;
+            }
             if (l == 0 && stats) {
                 hjgpu_stats ps;
                 if (in[l].n && hjgpu_get_stats(r.part, &ps) == HJGPU_OK) stats->ms_partition += ps.ms_total;
@@ -967,12 +1005,38 @@ struct CpraStep {
             u64 at = 0;
             for (int p = 0; p < G; ++p) { rcnt[l][p] = matrix[(size_t)p * Gs + r.global]; roff[l][p] = at; at += rcnt[l][p]; }
             recv_total[l] = at;
-            for (int p = 0; p < G; ++p) pieces[l][p] = roff[l][p];
-            pieces[l][G] = at;
-            // a quarter of headroom: the next slices rarely need a new allocation (hipFree waits for the device)
-            if ((at + 16) * tuple_bytes > b.rk->cap) CHKM(ensure(c, r, *b.rk, (at + at / 4 + 16) * tuple_bytes));
-            if (!k && (at + 4) * sizeof(uint32_t) > b.rv->cap) CHKM(ensure(c, r, *b.rv, (at + at / 4 + 4) * sizeof(uint32_t)));
-            ks.push_back(b.sk->p); vs.push_back(b.sv->p); kr.push_back(b.rk->p); vr.push_back(b.rv->p);
+            const u64 own = rcnt[l][r.global], n_local = in[l].n;
+            bool in_place = false;
+            if (own_last) {
+                const u64 need = n_local + (at - own);
+                in_place = (need + 16) * tuple_bytes <= b.sk->cap;
+                // too small this time (the others sent more than this rank's own chunk suggested): the copying path below,
+                // and the buffer grows before the next exchange through it
+                r.want_rows[which] = in_place ? (r.want_rows[which] > need ? r.want_rows[which] : need) : need + need / 4;
+            }
+            if (in_place) {
+                // rows [n_local - own, n_local): the own piece, where the partitioning wrote it; the others follow from row n_local
+                u64 row = n_local;
+                pieces[l][0] = n_local - own; pieces[l][1] = n_local;
+                int piece = 1;
+                for (int p = 0; p < G; ++p) {
+                    if (p == r.global) continue;
+                    roff[l][p] = row; row += rcnt[l][p];
+                    pieces[l][(size_t)++piece] = row;
+                }
+                roff[l][r.global] = n_local - own; rcnt[l][r.global] = 0; scnt[l][r.global] = 0;      // no message to itself
+                base[l] = b.sk->p;
+                ks.push_back(b.sk->p); vs.push_back(b.sv->p); kr.push_back(b.sk->p); vr.push_back(b.rv->p);
+            } else {
+                for (int p = 0; p < G; ++p) pieces[l][p] = roff[l][p];
+                pieces[l][G] = at;
+                // a quarter of headroom: the next slices rarely need a new allocation (hipFree waits for the device)
+                if ((at + 16) * tuple_bytes > b.rk->cap) CHKM(ensure(c, r, *b.rk, (at + at / 4 + 16) * tuple_bytes));
+                if (!k && (at + 4) * sizeof(uint32_t) > b.rv->cap) CHKM(ensure(c, r, *b.rv, (at + at / 4 + 4) * sizeof(uint32_t)));
+                base[l] = b.rk->p;
+                if (l == 0 && stats && own) stats->self_copies += 1;
+                ks.push_back(b.sk->p); vs.push_back(b.sv->p); kr.push_back(b.rk->p); vr.push_back(b.rv->p);
+            }
             so.push_back(soff[l].data()); sc.push_back(scnt[l].data()); ro.push_back(roff[l].data()); rc.push_back(rcnt[l].data());
             HIPM(c, hipStreamWaitEvent(r.comm, r.ev_part[slot], 0));
             if (which) HIPM(c, hipStreamWaitEvent(r.comm, r.ev_join[slot], 0));   // the slot's previous slice has been joined
@@ -1039,6 +1103,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     CHKM(step.exchange(in, 0, 0, from_host ? &Rank::ev_up_r : nullptr));
     const std::vector<u64> inner_recv = step.recv_total;
     const std::vector<std::vector<u64>> inner_pieces = step.pieces;
+    const std::vector<const void *> inner_base = step.base;
     std::vector<size_t> max_outer(L);
     for (int l = 0; l < L; ++l) {
         Rank &r = c->ranks[l];
@@ -1050,8 +1115,8 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         HIPM(c, hipStreamWaitEvent(r.main, r.ev_rx, 0));
         if (from_host && l == 0) HIPM(c, hipEventRecord(r.ev_t0, r.main));
         if (inner_recv[l] && K) {
-            const hjgpu_prepartitioned lay = layout_of(l, inner_pieces[l], 0, inner_recv[l]);
-            JOINM(c, r.join, hjgpu_phj_build_prepartitioned(r.join, static_cast<const uint64_t *>(r.rrecv_k.p), &lay, max_outer[l], prm, r.main));
+            const hjgpu_prepartitioned lay = layout_of(l, inner_pieces[l], inner_pieces[l][0], inner_pieces[l][0] + inner_recv[l]);
+            JOINM(c, r.join, hjgpu_phj_build_prepartitioned(r.join, static_cast<const uint64_t *>(inner_base[l]), &lay, max_outer[l], prm, r.main));
         } else if (inner_recv[l])
             JOINM(c, r.join, hjgpu_phj_build(r.join, static_cast<const uint32_t *>(r.rrecv_k.p), static_cast<const uint32_t *>(r.rrecv_v.p),
                                              (size_t)inner_recv[l], max_outer[l], prm, r.main));
@@ -1070,7 +1135,8 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     std::vector<u64> used(L, 0);                 // rows in the rank's result columns so far
     std::vector<char> row_pending(L, 0);         // hp_local()[0] will hold the rank's running count (char: the ranks' threads write their own element)
     u64 measured = 0;
-    auto join_slice = [&](int i, int slot, const std::vector<u64> &got, const std::vector<std::vector<u64>> &got_pieces) -> int {
+    auto join_slice = [&](int i, int slot, const std::vector<u64> &got, const std::vector<std::vector<u64>> &got_pieces,
+                          const std::vector<const void *> &got_base) -> int {
         measured = 0;
         CHKM(each_rank(L, [&](int l) -> int {
             Rank &r = c->ranks[l];
@@ -1107,8 +1173,9 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                     }
                     if (K) {
                         // a batch = rows [b, b + m) of what arrived: a contiguous piece of the pieces (still sorted by partition)
-                        const hjgpu_prepartitioned lay = layout_of(l, got_pieces[l], b, b + m);
-                        JOINM(c, r.join, hjgpu_phj_probe_prepartitioned_async(r.join, static_cast<const uint64_t *>(r.recv_k[slot].p), &lay,
+                        const u64 first = got_pieces[l][0];
+                        const hjgpu_prepartitioned lay = layout_of(l, got_pieces[l], first + b, first + b + m);
+                        JOINM(c, r.join, hjgpu_phj_probe_prepartitioned_async(r.join, static_cast<const uint64_t *>(got_base[l]), &lay,
                                                                               reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
                     } else
                     JOINM(c, r.join, hjgpu_phj_probe_async(r.join, sk + b, sv + b, m, reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
@@ -1129,6 +1196,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     };
     std::vector<u64> pending;
     std::vector<std::vector<u64>> pending_pieces;
+    std::vector<const void *> pending_base;
     int pending_slice = -1;
     for (int i = 0; i < slices; ++i) {
         const int slot = i & 1;
@@ -1145,12 +1213,13 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             if (hjgpu_get_stats(c->ranks[0].join, &js) == HJGPU_OK) { add_stats(&stats->join, js); stats->joins += 1; stats->tuples_joined += inner_recv[0]; }
             build_stats_pending = false;
         }
-        if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces));
+        if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
         pending = step.recv_total;
         pending_pieces = step.pieces;
+        pending_base = step.base;
         pending_slice = i;
     }
-    CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces));
+    CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
     const int status = reduce_results(c, result);
     if (status != HJGPU_OK && status != HJGPU_EOVERFLOW) return status;
     if (rows) for (int l = 0; l < L; ++l) rows[l].rows = hp_local(c->ranks[l], G)[0];
@@ -1350,6 +1419,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
         c->max_message_bytes = (size_t)x;
         return HJGPU_OK;
     }
+    if (strcmp(name, "exchange_in_place") == 0) { c->exchange_in_place = x != 0; return HJGPU_OK; }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }
     if (strcmp(name, "self_via_rccl") == 0) { c->self_via_rccl = x != 0; return HJGPU_OK; }

@@ -316,10 +316,12 @@ int hj_launch_hist_packed(const u64 *tuples, const HjChunks &ch, uint32_t f1, ui
 // --------------------------------------------------------------------------
 // K5b: per-range write bases of pass 1.  One workgroup per (chunk, partition):
 // base[range][p] = off1[chunk][p] + sum of the counts of earlier ranges of the chunk.
+// own_count > 0 (one chunk; hjgpu_partition_packed_own_last_async): partitions [own_first, own_first + own_count) are
+// laid out LAST, behind all others (which keep their order) - off1 stays the plain prefix of the counts.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void range_base_kernel(
     const uint32_t *__restrict__ range_counts, const u64 *__restrict__ off1,
-    u64 *__restrict__ range_base, uint32_t Rc, uint32_t F1)
+    u64 *__restrict__ range_base, uint32_t Rc, uint32_t F1, uint32_t own_first, uint32_t own_count)
 {
     __shared__ u64 scratch[256 / 64 + 1];
     const uint32_t c = blockIdx.x / F1, p = blockIdx.x - c * F1;
@@ -328,7 +330,13 @@ __global__ __launch_bounds__(256) void range_base_kernel(
     const u64 row0 = (u64)c * Rc;
     u64 sum = 0;
     for (uint32_t j = lo; j < hi; ++j) sum += range_counts[(row0 + j) * F1 + p];
-    u64 run = off1[(u64)c * F1 + p] + block_exclusive_scan<256, u64>(sum, scratch);
+    u64 first = off1[(u64)c * F1 + p];
+    if (own_count) {
+        const u64 ob = off1[own_first], oe = off1[own_first + own_count], n = off1[F1];
+        if (p >= own_first + own_count) first -= oe - ob;
+        else if (p >= own_first) first = n - (oe - ob) + (first - ob);
+    }
+    u64 run = first + block_exclusive_scan<256, u64>(sum, scratch);
     for (uint32_t j = lo; j < hi; ++j) {
         range_base[(row0 + j) * F1 + p] = run;
         run += range_counts[(row0 + j) * F1 + p];
@@ -336,10 +344,12 @@ __global__ __launch_bounds__(256) void range_base_kernel(
 }
 
 int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
-                         uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream)
+                         uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream,
+                         uint32_t own_first, uint32_t own_count)
 {
+    if (own_count && (chunks != 1 || (u64)own_first + own_count > F1)) return HJGPU_EINVAL;
     hipLaunchKernelGGL(range_base_kernel, dim3(chunks * F1), dim3(256), 0, stream, range_counts,
-                       off1, range_base, ranges_per_chunk, F1);
+                       off1, range_base, ranges_per_chunk, F1, own_first, own_count);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 

@@ -326,6 +326,19 @@ typedef struct {
 int  hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
                                   uint32_t factor, uint32_t fanout, uint64_t *d_tuples_out, uint64_t *d_offsets,
                                   void *stream);
+/* The same, with the partitions [own_first, own_first + own_count) laid out LAST: rows [n - own_rows, n) of d_tuples_out,
+ * behind all other partitions (which keep their order, rows [0, n - own_rows)).  d_offsets is still the plain prefix of
+ * the counts (d_offsets[p + 1] - d_offsets[p] rows in partition p); a partition's first row follows from it:
+ *   p <  own_first              d_offsets[p]
+ *   p in the own range          n - own_rows + d_offsets[p] - d_offsets[own_first]
+ *   p >= own_first + own_count  d_offsets[p] - own_rows              (own_rows = the own range's rows).
+ * What it is for: a rank of the multi-GPU CPRA keeps its own partitions where they were written - the message to itself
+ * (cpra2.cpp:1891-1959 gathers the owner's own chunk with the same memcpy as everybody else's) is never copied: the
+ * other ranks' pieces are received right behind row n, and rows [n - own_rows, n + received) are the `chunks` pieces of
+ * hjgpu_prepartitioned (the own piece first). */
+int  hjgpu_partition_packed_own_last_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                                           uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
+                                           uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream);
 int  hjgpu_phj_build_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *layout,
                                     size_t max_outer, const hjgpu_phj_params *params /* fanout2, factor2, table factors, flags */,
                                     void *stream);
@@ -460,7 +473,8 @@ typedef struct {
     float    ms_partition;       /* local rank 0: exchange-level partitioning (CPRA)                         */
     float    ms_exchange_wait;   /* local rank 0: stream time its joins spent waiting for an exchange        */
     uint32_t joins;              /* local rank 0: local join calls whose phase times are in `join`           */
-    uint32_t reserved;
+    uint32_t self_copies;        /* local rank 0, CPRA: exchanges whose message to ITSELF had to be copied (0 when every
+                                    exchange ran in place: the own partitions stay where the partitioning wrote them)  */
     uint64_t tuples_joined;      /* local rank 0: tuples those joins read                                    */
     uint64_t bytes_sent;         /* local rank 0: bytes sent to OTHER ranks                                  */
     float    ms_upload;          /* hjgpu_join_host_multi: wall clock of the call outside the join step itself (cutting the

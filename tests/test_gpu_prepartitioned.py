@@ -103,3 +103,43 @@ def test_prepartitioned_layout_errors(hj, oracle):
     assert e.value.status == H.api.EINVAL
     for c in (d, d_res, rk, rv):
         c.free()
+
+
+@pytest.mark.parametrize("n", [0, 1, 37, 70_001, 1_000_003])
+@pytest.mark.parametrize("fanout,own_first,own_count", [(192, 48, 24), (192, 0, 96), (192, 168, 24), (8, 3, 1), (6, 0, 6), (64, 10, 0)])
+def test_own_partitions_last(hj, oracle, n, fanout, own_first, own_count):
+    """hjgpu_partition_packed_own_last_async: the partitions [own_first, own_first + own_count) end the output, all
+    others keep their order in front of them; d_offsets stays the plain prefix of the counts (include/hjgpu.h gives a
+    partition's first row from it).  Every tuple of the chunk is in its partition's rows, none is lost."""
+    _, _, keys, vals = oracle.generate(max(n, 1), 16, seed=n % 97 + fanout)
+    keys, vals = keys[:n], vals[:n]
+    dk, dv = hj.column(np.concatenate([keys, np.zeros(1, np.uint32)])), hj.column(np.concatenate([vals, np.zeros(1, np.uint32)]))
+    dt, do = hj.column(n + 16, np.uint64), hj.column(fanout + 1, np.uint64)
+    hj.partition_packed_own_last_async(dk, dv, n, FACTOR1, fanout, own_first, own_count, dt, do)
+    hj.synchronize()
+    t, o = dt.download(n), do.download().astype(np.int64)
+    assert o[0] == 0 and o[-1] == n and np.all(np.diff(o) >= 0)
+    own_rows = o[own_first + own_count] - o[own_first]
+    first = np.array([o[p] if p < own_first else (n - own_rows + o[p] - o[own_first] if p < own_first + own_count else o[p] - own_rows)
+                      for p in range(fanout)], dtype=np.int64)
+    want = np.empty(n, np.int64)
+    for p in range(fanout):
+        want[first[p]:first[p] + o[p + 1] - o[p]] = p
+    got = mulhi_hash((t & np.uint64(0xFFFFFFFF)).astype(np.uint32), FACTOR1, fanout)
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.sort(t), np.sort((vals.astype(np.uint64) << np.uint64(32)) | keys.astype(np.uint64)))
+    # the counts are those of the plain operator
+    hj.partition_packed_async(dk, dv, n, FACTOR1, fanout, dt, do)
+    hj.synchronize()
+    assert np.array_equal(do.download().astype(np.int64), o)
+    for c in (dk, dv, dt, do):
+        c.free()
+
+
+def test_own_partitions_last_refuses_a_range_beyond_the_fanout(hj):
+    dk, dv, dt, do = hj.column(64), hj.column(64), hj.column(80, np.uint64), hj.column(9, np.uint64)
+    with pytest.raises(H.HjGpuError) as e:
+        hj.partition_packed_own_last_async(dk, dv, 64, FACTOR1, 8, 6, 3, dt, do)
+    assert e.value.status == H.api.EINVAL
+    for c in (dk, dv, dt, do):
+        c.free()
