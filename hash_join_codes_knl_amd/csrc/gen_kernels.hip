@@ -209,7 +209,7 @@ int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hi
 // Random 64-byte line reads (hjgpu_random_line_read_ms): the access shape of the NPJ probe without the join - the four
 // lanes of a quad fetch the four quarters of one pseudo-random line of the buffer with ONE load instruction, four lines
 // in flight per quad.  What it reaches is the memory system's rate for independent 64-byte reads out of a table that
-// does not fit the caches (DRAM row activations, not bytes, are the limit), i.e. the ceiling bench.py prices NPJ against.
+// does not fit the caches (requests per second, not bytes, are the limit: profiles/r03_request_size.txt), i.e. the ceiling bench.py prices NPJ against.
 __global__ __launch_bounds__(256) void random_line_read_kernel(const uint4 *__restrict__ in, u64 lines, u64 reads, uint4 *sink)
 {
     uint4 acc = make_uint4(0, 0, 0, 0);

@@ -424,7 +424,9 @@ hjgpu_ctx *hjgpu_comm_ctx(hjgpu_comm *comm, int local_rank);
  * (ncclCommGetAsyncError), and at the deadline the communicator is aborted (ncclCommAbort): the call returns
  * HJGPU_ERCCL naming the rank and stream that did not finish, every later call on the communicator fails fast, and
  * the process can exit.  "stall_rank" (k) / "stall_ms" (n): fault injection for tests, loopback transport only - rank
- * k arrives n ms late at every collective. */
+ * k arrives n ms late at every collective.  "exchange_in_place" (0 / 1, default 1): a CPRA rank keeps its own partitions
+ * where its partitioning wrote them and receives the others' pieces behind them (no copy of the message to itself);
+ * "cpra_two_level" (0 / 1): round 2's CPRA plan (used automatically beyond 8 ranks); "self_via_rccl" (tests). */
 int  hjgpu_comm_set_option(hjgpu_comm *comm, const char *name, const char *value);
 /* What the communicator really is: the transport's own view of the world (ncclCommCount / ncclCommUserRank /
  * ncclCommCuDevice of local rank 0, ncclGetVersion), so that a result line can prove that N ranks talked over RCCL. */
@@ -587,7 +589,8 @@ int  hjgpu_stream_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, float
 /* Measurement helper: duration of `reads` independent pseudo-random 64-byte line reads out of the `bytes` at d_ptr
  * (64-byte aligned), four lanes per line and four lines in flight per quad - the NPJ probe's access shape without the
  * join (npj.cpp:216-364 gathers one bucket per lane the same way).  The empirical ceiling bench.py prices NPJ against:
- * out of a table that does not fit the caches the limit is DRAM row activations per second, not bytes. */
+ * out of a table that does not fit the L2 the limit is memory-side requests per second (53-59 G/s for any request size
+ * from 16 to 128 bytes, profiles/r03_request_size.txt), not bytes. */
 int  hjgpu_random_line_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, size_t reads, float *ms, void *stream);
 
 #ifdef __cplusplus
