@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/hjgpu.h"
+#include "exchange_layout.hpp"
 
 typedef unsigned long long u64;
 
@@ -958,14 +959,7 @@ struct CpraStep {
             Rank &r = c->ranks[l];
             CHKM(wait_stream(c, l, r.prep, "partitioning"));
             const u64 *h_off = hp_off(r, Gs, slot);
-            const size_t per = k ? k : 1;                           // partitions per destination rank
-            for (int p = 0; p < G; ++p) { soff[l][p] = h_off[(size_t)p * per]; scnt[l][p] = h_off[(size_t)(p + 1) * per] - h_off[(size_t)p * per]; }
-            if (own_last) {
-                // own partitions last: the others close up, the own ones end the chunk's rows
-                const u64 own = scnt[l][r.global];
-                for (int p = r.global + 1; p < G; ++p) soff[l][p] -= own;
-                soff[l][r.global] = (u64)in[l].n - own;
-            }
+            hj_exchange::send_layout(h_off, k, G, r.global, (u64)in[l].n, own_last, soff[l].data(), scnt[l].data());
             if (l == 0 && stats) {
                 hjgpu_stats ps;
                 if (in[l].n && hjgpu_get_stats(r.part, &ps) == HJGPU_OK) stats->ms_partition += ps.ms_total;
@@ -1002,39 +996,25 @@ struct CpraStep {
             HIPM(c, hipSetDevice(r.device));
             if (l == 0) note_exchange();
             const u64 *matrix = hp_matrix(r, Gs);                   // matrix[src][dst]
-            u64 at = 0;
-            for (int p = 0; p < G; ++p) { rcnt[l][p] = matrix[(size_t)p * Gs + r.global]; roff[l][p] = at; at += rcnt[l][p]; }
+            // (the transport is told nothing about a message that stays: in place, counts for itself are 0 on both sides)
+            const hj_exchange::Receive rx = hj_exchange::receive_layout(matrix, G, r.global, (u64)in[l].n, own_last,
+                                                                        b.sk->cap / tuple_bytes > 16 ? b.sk->cap / tuple_bytes - 16 : 0,
+                                                                        roff[l].data(), rcnt[l].data(), pieces[l].data());
+            const u64 at = rx.rows;
             recv_total[l] = at;
-            const u64 own = rcnt[l][r.global], n_local = in[l].n;
-            bool in_place = false;
-            if (own_last) {
-                const u64 need = n_local + (at - own);
-                in_place = (need + 16) * tuple_bytes <= b.sk->cap;
-                // too small this time (the others sent more than this rank's own chunk suggested): the copying path below,
-                // and the buffer grows before the next exchange through it
-                r.want_rows[which] = in_place ? (r.want_rows[which] > need ? r.want_rows[which] : need) : need + need / 4;
-            }
-            if (in_place) {
-                // rows [n_local - own, n_local): the own piece, where the partitioning wrote it; the others follow from row n_local
-                u64 row = n_local;
-                pieces[l][0] = n_local - own; pieces[l][1] = n_local;
-                int piece = 1;
-                for (int p = 0; p < G; ++p) {
-                    if (p == r.global) continue;
-                    roff[l][p] = row; row += rcnt[l][p];
-                    pieces[l][(size_t)++piece] = row;
-                }
-                roff[l][r.global] = n_local - own; rcnt[l][r.global] = 0; scnt[l][r.global] = 0;      // no message to itself
+            // too small this time (the others sent more than this rank's own chunk suggested): the copying path, and the
+            // buffer grows before the next exchange through it
+            if (own_last) r.want_rows[which] = rx.in_place ? (r.want_rows[which] > rx.need ? r.want_rows[which] : rx.need) : rx.need + rx.need / 4;
+            if (rx.in_place) {
+                scnt[l][r.global] = 0;
                 base[l] = b.sk->p;
                 ks.push_back(b.sk->p); vs.push_back(b.sv->p); kr.push_back(b.sk->p); vr.push_back(b.rv->p);
             } else {
-                for (int p = 0; p < G; ++p) pieces[l][p] = roff[l][p];
-                pieces[l][G] = at;
                 // a quarter of headroom: the next slices rarely need a new allocation (hipFree waits for the device)
                 if ((at + 16) * tuple_bytes > b.rk->cap) CHKM(ensure(c, r, *b.rk, (at + at / 4 + 16) * tuple_bytes));
                 if (!k && (at + 4) * sizeof(uint32_t) > b.rv->cap) CHKM(ensure(c, r, *b.rv, (at + at / 4 + 4) * sizeof(uint32_t)));
                 base[l] = b.rk->p;
-                if (l == 0 && stats && own) stats->self_copies += 1;
+                if (l == 0 && stats && rcnt[l][r.global]) stats->self_copies += 1;
                 ks.push_back(b.sk->p); vs.push_back(b.sv->p); kr.push_back(b.rk->p); vr.push_back(b.rv->p);
             }
             so.push_back(soff[l].data()); sc.push_back(scnt[l].data()); ro.push_back(roff[l].data()); rc.push_back(rcnt[l].data());

@@ -1,0 +1,139 @@
+// CPU test of hash_join_codes_knl_amd/csrc/exchange_layout.hpp (compiled and run by tests/test_exchange_layout.py):
+// whole CPRA exchanges of G ranks played on the host.  Every rank's chunk is "partitioned" (tuples tagged with source,
+// destination partition and a serial number, laid out as the partitioning operators lay them out - the own partitions
+// last when asked), the messages move with memcpy exactly as the transports are told (send offset / count, receive
+// offset / count), and every receiver must then hold, piece by piece, exactly the tuples every source had for it.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "exchange_layout.hpp"
+
+using hj_exchange::u64;
+
+static u64 rng_state = 88172645463325252ull;
+static u64 rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+struct RankData {
+    u64 n;
+    std::vector<u64> prefix;          // [G * k + 1]
+    std::vector<u64> send;            // send buffer (capacity rows), tuples = src << 56 | partition << 40 | serial
+    std::vector<u64> recv;            // receive buffer (copying path)
+    std::vector<u64> soff, scnt, roff, rcnt, pieces;
+    hj_exchange::Receive rx;
+};
+
+static int fail(const char *what, int G, int k, int me) { fprintf(stderr, "FAIL: %s (G = %d, k = %d, rank %d)\n", what, G, k, me); return 1; }
+
+// shape: 0 even chunks, 1 ragged (some ranks hold almost nothing, one holds most), 2 empty ranks, 3 everything for one destination
+static int play(int G, int k, bool own_last, int shape, double headroom)
+{
+    const int per = k ? k : 1, F = G * per;
+    std::vector<RankData> r((size_t)G);
+    for (int g = 0; g < G; ++g) {
+        RankData &d = r[(size_t)g];
+        std::vector<u64> cnt((size_t)F, 0);
+        u64 base = 2000 + rnd() % 500;
+        if (shape == 1) base = (g == G - 1) ? 40000 : (g == 0 ? 3 : 100 + rnd() % 3000);
+        if (shape == 2 && (g & 1)) base = 0;
+        for (int p = 0; p < F; ++p) {
+            cnt[(size_t)p] = base ? rnd() % (2 * base / per + 1) : 0;
+            if (shape == 3 && p / per != G / 2) cnt[(size_t)p] = 0;
+        }
+        d.prefix.assign((size_t)F + 1, 0);
+        for (int p = 0; p < F; ++p) d.prefix[(size_t)p + 1] = d.prefix[(size_t)p] + cnt[(size_t)p];
+        d.n = d.prefix[(size_t)F];
+        // capacity as the communicator guesses it from the rank's own chunk
+        const u64 cap = own_last ? (u64)((double)d.n + (double)(d.n / (u64)G * (u64)(G - 1)) * headroom + 64) : d.n;
+        d.send.assign((size_t)cap + 16, ~0ull);
+        // the partitioning operator's layout (include/hjgpu.h, hjgpu_partition_packed_own_last_async)
+        const u64 ob = d.prefix[(size_t)g * per], oe = d.prefix[(size_t)(g + 1) * per], own = oe - ob;
+        for (int p = 0; p < F; ++p) {
+            u64 first = d.prefix[(size_t)p];
+            if (own_last) {
+                if (p >= (g + 1) * per) first -= own;
+                else if (p >= g * per) first = d.n - own + (first - ob);
+            }
+            for (u64 i = 0; i < cnt[(size_t)p]; ++i) d.send[(size_t)(first + i)] = ((u64)g << 56) | ((u64)p << 40) | (d.prefix[(size_t)p] + i);
+        }
+        d.soff.resize((size_t)G); d.scnt.resize((size_t)G); d.roff.resize((size_t)G); d.rcnt.resize((size_t)G); d.pieces.resize((size_t)G + 1);
+        hj_exchange::send_layout(d.prefix.data(), (size_t)k, G, g, d.n, own_last, d.soff.data(), d.scnt.data());
+    }
+    // the counts all-gather: matrix[src][dst]
+    std::vector<u64> matrix((size_t)G * G);
+    for (int s = 0; s < G; ++s) for (int t = 0; t < G; ++t) matrix[(size_t)s * G + t] = r[(size_t)s].scnt[(size_t)t];
+    int in_place = 0;
+    for (int g = 0; g < G; ++g) {
+        RankData &d = r[(size_t)g];
+        d.rx = hj_exchange::receive_layout(matrix.data(), G, g, d.n, own_last, (u64)d.send.size() - 16, d.roff.data(), d.rcnt.data(), d.pieces.data());
+        if (d.rx.in_place) { d.scnt[(size_t)g] = 0; ++in_place; }
+        else d.recv.assign((size_t)d.rx.rows + 16, ~0ull);
+        if (d.rx.in_place && d.rx.need > d.send.size() - 16) return fail("in place without room", G, k, g);
+    }
+    // the transport: every message is copied from where the sender says to where the receiver says; the messages of a
+    // rank are read before anything is written into its buffer only if the regions are disjoint - check that they are
+    for (int g = 0; g < G; ++g) {
+        const RankData &d = r[(size_t)g];
+        if (!d.rx.in_place) continue;
+        for (int p = 0; p < G; ++p) {
+            if (p == g) continue;
+            if (d.scnt[(size_t)p] && d.soff[(size_t)p] + d.scnt[(size_t)p] > d.n - matrix[(size_t)g * G + g]) return fail("a message to another rank overlaps the own piece", G, k, g);
+            if (d.rcnt[(size_t)p] && d.roff[(size_t)p] < d.n) return fail("a received piece overwrites rows of the chunk", G, k, g);
+        }
+    }
+    for (int s = 0; s < G; ++s)
+        for (int t = 0; t < G; ++t) {
+            const RankData &src = r[(size_t)s];
+            RankData &dst = r[(size_t)t];
+            if (src.scnt[(size_t)t] != dst.rcnt[(size_t)s]) return fail("send and receive counts disagree", G, k, s);
+            u64 *to = dst.rx.in_place ? dst.send.data() : dst.recv.data();
+            if (src.scnt[(size_t)t]) memcpy(to + dst.roff[(size_t)s], src.send.data() + src.soff[(size_t)t], (size_t)src.scnt[(size_t)t] * sizeof(u64));
+        }
+    // every receiver: G pieces, contiguous, each holding exactly one source's tuples for this rank's partitions, in partition order
+    for (int g = 0; g < G; ++g) {
+        const RankData &d = r[(size_t)g];
+        const u64 *arr = d.rx.in_place ? d.send.data() : d.recv.data();
+        if (d.pieces[(size_t)G] - d.pieces[0] != d.rx.rows) return fail("the pieces do not add up to the rank's rows", G, k, g);
+        std::vector<int> seen((size_t)G, 0);
+        for (int c = 0; c < G; ++c) {
+            const u64 b = d.pieces[(size_t)c], e = d.pieces[(size_t)c + 1];
+            if (e < b) return fail("piece boundaries decrease", G, k, g);
+            if (e == b) continue;
+            const int src = (int)(arr[b] >> 56);
+            if (src < 0 || src >= G || seen[(size_t)src]) return fail("a source appears in two pieces", G, k, g);
+            seen[(size_t)src] = 1;
+            if (e - b != matrix[(size_t)src * G + g]) return fail("a piece has the wrong length", G, k, g);
+            u64 want_serial = r[(size_t)src].prefix[(size_t)g * per];
+            for (u64 i = b; i < e; ++i) {
+                const u64 t = arr[i];
+                const int p = (int)((t >> 40) & 0xFFFF);
+                if ((int)(t >> 56) != src || p / per != g) return fail("a tuple in the wrong piece", G, k, g);
+                if ((t & 0xFFFFFFFFFFull) != want_serial++) return fail("tuples lost or out of order inside a piece", G, k, g);
+            }
+        }
+        u64 expect = 0;
+        for (int s = 0; s < G; ++s) expect += matrix[(size_t)s * G + g];
+        if (expect != d.rx.rows) return fail("rows", G, k, g);
+    }
+    return in_place << 8;       // how many ranks exchanged in place (reported, not an error)
+}
+
+int main()
+{
+    int cases = 0, in_place_ranks = 0, copying_ranks = 0;
+    for (int G = 1; G <= 8; ++G)
+        for (int k : {0, 1, 3, 192 / G})
+            for (int own_last = 0; own_last < 2; ++own_last) {
+                if (own_last && !k) continue;                 // the two-level plan copies
+                for (int shape = 0; shape < 4; ++shape)
+                    for (double headroom : {1.125, 0.5}) {
+                        const int rc = play(G, k, own_last != 0, shape, headroom);
+                        if (rc & 0xFF) return 1;
+                        ++cases;
+                        if (own_last) { in_place_ranks += rc >> 8; copying_ranks += G - (rc >> 8); }
+                    }
+            }
+    printf("ok: %d exchanges, %d ranks in place, %d ranks through the copying path\n", cases, in_place_ranks, copying_ranks);
+    return (in_place_ranks && copying_ranks) ? 0 : 2;
+}
