@@ -61,6 +61,8 @@ def parse(argv=None):
                     help="multi-GPU: replicate the build side with one ncclBroadcast instead of scatter + all-gather")
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="multi-GPU: CUs the partitioning kernels leave to RCCL's kernels (-1 = the library's default: 16 with > 1 rank)")
+    ap.add_argument("--comm-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="communicator options for measurements (hjgpu_comm_set_option), e.g. cpra_k=24, cpra_two_level=1")
     ap.add_argument("--exchange-slices", type=int, default=4,
                     help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap)")
     ap.add_argument("--comm-timeout-ms", type=int, default=120_000,
@@ -298,6 +300,9 @@ def main():
         except H.HjGpuError as ex:
             die_of_comm_error(rank, ex, "creating the communicator")
         comm.set_option("timeout_ms", args.comm_timeout_ms)
+        for nv in args.comm_option:
+            name, _, value = nv.partition("=")
+            comm.set_option(name, int(value))
         if args.ring_broadcast:
             comm.set_option("ring_broadcast", 1)
         if args.reserve_cus >= 0:

@@ -155,6 +155,8 @@ struct hjgpu_comm {
                                              // partitioning waits for the joins enqueued so far, bit 2 the exchange waits for them
     bool exchange_in_place = true;           // option "exchange_in_place": a CPRA rank keeps its own partitions where its partitioning wrote
                                              // them (last) and receives the other ranks' pieces right behind: the message to itself is never copied
+    int cpra_k = 0;                          // option "cpra_k": partitions per rank of the exchange-level pass (0 = 192 / ranks); measurements:
+                                             // k = 24 at world 1 gives the receiver the per-GPU work of an 8-GPU join
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
     char err[512];
     char why_broken[512];
@@ -1055,7 +1057,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     CpraStep step(c, stats);
     // one-level plan while the receiver can take one piece per source rank (<= 8 pieces): fan-out G * k with G * k <= 192,
     // the widest pass 1 whose whole-line carry still fits beside a 16 K-tuple tile
-    if (c->nranks <= 8 && !c->cpra_two_level) step.k = (uint32_t)(192 / c->nranks);
+    if (c->nranks <= 8 && !c->cpra_two_level) step.k = (uint32_t)(c->cpra_k > 0 && c->cpra_k * c->nranks <= 192 ? c->cpra_k : 192 / c->nranks);
     const uint32_t K = step.k;
     // the layout of what local rank l received (pieces = one per source rank), rows [lo, hi) of it
     auto layout_of = [&](int l, const std::vector<u64> &pieces, u64 lo, u64 hi) {
@@ -1400,6 +1402,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
         return HJGPU_OK;
     }
     if (strcmp(name, "exchange_in_place") == 0) { c->exchange_in_place = x != 0; return HJGPU_OK; }
+    if (strcmp(name, "cpra_k") == 0) { if (x < 0 || x > 192) return cfail(c, HJGPU_EINVAL, "cpra_k: 0 ... 192"); c->cpra_k = (int)x; return HJGPU_OK; }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }
     if (strcmp(name, "self_via_rccl") == 0) { c->self_via_rccl = x != 0; return HJGPU_OK; }
