@@ -63,8 +63,9 @@ def parse(argv=None):
                     help="multi-GPU: CUs the partitioning kernels leave to RCCL's kernels (-1 = the library's default: 16 with > 1 rank)")
     ap.add_argument("--comm-option", action="append", default=[], metavar="NAME=VALUE",
                     help="communicator options for measurements (hjgpu_comm_set_option), e.g. cpra_k=24, cpra_two_level=1")
-    ap.add_argument("--exchange-slices", type=int, default=4,
-                    help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap)")
+    ap.add_argument("--exchange-slices", type=int, default=0,
+                    help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap); "
+                         "0 = the library's choice: 4, or 1 in a world of one (nothing to overlap)")
     ap.add_argument("--comm-timeout-ms", type=int, default=120_000,
                     help="multi-GPU: deadline of every host-side wait inside the library (hjgpu_comm option timeout_ms); when it "
                          "expires the communicator is aborted (ncclCommAbort) and this process exits with status 3")
@@ -462,7 +463,7 @@ def main():
     if copart:
         parallelism = ("both sides chunked over %d GPU(s), %s: own-chunk partitioning, counts all-gather, all-to-all-v "
                        "(probe side in %d slices, transfers overlapped with partitioning and local PHJ), all-reduce"
-                       % (n_gpus, transport, args.exchange_slices))
+                       % (n_gpus, transport, args.exchange_slices or (1 if max(world, 1) == 1 else 4)))
     elif multi:
         parallelism = "probe side sharded over %d GPU(s), build side replicated each step by %s, %s, overlapped with " \
                       "probe-side partitioning, all-reduce" % (n_gpus, "one ncclBroadcast" if args.ring_broadcast else

@@ -913,11 +913,18 @@ struct CpraStep {
     // `ready`: which upload event of the rank the partitioning waits for (host path), or nullptr.
     int exchange(const std::vector<Slice> &in, int which, int slot, hipEvent_t Rank::*ready = nullptr)
     {
+        CHKM(begin_exchange(in, which, slot, ready));
+        return finish_exchange(in, which, slot);
+    }
+
+    // first half: the partitioning of every local rank's slice is enqueued (nothing waits on the host)
+    int begin_exchange(const std::vector<Slice> &in, int which, int slot, hipEvent_t Rank::*ready = nullptr)
+    {
         const size_t Gs = (size_t)G;
         const size_t F = fanout();                                  // partitions of the exchange-level pass
         const size_t tuple_bytes = k ? sizeof(u64) : sizeof(uint32_t);
         const bool own_last = k && c->exchange_in_place && !c->self_via_rccl;
-        CHKM(each_rank(L, [&](int l) -> int {
+        return each_rank(L, [&](int l) -> int {
             Rank &r = c->ranks[l];
             ExchangeBufs b = bufs_of(r, which);
             size_t hold = in[l].n;
@@ -955,8 +962,16 @@ struct CpraStep {
             HIPM(c, hipMemcpyAsync(h_off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
             HIPM(c, hipEventRecord(r.ev_part[slot], r.prep));
             return HJGPU_OK;
-        }));
-        // the host needs the counts: how much every peer gets decides the receive buffers
+        });
+    }
+
+    // second half: the host waits for the counts (how much every peer gets decides the receive buffers), the ranks
+    // exchange them, the transfers are enqueued
+    int finish_exchange(const std::vector<Slice> &in, int which, int slot)
+    {
+        const size_t Gs = (size_t)G;
+        const size_t tuple_bytes = k ? sizeof(u64) : sizeof(uint32_t);
+        const bool own_last = k && c->exchange_in_place && !c->self_via_rccl;
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
             CHKM(wait_stream(c, l, r.prep, "partitioning"));
@@ -1042,7 +1057,9 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
 {
     if (!c || !shards) return HJGPU_EINVAL;
     CHKM(refuse_broken(c));
-    if (slices <= 0) slices = 4;
+    // slices exist to overlap the exchange with the local passes; a world of one has nothing to overlap and every slice
+    // costs ~0.6 ms of launches, ramps and tails (world 1, 64 M x 1 G: 10.6 / 11.2 / 12.6 / 15.0 ms with 1 / 2 / 4 / 8 slices)
+    if (slices <= 0) slices = c->nranks == 1 ? 1 : 4;
     if (slices > 4096) return cfail(c, HJGPU_EINVAL, "at most 4096 slices");
     CHKM(check_rows(c, rows));
     const auto t0 = std::chrono::steady_clock::now();
@@ -1187,7 +1204,13 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             range_of(shards[l].outer, 16, (size_t)i, (size_t)slices, &b, &e);
             in[l] = {shards[l].outer ? shards[l].d_outer_keys + b : nullptr, shards[l].outer ? shards[l].d_outer_vals + b : nullptr, e - b};
         }
-        CHKM(step.exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr));
+        // partition(i) is enqueued first, then join(i-1) - which the device starts as soon as exchange(i-1) has arrived -
+        // and only then does the host wait for partition(i)'s counts: the device works on join(i-1) and partition(i)
+        // while the host and the ranks settle the sizes of exchange(i) (with the join enqueued after that wait, every
+        // slice cost a world of one ~0.75 ms of idle device: 4 slices 13.0 -> , 8 slices 16.7 -> ms)
+        CHKM(step.begin_exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr));
+        if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
+        CHKM(step.finish_exchange(in, 1 + slot, slot));
         if (build_stats_pending && i == 0) {
             // the host has just waited for this slice's partition counts and the counts gather; the build was enqueued
             // before both and is (nearly always) done: reading its events costs the pipeline nothing
@@ -1195,7 +1218,6 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             if (hjgpu_get_stats(c->ranks[0].join, &js) == HJGPU_OK) { add_stats(&stats->join, js); stats->joins += 1; stats->tuples_joined += inner_recv[0]; }
             build_stats_pending = false;
         }
-        if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
         pending = step.recv_total;
         pending_pieces = step.pieces;
         pending_base = step.base;

@@ -495,7 +495,7 @@ int  hjgpu_phj_multi(hjgpu_comm *comm, const hjgpu_shard *shards, int root, cons
 int  hjgpu_npj_multi(hjgpu_comm *comm, const hjgpu_shard *shards, int root, const hjgpu_npj_params *params,
                      hjgpu_result *result, hjgpu_multi_stats *stats);
 int  hjgpu_cpra_multi(hjgpu_comm *comm, const hjgpu_shard *shards, const hjgpu_phj_params *params,
-                      int slices /* 0 = 4 */, hjgpu_result *result, hjgpu_multi_stats *stats);
+                      int slices /* 0 = 4 (1 in a world of one) */, hjgpu_result *result, hjgpu_multi_stats *stats);
 /* Materialised rows (the reference's join_keys / join_outer_vals / join_inner_vals, which every worker writes:
  * npj.cpp:882-915, cpra2.cpp:1965-1982) through the multi-GPU joins: every rank materialises ITS share of the result
  * into its own three device columns (block protocol + close_gaps; CPRA: slice after slice, each behind the rows of
