@@ -6,6 +6,7 @@ KiB, and on gfx950 FETCH_SIZE reports exactly half of a wide coalesced read stre
     bytes_written =     WRITE_SIZE * 1024
 Run on the GPU box (rocprofv3 gets the program itself after `--`):
     python tools/collect_traffic.py [bench.py args...]
+    python tools/collect_traffic.py --materialized        (the materialising PHJ of tools/run_materialized.py instead)
 Writes gpurun_out/traffic.json; copy it to the file bench.py names (TRAFFIC_FILE, profiles/rNN_traffic.json).
 The file records the kernel-source hash of the library it was measured with (hjgpu_kernel_hash); bench.py attaches
 the counters to its `roofline.traffic` field only when that equals the running library's."""
@@ -26,8 +27,11 @@ def run_pass(counter, extra):
     shutil.rmtree(out, ignore_errors=True)          # a previous run's dispatches must not be averaged in
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-outer", "0", "--no-secondary"] + extra
+    if extra[:1] == ["--materialized"]:
+        program = [os.path.join(ROOT, "tools", "run_materialized.py"), "2"]
+    else:
+        program = [os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-outer", "0", "--no-secondary"] + extra
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable] + program
     subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -68,13 +72,15 @@ def main():
     import hash_join_codes_knl_amd as H
     out = {"kernel_hash": H.kernel_hash(),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
-                     "`bench.py --steps 2 --warmup 1 --cpu-outer 0 --no-secondary`, averaged over all launches of a kernel; "
+                     + ("`tools/run_materialized.py 2` (every join launch materialises its three result columns)"
+                        if extra[:1] == ["--materialized"] else "`bench.py --steps 2 --warmup 1 --cpu-outer 0 --no-secondary`") +
+                     ", averaged over all launches of a kernel; "
                      "read = 2*FETCH_SIZE KiB (gfx950 correction), written = WRITE_SIZE KiB",
            "bench_args": extra, "kernels": res}
     path = os.path.join(ROOT, "gpurun_out", "traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     for k, v in res.items():
-        if any(s in k for s in ("scatter", "join", "hist2", "npj")):
+        if any(s in k for s in ("scatter", "join", "hist2", "npj", "gaps")):
             print("%-40s read %.3f GB  written %.3f GB per launch (%d launches)"
                   % (k[:40], v["read_bytes_per_launch"] / 1e9, v["written_bytes_per_launch"] / 1e9, v["launches_seen"]))
 
