@@ -174,6 +174,12 @@ struct PlanArgs {
     uint32_t cap;             // build rows per LDS table fill of the join kernel that will run (JoinConfig::cap)
     uint32_t mask;            // bit 0: plan R, bit 1: plan S, bit 2: join work items
     uint32_t unique;          // _UNIQUE joins: all table fills of a probe slice stay with ONE work item (see join_kernel)
+    // Chunked relations (one-GPU CPRA), line-aligned final layout: the pass-1 output is laid out PARTITION-major - the
+    // chunks' regions of a pass-1 partition lie side by side, off1[c * F1 + p] still says where chunk c writes partition
+    // p - so pass 2 sees F1 segments [seg2[p], seg2[p + 1]) exactly as after an unchunked pass 1, and pass 1 of every
+    // chunk writes across the whole twin (chunk-major: 3.3 + 3.3 ms for the two passes at 2-8 chunks against 3.0 + 3.05)
+    uint32_t p_major = 0;
+    u64 *seg2[2] = {nullptr, nullptr};   // [F1 + 1] p_major: the pass-1 partitions' bounds
 };
 
 // A relation that arrives pass-1-partitioned in pieces (the multi-GPU CPRA's receiving side): piece c = rows

@@ -198,6 +198,7 @@ inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) 
 // Carves the meta buffer; must match between sizing and use.
 struct MetaLayout {
     u64 *counts[2], *off2[2], *end2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
+    u64 *seg2[2];                // [F1 + 1] partition-major pass-1 layout of a chunked relation: bounds of the pass-1 partitions
     u64 *slice_prefix, *slices;
     uint32_t *tickets;           // [64] work-claim counters of K4 / K6 (inside the block zeroed per join)
     uint32_t *item_part;         // [P + items_extra] partition of every join work item
@@ -235,6 +236,7 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
         m.tp1[r] = take(C + 1);
         m.seg1[r] = take(C + 1);
         m.tp2[r] = take((size_t)C * F1 + 1);
+        m.seg2[r] = take((size_t)F1 + 1);
     }
     m.slice_prefix = take((size_t)P + 1);
     m.slices = take(P);
@@ -397,6 +399,14 @@ Pass1Geom make_geom(const HjTuning &tune, const void *keys, size_t n, uint32_t C
         if (t > max_tiles) max_tiles = t;
     }
     g.ranges_per_chunk = capacity ? ranges_capacity(tune, max_tiles, F1) : ranges_of(tune, max_tiles, F1);
+    if (!capacity && C > 1) {
+        // chunks: as many tiles per range as the WHOLE relation would get (never fewer ranges' worth of table than the
+        // capacity above: tiles per range only grow with the tile count) - per-chunk sizing gave 8 chunks of 1/8 G tuples
+        // twice the ranges of an unchunked relation, and K4 / K5b 0.16 ms more work
+        const uint32_t k = range_tiles_for(tune, max_tiles * C, F1);
+        const uint32_t fewer = (uint32_t)((max_tiles + k - 1) / k);
+        if (fewer < g.ranges_per_chunk) g.ranges_per_chunk = fewer;
+    }
     return g;
 }
 
@@ -552,6 +562,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r]; pa.tdesc[r] = m.tdesc[r];
+        pa.seg2[r] = m.seg2[r];
     }
     pa.tdesc_cap = (uint32_t)m.tdesc_cap;
     pa.unique = pl.unique ? 1u : 0u;
@@ -559,6 +570,10 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     const bool pad2 = pl.F2 > 1 && !ctx->tune.dense2;
     pa.pad2 = pad2 ? 1u : 0u;
     pa.n[0] = inner; pa.n[1] = outer;
+    // chunked relations (one-GPU CPRA): the chunks' regions of a pass-1 partition side by side, so that pass 2 and the join
+    // see what they see after an unchunked pass 1 (the pieces of a pre-partitioned relation lie where they arrived)
+    const bool p_major = pl.C > 1 && pad2 && !pre;
+    pa.p_major = p_major ? 1u : 0u;
     // pre-partitioned pieces sit at absolute rows [b[0], b[C]) of the caller's array
     if (pre) for (int r = 0; r < 2; ++r) if (pre->tuples[r]) pa.n[r] = pre->ch[r].b[pl.C];
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
@@ -597,8 +612,8 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ScatterArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
-        sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
-        sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
+        sa.seg_off = p_major ? m.seg2[r] : m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
+        sa.nseg = p_major ? pl.F1 : pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
         sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
         sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
         sa.in_packed = 1; sa.out_packed = 1;

@@ -463,8 +463,23 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
         // join then sees one piece per partition, exactly as after PHJ's passes.  Block 0 lays the final
         // partitions out (entries [0, P) of off2 / end2 / cur2), every block its own chunk's pass-1 partitions.
         __shared__ u64 scratch2[4 * (PLAN_BLOCK / 64)];
+        // partition-major pass-1 layout (PlanArgs::p_major): rows of my pass-1 partitions in the chunks BEFORE mine
+        __shared__ u64 before[HJGPU_MAX_FANOUT];
+        const bool p_major = a.p_major != 0;
+        if (p_major) {
+            // one wave per pass-1 partition at a time: its lanes read the partition's F2 counters of every earlier chunk
+            // (coalesced, all loads of a partition in flight together), one wave reduction per partition
+            for (uint32_t p1 = threadIdx.x >> 6; p1 < a.F1; p1 += PLAN_BLOCK / 64) {
+                u64 s = 0;
+                for (uint32_t cc = 0; cc < c; ++cc)
+                    for (uint32_t h = threadIdx.x & 63u; h < a.F2; h += 64) s += a.counts[r][(u64)cc * P + (u64)p1 * a.F2 + h];
+                s = wave_reduce_sum(s);
+                if ((threadIdx.x & 63u) == 0) before[p1] = s;
+            }
+            __syncthreads();
+        }
         auto padded = [](u64 n) { return (n + HJ_LINE_TUPLES - 1) & ~(u64)(HJ_LINE_TUPLES - 1); };
-        u64 drun = base;                                              // dense offset of the tile's first partition
+        u64 drun = p_major ? a.chunk_beg[r][0] : base;                // dense offset of the tile's first partition
         u64 prun = 0;                                                 // padded one (block 0; the relation starts at row 0)
         const uint32_t F2 = a.F2;
         const u64 *__restrict__ all = a.counts[r];
@@ -478,18 +493,28 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
         int parity = 0;
         for (uint32_t tile = 0; tile < P; tile += 2 * PLAN_BLOCK, parity ^= 1) {
             const uint32_t q0 = tile + 2 * threadIdx.x, q1 = q0 + 1;
-            const u64 n0 = q0 < P ? cnt[q0] : 0, n1 = q1 < P ? cnt[q1] : 0;
-            const u64 t0 = (c == 0 && q0 < P) ? total_of(q0) : 0, t1 = (c == 0 && q1 < P) ? total_of(q1) : 0;
+            const bool totals = c == 0 || p_major;
+            const u64 t0 = (totals && q0 < P) ? total_of(q0) : 0, t1 = (totals && q1 < P) ? total_of(q1) : 0;
+            // the dense (pass-1) layout: my chunk's rows, or - partition-major - the rows of all chunks
+            const u64 n0 = p_major ? t0 : (q0 < P ? cnt[q0] : 0), n1 = p_major ? t1 : (q1 < P ? cnt[q1] : 0);
             u64 d = n0 + n1, pd = padded(t0) + padded(t1), dt, pt;
             plan_scan2(d, pd, dt, pt, scratch2, parity);
             d += drun; pd += prun;
             if (q0 < P) {
-                if (q0 % F2 == 0) { a.off1[r][(u64)c * a.F1 + q0 / F2] = d; a.cur1[r][(u64)c * a.F1 + q0 / F2] = d; }
+                if (q0 % F2 == 0) {
+                    const u64 mine = d + (p_major ? before[q0 / F2] : 0);
+                    a.off1[r][(u64)c * a.F1 + q0 / F2] = mine; a.cur1[r][(u64)c * a.F1 + q0 / F2] = mine;
+                    if (p_major && c == 0) a.seg2[r][q0 / F2] = d;
+                }
                 if (c == 0) { fo[q0] = pd; fe[q0] = pd + t0; fc[q0] = 0; }      // cursor: lines claimed | tail tuples << 32
             }
             if (q1 < P) {
                 const u64 d1 = d + n0, p1 = pd + padded(t0);
-                if (q1 % F2 == 0) { a.off1[r][(u64)c * a.F1 + q1 / F2] = d1; a.cur1[r][(u64)c * a.F1 + q1 / F2] = d1; }
+                if (q1 % F2 == 0) {
+                    const u64 mine = d1 + (p_major ? before[q1 / F2] : 0);
+                    a.off1[r][(u64)c * a.F1 + q1 / F2] = mine; a.cur1[r][(u64)c * a.F1 + q1 / F2] = mine;
+                    if (p_major && c == 0) a.seg2[r][q1 / F2] = d1;
+                }
                 if (c == 0) { fo[q1] = p1; fe[q1] = p1 + t1; fc[q1] = 0; }
             }
             drun += dt; prun += pt;
@@ -498,6 +523,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
     if (threadIdx.x == 0) {
         a.seg1[r][c] = base;
         if (c == C - 1) { a.seg1[r][C] = a.n[r]; a.off1[r][(u64)C * a.F1] = a.n[r]; }
+        if (PAD && a.p_major && c == 0) a.seg2[r][a.F1] = a.n[r];
     }
 }
 
@@ -516,8 +542,9 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
         plan_scan<8>(C, [&](uint32_t i) { return hj_tiles_of(seg1[i], seg1[i + 1], al, tile1); },
                      a.tp1[r], 0, scratch);
         // pass-2 tiles: segments are the pass-1 partitions inside the (aligned) workspace
-        const u64 *off1 = a.off1[r];
-        plan_scan<8>(C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile2); },
+        // (partition-major pass-1 layout: F1 segments, the chunks' regions of a partition side by side)
+        const u64 *off1 = a.p_major ? a.seg2[r] : a.off1[r];
+        plan_scan<8>(a.p_major ? a.F1 : C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile2); },
                      a.tp2[r], 0, scratch);
     }
 }
@@ -531,8 +558,8 @@ __global__ __launch_bounds__(PLAN_BLOCK) void tile_desc_kernel(PlanArgs a)
 {
     const int r = blockIdx.y;
     if (!((a.mask >> r) & 1u) || !a.tdesc[r]) return;
-    const uint32_t nseg = a.chunks * a.F1, tile2 = a.tile2;
-    const u64 *__restrict__ off1 = a.off1[r];
+    const uint32_t nseg = a.p_major ? a.F1 : a.chunks * a.F1, tile2 = a.tile2;
+    const u64 *__restrict__ off1 = a.p_major ? a.seg2[r] : a.off1[r];
     const u64 *__restrict__ tp2 = a.tp2[r];
     uint4 *td = a.tdesc[r];
     for (uint32_t sgm = blockIdx.x * (PLAN_BLOCK / 64) + (threadIdx.x >> 6); sgm < nseg; sgm += TDESC_BLOCKS * (PLAN_BLOCK / 64)) {
