@@ -55,6 +55,7 @@ struct HjTuning {
     bool force_chained = false;     // "force_chained": chained fallback tables everywhere (tests)
     bool scatter_prof = false;      // "scatter_prof": K6 phase stamps (diagnostics; synchronises)
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
+    bool piece_interleave = true;   // "piece_interleave": pass 2 over arrived pieces takes its tiles partition by partition (PlanArgs::seg_interleave)
     bool merged_plan = true;        // "merged_plan": whole joins on resident columns plan both relations with one set of K5 launches
     int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
@@ -179,6 +180,10 @@ struct PlanArgs {
     // p - so pass 2 sees F1 segments [seg2[p], seg2[p + 1]) exactly as after an unchunked pass 1, and pass 1 of every
     // chunk writes across the whole twin (chunk-major: 3.3 + 3.3 ms for the two passes at 2-8 chunks against 3.0 + 3.05)
     uint32_t p_major = 0;
+    // Pieces that lie where they arrived (pre-partitioned relations, chunk-major in memory): pass 2 still takes its tiles
+    // partition by partition - all pieces of pass-1 partition 0, then of partition 1 ... - so that every final partition
+    // is written in one go (tile order only: entry i of the tile prefix is segment (i % chunks) * F1 + i / chunks)
+    uint32_t seg_interleave = 0;
     u64 *seg2[2] = {nullptr, nullptr};   // [F1 + 1] p_major: the pass-1 partitions' bounds
 };
 

@@ -574,6 +574,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     // see what they see after an unchunked pass 1 (the pieces of a pre-partitioned relation lie where they arrived)
     const bool p_major = pl.C > 1 && pad2 && !pre;
     pa.p_major = p_major ? 1u : 0u;
+    pa.seg_interleave = (pre && pl.C > 1 && pad2 && ctx->tune.piece_interleave) ? 1u : 0u;
     // pre-partitioned pieces sit at absolute rows [b[0], b[C]) of the caller's array
     if (pre) for (int r = 0; r < 2; ++r) if (pre->tuples[r]) pa.n[r] = pre->ch[r].b[pl.C];
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];

@@ -544,8 +544,11 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_tiles_kernel(PlanArgs a)
         // pass-2 tiles: segments are the pass-1 partitions inside the (aligned) workspace
         // (partition-major pass-1 layout: F1 segments, the chunks' regions of a partition side by side)
         const u64 *off1 = a.p_major ? a.seg2[r] : a.off1[r];
-        plan_scan<8>(a.p_major ? a.F1 : C * a.F1, [&](uint32_t i) { return hj_tiles_of(off1[i], off1[i + 1], 0, tile2); },
-                     a.tp2[r], 0, scratch);
+        const uint32_t F1 = a.F1, inter = a.seg_interleave;
+        plan_scan<8>(a.p_major ? a.F1 : C * a.F1, [&](uint32_t i) {
+                         const uint32_t sgm = inter ? (i % C) * F1 + i / C : i;
+                         return hj_tiles_of(off1[sgm], off1[sgm + 1], 0, tile2);
+                     }, a.tp2[r], 0, scratch);
     }
 }
 
@@ -562,9 +565,10 @@ __global__ __launch_bounds__(PLAN_BLOCK) void tile_desc_kernel(PlanArgs a)
     const u64 *__restrict__ off1 = a.p_major ? a.seg2[r] : a.off1[r];
     const u64 *__restrict__ tp2 = a.tp2[r];
     uint4 *td = a.tdesc[r];
-    for (uint32_t sgm = blockIdx.x * (PLAN_BLOCK / 64) + (threadIdx.x >> 6); sgm < nseg; sgm += TDESC_BLOCKS * (PLAN_BLOCK / 64)) {
+    for (uint32_t i = blockIdx.x * (PLAN_BLOCK / 64) + (threadIdx.x >> 6); i < nseg; i += TDESC_BLOCKS * (PLAN_BLOCK / 64)) {
+        const uint32_t sgm = a.seg_interleave ? (i % a.chunks) * a.F1 + i / a.chunks : i;      // the i-th segment in tile order
         const u64 gb = off1[sgm], ge = off1[sgm + 1];
-        const u64 t0 = tp2[sgm], t1 = min(tp2[sgm + 1], (u64)a.tdesc_cap);
+        const u64 t0 = tp2[i], t1 = min(tp2[i + 1], (u64)a.tdesc_cap);
         for (u64 t = t0 + (threadIdx.x & 63); t < t1; t += 64) {
             const u64 g0 = (gb & ~3ull) + (t - t0) * tile2;
             td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
@@ -1375,6 +1379,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("scatter_prof")) return parse_flag(value, &t->scatter_prof);
     if (is("unique")) return parse_flag(value, &t->unique);
     if (is("merged_plan")) return parse_flag(value, &t->merged_plan);
+    if (is("piece_interleave")) return parse_flag(value, &t->piece_interleave);
     if (is("placement")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1424,7 +1429,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);
