@@ -59,6 +59,7 @@ struct HjTuning {
     bool merged_plan = true;        // "merged_plan": whole joins on resident columns plan both relations with one set of K5 launches
     int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
+    long long host_batch = 64ll << 20;   // "host_batch": probe rows per batch of hjgpu_join_host's PHJ / CPRA (0 = the whole probe side at once)
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned

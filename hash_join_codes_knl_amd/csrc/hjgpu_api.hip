@@ -60,6 +60,10 @@ struct hjgpu_ctx {
     size_t prepared_inner = 0, prepared_max_outer = 0;
     unsigned char prepared_plan[128];
     HjTuning tune;          // tuning / test switches: environment at hjgpu_create, hjgpu_set_option afterwards
+    // hjgpu_join_host*: two page-locked staging buffers for PAGEABLE host columns, made when the first one is seen and kept
+    // (hipHostMalloc + hipHostFree of 2 x 32 MiB cost 22 ms per call; page-locked columns never need them)
+    void *host_stage[2] = {nullptr, nullptr};
+    hipEvent_t host_stage_ev[2] = {nullptr, nullptr};
     // hjgpu_set_async_output: the next *_async join of this context materialises into these columns (one-shot)
     hjgpu_output pending_out;
     bool has_pending_out = false;
@@ -963,6 +967,10 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->host_stage[b]) (void)hipHostFree(ctx->host_stage[b]);
+        if (ctx->host_stage_ev[b]) (void)hipEventDestroy(ctx->host_stage_ev[b]);
+    }
     delete ctx;
     return HJGPU_OK;
 }
@@ -1749,8 +1757,17 @@ int hjgpu_cpra_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, siz
 // Host column -> HBM on `copy`.  Page-locked memory (hjgpu_host_alloc, hipHostRegister'ed, ...) is
 // DMA'd directly; pageable memory goes through two pinned staging buffers so that the CPU's copy
 // of chunk i+1 overlaps the DMA of chunk i.
-static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, hipStream_t copy,
-                         void *stage[2], hipEvent_t stage_free[2], size_t stage_bytes, int *next)
+constexpr size_t HJ_HOST_STAGE = 32u << 20;
+static int host_stage(hjgpu_ctx *ctx)
+{
+    for (int b = 0; b < 2; ++b) {
+        if (!ctx->host_stage[b]) HIPCHK(ctx, hipHostMalloc(&ctx->host_stage[b], HJ_HOST_STAGE, hipHostMallocDefault));
+        if (!ctx->host_stage_ev[b]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->host_stage_ev[b], hipEventDisableTiming));
+    }
+    return HJGPU_OK;
+}
+
+static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, hipStream_t copy, int *next)
 {
     if (!bytes) return HJGPU_OK;
     hipPointerAttribute_t at;
@@ -1760,6 +1777,10 @@ static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, h
         HIPCHK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, copy));
         return HJGPU_OK;
     }
+    CHK(host_stage(ctx));
+    void **stage = ctx->host_stage;
+    hipEvent_t *stage_free = ctx->host_stage_ev;
+    const size_t stage_bytes = HJ_HOST_STAGE;
     for (size_t at_ = 0; at_ < bytes; at_ += stage_bytes) {
         const size_t n = bytes - at_ < stage_bytes ? bytes - at_ : stage_bytes;
         const int b = *next; *next ^= 1;
@@ -1773,8 +1794,7 @@ static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, h
 
 // HBM column -> host column on `copy`: the mirror image of upload_column.  Pageable destinations are
 // filled from two pinned staging buffers, the CPU's copy of chunk i overlapping the DMA of chunk i+1.
-static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes, hipStream_t copy,
-                           void *stage[2], hipEvent_t stage_done[2], size_t stage_bytes)
+static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes, hipStream_t copy)
 {
     if (!bytes) return HJGPU_OK;
     hipPointerAttribute_t at;
@@ -1784,6 +1804,10 @@ static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes,
         HIPCHK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, copy));
         return HJGPU_OK;
     }
+    CHK(host_stage(ctx));
+    void **stage = ctx->host_stage;
+    hipEvent_t *stage_done = ctx->host_stage_ev;
+    const size_t stage_bytes = HJ_HOST_STAGE;
     const size_t chunks = (bytes + stage_bytes - 1) / stage_bytes;
     auto len = [&](size_t c) { return c + 1 < chunks ? stage_bytes : bytes - c * stage_bytes; };
     auto fetch = [&](size_t c) -> hipError_t {
@@ -1827,6 +1851,140 @@ int hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm,
     return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result, stats);
 }
 
+
+// Joins from host columns, aggregates only: the probe side never exists on the device as a whole.  R is uploaded and
+// prepared (PHJ / CPRA: hjgpu_phj_build's passes; NPJ: the table, npj.cpp:865-877), then the probe side travels in
+// batches of `host_batch` rows through two device buffers: batch i is joined against the prepared build side (K4 .. K8,
+// or NPJ's probe, on `run`) while batch i + 1 is on the bus (`copy`).  R join S = union over the batches
+// (phj.cpp:1869-1924 runs per partition; the reference's CPRA partitions every chunk of S on its own,
+// cpra2.cpp:1757-1827: a batch is such a chunk; an NPJ worker probes its own range of S, npj.cpp:882-901).  What the
+// call costs is the upload plus the last batch's join; the device holds R, two batches and a workspace for ONE batch
+// (no 8.5 GB columns, no placement search of the twin; a probe side larger than the device's memory is fine).
+// Returns HJGPU_OK with *done = false when the call should take the monolithic path instead.
+static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, const uint32_t *iv, size_t inner,
+                             const uint32_t *ok, const uint32_t *ov, size_t outer, const hjgpu_phj_params *pp,
+                             const hjgpu_npj_params *np, hjgpu_result *result, hjgpu_stats *stats, bool *done)
+{
+    *done = false;
+    const size_t B = ((size_t)ctx->tune.host_batch + 15) & ~size_t(15);       // rows per batch (batches start 64-byte aligned)
+    if (!B || !inner || outer < 2 * B || ctx->tune.batch_tuples) return HJGPU_OK;
+    const size_t nb = (outer + B - 1) / B;
+    void *d_r[2] = {nullptr, nullptr}, *d_s[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *d_res = nullptr;
+    hipEvent_t r_ready = nullptr, s_ready[2] = {nullptr, nullptr}, s_free[2] = {nullptr, nullptr}, b0 = nullptr, b1 = nullptr;
+    hipStream_t copy = nullptr, run = nullptr;
+    std::vector<hjgpu_result> parts(nb);
+    const bool npj = algorithm == 0;
+    int rc = HJGPU_OK;
+    auto hip_ok = [&](hipError_t e, const char *what) { if (rc == HJGPU_OK && e != hipSuccess) rc = fail(ctx, HJGPU_EHIP, what, e); };
+    for (int i = 0; i < 2 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_r[i], inner * sizeof(uint32_t));
+    for (int s = 0; s < 2; ++s) for (int i = 0; i < 2 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_s[s][i], B * sizeof(uint32_t));
+    if (rc == HJGPU_OK) rc = hjgpu_malloc(ctx, &d_res, nb * sizeof(hjgpu_result));
+    int least = 0, greatest = 0;
+    hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    hip_ok(hipStreamCreateWithPriority(&copy, hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
+    hip_ok(hipStreamCreateWithFlags(&run, hipStreamNonBlocking), "hipStreamCreate(run)");
+    hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
+    if (npj) { hip_ok(hipEventCreate(&b0), "hipEventCreate"); hip_ok(hipEventCreate(&b1), "hipEventCreate"); }
+    for (int b = 0; b < 2; ++b) {
+        hip_ok(hipEventCreateWithFlags(&s_ready[b], hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&s_free[b], hipEventDisableTiming), "hipEventCreate");
+    }
+    PhjPlan pl;
+    size_t buckets = 0; uint32_t factor = 0;
+    // the workspace (for ONE batch) before the clocks start, like the reference's mamalloc()s (npj.cpp:982-1000 vs 861-863)
+    if (rc == HJGPU_OK) rc = npj ? npj_prepare(ctx, inner, np, &buckets, &factor) : phj_prepare(ctx, inner, B, pp, 1, &pl);
+    const bool line = !ctx->tune.npj_refhash, unique = npj && npj_unique(ctx, np);
+    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
+    u64 *table = reinterpret_cast<u64 *>(ctx->table.p);
+    float ms_upload = 0;
+    if (rc == HJGPU_OK) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int next = 0;
+        rc = upload_column(ctx, d_r[0], ik, inner * sizeof(uint32_t), copy, &next);
+        if (rc == HJGPU_OK) rc = upload_column(ctx, d_r[1], iv, inner * sizeof(uint32_t), copy, &next);
+        hip_ok(hipEventRecord(r_ready, copy), "hipEventRecord");
+        hip_ok(hipStreamWaitEvent(run, r_ready, 0), "hipStreamWaitEvent");
+        if (rc == HJGPU_OK && npj) {
+            // K1 set() npj.cpp:865-868 ; K2 build() 871-877; the probes of all batches add to ONE result (atomics on the state)
+            rc = refuse_capture(ctx, run);
+            hip_ok(hipEventRecord(b0, run), "hipEventRecord");
+            hip_ok(hipMemsetAsync(st, 0, sizeof(DevState), run), "hipMemsetAsync(state)");
+            hip_ok(hipMemsetAsync(table, 0, buckets * sizeof(u64), run), "hipMemsetAsync(table)");
+            if (rc == HJGPU_OK) rc = hj_launch_npj_build((const uint32_t *)d_r[0], (const uint32_t *)d_r[1], inner, table, buckets, factor,
+                                                        &st->zero_key, ctx->cus, run, line);
+            hip_ok(hipEventRecord(b1, run), "hipEventRecord");
+        } else if (rc == HJGPU_OK)
+            rc = phj_enqueue(ctx, pl, (const uint32_t *)d_r[0], (const uint32_t *)d_r[1], inner, nullptr, nullptr, 0, nullptr, run, nullptr, PHJ_BUILD_ONLY);
+        for (size_t i = 0; i < nb && rc == HJGPU_OK; ++i) {
+            const int slot = (int)(i & 1);
+            const size_t b = i * B, m = outer - b < B ? outer - b : B;
+            if (i >= 2) hip_ok(hipStreamWaitEvent(copy, s_free[slot], 0), "hipStreamWaitEvent");      // batch i - 2 has been joined
+            if (rc == HJGPU_OK) rc = upload_column(ctx, d_s[slot][0], ok + b, m * sizeof(uint32_t), copy, &next);
+            if (rc == HJGPU_OK) rc = upload_column(ctx, d_s[slot][1], ov + b, m * sizeof(uint32_t), copy, &next);
+            hip_ok(hipEventRecord(s_ready[slot], copy), "hipEventRecord");
+            hip_ok(hipStreamWaitEvent(run, s_ready[slot], 0), "hipStreamWaitEvent");
+            if (rc == HJGPU_OK && npj) {
+                // the phase events describe the LAST batch's probe (the build has its own pair)
+                for (int e = 0; e < EV_COUNT; ++e) ctx->ev_valid[e] = false;
+                record(ctx, EV_BEGIN, run);
+                record(ctx, EV_R_HIST, run);
+                rc = npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor, nullptr, run,
+                                       line, unique);
+                ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets; ctx->last_algo = 0;
+            } else if (rc == HJGPU_OK) {
+                rc = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, nullptr, run,
+                                 nullptr, PHJ_PROBE_ONLY);
+                hip_ok(hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + i, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run),
+                       "hipMemcpyAsync(result)");
+            }
+            hip_ok(hipEventRecord(s_free[slot], run), "hipEventRecord");
+        }
+        if (rc == HJGPU_OK) {
+            hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
+            ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (npj) rc = finish_blocking(ctx, result, nullptr, run);      // one accumulated result; key 0 in R -> HJGPU_EZEROKEY
+            else {
+                hip_ok(hipMemcpyAsync(parts.data(), d_res, nb * sizeof(hjgpu_result), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(results)");
+                hip_ok(hipStreamSynchronize(run), "hipStreamSynchronize(run)");
+            }
+        }
+    }
+    if (rc == HJGPU_OK || (npj && rc == HJGPU_EZEROKEY)) {
+        if (!npj) {
+            hjgpu_result sum;
+            memset(&sum, 0, sizeof(sum));
+            for (const hjgpu_result &p : parts) { sum.count += p.count; sum.sum_keys += p.sum_keys; sum.sum_outer_vals += p.sum_outer_vals; sum.sum_inner_vals += p.sum_inner_vals; }
+            if (result) *result = sum;
+        }
+        if (stats) {
+            const int rs = hjgpu_get_stats(ctx, stats);          // the phase times of the LAST batch's join
+            if (rc == HJGPU_OK) rc = rs;
+            if (npj) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, b0, b1) == hipSuccess) { stats->ms_build = ms; stats->ms_total += ms; }
+            }
+            stats->ms_upload = ms_upload; stats->ms_download = 0;
+            stats->batches = (uint32_t)nb;
+        }
+        *done = true;
+    }
+    (void)hipDeviceSynchronize();
+    ctx->prepared = false;                             // the build columns are about to be freed with everything else
+    for (int i = 0; i < 2; ++i) if (d_r[i]) (void)hipFree(d_r[i]);
+    for (int s = 0; s < 2; ++s) for (int i = 0; i < 2; ++i) if (d_s[s][i]) (void)hipFree(d_s[s][i]);
+    if (d_res) (void)hipFree(d_res);
+    for (int b = 0; b < 2; ++b) {
+        if (s_ready[b]) (void)hipEventDestroy(s_ready[b]);
+        if (s_free[b]) (void)hipEventDestroy(s_free[b]);
+    }
+    if (r_ready) (void)hipEventDestroy(r_ready);
+    if (b0) (void)hipEventDestroy(b0);
+    if (b1) (void)hipEventDestroy(b1);
+    if (copy) (void)hipStreamDestroy(copy);
+    if (run) (void)hipStreamDestroy(run);
+    return rc;
+}
+
 static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
                           const uint32_t *ik, const uint32_t *iv, size_t inner,
                           const uint32_t *ok, const uint32_t *ov, size_t outer,
@@ -1836,6 +1994,12 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     if (!ctx || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
     if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return fail(ctx, HJGPU_EINVAL, "null column");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!rows) {
+        // aggregates only: the probe side in batches behind the DMA (join_host_batched)
+        bool done = false;
+        const int brc = join_host_batched(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, result, stats, &done);
+        if (brc != HJGPU_OK || done) return brc;
+    }
     // materialised result: device columns of the caller's capacity plus one open block per worker
     // (the reference sizes its output the same way: 1.05 J + 2T blocks, npj.cpp:997-1000)
     hjgpu_output dev_out;
@@ -1847,9 +2011,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     void *d[4] = {nullptr, nullptr, nullptr, nullptr};
     const void *h[4] = {ik, iv, ok, ov};
     const size_t n[4] = {inner, inner, outer, outer};
-    constexpr size_t STAGE = 32u << 20;
-    void *stage[2] = {nullptr, nullptr};
-    hipEvent_t stage_free[2] = {nullptr, nullptr}, r_ready = nullptr, s_ready = nullptr;
+    hipEvent_t r_ready = nullptr, s_ready = nullptr;
     hipStream_t copy = nullptr, run = nullptr;
     int rc = HJGPU_OK;
     auto hip_ok = [&](hipError_t e, const char *what) { if (rc == HJGPU_OK && e != hipSuccess) rc = fail(ctx, HJGPU_EHIP, what, e); };
@@ -1871,10 +2033,6 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     hip_ok(hipStreamCreateWithFlags(&run, hipStreamNonBlocking), "hipStreamCreate(run)");
     hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
     hip_ok(hipEventCreateWithFlags(&s_ready, hipEventDisableTiming), "hipEventCreate");
-    for (int b = 0; b < 2; ++b) {
-        hip_ok(hipHostMalloc(&stage[b], STAGE, hipHostMallocDefault), "hipHostMalloc(stage)");
-        hip_ok(hipEventCreateWithFlags(&stage_free[b], hipEventDisableTiming), "hipEventCreate");
-    }
     PhjPlan pl;
     size_t buckets = 0; uint32_t factor = 0;
     if (rc == HJGPU_OK) {
@@ -1891,7 +2049,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
         const int order[4] = {2, 3, 0, 1};
         for (int k = 0; k < 4 && rc == HJGPU_OK; ++k) {
             const int i = order[k];
-            rc = upload_column(ctx, d[i], h[i], n[i] * sizeof(uint32_t), copy, stage, stage_free, STAGE, &next);
+            rc = upload_column(ctx, d[i], h[i], n[i] * sizeof(uint32_t), copy, &next);
             if (rc == HJGPU_OK && i == 3) hip_ok(hipEventRecord(s_ready, copy), "hipEventRecord");
         }
         hip_ok(hipEventRecord(r_ready, copy), "hipEventRecord");
@@ -1922,7 +2080,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
             const auto t0 = std::chrono::steady_clock::now();
             void *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
             for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
-                rc = download_column(ctx, hcol[i], d_rows[i], result->count * sizeof(uint32_t), copy, stage, stage_free, STAGE);
+                rc = download_column(ctx, hcol[i], d_rows[i], result->count * sizeof(uint32_t), copy);
             if (rc == HJGPU_OK) hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
             ms_download = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
@@ -1935,7 +2093,6 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
     for (int i = 0; i < 3; ++i) if (d_rows[i]) (void)hipFree(d_rows[i]);
-    for (int b = 0; b < 2; ++b) { if (stage[b]) (void)hipHostFree(stage[b]); if (stage_free[b]) (void)hipEventDestroy(stage_free[b]); }
     if (r_ready) (void)hipEventDestroy(r_ready);
     if (s_ready) (void)hipEventDestroy(s_ready);
     if (copy) (void)hipStreamDestroy(copy);

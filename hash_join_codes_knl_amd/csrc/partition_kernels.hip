@@ -1394,6 +1394,13 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
         t->reserve_cus = (int)x;
         return true;
     }
+    if (is("host_batch")) {
+        char *end = nullptr;
+        const long long x = strtoll(value, &end, 10);
+        if (end == value || *end || x < 0) return false;
+        t->host_batch = x;
+        return true;
+    }
     if (is("batch_tuples")) {
         char *end = nullptr;
         const long long x = strtoll(value, &end, 10);
@@ -1429,7 +1436,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "host_batch", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

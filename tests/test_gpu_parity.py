@@ -445,6 +445,42 @@ def test_join_host_from_pinned_columns(hj, oracle, algorithm):
     assert st["ms_upload"] > 0 and st2["ms_upload"] > 0
 
 
+@pytest.mark.parametrize("algorithm", [0, 1, 2])
+@pytest.mark.parametrize("batch", [4096, 65_536, 1_000_000])
+def test_join_host_in_batches_behind_the_upload(hj, oracle, algorithm, batch):
+    """hjgpu_join_host, aggregates only: the build side is prepared once and the probe side travels in batches of
+    option "host_batch" rows through two device buffers, batch i joined while batch i + 1 is uploaded (R join S = union
+    over the batches; phj.cpp:1869-1924, cpra2.cpp:1757-1827, npj.cpp:882-901).  Ragged last batch, page-locked and
+    pageable columns, duplicates on the build side, _UNIQUE, and NPJ's reserved key on the build side."""
+    with H.HjGpu() as ctx:
+        ctx.set_option("host_batch", batch)
+        ik, iv, ok, ov = oracle.generate(2_500_037, 120_011, seed=batch % 89)      # 2.5 M probe rows, 120 K build rows
+        want = oracle.join_definition(ik, iv, ok, ov)
+        got, st = ctx.join_host(algorithm, ik, iv, ok, ov)
+        assert got == want
+        assert st["batches"] == -(-len(ok) // ((batch + 15) // 16 * 16)) and st["ms_upload"] > 0 and st["ms_join"] > 0
+        pinned = [ctx.host_column(len(c)) for c in (ik, iv, ok, ov)]
+        for dst, src in zip(pinned, (ik, iv, ok, ov)):
+            dst.array[:] = src
+        assert ctx.join_host(algorithm, *pinned)[0] == want
+        for c in pinned:
+            c.free()
+        # build keys repeat (4 copies): every probe tuple matches four times; _UNIQUE: once
+        ik2, iv2, ok2, ov2 = oracle.generate(300_000, 1_200_000, seed=7)
+        assert ctx.join_host(algorithm, ik2, iv2, ok2, ov2)[0] == oracle.join_definition(ik2, iv2, ok2, ov2)
+        U = H.api.FLAG_UNIQUE
+        got_u = ctx.join_host(algorithm, ik2, iv2, ok2, ov2, H.PhjParams(flags=U), H.NpjParams(flags=U))[0]
+        assert got_u[:3] == oracle.join_definition_unique(ik2, iv2, ok2, ov2)
+        # fewer than two batches: the whole probe side at once, as before
+        assert ctx.join_host(algorithm, ik, iv, ok[:batch], ov[:batch])[1]["batches"] == 0
+        if algorithm == 0:
+            bad = ik.copy()
+            bad[len(bad) // 2] = 0
+            with pytest.raises(H.HjGpuError) as e:
+                ctx.join_host(0, bad, iv, ok, ov)
+            assert e.value.status == H.api.EZEROKEY
+
+
 def test_host_programs_end_to_end(hj, oracle, tmp_path):
     """./write -> ./npj ./phj ./cpra on the GPU box: same CLI, files and stdout formats as the
     reference's programs (npj.cpp:1114, phj.cpp:2197, cpra2.cpp:1984/2208); the aggregates on
