@@ -247,6 +247,33 @@ __global__ __launch_bounds__(1024) void fill_probe_kernel(uint4 *__restrict__ ou
     for (u64 i = (u64)blockIdx.x * 1024 + threadIdx.x; i < n; i += (u64)gridDim.x * 1024) out[i] = v;
 }
 
+// Result rows -> page-locked host memory by a KERNEL (16-byte stores over PCIe; few workgroups: the bus, not the CUs, is the
+// limit).  hjgpu_join_host_rows sends a batch's rows home while the next batch is uploaded: with hipMemcpyAsync in both
+// directions the runtime put upload and download on the same DMA engine from the second call of a process on (one after
+// the other: 430 ms instead of 255 for 8.5 GB up and 12 GB down); the DMA engines now carry the upload only.
+__global__ __launch_bounds__(256) void copy_to_host_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, u64 n)
+{
+    // 32-bit elements (a batch's rows start wherever the batches before it ended): a wave's store is 256 contiguous bytes
+    const u64 stride = (u64)gridDim.x * 256;
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[i + j * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[i + j * stride] = v[j];
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+int hj_launch_copy_to_host(void *host_mapped, const void *d, size_t bytes, hipStream_t stream)
+{
+    if (!bytes) return HJGPU_OK;
+    if (((uintptr_t)host_mapped & 3) || ((uintptr_t)d & 3) || (bytes & 3)) return HJGPU_EALIGN;
+    hipLaunchKernelGGL(copy_to_host_kernel, dim3(64), dim3(256), 0, stream, (uint32_t *)host_mapped, (const uint32_t *)d, (u64)(bytes / 4));
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
 int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream)
 {
     if (((uintptr_t)p & 15) || bytes < 16) return HJGPU_EINVAL;

@@ -273,6 +273,7 @@ int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_
                        uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hipStream_t stream,
                        double zipf = 0.0, double selectivity = 1.0, u64 *d_expect = nullptr);
 int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hipStream_t stream);
+int hj_launch_copy_to_host(void *host_mapped, const void *d, size_t bytes, hipStream_t stream);
 int hj_launch_random_line_read(const void *p, size_t bytes, size_t reads, void *sink16, int cus, hipStream_t stream);
 int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream);
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,

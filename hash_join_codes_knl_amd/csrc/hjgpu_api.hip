@@ -62,8 +62,12 @@ struct hjgpu_ctx {
     HjTuning tune;          // tuning / test switches: environment at hjgpu_create, hjgpu_set_option afterwards
     // hjgpu_join_host*: two page-locked staging buffers for PAGEABLE host columns, made when the first one is seen and kept
     // (hipHostMalloc + hipHostFree of 2 x 32 MiB cost 22 ms per call; page-locked columns never need them)
-    void *host_stage[2] = {nullptr, nullptr};
-    hipEvent_t host_stage_ev[2] = {nullptr, nullptr};
+    // the batched host calls' three streams (upload / join / download), made once: the runtime binds a stream's copies to a
+    // DMA engine when it first uses it, and fresh streams in every call ended up with upload and download on ONE engine
+    // from the second call on (one after the other: 430 ms instead of 275 for 8.5 GB up and 12 GB down)
+    hipStream_t host_streams[3] = {nullptr, nullptr, nullptr};
+    void *host_stage[4] = {nullptr, nullptr, nullptr, nullptr};          // [0..1] uploads, [2..3] downloads (both run at once
+    hipEvent_t host_stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // when result rows go home behind the upload)
     // hjgpu_set_async_output: the next *_async join of this context materialises into these columns (one-shot)
     hjgpu_output pending_out;
     bool has_pending_out = false;
@@ -967,7 +971,8 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-    for (int b = 0; b < 2; ++b) {
+    for (hipStream_t s : ctx->host_streams) if (s) (void)hipStreamDestroy(s);
+    for (int b = 0; b < 4; ++b) {
         if (ctx->host_stage[b]) (void)hipHostFree(ctx->host_stage[b]);
         if (ctx->host_stage_ev[b]) (void)hipEventDestroy(ctx->host_stage_ev[b]);
     }
@@ -1758,9 +1763,9 @@ int hjgpu_cpra_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, siz
 // DMA'd directly; pageable memory goes through two pinned staging buffers so that the CPU's copy
 // of chunk i+1 overlaps the DMA of chunk i.
 constexpr size_t HJ_HOST_STAGE = 32u << 20;
-static int host_stage(hjgpu_ctx *ctx)
+static int host_stage(hjgpu_ctx *ctx, int first)
 {
-    for (int b = 0; b < 2; ++b) {
+    for (int b = first; b < first + 2; ++b) {
         if (!ctx->host_stage[b]) HIPCHK(ctx, hipHostMalloc(&ctx->host_stage[b], HJ_HOST_STAGE, hipHostMallocDefault));
         if (!ctx->host_stage_ev[b]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->host_stage_ev[b], hipEventDisableTiming));
     }
@@ -1777,7 +1782,7 @@ static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, h
         HIPCHK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, copy));
         return HJGPU_OK;
     }
-    CHK(host_stage(ctx));
+    CHK(host_stage(ctx, 0));
     void **stage = ctx->host_stage;
     hipEvent_t *stage_free = ctx->host_stage_ev;
     const size_t stage_bytes = HJ_HOST_STAGE;
@@ -1794,19 +1799,24 @@ static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, h
 
 // HBM column -> host column on `copy`: the mirror image of upload_column.  Pageable destinations are
 // filled from two pinned staging buffers, the CPU's copy of chunk i overlapping the DMA of chunk i+1.
-static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes, hipStream_t copy)
+static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes, hipStream_t copy, bool by_kernel = false)
 {
     if (!bytes) return HJGPU_OK;
     hipPointerAttribute_t at;
     const bool pinned = hipPointerGetAttributes(&at, h) == hipSuccess && at.type == hipMemoryTypeHost;
     (void)hipGetLastError();
+    // (by_kernel: the DMA engines are busy with an upload in the other direction, see copy_to_host_kernel)
+    if (pinned && by_kernel && at.devicePointer && !(((uintptr_t)at.devicePointer | (uintptr_t)d | bytes) & 3)) {
+        if (hj_launch_copy_to_host(at.devicePointer, d, bytes, copy) != HJGPU_OK) return fail(ctx, HJGPU_EHIP, "copy_to_host_kernel");
+        return HJGPU_OK;
+    }
     if (pinned) {
         HIPCHK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, copy));
         return HJGPU_OK;
     }
-    CHK(host_stage(ctx));
-    void **stage = ctx->host_stage;
-    hipEvent_t *stage_done = ctx->host_stage_ev;
+    CHK(host_stage(ctx, 2));
+    void **stage = ctx->host_stage + 2;
+    hipEvent_t *stage_done = ctx->host_stage_ev + 2;
     const size_t stage_bytes = HJ_HOST_STAGE;
     const size_t chunks = (bytes + stage_bytes - 1) / stage_bytes;
     auto len = [&](size_t c) { return c + 1 < chunks ? stage_bytes : bytes - c * stage_bytes; };
@@ -1863,12 +1873,33 @@ int hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm,
 // Returns HJGPU_OK with *done = false when the call should take the monolithic path instead.
 static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, const uint32_t *iv, size_t inner,
                              const uint32_t *ok, const uint32_t *ov, size_t outer, const hjgpu_phj_params *pp,
-                             const hjgpu_npj_params *np, hjgpu_result *result, hjgpu_stats *stats, bool *done)
+                             const hjgpu_npj_params *np, const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats,
+                             bool *done)
 {
     *done = false;
     const size_t B = ((size_t)ctx->tune.host_batch + 15) & ~size_t(15);       // rows per batch (batches start 64-byte aligned)
     if (!B || !inner || outer < 2 * B || ctx->tune.batch_tuples) return HJGPU_OK;
+    // Materialised rows (PHJ / CPRA): every batch's rows are made dense on the device (close_gaps per batch) and travel to
+    // the caller's host columns on a third stream while the next batch is joined and the one after it uploaded - PCIe is
+    // full duplex, the 12 bytes per result row hide behind the 8 bytes per probe tuple of the upload as far as they can.
+    // The per-batch device columns hold the batch's share of rows->capacity with a quarter of headroom: a batch that
+    // needs more (or a result beyond the caller's capacity) sends the call down the whole-column path, which knows how
+    // to report the needed capacity.
+    if (rows && algorithm == 0) return HJGPU_OK;
     const size_t nb = (outer + B - 1) / B;
+    const u64 row_bs = 4096;
+    const size_t workers = rows ? (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true)) : 0;
+    const size_t want_b = rows ? (size_t)((double)rows->capacity * (double)B / (double)outer * 1.25) + row_bs : 0;
+    const size_t cap_b = rows ? (want_b / row_bs + 1 + workers) * row_bs : 0;
+    void *d_rows[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hjgpu_output dev_out[2];
+    memset(dev_out, 0, sizeof(dev_out));
+    DevState *h_state = nullptr;                                     // page-locked: one per batch (dense count, overflow flag)
+    hipEvent_t joined[2] = {nullptr, nullptr}, rows_free[2] = {nullptr, nullptr};
+    hipStream_t down = nullptr;
+    u64 rows_at = 0;                                                 // rows in the caller's columns so far
+    bool abandon = false;                                            // take the whole-column path instead
+    float ms_download = 0;
     void *d_r[2] = {nullptr, nullptr}, *d_s[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *d_res = nullptr;
     hipEvent_t r_ready = nullptr, s_ready[2] = {nullptr, nullptr}, s_free[2] = {nullptr, nullptr}, b0 = nullptr, b1 = nullptr;
     hipStream_t copy = nullptr, run = nullptr;
@@ -1879,16 +1910,49 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     for (int i = 0; i < 2 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_r[i], inner * sizeof(uint32_t));
     for (int s = 0; s < 2; ++s) for (int i = 0; i < 2 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_s[s][i], B * sizeof(uint32_t));
     if (rc == HJGPU_OK) rc = hjgpu_malloc(ctx, &d_res, nb * sizeof(hjgpu_result));
+    if (rows) {
+        for (int s = 0; s < 2; ++s) {
+            for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_rows[s][i], cap_b * sizeof(uint32_t));
+            dev_out[s].d_keys = (uint32_t *)d_rows[s][0]; dev_out[s].d_outer_vals = (uint32_t *)d_rows[s][1];
+            dev_out[s].d_inner_vals = (uint32_t *)d_rows[s][2];
+            dev_out[s].capacity = cap_b; dev_out[s].block_size = row_bs;
+        }
+        if (rc == HJGPU_OK && hipHostMalloc(reinterpret_cast<void **>(&h_state), nb * sizeof(DevState), hipHostMallocDefault) != hipSuccess)
+            rc = fail(ctx, HJGPU_ENOMEM, "hipHostMalloc(batch states)");
+    }
     int least = 0, greatest = 0;
     hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    hip_ok(hipStreamCreateWithPriority(&copy, hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
-    hip_ok(hipStreamCreateWithFlags(&run, hipStreamNonBlocking), "hipStreamCreate(run)");
+    // three priority classes = three hardware-queue pools: upload, join and download never share a queue
+    if (!ctx->host_streams[0]) hip_ok(hipStreamCreateWithPriority(&ctx->host_streams[0], hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
+    if (!ctx->host_streams[1]) hip_ok(hipStreamCreateWithFlags(&ctx->host_streams[1], hipStreamNonBlocking), "hipStreamCreate(run)");
+    if (!ctx->host_streams[2]) hip_ok(hipStreamCreateWithPriority(&ctx->host_streams[2], hipStreamNonBlocking, least), "hipStreamCreate(down)");
+    copy = ctx->host_streams[0]; run = ctx->host_streams[1];
     hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
     if (npj) { hip_ok(hipEventCreate(&b0), "hipEventCreate"); hip_ok(hipEventCreate(&b1), "hipEventCreate"); }
     for (int b = 0; b < 2; ++b) {
         hip_ok(hipEventCreateWithFlags(&s_ready[b], hipEventDisableTiming), "hipEventCreate");
         hip_ok(hipEventCreateWithFlags(&s_free[b], hipEventDisableTiming), "hipEventCreate");
+        if (rows) {
+            hip_ok(hipEventCreateWithFlags(&joined[b], hipEventDisableTiming), "hipEventCreate");
+            hip_ok(hipEventCreateWithFlags(&rows_free[b], hipEventDisableTiming), "hipEventCreate");
+        }
     }
+    down = ctx->host_streams[2];
+    // batch j's rows -> the caller's columns (its dense count is on the host once `joined` has fired)
+    auto download_batch = [&](size_t j) {
+        const int slot = (int)(j & 1);
+        hip_ok(hipEventSynchronize(joined[slot]), "hipEventSynchronize(joined)");
+        if (rc != HJGPU_OK) return;
+        const DevState &hs = h_state[j];
+        if (hs.overflow || rows_at + hs.dense > rows->capacity) { abandon = true; return; }
+        const auto d0 = std::chrono::steady_clock::now();
+        uint32_t *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
+        for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
+            rc = download_column(ctx, hcol[i] + rows_at, d_rows[slot][i], hs.dense * sizeof(uint32_t), down, true);
+        hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord");
+        rows_at += hs.dense;
+        ms_download += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - d0).count();
+    };
     PhjPlan pl;
     size_t buckets = 0; uint32_t factor = 0;
     // the workspace (for ONE batch) before the clocks start, like the reference's mamalloc()s (npj.cpp:982-1000 vs 861-863)
@@ -1932,24 +1996,34 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                                        line, unique);
                 ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets; ctx->last_algo = 0;
             } else if (rc == HJGPU_OK) {
-                rc = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, nullptr, run,
-                                 nullptr, PHJ_PROBE_ONLY);
+                if (rows && i >= 2) hip_ok(hipStreamWaitEvent(run, rows_free[slot], 0), "hipStreamWaitEvent");   // batch i - 2's rows have left
+                rc = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m,
+                                 rows ? &dev_out[slot] : nullptr, run, nullptr, PHJ_PROBE_ONLY);
                 hip_ok(hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + i, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run),
                        "hipMemcpyAsync(result)");
+                if (rows) {
+                    hip_ok(hipMemcpyAsync(&h_state[i], ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");
+                    hip_ok(hipEventRecord(joined[slot], run), "hipEventRecord");
+                }
             }
             hip_ok(hipEventRecord(s_free[slot], run), "hipEventRecord");
+            // the previous batch's rows go home while this one is joined (its count is on the host by now, or soon)
+            if (rows && i >= 1 && rc == HJGPU_OK && !abandon) download_batch(i - 1);
+            if (abandon) break;
         }
+        if (rows && rc == HJGPU_OK && !abandon) download_batch(nb - 1);
+        if (rows && rc == HJGPU_OK && !abandon) hip_ok(hipStreamSynchronize(down), "hipStreamSynchronize(down)");
         if (rc == HJGPU_OK) {
             hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
             ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (npj) rc = finish_blocking(ctx, result, nullptr, run);      // one accumulated result; key 0 in R -> HJGPU_EZEROKEY
-            else {
+            else if (!abandon) {
                 hip_ok(hipMemcpyAsync(parts.data(), d_res, nb * sizeof(hjgpu_result), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(results)");
                 hip_ok(hipStreamSynchronize(run), "hipStreamSynchronize(run)");
             }
         }
     }
-    if (rc == HJGPU_OK || (npj && rc == HJGPU_EZEROKEY)) {
+    if (!abandon && (rc == HJGPU_OK || (npj && rc == HJGPU_EZEROKEY))) {
         if (!npj) {
             hjgpu_result sum;
             memset(&sum, 0, sizeof(sum));
@@ -1963,13 +2037,17 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                 float ms = 0;
                 if (hipEventElapsedTime(&ms, b0, b1) == hipSuccess) { stats->ms_build = ms; stats->ms_total += ms; }
             }
-            stats->ms_upload = ms_upload; stats->ms_download = 0;
+            stats->ms_upload = ms_upload; stats->ms_download = ms_download;
             stats->batches = (uint32_t)nb;
         }
         *done = true;
     }
     (void)hipDeviceSynchronize();
     ctx->prepared = false;                             // the build columns are about to be freed with everything else
+    for (int s2 = 0; s2 < 2; ++s2) for (int i = 0; i < 3; ++i) if (d_rows[s2][i]) (void)hipFree(d_rows[s2][i]);
+    if (h_state) (void)hipHostFree(h_state);
+    for (int b = 0; b < 2; ++b) { if (joined[b]) (void)hipEventDestroy(joined[b]); if (rows_free[b]) (void)hipEventDestroy(rows_free[b]); }
+
     for (int i = 0; i < 2; ++i) if (d_r[i]) (void)hipFree(d_r[i]);
     for (int s = 0; s < 2; ++s) for (int i = 0; i < 2; ++i) if (d_s[s][i]) (void)hipFree(d_s[s][i]);
     if (d_res) (void)hipFree(d_res);
@@ -1980,8 +2058,6 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     if (r_ready) (void)hipEventDestroy(r_ready);
     if (b0) (void)hipEventDestroy(b0);
     if (b1) (void)hipEventDestroy(b1);
-    if (copy) (void)hipStreamDestroy(copy);
-    if (run) (void)hipStreamDestroy(run);
     return rc;
 }
 
@@ -1994,10 +2070,12 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     if (!ctx || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
     if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return fail(ctx, HJGPU_EINVAL, "null column");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!rows) {
-        // aggregates only: the probe side in batches behind the DMA (join_host_batched)
+    {
+        // the probe side in batches behind the DMA (join_host_batched); not taken: small probe sides, NPJ with rows, a
+        // batch whose rows outgrow their share of the capacity
         bool done = false;
-        const int brc = join_host_batched(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, result, stats, &done);
+        hjgpu_result batched_result;
+        const int brc = join_host_batched(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result ? result : &batched_result, stats, &done);
         if (brc != HJGPU_OK || done) return brc;
     }
     // materialised result: device columns of the caller's capacity plus one open block per worker

@@ -347,12 +347,15 @@ int  hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tupl
 
 /* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
  * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates.
- * Aggregates only (this call) and a probe side of at least two batches (option "host_batch", 64 Mi rows): the build side
- * is uploaded and prepared once, the probe side travels in batches through two device buffers - batch i is joined while
- * batch i + 1 is on the bus (R join S = union over the batches); the device never holds the probe side as a whole (it
- * may be larger than the device's memory), the call costs the upload plus the last batch's join, stats->batches says how
- * many there were and the phase times are those of the LAST batch (NPJ: ms_build = the table's build).
- * Otherwise (hjgpu_join_host_rows, small probe sides, host_batch = 0) the columns are uploaded whole on their own
+ * A probe side of at least two batches (option "host_batch", 64 Mi rows): the build side is uploaded and prepared once, the
+ * probe side travels in batches through two device buffers - batch i is joined while batch i + 1 is on the bus (R join S
+ * = union over the batches); the device never holds the probe side as a whole (it may be larger than the device's
+ * memory), the call costs the upload plus the last batch's join, stats->batches says how many there were and the phase
+ * times are those of the LAST batch (NPJ: ms_build = the table's build).  hjgpu_join_host_rows (PHJ / CPRA) works the
+ * same way: every batch's rows are made dense on the device and go home - into page-locked columns by a copy kernel, so
+ * that the DMA engines carry the upload only - while the next batch is joined; a batch that outgrows its share of
+ * rows->capacity sends the call down the whole-column path.
+ * Otherwise (small probe sides, NPJ with rows, host_batch = 0) the columns are uploaded whole on their own
  * stream, probe side first, build side behind it; PHJ / CPRA partition the probe side while the build side is still
  * arriving.  Page-locked columns (hjgpu_host_alloc) are DMA'd where they are, pageable ones staged
  * through two 32 MiB page-locked buffers the context keeps.

@@ -565,6 +565,43 @@ def test_join_host_rows_returns_the_materialised_join(hj, algorithm, pinned):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("algorithm", [1, 2])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_join_host_rows_in_batches_go_home_behind_the_upload(hj, algorithm, pinned):
+    """hjgpu_join_host_rows with the probe side in batches (option "host_batch"): every batch's rows are made dense on the
+    device and copied into the caller's columns while the next batch is joined; the batches' rows follow each other,
+    the whole is the join row for row.  Duplicates on the build side (J != |S|); then a probe side whose matches sit
+    in ONE batch; then too small a capacity (the batched attempt is abandoned, the whole-column path reports
+    HJGPU_EOVERFLOW with the count, as without batches)."""
+    with H.HjGpu() as ctx:
+        ctx.set_option("host_batch", 300_000)
+        rng = np.random.default_rng(177 + algorithm)
+        base = np.unique(rng.integers(1, 2**32, size=200_000, dtype=np.uint64).astype(np.uint32))
+        ik = np.concatenate([base, base[:50_000]])
+        iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+        ok = base[rng.integers(0, len(base), size=2_700_011)]
+        ov = rng.integers(0, 2**32, size=len(ok), dtype=np.uint64).astype(np.uint32)
+        want = numpy_join(ik, iv, ok, ov)
+        got, st, rows = ctx.join_host_rows(algorithm, ik, iv, ok, ov, want[0] + 12345, pinned=pinned)
+        assert got == want and len(rows[0]) == want[0]
+        assert st["batches"] == 10 and st["ms_download"] > 0
+        for a, b in zip(sort_rows(*rows), materialised_rows(ik, iv, ok, ov)):
+            assert np.array_equal(a, b)
+        # all matches in the first batch, none elsewhere
+        ok2 = ok.copy()
+        ok2[300_000:] = (ok2[300_000:] ^ np.uint32(0x5a5a5a5a)) | np.uint32(1)
+        hit = np.isin(ok2, ik)
+        want2 = numpy_join(ik, iv, ok2, ov)
+        assert want2[0] > 0 and hit[300_000:].sum() < want2[0] // 4
+        got2, st2, rows2 = ctx.join_host_rows(algorithm, ik, iv, ok2, ov, want2[0], pinned=pinned)
+        assert got2 == want2 and len(rows2[0]) == want2[0]
+        for a, b in zip(sort_rows(*rows2), materialised_rows(ik, iv, ok2, ov)):
+            assert np.array_equal(a, b)
+        with pytest.raises(H.HjGpuError) as e:
+            ctx.join_host_rows(algorithm, ik, iv, ok, ov, want[0] // 2, pinned=pinned)
+        assert e.value.status == H.api.EOVERFLOW
+
+
 def test_join_host_rows_reports_overflow_with_the_row_count(hj, oracle):
     """More result rows than rows->capacity: HJGPU_EOVERFLOW, and the caller can size a retry."""
     ik, iv, ok, ov = oracle.generate(300_000, 60_000, seed=46)

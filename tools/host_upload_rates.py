@@ -30,3 +30,24 @@ for label, cols in (("pinned", pinned), ("pageable", [np.array(p.array) for p in
         gb = 8.0 * (inner + outer) / 1e9
         print("%-8s %s: upload %.1f ms (%.1f GB/s), device join %.1f ms, call %.1f ms -> %.2f Gtuples/s PCIe-inclusive"
               % (label, name, st["ms_upload"], gb / st["ms_upload"] * 1e3, st["ms_total"], wall * 1e3, outer / wall / 1e9), flush=True)
+
+# the materialising host call (three result columns of |S| rows into page-locked host columns): rows go home per batch
+# behind the upload (option host_batch), or after the join (host_batch = 0); the C entry point directly, columns made once
+if len(sys.argv) > 2 and sys.argv[2] == "rows":
+    import ctypes as C
+    from hash_join_codes_knl_amd import api
+    cap = outer + 4096
+    out = [hj.host_column(cap) for _ in range(3)]
+    rows = api.HostRows(out[0].array.ctypes.data, out[1].array.ctypes.data, out[2].array.ctypes.data, cap)
+    a = [p.array for p in pinned]
+    for hb in (64 << 20, 64 << 20, 64 << 20, 0, 64 << 20):
+        hj.set_option("host_batch", hb)
+        r, st = api.Result(), api.Stats()
+        t0 = time.perf_counter()
+        rc = hj.lib.hjgpu_join_host_rows(hj.handle, 1, a[0].ctypes.data, a[1].ctypes.data, a[0].size, a[2].ctypes.data, a[3].ctypes.data,
+                                         a[2].size, None, None, C.byref(rows), C.byref(r), C.byref(st))
+        wall = time.perf_counter() - t0
+        assert rc == 0 and r.as_tuple() == want, (rc, r.as_tuple())
+        print("rows, host_batch %9d: upload %.1f ms, download %.1f ms, batches %d, call %.1f ms -> %.2f Gtuples/s PCIe-inclusive"
+              % (hb, st.ms_upload, st.ms_download, st.batches, wall * 1e3, outer / wall / 1e9), flush=True)
+    assert int(out[0].array[:outer].astype(np.uint64).sum()) == want[1]
