@@ -23,7 +23,7 @@ EXPORTS = [
     "hjgpu_kernel_hash", "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
     "hjgpu_get_device_info", "hjgpu_set_option", "hjgpu_reserve", "hjgpu_get_stats",
     "hjgpu_get_async_status", "hjgpu_accumulate_async_status", "hjgpu_set_async_output", "hjgpu_output_capacity",
-    "hjgpu_malloc", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
+    "hjgpu_malloc", "hjgpu_malloc_placed", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize",
     "hjgpu_host_alloc", "hjgpu_host_free",
     "hjgpu_histogram", "hjgpu_partition", "hjgpu_partition_async", "hjgpu_join_partitions",
     "hjgpu_npj_build", "hjgpu_npj_probe",
@@ -194,6 +194,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_set_async_output.argtypes = [vp, C.POINTER(Output)]
     L.hjgpu_output_capacity.argtypes = [vp, C.c_int, sz, sz, sz, C.POINTER(sz)]
     L.hjgpu_malloc.argtypes = [vp, C.POINTER(vp), sz]
+    L.hjgpu_malloc_placed.argtypes = [vp, C.POINTER(vp), sz]
     L.hjgpu_free.argtypes = [vp, vp]
     L.hjgpu_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.hjgpu_memcpy_d2h.argtypes = [vp, vp, vp, sz]
@@ -273,10 +274,11 @@ def kernel_hash():
 class DeviceColumn:
     """A uint32/uint64 column in HBM owned through hjgpu_malloc."""
 
-    def __init__(self, ctx, n, dtype=np.uint32):
+    def __init__(self, ctx, n, dtype=np.uint32, placed=False):
         self.ctx, self.n, self.dtype = ctx, int(n), np.dtype(dtype)
         p = C.c_void_p()
-        ctx._check(ctx.lib.hjgpu_malloc(ctx.handle, C.byref(p), self.n * self.dtype.itemsize))
+        alloc = ctx.lib.hjgpu_malloc_placed if placed else ctx.lib.hjgpu_malloc
+        ctx._check(alloc(ctx.handle, C.byref(p), self.n * self.dtype.itemsize))
         self.ptr = p.value
 
     @property
@@ -335,9 +337,10 @@ class HjGpu:
                                              self.lib.hjgpu_last_error(self.handle).decode()))
 
     # ---- helpers -----------------------------------------------------------------
-    def column(self, host_or_n, dtype=np.uint32):
+    def column(self, host_or_n, dtype=np.uint32, placed=False):
+        """placed: hjgpu_malloc_placed (result columns of a gigabyte and more: the placement search of the workspace)"""
         if isinstance(host_or_n, (int, np.integer)):
-            return DeviceColumn(self, host_or_n, dtype)
+            return DeviceColumn(self, host_or_n, dtype, placed)
         host = np.ascontiguousarray(host_or_n, dtype=dtype)
         return DeviceColumn(self, host.size, dtype).upload(host)
 

@@ -1120,6 +1120,22 @@ int hjgpu_malloc(hjgpu_ctx *ctx, void **p, size_t bytes)
     if (e != hipSuccess) { *p = nullptr; return fail(ctx, HJGPU_ENOMEM, "hipMalloc", e); }
     return HJGPU_OK;
 }
+// A large buffer that a join WRITES into at many places at once - the three result columns of a materialising join -
+// is as sensitive to where it lies as the library's own pass-1 twin: the same materialising join of 64 M x 1 G takes
+// 3.72 to 4.22 ms depending on the allocation of its result columns (tools/rows_luck.py, profiles/r03_rows_luck.txt).
+// The placement search the workspace uses (ensure_placed), for the caller's buffers.
+int hjgpu_malloc_placed(hjgpu_ctx *ctx, void **p, size_t bytes)
+{
+    if (!ctx || !p) return HJGPU_EINVAL;
+    *p = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    DevBuf b;
+    CHK(ensure_placed(ctx, b, bytes + 16));
+    ctx->ms_reserve += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *p = b.p;
+    return HJGPU_OK;
+}
 int hjgpu_free(hjgpu_ctx *ctx, void *p)
 {
     if (!ctx) return HJGPU_EINVAL;

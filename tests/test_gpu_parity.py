@@ -602,6 +602,25 @@ def test_join_host_rows_in_batches_go_home_behind_the_upload(hj, algorithm, pinn
         assert e.value.status == H.api.EOVERFLOW
 
 
+def test_placed_allocations_for_the_callers_result_columns(hj, oracle):
+    """hjgpu_malloc_placed: the workspace's placement search for a caller's buffer of a gigabyte and more (the result
+    columns of a materialising join); smaller buffers are plain allocations.  The memory behaves like any other, the
+    search's time shows up in ms_reserve."""
+    before = hj.stats()["ms_reserve"]
+    small = hj.column(1 << 20, placed=True)
+    big = hj.column((1 << 28) + 4096, placed=True)              # 1 GiB + 16 KiB
+    assert hj.stats()["ms_reserve"] > before
+    ik, iv, ok, ov = oracle.generate(600_000, 150_000, seed=91)
+    want = oracle.join_definition(ik, iv, ok, ov)
+    rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+    cap = big.n // 4096 * 4096
+    got = hj.phj(rk, rv, len(ik), sk, sv, len(ok), out=(big.ptr, big.ptr + 4 * (cap // 3 // 4096 * 4096), big.ptr + 8 * (cap // 3 // 4096 * 4096), cap // 3 // 4096 * 4096, 4096))
+    assert got == want
+    assert hj.column_sums(big.ptr, want[0], 1, 1)[0] == want[1]
+    for c in (small, big, rk, rv, sk, sv):
+        c.free()
+
+
 def test_join_host_rows_reports_overflow_with_the_row_count(hj, oracle):
     """More result rows than rows->capacity: HJGPU_EOVERFLOW, and the caller can size a retry."""
     ik, iv, ok, ov = oracle.generate(300_000, 60_000, seed=46)

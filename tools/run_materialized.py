@@ -22,9 +22,9 @@ def main():
         hj.generate(1, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
         sums = hj.column_sums(ok, outer, fo, fi)
         want = (outer, sums[0], sums[1], sums[2])
-        block = 16384
-        cap = ((outer + block - 1) // block + 4096 + 8) * block
-        jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+        block = 4096
+        cap = ((outer + block - 1) // block + 8192 + 8) * block
+        jk, jo, ji = (hj.column(cap, placed=True) for _ in range(3))      # as bench.py's `materialized` leg
         hj.reserve(inner, outer)
         t = {"ms_join": [], "ms_close_gaps": [], "ms_total": []}
         for i in range(steps + 1):
