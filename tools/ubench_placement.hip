@@ -49,6 +49,7 @@ int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 10;
     const bool stacked = argc > 2 && atoi(argv[2]);
+    const bool contiguous = argc > 3 && atoi(argv[3]);          // hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous
     const u64 bytes = 8512ull * 1000 * 1000 / TILE_BYTES * TILE_BYTES, tiles = bytes / TILE_BYTES;
     uint4 *in; unsigned *ticket;
     CK(hipMalloc(&in, bytes)); CK(hipMalloc(&ticket, 4)); CK(hipMemset(in, 1, bytes));
@@ -66,11 +67,13 @@ int main(int argc, char **argv)
     void *keep[64]; int kept = 0;
     for (int i = 0; i < n; ++i) {
         uint4 *out;
-        CK(hipMalloc(&out, bytes + F * 256));
+        if (contiguous) {
+            if (hipExtMallocWithFlags((void **)&out, bytes + F * 256, hipDeviceMallocContiguous) != hipSuccess) { printf("contiguous allocation %d refused\n", i); (void)hipGetLastError(); break; }
+        } else CK(hipMalloc(&out, bytes + F * 256));
         const float w = timed([&] { hipLaunchKernelGGL(scatter_like<false>, dim3(256), dim3(BLOCK), 0, 0, in, out, tiles, 15, ticket); });
         const float rw = timed([&] { hipLaunchKernelGGL(scatter_like<true>, dim3(256), dim3(BLOCK), 0, 0, in, out, tiles, 15, ticket); });
         const float f = timed([&] { hipLaunchKernelGGL(fill, dim3(1024), dim3(BLOCK), 0, 0, out, bytes / 16); });
-        printf("allocation %2d at %p: scattered writes %.3f ms, read + scattered writes %.3f ms, streaming fill %.3f ms\n", i, (void *)out, w, rw, f);
+        printf("%sallocation %2d at %p: scattered writes %.3f ms, read + scattered writes %.3f ms, streaming fill %.3f ms\n", contiguous ? "contiguous " : "", i, (void *)out, w, rw, f);
         fflush(stdout);
         if (stacked && kept < 8) keep[kept++] = out; else CK(hipFree(out));
     }
