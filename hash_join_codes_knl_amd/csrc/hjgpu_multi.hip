@@ -228,6 +228,21 @@ int ensure(hjgpu_comm *c, const Rank &r, Buf &b, size_t bytes)
     return HJGPU_OK;
 }
 
+// The buffer the exchange-level partitioning scatters into (K6 pass 1 writes it through G * k frontiers): as sensitive to
+// WHICH allocation it is as the join's own pass-1 twin (2.82 or 3.17 ms per 10^9 tuples) - it comes from
+// the partition context's placement search (hjgpu_malloc_placed; plain allocation below 1 GiB).
+int ensure_scatter_target(hjgpu_comm *c, const Rank &r, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return HJGPU_OK;
+    HIPM(c, hipSetDevice(r.device));
+    if (b.p) { HIPM(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = (bytes + 4095) / 4096 * 4096 + 256;
+    void *p = nullptr;
+    JOINM(c, r.part, hjgpu_malloc_placed(r.part, &p, want));
+    b.p = p; b.cap = want;
+    return HJGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Transport: collectives over ALL ranks, issued for all LOCAL ranks at once (arrays indexed by local rank).
 // Every operation is enqueue-only on the given streams (one per local rank).
@@ -934,7 +949,7 @@ struct CpraStep {
                 const u64 guess = (u64)in[l].n + (u64)in[l].n / Gs * (Gs - 1) * 9 / 8 + 4096;
                 hold = (size_t)(r.want_rows[which] > guess ? r.want_rows[which] : guess);
             }
-            CHKM(ensure(c, r, *b.sk, (hold + 16) * tuple_bytes));
+            CHKM(ensure_scatter_target(c, r, *b.sk, (hold + 16) * tuple_bytes));
             if (!k) CHKM(ensure(c, r, *b.sv, (in[l].n + 4) * sizeof(uint32_t)));
             u64 *d_off = static_cast<u64 *>(r.d_off.p) + (size_t)slot * OFF_WORDS;
             u64 *h_off = hp_off(r, Gs, slot);
