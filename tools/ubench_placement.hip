@@ -49,7 +49,11 @@ int main(int argc, char **argv)
 {
     const int n = argc > 1 ? atoi(argv[1]) : 10;
     const bool stacked = argc > 2 && atoi(argv[2]);
-    const bool contiguous = argc > 3 && atoi(argv[3]);          // hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous
+    const bool contiguous = argc > 3 && atoi(argv[3]) == 1;     // hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous
+    // 2 / 3: one virtual range stitched from physical chunks of <chunk MiB> (argv[4], default 32) with the virtual-memory API,
+    // the chunks mapped in creation order (2) or in a shuffled order (3): does the ORDER of a block's pages decide its kind?
+    const int vmm = argc > 3 ? (atoi(argv[3]) >= 2 ? atoi(argv[3]) : 0) : 0;
+    const size_t chunk_mib = argc > 4 ? (size_t)atoi(argv[4]) : 32;
     const u64 bytes = 8512ull * 1000 * 1000 / TILE_BYTES * TILE_BYTES, tiles = bytes / TILE_BYTES;
     uint4 *in; unsigned *ticket;
     CK(hipMalloc(&in, bytes)); CK(hipMalloc(&ticket, 4)); CK(hipMemset(in, 1, bytes));
@@ -67,14 +71,36 @@ int main(int argc, char **argv)
     void *keep[64]; int kept = 0;
     for (int i = 0; i < n; ++i) {
         uint4 *out;
-        if (contiguous) {
+        if (vmm) {
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+            size_t gran = 0;
+            CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+            size_t chunk = chunk_mib << 20;
+            chunk = (chunk + gran - 1) / gran * gran;
+            const size_t total = (bytes + F * 256 + chunk - 1) / chunk * chunk, nchunks = total / chunk;
+            void *va = nullptr;
+            CK(hipMemAddressReserve(&va, total, 0, nullptr, 0));
+            size_t *order = (size_t *)malloc(nchunks * sizeof(size_t));
+            for (size_t k = 0; k < nchunks; ++k) order[k] = k;
+            if (vmm == 3) { unsigned long long x = 88172645463325252ull + i; for (size_t k = nchunks - 1; k > 0; --k) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; size_t j = x % (k + 1); size_t t = order[k]; order[k] = order[j]; order[j] = t; } }
+            hipMemGenericAllocationHandle_t *h = (hipMemGenericAllocationHandle_t *)malloc(nchunks * sizeof(*h));
+            for (size_t k = 0; k < nchunks; ++k) CK(hipMemCreate(&h[k], chunk, &prop, 0));
+            for (size_t k = 0; k < nchunks; ++k) CK(hipMemMap((char *)va + k * chunk, chunk, 0, h[order[k]], 0));
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+            CK(hipMemSetAccess(va, total, &acc, 1));
+            out = (uint4 *)va;
+            free(order); free(h);                                     // (the handles and the range live until the process ends)
+        } else if (contiguous) {
             if (hipExtMallocWithFlags((void **)&out, bytes + F * 256, hipDeviceMallocContiguous) != hipSuccess) { printf("contiguous allocation %d refused\n", i); (void)hipGetLastError(); break; }
         } else CK(hipMalloc(&out, bytes + F * 256));
         const float w = timed([&] { hipLaunchKernelGGL(scatter_like<false>, dim3(256), dim3(BLOCK), 0, 0, in, out, tiles, 15, ticket); });
         const float rw = timed([&] { hipLaunchKernelGGL(scatter_like<true>, dim3(256), dim3(BLOCK), 0, 0, in, out, tiles, 15, ticket); });
         const float f = timed([&] { hipLaunchKernelGGL(fill, dim3(1024), dim3(BLOCK), 0, 0, out, bytes / 16); });
-        printf("%sallocation %2d at %p: scattered writes %.3f ms, read + scattered writes %.3f ms, streaming fill %.3f ms\n", contiguous ? "contiguous " : "", i, (void *)out, w, rw, f);
+        printf("%sallocation %2d at %p: scattered writes %.3f ms, read + scattered writes %.3f ms, streaming fill %.3f ms\n", vmm == 3 ? "stitched, shuffled " : vmm == 2 ? "stitched, in order " : contiguous ? "contiguous " : "", i, (void *)out, w, rw, f);
         fflush(stdout);
+        if (vmm) continue;                                            // stays mapped
         if (stacked && kept < 8) keep[kept++] = out; else CK(hipFree(out));
     }
     return 0;
