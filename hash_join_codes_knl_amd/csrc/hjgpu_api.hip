@@ -1895,16 +1895,16 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     *done = false;
     const size_t B = ((size_t)ctx->tune.host_batch + 15) & ~size_t(15);       // rows per batch (batches start 64-byte aligned)
     if (!B || !inner || outer < 2 * B || ctx->tune.batch_tuples) return HJGPU_OK;
-    // Materialised rows (PHJ / CPRA): every batch's rows are made dense on the device (close_gaps per batch) and travel to
+    // Materialised rows: every batch's rows are made dense on the device (close_gaps per batch) and travel to
     // the caller's host columns on a third stream while the next batch is joined and the one after it uploaded - PCIe is
     // full duplex, the 12 bytes per result row hide behind the 8 bytes per probe tuple of the upload as far as they can.
     // The per-batch device columns hold the batch's share of rows->capacity with a quarter of headroom: a batch that
     // needs more (or a result beyond the caller's capacity) sends the call down the whole-column path, which knows how
     // to report the needed capacity.
-    if (rows && algorithm == 0) return HJGPU_OK;
     const size_t nb = (outer + B - 1) / B;
     const u64 row_bs = 4096;
-    const size_t workers = rows ? (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true)) : 0;
+    const size_t workers = !rows ? 0 : algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, B) * 4
+                         : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true));
     const size_t want_b = rows ? (size_t)((double)rows->capacity * (double)B / (double)outer * 1.25) + row_bs : 0;
     const size_t cap_b = rows ? (want_b / row_bs + 1 + workers) * row_bs : 0;
     void *d_rows[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -2008,9 +2008,20 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                 for (int e = 0; e < EV_COUNT; ++e) ctx->ev_valid[e] = false;
                 record(ctx, EV_BEGIN, run);
                 record(ctx, EV_R_HIST, run);
-                rc = npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor, nullptr, run,
-                                       line, unique);
+                if (rows) {
+                    // the output protocol's counters start over with every batch; the result and the zero-key flag add up
+                    if (i >= 2) hip_ok(hipStreamWaitEvent(run, rows_free[slot], 0), "hipStreamWaitEvent");   // batch i - 2's rows have left
+                    hip_ok(hipMemsetAsync(&st->block_counter, 0, 3 * sizeof(u64), run), "hipMemsetAsync(counters)");
+                    hip_ok(hipMemsetAsync(&st->overflow, 0, sizeof(uint32_t), run), "hipMemsetAsync(overflow)");
+                    hip_ok(hipMemsetAsync(&st->nmoves, 0, sizeof(uint32_t), run), "hipMemsetAsync(nmoves)");
+                }
+                rc = npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor,
+                                       rows ? &dev_out[slot] : nullptr, run, line, unique);
                 ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets; ctx->last_algo = 0;
+                if (rows) {
+                    hip_ok(hipMemcpyAsync(&h_state[i], ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");
+                    hip_ok(hipEventRecord(joined[slot], run), "hipEventRecord");
+                }
             } else if (rc == HJGPU_OK) {
                 if (rows && i >= 2) hip_ok(hipStreamWaitEvent(run, rows_free[slot], 0), "hipStreamWaitEvent");   // batch i - 2's rows have left
                 rc = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m,
@@ -2032,8 +2043,16 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
         if (rc == HJGPU_OK) {
             hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
             ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (npj) rc = finish_blocking(ctx, result, nullptr, run);      // one accumulated result; key 0 in R -> HJGPU_EZEROKEY
-            else if (!abandon) {
+            if (npj && !abandon) {
+                // one accumulated result; key 0 in R -> HJGPU_EZEROKEY (the output counters are the last batch's: not checked here)
+                DevState hs;
+                hip_ok(hipMemcpyAsync(&hs, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");
+                hip_ok(hipStreamSynchronize(run), "hipStreamSynchronize(run)");
+                if (rc == HJGPU_OK) {
+                    if (result) *result = hs.result;
+                    if (hs.zero_key) rc = fail(ctx, HJGPU_EZEROKEY, "NPJ: a build key is 0, the empty-bucket sentinel");
+                }
+            } else if (!abandon) {
                 hip_ok(hipMemcpyAsync(parts.data(), d_res, nb * sizeof(hjgpu_result), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(results)");
                 hip_ok(hipStreamSynchronize(run), "hipStreamSynchronize(run)");
             }

@@ -356,11 +356,11 @@ int  hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tupl
  * probe side travels in batches through two device buffers - batch i is joined while batch i + 1 is on the bus (R join S
  * = union over the batches); the device never holds the probe side as a whole (it may be larger than the device's
  * memory), the call costs the upload plus the last batch's join, stats->batches says how many there were and the phase
- * times are those of the LAST batch (NPJ: ms_build = the table's build).  hjgpu_join_host_rows (PHJ / CPRA) works the
+ * times are those of the LAST batch (NPJ: ms_build = the table's build).  hjgpu_join_host_rows works the
  * same way: every batch's rows are made dense on the device and go home - into page-locked columns by a copy kernel, so
  * that the DMA engines carry the upload only - while the next batch is joined; a batch that outgrows its share of
  * rows->capacity sends the call down the whole-column path.
- * Otherwise (small probe sides, NPJ with rows, host_batch = 0) the columns are uploaded whole on their own
+ * Otherwise (small probe sides, host_batch = 0) the columns are uploaded whole on their own
  * stream, probe side first, build side behind it; PHJ / CPRA partition the probe side while the build side is still
  * arriving.  Page-locked columns (hjgpu_host_alloc) are DMA'd where they are, pageable ones staged
  * through two 32 MiB page-locked buffers the context keeps.

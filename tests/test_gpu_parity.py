@@ -565,7 +565,7 @@ def test_join_host_rows_returns_the_materialised_join(hj, algorithm, pinned):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("algorithm", [1, 2])
+@pytest.mark.parametrize("algorithm", [0, 1, 2])
 @pytest.mark.parametrize("pinned", [False, True])
 def test_join_host_rows_in_batches_go_home_behind_the_upload(hj, algorithm, pinned):
     """hjgpu_join_host_rows with the probe side in batches (option "host_batch"): every batch's rows are made dense on the
