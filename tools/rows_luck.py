@@ -18,14 +18,23 @@ cap = ((outer + block - 1) // block + 4096 + 8) * block
 keep = []
 placed = len(sys.argv) > 1 and sys.argv[1] == "placed"
 for rnd in range(8):
-    cols = [hj.column(cap, placed=placed) for _ in range(3)]
+    if len(sys.argv) > 1 and sys.argv[1] in ("oneblock", "oneblock_placed"):
+        # ONE allocation for the three columns (the two kinds of allocations are sharp for blocks of 8 GB and more)
+        blk = hj.column(3 * cap, placed=sys.argv[1] == "oneblock_placed")
+        class View:
+            def __init__(self, ptr): self.ptr = ptr
+            def free(self): pass
+        cols = [View(blk.ptr + 4 * cap * i) for i in range(3)]
+        cols[0].free = blk.free
+    else:
+        cols = [hj.column(cap, placed=placed) for _ in range(3)]
     best = None
     for _ in range(3):
-        assert hj.phj(ik, iv, inner, ok, ov, outer, out=(*cols, cap, block)) == want
+        assert hj.phj(ik, iv, inner, ok, ov, outer, out=(*(c.ptr for c in cols), cap, block)) == want
         st = hj.stats()
         if best is None or st["ms_join"] < best["ms_join"]:
             best = st
-    print(("placed " if placed else "") + "result columns %d: join %.3f + gaps %.3f ms, scatter1 %.3f" % (rnd, best["ms_join"], best["ms_close_gaps"], best["ms_scatter1"]), flush=True)
+    print((sys.argv[1] + " " if len(sys.argv) > 1 else "") + "result columns %d: join %.3f + gaps %.3f ms, scatter1 %.3f" % (rnd, best["ms_join"], best["ms_close_gaps"], best["ms_scatter1"]), flush=True)
     keep.append(cols)
     if len(keep) > 4:
         for c in keep.pop(0):
