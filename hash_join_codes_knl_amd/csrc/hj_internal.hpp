@@ -59,7 +59,12 @@ struct HjTuning {
     bool merged_plan = true;        // "merged_plan": whole joins on resident columns plan both relations with one set of K5 launches
     int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
-    long long host_batch = 64ll << 20;   // "host_batch": probe rows per batch of hjgpu_join_host's PHJ / CPRA (0 = the whole probe side at once)
+    // "host_batch": probe rows per batch of the host calls.  -1 (default): the materialising call in batches of 64 Mi rows
+    // (its rows go home behind the upload); the aggregate call uploads whole columns while they fit the device's free
+    // memory (its device time is then that of ONE join over the whole probe side: 8.5 ms at 64 M x 1 G against 20 ms as the
+    // sum of fifteen 64 Mi-row joins - the wall clock is the upload's either way) and falls back to batches when they do not.
+    // 0: never batch; n > 0: always, n rows per batch.
+    long long host_batch = -1;
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned

@@ -1893,7 +1893,16 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                              bool *done)
 {
     *done = false;
-    const size_t B = ((size_t)ctx->tune.host_batch + 15) & ~size_t(15);       // rows per batch (batches start 64-byte aligned)
+    long long want_batch = ctx->tune.host_batch;
+    if (want_batch < 0) {
+        // default: rows in batches; aggregates in batches only when whole columns plus their workspace (two packed twins of
+        // the probe side: 8 + 16 bytes per probe tuple, 8 + 24 per build tuple) would not fit what is free on the device
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const double need = 24.0 * (double)outer + 32.0 * (double)inner + 4e9;
+        want_batch = (rows || need > (double)free_b) ? (64ll << 20) : 0;
+    }
+    const size_t B = ((size_t)want_batch + 15) & ~size_t(15);       // rows per batch (batches start 64-byte aligned)
     if (!B || !inner || outer < 2 * B || ctx->tune.batch_tuples) return HJGPU_OK;
     // Materialised rows: every batch's rows are made dense on the device (close_gaps per batch) and travel to
     // the caller's host columns on a third stream while the next batch is joined and the one after it uploaded - PCIe is
@@ -1944,7 +1953,11 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     if (!ctx->host_streams[2]) hip_ok(hipStreamCreateWithPriority(&ctx->host_streams[2], hipStreamNonBlocking, least), "hipStreamCreate(down)");
     copy = ctx->host_streams[0]; run = ctx->host_streams[1];
     hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
-    if (npj) { hip_ok(hipEventCreate(&b0), "hipEventCreate"); hip_ok(hipEventCreate(&b1), "hipEventCreate"); }
+    hip_ok(hipEventCreate(&b0), "hipEventCreate"); hip_ok(hipEventCreate(&b1), "hipEventCreate");     // around the build side's work
+    // one timed pair per batch: the call's device time is the SUM of the build and of every batch's join (what the
+    // reference's programs print is the time of the join, npj.cpp:1104-1114), read once after the pipeline
+    std::vector<hipEvent_t> bev(2 * nb, nullptr);
+    for (hipEvent_t &e : bev) hip_ok(hipEventCreate(&e), "hipEventCreate");
     for (int b = 0; b < 2; ++b) {
         hip_ok(hipEventCreateWithFlags(&s_ready[b], hipEventDisableTiming), "hipEventCreate");
         hip_ok(hipEventCreateWithFlags(&s_free[b], hipEventDisableTiming), "hipEventCreate");
@@ -1972,7 +1985,12 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     PhjPlan pl;
     size_t buckets = 0; uint32_t factor = 0;
     // the workspace (for ONE batch) before the clocks start, like the reference's mamalloc()s (npj.cpp:982-1000 vs 861-863)
-    if (rc == HJGPU_OK) rc = npj ? npj_prepare(ctx, inner, np, &buckets, &factor) : phj_prepare(ctx, inner, B, pp, 1, &pl);
+    if (rc == HJGPU_OK) {
+        const int placement = ctx->tune.placement;          // no placement search in a call that is bound by its upload
+        ctx->tune.placement = 1;
+        rc = npj ? npj_prepare(ctx, inner, np, &buckets, &factor) : phj_prepare(ctx, inner, B, pp, 1, &pl);
+        ctx->tune.placement = placement;
+    }
     const bool line = !ctx->tune.npj_refhash, unique = npj && npj_unique(ctx, np);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 *table = reinterpret_cast<u64 *>(ctx->table.p);
@@ -1993,8 +2011,11 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             if (rc == HJGPU_OK) rc = hj_launch_npj_build((const uint32_t *)d_r[0], (const uint32_t *)d_r[1], inner, table, buckets, factor,
                                                         &st->zero_key, ctx->cus, run, line);
             hip_ok(hipEventRecord(b1, run), "hipEventRecord");
-        } else if (rc == HJGPU_OK)
+        } else if (rc == HJGPU_OK) {
+            hip_ok(hipEventRecord(b0, run), "hipEventRecord");
             rc = phj_enqueue(ctx, pl, (const uint32_t *)d_r[0], (const uint32_t *)d_r[1], inner, nullptr, nullptr, 0, nullptr, run, nullptr, PHJ_BUILD_ONLY);
+            hip_ok(hipEventRecord(b1, run), "hipEventRecord");
+        }
         for (size_t i = 0; i < nb && rc == HJGPU_OK; ++i) {
             const int slot = (int)(i & 1);
             const size_t b = i * B, m = outer - b < B ? outer - b : B;
@@ -2003,6 +2024,8 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             if (rc == HJGPU_OK) rc = upload_column(ctx, d_s[slot][1], ov + b, m * sizeof(uint32_t), copy, &next);
             hip_ok(hipEventRecord(s_ready[slot], copy), "hipEventRecord");
             hip_ok(hipStreamWaitEvent(run, s_ready[slot], 0), "hipStreamWaitEvent");
+            if (rows && i >= 2) hip_ok(hipStreamWaitEvent(run, rows_free[slot], 0), "hipStreamWaitEvent");   // batch i - 2's rows have left
+            hip_ok(hipEventRecord(bev[2 * i], run), "hipEventRecord");
             if (rc == HJGPU_OK && npj) {
                 // the phase events describe the LAST batch's probe (the build has its own pair)
                 for (int e = 0; e < EV_COUNT; ++e) ctx->ev_valid[e] = false;
@@ -2010,7 +2033,6 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                 record(ctx, EV_R_HIST, run);
                 if (rows) {
                     // the output protocol's counters start over with every batch; the result and the zero-key flag add up
-                    if (i >= 2) hip_ok(hipStreamWaitEvent(run, rows_free[slot], 0), "hipStreamWaitEvent");   // batch i - 2's rows have left
                     hip_ok(hipMemsetAsync(&st->block_counter, 0, 3 * sizeof(u64), run), "hipMemsetAsync(counters)");
                     hip_ok(hipMemsetAsync(&st->overflow, 0, sizeof(uint32_t), run), "hipMemsetAsync(overflow)");
                     hip_ok(hipMemsetAsync(&st->nmoves, 0, sizeof(uint32_t), run), "hipMemsetAsync(nmoves)");
@@ -2023,7 +2045,6 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                     hip_ok(hipEventRecord(joined[slot], run), "hipEventRecord");
                 }
             } else if (rc == HJGPU_OK) {
-                if (rows && i >= 2) hip_ok(hipStreamWaitEvent(run, rows_free[slot], 0), "hipStreamWaitEvent");   // batch i - 2's rows have left
                 rc = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m,
                                  rows ? &dev_out[slot] : nullptr, run, nullptr, PHJ_PROBE_ONLY);
                 hip_ok(hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + i, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run),
@@ -2033,6 +2054,7 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                     hip_ok(hipEventRecord(joined[slot], run), "hipEventRecord");
                 }
             }
+            hip_ok(hipEventRecord(bev[2 * i + 1], run), "hipEventRecord");
             hip_ok(hipEventRecord(s_free[slot], run), "hipEventRecord");
             // the previous batch's rows go home while this one is joined (its count is on the host by now, or soon)
             if (rows && i >= 1 && rc == HJGPU_OK && !abandon) download_batch(i - 1);
@@ -2066,12 +2088,18 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             if (result) *result = sum;
         }
         if (stats) {
-            const int rs = hjgpu_get_stats(ctx, stats);          // the phase times of the LAST batch's join
+            const int rs = hjgpu_get_stats(ctx, stats);          // the phase times of the LAST batch's join ...
             if (rc == HJGPU_OK) rc = rs;
-            if (npj) {
-                float ms = 0;
-                if (hipEventElapsedTime(&ms, b0, b1) == hipSuccess) { stats->ms_build = ms; stats->ms_total += ms; }
-            }
+            // ... scaled to the sum over all batches (the batches have one shape; the last may be shorter), plus the
+            // build side's work: ms_total is the device time of the whole join, as after a call without batches
+            float build_ms = 0, sum = 0, last = 0;
+            (void)hipEventElapsedTime(&build_ms, b0, b1);
+            for (size_t i = 0; i < nb; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, bev[2 * i], bev[2 * i + 1]) == hipSuccess) { sum += ms; last = ms; } }
+            const float k = last > 0 ? sum / last : 1.0f;
+            stats->ms_histogram *= k; stats->ms_plan *= k; stats->ms_scatter1 *= k; stats->ms_scatter2 *= k;
+            stats->ms_join *= k; stats->ms_close_gaps *= k;
+            if (npj) stats->ms_build = build_ms;
+            stats->ms_total = build_ms + sum;
             stats->ms_upload = ms_upload; stats->ms_download = ms_download;
             stats->batches = (uint32_t)nb;
         }
@@ -2093,6 +2121,7 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     if (r_ready) (void)hipEventDestroy(r_ready);
     if (b0) (void)hipEventDestroy(b0);
     if (b1) (void)hipEventDestroy(b1);
+    for (hipEvent_t e : bev) if (e) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -2150,7 +2179,8 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     size_t buckets = 0; uint32_t factor = 0;
     if (rc == HJGPU_OK) {
         // allocate the workspace before the clocks start, like the reference's mamalloc()s before
-        // its timed region (npj.cpp:982-1000 vs 861-863)
+        // its timed region (npj.cpp:982-1000 vs 861-863); with the placement search: what the host programs print is the
+        // device time of the join, and the twin's placement is 0.4 ms of it
         if (algorithm == 0) rc = npj_prepare(ctx, inner, np, &buckets, &factor);
         else rc = phj_prepare(ctx, inner, outer, pp, algorithm == 2 ? ((pp && pp->chunks) ? pp->chunks : 8) : 1, &pl);
     }

@@ -1397,7 +1397,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("host_batch")) {
         char *end = nullptr;
         const long long x = strtoll(value, &end, 10);
-        if (end == value || *end || x < 0) return false;
+        if (end == value || *end || x < -1) return false;
         t->host_batch = x;
         return true;
     }

@@ -352,11 +352,14 @@ int  hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tupl
 
 /* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
  * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates.
- * A probe side of at least two batches (option "host_batch", 64 Mi rows): the build side is uploaded and prepared once, the
+ * Batches (option "host_batch": -1 = the default: hjgpu_join_host_rows always, hjgpu_join_host when whole columns and
+ * their workspace would not fit the device's free memory; 0 = never; n = always, n rows per batch; a probe side of at
+ * least two batches of 64 Mi rows): the build side is uploaded and prepared once, the
  * probe side travels in batches through two device buffers - batch i is joined while batch i + 1 is on the bus (R join S
  * = union over the batches); the device never holds the probe side as a whole (it may be larger than the device's
- * memory), the call costs the upload plus the last batch's join, stats->batches says how many there were and the phase
- * times are those of the LAST batch (NPJ: ms_build = the table's build).  hjgpu_join_host_rows works the
+ * memory), the call costs the upload plus the last batch's join.  stats->batches says how many there were; ms_total is
+ * the device time of the whole join - the build side's work plus every batch's join, as after a call without batches -
+ * and the phase times are the last batch's scaled to that sum (NPJ: ms_build = the table's build).  hjgpu_join_host_rows works the
  * same way: every batch's rows are made dense on the device and go home - into page-locked columns by a copy kernel, so
  * that the DMA engines carry the upload only - while the next batch is joined; a batch that outgrows its share of
  * rows->capacity sends the call down the whole-column path.

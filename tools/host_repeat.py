@@ -15,4 +15,4 @@ for i in range(4):
     t0 = time.perf_counter()
     got, st = hj.join_host(1, *pinned)
     wall = time.perf_counter() - t0
-    print("call %d: upload %.1f ms, reserve so far %.1f ms, wall %.1f ms" % (i, st["ms_upload"], st["ms_reserve"], wall * 1e3), flush=True)
+    print("call %d: upload %.1f ms, device join %.2f ms in %d batches, reserve so far %.1f ms, wall %.1f ms" % (i, st["ms_upload"], st["ms_total"], st["batches"], st["ms_reserve"], wall * 1e3), flush=True)
