@@ -74,6 +74,11 @@ def parse(argv=None):
                          "device 0 with its own one-rank RCCL communicator (no exchange between the processes: RCCL wants one "
                          "device per rank), so that everything around the data plane - gloo gathers, barriers, per-rank "
                          "statistics, the N > 1 JSON line - executes with more than one process; its numbers mean nothing")
+    ap.add_argument("--configs4-inner", type=int, default=128_000_000,
+                    help="N > 1 line, secondary.cpra_multi (BASELINE configs[4]: CPRA |R|=1 G x |S|=16 G on 8 GPUs): build tuples PER GPU")
+    ap.add_argument("--configs4-outer", type=int, default=2_000_000_000,
+                    help="secondary.cpra_multi: probe tuples PER GPU")
+    ap.add_argument("--configs4-steps", type=int, default=4, help="secondary.cpra_multi: timed steps (after one warm-up step)")
     ap.add_argument("--preflight-bytes", type=int, default=256 << 20,
                     help="multi-GPU: bytes per peer of the link-bandwidth preflight before the timed region (0 = skip it)")
     return ap.parse_args(argv)
@@ -262,6 +267,84 @@ def attach_traffic(H, kernels, args, n_gpus):
             entry["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["launches_seen"] for h in hit)
                                    / max(1, sum(h["launches_seen"] for h in hit)))
     return "%s (kernels %s)" % (name, t["kernel_hash"])
+
+
+def cpra_multi_leg(args, H, torch, dist, comm, hj, dev, rank, n_gpus):
+    """BASELINE configs[4] inside the N > 1 line: CPRA with BOTH relations chunked over the ranks (cpra2.cpp:1757-1827 the
+    own-chunk partitioning, 1868-1872 ownership, 1891-1959 the gather = one all-to-all-v over xGMI), 128 M build and
+    2 G probe tuples per rank (|R| = 1 G x |S| = 16 G at 8 GPUs), default slices.  Every rank calls this (collectives).
+    --rehearse-solo: every process joins a self-contained pair of relations through its own one-rank communicator."""
+    inner, outer = args.configs4_inner, args.configs4_outer
+    solo = args.rehearse_solo
+    stream = torch.cuda.current_stream().cuda_stream
+    cols = [torch.empty(n + 4, dtype=torch.int32, device=dev) for n in (inner, inner, outer, outer)]
+    rk, rv, sk, sv = (c.data_ptr() for c in cols)
+    if solo:
+        hj.generate_range(1 + rank, inner, outer, 0, inner, 0, outer, INNER_FACTOR, OUTER_FACTOR, rk, rv, sk, sv, stream)
+    else:
+        hj.generate_range(1, inner * n_gpus, outer * n_gpus, rank * inner, inner, rank * outer, outer,
+                          INNER_FACTOR, OUTER_FACTOR, rk, rv, sk, sv, stream)
+    sums = hj.column_sums(sk, outer, OUTER_FACTOR, INNER_FACTOR, stream)
+    expect = sum_over_ranks(dist, torch, [outer, sums[0], sums[1], sums[2]])
+    shards = [(rk, rv, inner, sk, sv, outer)]
+    prm = H.PhjParams()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one():
+        res, ms = comm.cpra_multi(shards, prm, args.exchange_slices)
+        res = list(res)
+        if solo:
+            res = sum_over_ranks(dist, torch, res)
+        return res, ms
+
+    try:
+        ok = one()[0] == expect                        # warm-up: buffers, workspaces, RCCL's channels
+        sync()
+        t0 = time.perf_counter()
+        steps = []
+        for _ in range(args.configs4_steps):
+            res, ms = one()
+            ok = ok and res == expect
+            steps.append(ms)
+        sync()
+    except H.HjGpuError as ex:
+        die_of_comm_error(rank, ex, "secondary.cpra_multi")
+    elapsed = max_over_ranks(dist, torch, time.perf_counter() - t0)
+    k = len(steps)
+    mine = {"ms_wall_inside_library": sum(m["ms_wall"] for m in steps) / k,
+            "ms_exchange": sum(m["ms_exchange"] for m in steps) / k,
+            "ms_partition": sum(m["ms_partition"] for m in steps) / k,
+            "ms_joins_waited_for_exchange": sum(m["ms_exchange_wait"] for m in steps) / k,
+            "MB_sent": sum(m["bytes_sent"] for m in steps) / k / 1e6,
+            "self_copies": sum(m["self_copies"] for m in steps) / k,
+            "ms_join_kernel_last_batch": steps[-1]["join"]["ms_join"],
+            "fanout": [steps[-1]["join"]["fanout1"], steps[-1]["join"]["fanout2"]]}
+    mine["exchange_GBs_sent"] = mine["MB_sent"] / mine["ms_exchange"] if mine["ms_exchange"] > 0 else 0.0
+    every = gather_objects(dist, mine)
+    ms_step = elapsed / k * 1e3
+    total_outer = outer * n_gpus
+    keys = ["ms_wall_inside_library", "ms_exchange", "ms_partition", "ms_joins_waited_for_exchange", "MB_sent", "exchange_GBs_sent",
+            "ms_join_kernel_last_batch"]
+    leg = {"workload": "CPRA |R|=%d x |S|=%d over %d GPU(s): %d build and %d probe tuples per rank (BASELINE configs[4]'s shape), both "
+                       "sides chunked, exchange-level fan-out = pass 1, one all-to-all-v per slice, %s slices"
+                       % (inner * n_gpus, total_outer, n_gpus, inner, outer, args.exchange_slices or "default"),
+           "steps": k, "ms_per_step": round(ms_step, 4), "gtuples_per_s": round(total_outer / ms_step / 1e6, 3),
+           "gtuples_per_s_per_gpu": round(outer / ms_step / 1e6, 3), "checksum_ok": bool(ok),
+           "fanout_of_rank0": mine["fanout"],
+           "rank0": {k2: round(mine[k2], 4) for k2 in keys},
+           "all_ranks": {k2: spread([e[k2] for e in every]) for k2 in keys},
+           # HBM bytes per tuple and rank (DESIGN section 7): sender 4 + 16, receiver 8 + 16 + 8, exchange 16 (G - 1) / G
+           "hbm_bytes_per_tuple": 52 + 16.0 * (n_gpus - 1) / n_gpus if not solo else 52}
+    if solo:
+        leg["rehearsal"] = "--rehearse-solo: one-rank communicators, self-contained relations per process"
+    del cols
+    torch.cuda.empty_cache()
+    return leg
 
 
 def main():
@@ -544,6 +627,15 @@ def main():
                                              "all_to_all_v": round(preflight["ms_all_to_all"], 3),
                                              "all_reduce": round(preflight["ms_all_reduce"], 3)}}
 
+    # ---- BASELINE configs[4] beside configs[3], N > 1 (one driver command measures both multi-GPU configurations) -----
+    if (multi and args.algo == "phj" and not args.no_secondary and args.zipf <= 0
+            and (args.inner, args.outer) == (64_000_000, 1_000_000_000)):
+        del shards
+        rk = rv = sk = sv = None                       # the headline's columns make room (torch frees, the library keeps its workspaces)
+        torch.cuda.empty_cache()
+        leg = cpra_multi_leg(args, H, torch, dist, comm, hj, dev, rank, n_gpus)
+        out.setdefault("secondary", {})["cpra_multi"] = leg
+
     # ---- the other BASELINE configurations, same process, N = 1 ---------------------------------------------------
     extras = (not multi and rank == 0 and not args.no_secondary and args.algo == "phj" and args.zipf <= 0
               and (args.inner, args.outer) == (64_000_000, 1_000_000_000))
@@ -595,6 +687,16 @@ def main():
                        "phase_ms": {k2: round(ph[k2], 4) for k2 in phases if k2 in ph},
                        "roofline_scatter": roof(2 * 16 * (inner + outer), ph["ms_scatter1"] + ph["ms_scatter2"], 4, stream_read_gbs),
                        "roofline_join": roof(8 * (inner + outer), ph["ms_join"], 1, stream_read_gbs)}
+        # the reference's -D_UNIQUE build (npj.cpp:288-290, phj.cpp:635-637): a probe tuple reports its first
+        # match.  Same relations (unique build keys: same result), HJGPU_FLAG_UNIQUE
+        uprm = H.PhjParams(fanout1=args.fanout1, fanout2=args.fanout2, flags=H.FLAG_UNIQUE)
+        ms, ph = time_steps(lambda: hj.phj_async(*a, uprm, d_result.data_ptr(), stream))
+        ok_ = [int(x) & MASK64 for x in d_result.tolist()] == expect_local
+        sec["phj_unique"] = {"workload": "PHJ |R|=%d join |S|=%d with HJGPU_FLAG_UNIQUE (-D_UNIQUE: first match only)" % (inner, outer),
+                             "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2), "checksum_ok": ok_,
+                             "ms_join": round(ph["ms_join"], 4),
+                             "join_vs_default_instance": round(ph["ms_join"] / join_ms, 4) if join_ms > 0 else None,
+                             "roofline_join": roof(8 * (inner + outer), ph["ms_join"], 1, stream_read_gbs)}
         out["secondary"] = sec
         # rows (key, outer payload, inner payload) written through the block
         # protocol, compacted by close_gaps; priced against read + written bytes.
@@ -609,23 +711,32 @@ def main():
         # come from the library's placement-aware allocator (hjgpu_malloc_placed), outside the timed calls
         jcols = [hj.column(cap, placed=True) for _ in range(3)]
         jk, jo, ji = (torch.empty(0, dtype=torch.int32, device=dev) for _ in range(3))
+        # MEAN over as many steps as the headline (after one untimed call), min / max beside it - not a best-of
         mt = {"ms_join": [], "ms_close_gaps": [], "ms_total": []}
-        for _ in range(3):
+        for it in range(args.steps + 1):
             res = hj.phj(rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer, prm,
                          out=(jcols[0].ptr, jcols[1].ptr, jcols[2].ptr, cap, block),
                          stream=torch.cuda.current_stream().cuda_stream)
             stx = hj.stats()
             for k2 in mt:
-                mt[k2].append(stx[k2])
+                if it:
+                    mt[k2].append(stx[k2])
         j = res[0]
         ok_rows = list(res) == expect_local and hj.column_sums(jcols[0].ptr, j, 1, 1)[0] == expect_local[1]
-        tj = min(mt["ms_join"]) + min(mt["ms_close_gaps"])
-        out["materialized"] = {"rows": j, "ms_join": round(min(mt["ms_join"]), 4),
-                               "ms_close_gaps": round(min(mt["ms_close_gaps"]), 4),
-                               "ms_total": round(min(mt["ms_total"]), 4),
-                               "gtuples_per_s": round(outer / min(mt["ms_total"]) / 1e6, 2),
-                               "join_phase_rw_GBs": round((8 * n_tuples + 12 * j) / (tj * 1e-3) / 1e9, 1),
-                               "join_phase_rw_frac": round((8 * n_tuples + 12 * j) / (tj * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        mean = {k2: sum(v) / len(v) for k2, v in mt.items()}
+        tj = mean["ms_join"] + mean["ms_close_gaps"]
+        rw = 8 * n_tuples + 12 * j
+        tj_each = [a_ + b_ for a_, b_ in zip(mt["ms_join"], mt["ms_close_gaps"])]
+        out["materialized"] = {"rows": j, "steps": len(mt["ms_total"]), "statistic": "mean over the steps (min / max beside it)",
+                               "ms_join": round(mean["ms_join"], 4), "ms_close_gaps": round(mean["ms_close_gaps"], 4),
+                               "ms_total": round(mean["ms_total"], 4),
+                               "ms_join_min_max": [round(min(mt["ms_join"]), 4), round(max(mt["ms_join"]), 4)],
+                               "ms_total_min_max": [round(min(mt["ms_total"]), 4), round(max(mt["ms_total"]), 4)],
+                               "gtuples_per_s": round(outer / mean["ms_total"] / 1e6, 2),
+                               "join_phase_rw_GBs": round(rw / (tj * 1e-3) / 1e9, 1),
+                               "join_phase_rw_frac": round(rw / (tj * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "join_phase_rw_frac_min_max": [round(rw / (max(tj_each) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                              round(rw / (min(tj_each) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)],
                                "block_size": block, "rows_checksum_ok": bool(ok_rows)}
         del jk, jo, ji
         for c in jcols:

@@ -1385,6 +1385,9 @@ int hjgpu_npj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size
                     const hjgpu_npj_params *prm, hjgpu_result *d_result, void *stream_)
 {
     if (!ctx) return HJGPU_EINVAL;
+    // the one-shot output is consumed by THIS call whether it succeeds or not: taken before any early return, so that a
+    // failed call never leaves it to an unrelated later join (whose caller may have freed the columns by then)
+    const hjgpu_output *out = take_async_output(ctx, nullptr);
     CHK(check_columns(ctx, rk, rv, inner));
     CHK(check_columns(ctx, sk, sv, outer));
     hipStream_t stream = (hipStream_t)stream_;
@@ -1392,7 +1395,6 @@ int hjgpu_npj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size
     size_t buckets; uint32_t factor;
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
     CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
-    const hjgpu_output *out = take_async_output(ctx, nullptr);
     ctx->last_had_output = out && out->d_keys;
     CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream, npj_unique(ctx, prm)));
     if (d_result)
@@ -1512,13 +1514,13 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
                     const hjgpu_output *out, void *stream_, bool blocking, void *inner_ready = nullptr)
 {
     if (!ctx) return HJGPU_EINVAL;
+    if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
     CHK(check_columns(ctx, rk, rv, inner));
     CHK(check_columns(ctx, sk, sv, outer));
     if (chunks < 1 || chunks > 8) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 8]");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
-    if (!blocking) out = take_async_output(ctx, out);
     ctx->last_had_output = out && out->d_keys;
     if (broadcast_applies(ctx->tune, inner, outer, chunks, prm)) {
         CHK(broadcast_enqueue(ctx, rk, rv, inner, sk, sv, outer, prm, out, stream, (hipEvent_t)inner_ready));
@@ -1579,6 +1581,7 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
                               void *stream_, bool blocking)
 {
     if (!ctx) return HJGPU_EINVAL;
+    if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
     if (!ctx->prepared)
         return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe: no prepared build side (hjgpu_phj_build), or another "
                                        "entry point has used the workspace since");
@@ -1589,7 +1592,6 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PhjPlan pl;
     memcpy(&pl, ctx->prepared_plan, sizeof(pl));
-    if (!blocking) out = take_async_output(ctx, out);
     ctx->last_had_output = out && out->d_keys;
     // the build columns themselves are not read again: their partitions live in the workspace
     CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, sk, sv, outer, out, stream, nullptr, PHJ_PROBE_ONLY));
@@ -1737,6 +1739,7 @@ int hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuple
                                          hjgpu_result *d_result, void *stream_)
 {
     if (!ctx) return HJGPU_EINVAL;
+    const hjgpu_output *out = take_async_output(ctx, nullptr);   // consumed by this call even if it fails below (see hjgpu_npj_async)
     if (!ctx->prepared) return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe_prepartitioned_async: no prepared build side, or another entry point has used the workspace since");
     PhjPlan pl;
     memcpy(&pl, ctx->prepared_plan, sizeof(pl));
@@ -1751,7 +1754,6 @@ int hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuple
     pre.tuples[1] = reinterpret_cast<const u64 *>(d_tuples);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const hjgpu_output *out = take_async_output(ctx, nullptr);
     ctx->last_had_output = out && out->d_keys;
     CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, nullptr, nullptr, outer, out, stream, nullptr, PHJ_PROBE_ONLY, &pre));
     if (d_result)

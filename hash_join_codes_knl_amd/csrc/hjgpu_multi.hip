@@ -36,6 +36,20 @@
 
 typedef unsigned long long u64;
 
+#ifndef HJ_SCRATCH_EXPERIMENT
+#define HJ_SCRATCH_EXPERIMENT 0
+#endif
+#if HJ_SCRATCH_EXPERIMENT
+// Variant builds only (tools/build_variant.py -DHJ_SCRATCH_EXPERIMENT=n, see partition_kernels.hip): forensics of the
+// slice pipeline with option debug_forensics=1, world 1, exchange_in_place=0, <= 8 slices.  For every probe slice:
+// [0] the input columns' sums (partitioning stream), [1] the pass-1 output verified right behind pass 1 on the SAME
+// stream, [2] the received copy verified on the JOIN stream right before its join, [3] send and [4] receive buffer
+// verified once the step is over and the device quiet.  (misplaced tuples, sum of keys, sum of payloads, tuples seen)
+int hj_debug_verify(const u64 *tuples, const u64 *d_off, uint32_t F, uint32_t factor, u64 n, u64 *d_res, hipStream_t s);
+int hj_debug_sums(const uint32_t *k, const uint32_t *v, u64 n, u64 *d_res, hipStream_t s);
+constexpr int DBG_SLICES = 8, DBG_STAGES = 5, DBG_OFF = 1032;
+#endif
+
 namespace {
 
 const uint32_t TOP_LEVEL_FACTOR = 0x2C1B3C6Du;        // odd multiplier of the exchange-level partitioning
@@ -117,7 +131,11 @@ struct Rank {
     hipEvent_t ev_xchg[2] = {nullptr, nullptr};       // receive buffers of slot b filled
     hipEvent_t ev_join[2] = {nullptr, nullptr};       // receive buffers of slot b joined (free again)
     hipEvent_t ev_rx = nullptr;                       // build side received (CPRA)
-    hipEvent_t ev_dbg = nullptr;                      // option "debug_serialize"
+    hipEvent_t ev_dbg = nullptr, ev_dbg2 = nullptr;   // option "debug_serialize"
+#if HJ_SCRATCH_EXPERIMENT
+    u64 *dbg = nullptr;                               // [DBG_SLICES][DBG_STAGES][4] results + [DBG_SLICES][DBG_OFF] offsets of every slice
+    u64 dbg_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // tuples of every slice
+#endif
     hipEvent_t ev_up_s = nullptr, ev_up_r = nullptr;  // host path: probe shard / build columns uploaded
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;      // host path: first kernel of the join started / upload finished (timing)
     hipEvent_t lb_in = nullptr, lb_out = nullptr;     // loopback transport
@@ -151,8 +169,10 @@ struct hjgpu_comm {
     int stall_rank = -1, stall_ms = 0;       // loopback fault injection (options "stall_rank", "stall_ms")
     bool self_via_rccl = false;              // option "self_via_rccl": a rank's message to itself goes through ncclSend / ncclRecv too (tests:
                                              // grouped point-to-point RCCL calls run on a one-GPU box that way)
+    int debug_forensics = 0;                 // option "debug_forensics" (variant builds only)
     int debug_serialize = 0;                 // option "debug_serialize" (diagnostics): bit 0 host waits after every slice's join, bit 1 the
-                                             // partitioning waits for the joins enqueued so far, bit 2 the exchange waits for them
+                                             // partitioning waits for the joins enqueued so far, bit 2 the exchange waits for them,
+                                             // bit 3 a join waits for the partitioning enqueued so far (with bit 1: the two never overlap)
     bool exchange_in_place = true;           // option "exchange_in_place": a CPRA rank keeps its own partitions where its partitioning wrote
                                              // them (last) and receives the other ranks' pieces right behind: the message to itself is never copied
     int cpra_k = 0;                          // option "cpra_k": partitions per rank of the exchange-level pass (0 = 192 / ranks); measurements:
@@ -161,6 +181,7 @@ struct hjgpu_comm {
     char err[512];
     char why_broken[512];
     std::mutex err_mu;                       // the local ranks' enqueue work runs on one host thread per rank (each_rank)
+    std::mutex abort_mu;                     // give_up(): one abort per communicator
 };
 
 namespace {
@@ -561,6 +582,9 @@ __global__ void add_result_kernel(u64 *__restrict__ dst, const u64 *__restrict__
     if (threadIdx.x < 4) dst[threadIdx.x] += src[threadIdx.x];
 }
 
+// a status flag raised from the host side of the pipeline (stream-ordered with the joins that read / reduce it)
+__global__ void bump_kernel(u64 *flag) { *flag += 1; }
+
 // ---- construction ---------------------------------------------------------------------------------
 int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
 {
@@ -578,13 +602,16 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     // the next persistent grid), a join never behind the upload or the partitioning it is meant to overlap.
     int least = 0, greatest = 0;
     HIPM(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // (diagnostics, read when the communicator is made: HJGPU_DEBUG_FLAT_PRIORITIES=1 puts all four streams at the default priority)
+    const char *flat = getenv("HJGPU_DEBUG_FLAT_PRIORITIES");
+    if (flat && flat[0] == '1') least = greatest = 0;
     HIPM(c, hipStreamCreateWithFlags(&r.main, hipStreamNonBlocking));
     HIPM(c, hipStreamCreateWithPriority(&r.prep, hipStreamNonBlocking, least));
     for (hipStream_t *s : {&r.comm, &r.up}) HIPM(c, hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest));
     hipEvent_t *timed[] = {&r.ev_x0, &r.ev_x1, &r.ev_t0, &r.ev_t1};
     for (hipEvent_t *e : timed) HIPM(c, hipEventCreate(e));
     hipEvent_t *plain[] = {&r.ev_ready, &r.ev_part[0], &r.ev_part[1], &r.ev_xchg[0], &r.ev_xchg[1],
-                           &r.ev_join[0], &r.ev_join[1], &r.ev_rx, &r.ev_dbg, &r.ev_up_s, &r.ev_up_r, &r.lb_in, &r.lb_out};
+                           &r.ev_join[0], &r.ev_join[1], &r.ev_rx, &r.ev_dbg, &r.ev_dbg2, &r.ev_up_s, &r.ev_up_r, &r.lb_in, &r.lb_out};
     for (hipEvent_t *e : plain) HIPM(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
     const size_t G = (size_t)c->nranks;
     HIPM(c, hipHostMalloc(reinterpret_cast<void **>(&r.h_pin), hp_words(G) * sizeof(u64), hipHostMallocDefault));
@@ -623,7 +650,7 @@ void destroy_rank(Rank &r)
                    &r.rows_col[1], &r.rows_col[2]};
     for (Buf *b : bufs) if (b->p) (void)hipFree(b->p);
     hipEvent_t evs[] = {r.ev_ready, r.ev_x0, r.ev_x1, r.ev_t0, r.ev_t1, r.ev_part[0], r.ev_part[1], r.ev_xchg[0],
-                        r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.ev_dbg, r.ev_up_s, r.ev_up_r, r.lb_in, r.lb_out};
+                        r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.ev_dbg, r.ev_dbg2, r.ev_up_s, r.ev_up_r, r.lb_in, r.lb_out};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r.ev_w) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {r.main, r.comm, r.prep, r.up}) if (s) (void)hipStreamDestroy(s);
@@ -651,9 +678,16 @@ std::vector<hipStream_t> streams_of(hjgpu_comm *c, hipStream_t Rank::*which)
 // The communicator gives up: whatever RCCL has in flight is cancelled (ncclCommAbort), every later call fails fast.
 int give_up(hjgpu_comm *c, const char *why)
 {
-    snprintf(c->why_broken, sizeof(c->why_broken), "%s", why);
-    if (c->transport) c->transport->abort();
-    c->broken = true;
+    // the local ranks' host threads (each_rank) may hit the deadline or an asynchronous error at the same time: the
+    // abort runs exactly once, the first caller's reason stays
+    {
+        std::lock_guard<std::mutex> g(c->abort_mu);
+        if (!c->broken) {
+            snprintf(c->why_broken, sizeof(c->why_broken), "%s", why);
+            if (c->transport) c->transport->abort();
+            c->broken = true;
+        }
+    }
     return cfail(c, HJGPU_ERCCL, c->why_broken);
 }
 
@@ -898,6 +932,7 @@ struct CpraStep {
     // rank's SEND buffer - its own partitions were written last (hjgpu_partition_packed_own_last_async), the other ranks'
     // pieces are received right behind them: piece 0 = the own one, never copied; pieces 1.. = the other ranks in order.
     std::vector<const void *> base;
+    int dbg_slice = -1;                                       // variant builds, option debug_forensics: the probe slice being partitioned
     bool exchange_in_flight = false;                          // local rank 0's ev_x0 / ev_x1 hold an unread exchange
     bool from_host = false;                                   // the inputs are being uploaded (hjgpu_join_host_multi)
     float exchange_ms = 0;
@@ -975,6 +1010,16 @@ struct CpraStep {
                                                        reinterpret_cast<uint64_t *>(d_off), r.prep));
             else HIPM(c, hipMemsetAsync(d_off, 0, (F + 1) * sizeof(u64), r.prep));
             HIPM(c, hipMemcpyAsync(h_off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
+#if HJ_SCRATCH_EXPERIMENT
+            if (c->debug_forensics && which && k && !own_last && G == 1 && dbg_slice >= 0 && dbg_slice < DBG_SLICES && r.dbg) {
+                u64 *res = r.dbg + (size_t)dbg_slice * DBG_STAGES * 4;
+                u64 *off = r.dbg + (size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)dbg_slice * DBG_OFF;
+                r.dbg_n[dbg_slice] = in[l].n;
+                HIPM(c, hipMemcpyAsync(off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToDevice, r.prep));
+                CHKM(hj_debug_sums(in[l].keys, in[l].vals, in[l].n, res + 0, r.prep));
+                CHKM(hj_debug_verify(static_cast<const u64 *>(b.sk->p), off, (uint32_t)F, TOP_LEVEL_FACTOR, in[l].n, res + 4, r.prep));
+            }
+#endif
             HIPM(c, hipEventRecord(r.ev_part[slot], r.prep));
             return HJGPU_OK;
         });
@@ -1087,6 +1132,16 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             return cfail(c, HJGPU_EINVAL, "null column in a shard");
     }
     CpraStep step(c, stats);
+#if HJ_SCRATCH_EXPERIMENT
+    if (c->debug_forensics)
+        for (Rank &r : c->ranks) {
+            const size_t bytes = ((size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)DBG_SLICES * DBG_OFF) * sizeof(u64);
+            HIPM(c, hipSetDevice(r.device));
+            if (!r.dbg) HIPM(c, hipMalloc(reinterpret_cast<void **>(&r.dbg), bytes));
+            HIPM(c, hipDeviceSynchronize());
+            HIPM(c, hipMemset(r.dbg, 0, bytes));
+        }
+#endif
     // one-level plan while the receiver can take one piece per source rank (<= 8 pieces): fan-out G * k with G * k <= 192,
     // the widest pass 1 whose whole-line carry still fits beside a 16 K-tuple tile
     if (c->nranks <= 8 && !c->cpra_two_level) step.k = (uint32_t)(c->cpra_k > 0 && c->cpra_k * c->nranks <= 192 ? c->cpra_k : 192 / c->nranks);
@@ -1155,11 +1210,20 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         CHKM(each_rank(L, [&](int l) -> int {
             Rank &r = c->ranks[l];
             HIPM(c, hipSetDevice(r.device));
+            if (c->debug_serialize & 8) {            // the join waits for whatever the partitioning stream has been given so far
+                HIPM(c, hipEventRecord(r.ev_dbg2, r.prep));
+                HIPM(c, hipStreamWaitEvent(r.main, r.ev_dbg2, 0));
+            }
             HIPM(c, hipEventRecord(r.ev_w[2 * (size_t)i], r.main));
             HIPM(c, hipStreamWaitEvent(r.main, r.ev_xchg[slot], 0));
             HIPM(c, hipEventRecord(r.ev_w[2 * (size_t)i + 1], r.main));
             const uint32_t *sk = static_cast<const uint32_t *>(r.recv_k[slot].p), *sv = static_cast<const uint32_t *>(r.recv_v[slot].p);
             u64 *acc = static_cast<u64 *>(r.d_res.p);
+#if HJ_SCRATCH_EXPERIMENT
+            if (c->debug_forensics && K && !c->exchange_in_place && G == 1 && i < DBG_SLICES && r.dbg && got[l] == r.dbg_n[i])
+                CHKM(hj_debug_verify(static_cast<const u64 *>(got_base[l]) + got_pieces[l][0], r.dbg + (size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)i * DBG_OFF,
+                                     (uint32_t)c->nranks * K, TOP_LEVEL_FACTOR, got[l], r.dbg + ((size_t)i * DBG_STAGES + 2) * 4, r.main));
+#endif
             if (inner_recv[l])
                 for (u64 b = 0; b < got[l]; b += max_outer[l]) {
                     const size_t m = got[l] - b < max_outer[l] ? (size_t)(got[l] - b) : max_outer[l];
@@ -1176,14 +1240,16 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                         if (used[l] + bs <= o.capacity) {
                             piece.d_keys = o.d_keys + used[l]; piece.d_outer_vals = o.d_outer_vals + used[l]; piece.d_inner_vals = o.d_inner_vals + used[l];
                             piece.capacity = (o.capacity - used[l]) / bs * bs;
+                            JOINM(c, r.join, hjgpu_set_async_output(r.join, &piece));
                         } else {
-                            // no block left: the batch writes into the last block (its rows are lost) and raises the
-                            // overflow flag through a capacity of exactly one block that it cannot fit... unless it is empty
-                            const size_t at = o.capacity - bs;
-                            piece.d_keys = o.d_keys + at; piece.d_outer_vals = o.d_outer_vals + at; piece.d_inner_vals = o.d_inner_vals + at;
-                            piece.capacity = bs;
+                            // no block left in this rank's columns: the batch is joined WITHOUT output (its count still joins
+                            // the running count: hjgpu_shard_rows.rows reports what the rank needs) and the overflow flag is
+                            // raised here.  (Pointing the batch at the last block relied on the emitter to flag the overflow,
+                            // which it does only when a second block is claimed: a batch with few matches overwrote valid rows
+                            // of earlier slices and the call returned HJGPU_OK.)
+                            hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, r.main, acc + 5);
+                            HIPM(c, hipGetLastError());
                         }
-                        JOINM(c, r.join, hjgpu_set_async_output(r.join, &piece));
                     }
                     if (K) {
                         // a batch = rows [b, b + m) of what arrived: a contiguous piece of the pieces (still sorted by partition)
@@ -1223,6 +1289,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         // and only then does the host wait for partition(i)'s counts: the device works on join(i-1) and partition(i)
         // while the host and the ranks settle the sizes of exchange(i) (with the join enqueued after that wait, every
         // slice cost a world of one ~0.15-0.2 ms of idle device: 4 slices 13.0 -> 12.2-12.6 ms, 8 slices 16.7 -> 14.9-15.0 ms)
+        step.dbg_slice = i;
         CHKM(step.begin_exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr));
         if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
         CHKM(step.finish_exchange(in, 1 + slot, slot));
@@ -1241,7 +1308,51 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
     const int status = reduce_results(c, result);
     if (status != HJGPU_OK && status != HJGPU_EOVERFLOW) return status;
-    if (rows) for (int l = 0; l < L; ++l) rows[l].rows = hp_local(c->ranks[l], G)[0];
+#if HJ_SCRATCH_EXPERIMENT
+    if (c->debug_forensics && K && !c->exchange_in_place && G == 1 && slices <= 2) {
+        // two slices = both slots used once: their buffers still hold the slices
+        Rank &r = c->ranks[0];
+        HIPM(c, hipSetDevice(r.device));
+        HIPM(c, hipDeviceSynchronize());
+        for (int i = 0; i < slices && r.dbg; ++i) {
+            const u64 *off = r.dbg + (size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)i * DBG_OFF;
+            u64 *res = r.dbg + (size_t)i * DBG_STAGES * 4;
+            CHKM(hj_debug_verify(static_cast<const u64 *>(r.send_k[i & 1].p), off, (uint32_t)K, TOP_LEVEL_FACTOR, r.dbg_n[i], res + 12, r.main));
+            CHKM(hj_debug_verify(static_cast<const u64 *>(r.recv_k[i & 1].p), off, (uint32_t)K, TOP_LEVEL_FACTOR, r.dbg_n[i], res + 16, r.main));
+        }
+        HIPM(c, hipDeviceSynchronize());
+    }
+    if (c->debug_forensics && c->ranks[0].dbg) {
+        Rank &r = c->ranks[0];
+        u64 h[DBG_SLICES * DBG_STAGES * 4];
+        HIPM(c, hipSetDevice(r.device));
+        HIPM(c, hipDeviceSynchronize());
+        HIPM(c, hipMemcpy(h, r.dbg, sizeof(h), hipMemcpyDeviceToHost));
+        static const char *stage[DBG_STAGES] = {"input columns", "pass-1 output, same stream", "received copy, join stream", "send buffer, quiet", "receive buffer, quiet"};
+        for (int i = 0; i < slices && i < DBG_SLICES; ++i) {
+            const u64 *in0 = h + (size_t)i * DBG_STAGES * 4;
+            bool any = false;
+            for (int st = 1; st < DBG_STAGES; ++st) {
+                const u64 *x = in0 + st * 4;
+                if (x[3] && (x[0] || x[1] != in0[1] || x[2] != in0[2] || x[3] != in0[3])) any = true;
+            }
+            if (!any) continue;
+            fprintf(stderr, "forensics slice %d (%llu tuples):", i, (unsigned long long)in0[3]);
+            for (int st = 1; st < DBG_STAGES; ++st) {
+                const u64 *x = in0 + st * 4;
+                if (!x[3]) { fprintf(stderr, " [%s: -]", stage[st]); continue; }
+                fprintf(stderr, " [%s: %llu misplaced, key sum %+lld, payload sum %+lld]", stage[st], (unsigned long long)x[0],
+                        (long long)(x[1] - in0[1]), (long long)(x[2] - in0[2]));
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+    bool rows_fit = true;
+    if (rows) for (int l = 0; l < L; ++l) {
+        rows[l].rows = hp_local(c->ranks[l], G)[0];
+        if (rows[l].rows > rows[l].out.capacity) rows_fit = false;
+    }
     step.note_exchange();
     if (stats) {
         Rank &r = c->ranks[0];
@@ -1252,6 +1363,9 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         stats->ms_exchange = step.exchange_ms;
         stats->ms_wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    // belt and braces: whatever the flags say, more rows than a rank's columns hold is an overflow
+    if (status == HJGPU_OK && !rows_fit)
+        return cfail(c, HJGPU_EOVERFLOW, "materialised output exceeded the capacity of a local rank's result columns (rows needed per rank: hjgpu_shard_rows.rows)");
     return status;
 }
 
@@ -1298,9 +1412,28 @@ int hjgpu_comm_destroy(hjgpu_comm *c)
     if (!c) return HJGPU_OK;
     // RCCL first when the communicator gave up: its kernels may still sit on the streams, waiting for a peer
     if (c->broken) c->transport.reset();
-    for (Rank &r : c->ranks) { (void)hipSetDevice(r.device); (void)hipDeviceSynchronize(); }
+    bool drained = true;
+    if (!c->broken) for (Rank &r : c->ranks) { (void)hipSetDevice(r.device); (void)hipDeviceSynchronize(); }
+    else {
+        // a communicator that gave up: whatever is still on its streams may never finish (a kernel waiting for a peer
+        // that is gone).  The streams are polled for at most the communicator's deadline (2 s without one); if they
+        // have not drained by then the ranks' device resources are LEAKED rather than freed - hipFree, hipStreamDestroy
+        // and hipDeviceSynchronize all wait for the device - so that "never a hang" holds for the clean-up too
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(c->timeout_ms > 0 ? c->timeout_ms : 2000);
+        for (Rank &r : c->ranks) {
+            (void)hipSetDevice(r.device);
+            for (hipStream_t st : {r.up, r.prep, r.comm, r.main}) {
+                if (!st) continue;
+                hipError_t e;
+                while ((e = hipStreamQuery(st)) == hipErrorNotReady && std::chrono::steady_clock::now() < until)
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                if (e == hipErrorNotReady) drained = false;
+            }
+            (void)hipGetLastError();
+        }
+    }
     c->transport.reset();                    // communicators before the streams they used
-    for (Rank &r : c->ranks) destroy_rank(r);
+    if (drained) for (Rank &r : c->ranks) destroy_rank(r);
     delete c;
     return HJGPU_OK;
 }
@@ -1442,6 +1575,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
     if (strcmp(name, "cpra_k") == 0) { if (x < 0 || x > 192) return cfail(c, HJGPU_EINVAL, "cpra_k: 0 ... 192"); c->cpra_k = (int)x; return HJGPU_OK; }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }
+    if (strcmp(name, "debug_forensics") == 0) { c->debug_forensics = (int)x; return HJGPU_OK; }
     if (strcmp(name, "self_via_rccl") == 0) { c->self_via_rccl = x != 0; return HJGPU_OK; }
     if (strcmp(name, "timeout_ms") == 0) {
         if (x < 0 || x > (1 << 30)) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: timeout_ms outside 0..2^30");

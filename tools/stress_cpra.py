@@ -21,10 +21,19 @@ def main():
     ap.add_argument("--option", action="append", default=[])
     ap.add_argument("--ctx-option", action="append", default=[], help="hjgpu_set_option on every rank's join context")
     a = ap.parse_args()
+    import ctypes
     import torch
     torch.cuda.init()
     import hash_join_codes_knl_amd as H
+    from hash_join_codes_knl_amd import api
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    lib = api.load_library()
+    knobs = {k: v for k, v in os.environ.items() if k.startswith(("HSA_", "GPU_MAX_HW", "HJGPU_LIBRARY", "AMD_SERIALIZE", "HIP_LAUNCH_BLOCKING"))}
+    print("library %s, kernel hash %s, env %s" % (os.path.basename(os.environ.get("HJGPU_LIBRARY", "libhjgpu.so")), H.kernel_hash(), knobs), flush=True)
+    has_dbg = hasattr(lib, "hjgpu_debug_scratch")
+    if has_dbg:
+        lib.hjgpu_debug_scratch.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        lib.hjgpu_debug_scratch(None, 1)
     comm = H.HjComm.local(a.world, [0] * a.world, H.TRANSPORT_RCCL if a.transport == "rccl" else H.TRANSPORT_LOOPBACK)
     for o in a.option:
         n, v = o.split("=")
@@ -52,6 +61,15 @@ def main():
             bad += 1
             print("step %d WRONG: count %+d, sums %s" % (s, got[0] - expect[0], ["%+d" % ((x - y + (1 << 63)) % (1 << 64) - (1 << 63)) for x, y in zip(got[1:], expect[1:])]), flush=True)
     print("%s world %d slices %d options %s: %d of %d steps wrong, last %.2f ms" % (a.transport, G, a.slices, a.option + a.ctx_option + (["unique"] if a.unique else []), bad, a.steps, st["ms_wall"]), flush=True)
+    if has_dbg:
+        # HJ_SCRATCH_EXPERIMENT variants 2-4: values that came back from the private segment, compared in the kernel
+        d = (ctypes.c_uint64 * 40)()
+        lib.hjgpu_debug_scratch(d, 0)
+        print("private segment: %d values re-read and compared in the kernel, %d MISMATCHES" % (d[1], d[0]), flush=True)
+        if d[5]:
+            print("pass 1, time between two tiles of a workgroup: longest %.1f us; %d of %d gaps > 100 us, %d > 1 ms" % (d[2] / 100.0, d[4], d[5], d[3]), flush=True)
+        for i in range(min(int(d[0]), 8)):
+            print("    block %d thread %d slot %d: expected %016x got %016x" % (d[8 + 4 * i] >> 32, d[8 + 4 * i] & 0xFFFFFFFF, d[9 + 4 * i], d[10 + 4 * i], d[11 + 4 * i]), flush=True)
     comm.close()
 
 
