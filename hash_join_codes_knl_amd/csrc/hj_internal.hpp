@@ -154,6 +154,11 @@ struct JoinArgs {
     const uint32_t *sentinel;
     uint32_t force_chained;              // tests: skip the cuckoo fast path (option "force_chained")
     uint32_t unique;                     // _UNIQUE (npj.cpp:288-290): a probe key reports its first match only
+    // a _UNIQUE join is two launches (join_kernel<.., UNIQUE, DEDUP>): the multi-fill half has its own work counter and
+    // worker slots and returns at once when the plan counted no multi-fill partition (multi_fill, may be NULL = unknown)
+    u64 *work_counter2;
+    const uint32_t *multi_fill;
+    uint32_t worker_base;                // first final_offsets entry of this launch's waves
 };
 
 struct PlanArgs {
@@ -181,6 +186,7 @@ struct PlanArgs {
     uint32_t cap;             // build rows per LDS table fill of the join kernel that will run (JoinConfig::cap)
     uint32_t mask;            // bit 0: plan R, bit 1: plan S, bit 2: join work items
     uint32_t unique;          // _UNIQUE joins: all table fills of a probe slice stay with ONE work item (see join_kernel)
+    uint32_t *multi_fill = nullptr;   // += partitions with work whose build rows take more than one table fill (zeroed per join)
     // Chunked relations (one-GPU CPRA), line-aligned final layout: the pass-1 output is laid out PARTITION-major - the
     // chunks' regions of a pass-1 partition lie side by side, off1[c * F1 + p] still says where chunk c writes partition
     // p - so pass 2 sees F1 segments [seg2[p], seg2[p + 1]) exactly as after an unchunked pass 1, and pass 1 of every
@@ -259,7 +265,7 @@ int hj_launch_close_gaps_ex(uint32_t *k, uint32_t *ov, uint32_t *iv, const u64 *
                             uint32_t nworkers, u64 block_size, const u64 *block_counter,
                             const uint32_t *overflow, void *moves, uint32_t *nmoves,
                             u64 *dense_count, int cus, hipStream_t stream);
-int hj_join_workers(const HjTuning &t, int cus, bool big_tables = false);
+int hj_join_workers(const HjTuning &t, int cus, bool big_tables = false, bool unique = false);
 // Metadata of a broadcast join, written on the device: one partition holding all of R ([0, inner)) and all of S
 // ([0, outer)), `nslices` probe slices x `groups` fill groups (item_part must be zeroed by the caller), and a
 // sentinel: a value whose low 14 bits no build key shares (inner <= 16383).

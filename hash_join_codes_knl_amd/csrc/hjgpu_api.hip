@@ -30,6 +30,7 @@ struct DevState {
     uint32_t zero_key;
     uint32_t nmoves;
     uint32_t pad;
+    u64 work_counter2;      // the multi-fill half of a _UNIQUE join (hj_launch_join)
 };
 
 // probe side (S) is partitioned first, then the build side (R): a caller can overlap the
@@ -532,7 +533,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2, pl.batch_cap, pl.tdesc_b_cap);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables), &bs, &bl));
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables, pl.unique), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
     // counts[0] | counts[1] | tickets are contiguous: a whole join zeroes all, a prepared build its own
@@ -574,6 +575,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     }
     pa.tdesc_cap = (uint32_t)m.tdesc_cap;
     pa.unique = pl.unique ? 1u : 0u;
+    pa.multi_fill = m.tickets + 32;          // zeroed with the tickets; counted by the work-item plan, read by the _UNIQUE join
     // two-pass plans: final partitions start on 128-byte lines (pass 2 claims whole lines); option "dense2": dense
     const bool pad2 = pl.F2 > 1 && !ctx->tune.dense2;
     pa.pad2 = pad2 ? 1u : 0u;
@@ -771,6 +773,8 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.unique = pl.unique ? 1u : 0u;
         ja.result = &st->result;
         ja.work_counter = &st->work_counter;
+        ja.work_counter2 = &st->work_counter2;
+        ja.multi_fill = m.tickets + 32;
         if (bs) {
             ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
             ja.block_size = bs; ja.block_limit = bl;
@@ -784,7 +788,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     if (bs && inner && outer && mode != PHJ_BUILD_ONLY) {
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
                                     (const u64 *)ctx->final_offsets.p,
-                                    (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables), bs, &st->block_counter,
+                                    (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables, pl.unique), bs, &st->block_counter,
                                     &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
     }
     record(ctx, EV_GAPS, stream);
@@ -1106,7 +1110,7 @@ int hjgpu_output_capacity(hjgpu_ctx *ctx, int algorithm, size_t outer_tuples, si
     const size_t bs = block_size ? block_size : 65536;
     if (bs < 256 || (bs & (bs - 1))) return fail(ctx, HJGPU_EINVAL, "block_size must be a power of two >= 256");
     const size_t workers = algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, outer_tuples) * 4
-                                          : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true));
+                                          : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false, true), hj_join_workers(ctx->tune, ctx->cus, true, true));
     *capacity = (rows / bs + 1 + workers) * bs;
     return HJGPU_OK;
 }
@@ -1298,7 +1302,8 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P, 1, items_extra);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus), &bs, &bl));
+    const bool unique = ctx->tune.unique || (passes->flags & HJGPU_FLAG_UNIQUE);
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, false, unique), &bs, &bl));
     record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
     // counts = adjacent differences of the caller's offsets, then the usual plan
@@ -1311,7 +1316,6 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
     }
-    const bool unique = ctx->tune.unique || (passes->flags & HJGPU_FLAG_UNIQUE);
     pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = unique ? 1u : 0u;
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
@@ -1329,6 +1333,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     ja.P = pl.P; ja.chunks = 1;
     ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2; ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
     ja.s_align = 0; ja.result = &st->result; ja.work_counter = &st->work_counter;
+    ja.work_counter2 = &st->work_counter2;       // (multi_fill stays NULL: the caller's partitions were not counted)
     ja.unique = unique ? 1u : 0u;
     if (bs) {
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
@@ -1340,7 +1345,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     if (bs)
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
                                     (const u64 *)ctx->final_offsets.p,
-                                    (uint32_t)hj_join_workers(ctx->tune, ctx->cus), bs, &st->block_counter,
+                                    (uint32_t)hj_join_workers(ctx->tune, ctx->cus, false, unique), bs, &st->block_counter,
                                     &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
     record(ctx, EV_GAPS, stream);
     ctx->last_algo = 1;
@@ -1468,7 +1473,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     uint32_t *item_part = reinterpret_cast<uint32_t *>(d + 16);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, big), &bs, &bl));
+    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, big, unique), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
@@ -1488,7 +1493,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     ja.tf0 = tf0; ja.tf1 = tf1;
     ja.s_align = align_of(sk); ja.packed = 0;
     ja.broadcast = 1; ja.sentinel = bm.sentinel; ja.big_tables = big ? 1u : 0u; ja.unique = unique ? 1u : 0u;
-    ja.result = &st->result; ja.work_counter = &st->work_counter;
+    ja.result = &st->result; ja.work_counter = &st->work_counter; ja.work_counter2 = &st->work_counter2;
     if (bs) {
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
@@ -1498,7 +1503,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     record(ctx, EV_JOIN, stream);
     if (bs)
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
-                                    (const u64 *)ctx->final_offsets.p, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, big), bs,
+                                    (const u64 *)ctx->final_offsets.p, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, big, unique), bs,
                                     &st->block_counter, &st->overflow, ctx->moves.p, &st->nmoves, &st->dense,
                                     ctx->cus, stream));
     record(ctx, EV_GAPS, stream);
@@ -1915,7 +1920,7 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     const size_t nb = (outer + B - 1) / B;
     const u64 row_bs = 4096;
     const size_t workers = !rows ? 0 : algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, B) * 4
-                         : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true));
+                         : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false, true), hj_join_workers(ctx->tune, ctx->cus, true, true));
     const size_t want_b = rows ? (size_t)((double)rows->capacity * (double)B / (double)outer * 1.25) + row_bs : 0;
     const size_t cap_b = rows ? (want_b / row_bs + 1 + workers) * row_bs : 0;
     void *d_rows[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -2162,7 +2167,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
     if (rows && inner && outer) {
         const size_t workers = algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, outer) * 4
-                                              : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false), hj_join_workers(ctx->tune, ctx->cus, true));
+                                              : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false, true), hj_join_workers(ctx->tune, ctx->cus, true, true));
         dev_out.block_size = rows->capacity >= (64u << 20) ? 65536 : 1024;
         dev_out.capacity = (rows->capacity / dev_out.block_size + 1 + workers) * dev_out.block_size;
         for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_rows[i], dev_out.capacity * sizeof(uint32_t));

@@ -42,6 +42,11 @@
 // a build partition that takes several table fills keeps one bit per probe row of the work item in LDS
 // (`matched`), so that a row reported by an earlier fill is skipped by the later ones (such partitions
 // are then planned as ONE fill group: all fills of a probe slice stay with one workgroup).
+// Round 4: that bookkeeping is needed by multi-fill partitions only - skew, never the planned case - but its code cost
+// every _UNIQUE join 26 VGPRs (one probe vector per lane, no build-row prefetch: join phase 1.88 instead of 1.59 ms at
+// 64 M x 1 G).  A _UNIQUE join is therefore TWO launches: <UNIQUE, !DEDUP> takes the work items whose build rows fit
+// one fill, with the default instance's geometry (two vectors per lane, prefetch, no `matched` words), and skips the
+// others; <UNIQUE, DEDUP> takes exactly those and returns at once when the plan counted none (JoinArgs::multi_fill).
 // Waves per SIMD the geometry runs at: workgroups per CU (LDS: one table + ~10 KiB each in 160 KiB; threads: 2048
 // per CU) x waves per workgroup / 4 SIMDs.  It is the second argument of __launch_bounds__ (HIP: minimum waves per
 // execution unit), i.e. the register budget: 512 / waves VGPRs per lane.  More bytes in flight per lane at the price
@@ -60,9 +65,12 @@ constexpr int hj_join_waves_per_simd(int block, int log2slots)
     return w < 1 ? 1 : w;
 }
 
-template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE>
+template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE, bool DEDUP = false>
 __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) void join_kernel(JoinArgs a)
 {
+    static_assert(UNIQUE || !DEDUP, "DEDUP is the multi-fill half of a _UNIQUE join");
+    // the plan found no partition that takes several fills (the planned case): nothing for this launch to do
+    if (DEDUP && a.multi_fill && *a.multi_fill == 0) return;
     constexpr uint32_t SLOTS = 1u << LOG2SLOTS;
     constexpr uint32_t MASK = SLOTS - 1;
     constexpr uint32_t CAP = SLOTS / 2;
@@ -75,9 +83,9 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     __shared__ u64 wave_cursor[NW];
     __shared__ uint32_t cuckoo_failed;
     // UNIQUE: one bit per probe row of the current work item (<= HJ_JOIN_SLICE + 1 rows per chunk piece)
-    constexpr uint32_t MATCHED_WORDS = UNIQUE ? (HJ_JOIN_SLICE + 64) / 32 + 2 : 1;
+    constexpr uint32_t MATCHED_WORDS = DEDUP ? (HJ_JOIN_SLICE + 64) / 32 + 2 : 1;
     __shared__ uint32_t matched[MATCHED_WORDS];
-    bool dedup = false;                          // UNIQUE and this item's build rows take more than one fill (uniform)
+    constexpr bool dedup = DEDUP;                // every item of the DEDUP launch takes more than one fill, none of the other's
     uint2 *tab = reinterpret_cast<uint2 *>(tab64);   // chained view: .x = key, .y = payload
 
     const int tid = threadIdx.x;
@@ -364,8 +372,14 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
         }
         const u64 EMPTY64 = (u64)empty;
         if (UNIQUE) {
-            dedup = rows_end - rows_beg > CAP;
-            if (dedup) for (uint32_t i = tid; i < MATCHED_WORDS; i += BLOCK) matched[i] = 0;    // published by the clear barrier
+            // single-fill items belong to the <UNIQUE, !DEDUP> launch, multi-fill items to <UNIQUE, DEDUP>
+            const bool multi = rows_end - rows_beg > CAP;
+            if (multi != DEDUP) {
+                __syncthreads();                          // everybody has read this item's slot; publishes the next claim
+                par ^= 1;
+                continue;
+            }
+            if (DEDUP) for (uint32_t i = tid; i < MATCHED_WORDS; i += BLOCK) matched[i] = 0;    // published by the clear barrier
         }
 
         for (u64 fill_beg = rows_beg; fill_beg < rows_end; fill_beg += CAP) {
@@ -397,9 +411,9 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
             for_each_build_row(fill_beg, fill_end, from_regs, cuckoo_insert);
             __syncthreads();
             // build rows of the NEXT item: issue the loads now, they land during this probe
-            // (not in the _UNIQUE instances: the 16 prefetch registers are what they would spill to scratch, and no shipped
+            // (not in the DEDUP instance: the 16 prefetch registers are what it would spill to scratch, and no shipped
             // kernel may use scratch - see the note at hj_launch_join)
-            if (!UNIQUE && fill_beg == 0 && C == 1 && PACKED && d_item[par ^ 1] < total_items) {
+            if (!DEDUP && fill_beg == 0 && C == 1 && PACKED && d_item[par ^ 1] < total_items) {
                 const u64 nb = d_rb[par ^ 1];
                 pre_rows = min(min(d_rn[par ^ 1], (u64)BLOCK * RB), (u64)CAP);
 #pragma unroll
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
 
     // ---- per-wave cursors -> final offsets (close_gaps input) ---------------------
     if (a.ok && hj_lane() == 0)
-        a.final_offsets[(u64)blockIdx.x * NW + wave] = wave_cursor[wave];
+        a.final_offsets[(DEDUP ? (u64)a.worker_base : 0ull) + (u64)blockIdx.x * NW + wave] = wave_cursor[wave];
 
     // ---- workgroup reduction of the aggregates, 4 atomics per workgroup ---------
     acc_n = wave_reduce_sum(acc_n); acc_k = wave_reduce_sum(acc_k);
@@ -504,10 +518,13 @@ static int join_wgs_per_cu(const JoinConfig &c)
 }
 
 static int join_grid(int cus, const JoinConfig &c) { return cus * join_wgs_per_cu(c); }
-int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
+// Worker slots (final_offsets entries, one open output block each) of a join; a _UNIQUE join is two launches (see
+// join_kernel) and has two launches' worth: the slots of the half that returns at once hold HJ_NO_CURSOR
+// (hj_launch_join fills them in).
+int hj_join_workers(const HjTuning &t, int cus, bool big_tables, bool unique)
 {
     const JoinConfig &c = hj_join_config_of(t, big_tables);
-    return join_grid(cus, c) * (c.block / 64);
+    return (unique || t.unique ? 2 : 1) * join_grid(cus, c) * (c.block / 64);
 }
 
 #define JOIN_CASE(B, L, U, UNQ)                                                                   \
@@ -518,12 +535,12 @@ int hj_join_workers(const HjTuning &t, int cus, bool big_tables)
     }
 
 // The geometries that are built (option "join_cfg"): {block, log2slots, batch, a UNIQUE instance exists}.
-// NO SHIPPED INSTANCE MAY USE SCRATCH (tests/test_kernel_resources.py reads the compiler's remarks).  Round 3's
-// multi-GPU stress runs (tools/stress_cpra.py) lost a few hundred tuples in ~5 % of the steps while K6's pass-2
-// instance spilled 6 VGPRs and ran next to another stream's kernels, and none in 600 steps once it was free of
-// scratch: a wave's scratch slot is not safe here when kernels of several queues share the CUs.  The _UNIQUE instances
-// therefore run with ONE probe vector per lane and without the build-row prefetch (that is what fits 128 VGPRs), and
-// the geometries that spill (512,13,1 and 512,13,4 without _UNIQUE) are no longer built.
+// NO SHIPPED INSTANCE MAY USE SCRATCH (tests/test_kernel_resources.py reads the compiler's remarks): a K6 instance with a
+// private segment loses stores next to other streams' kernels (DESIGN section 3 "Round 4": found by round 3's multi-GPU
+// stress runs, narrowed down in round 4 - the private values themselves are never wrong; the cause is below the ISA), and
+// nothing says the other kernels would be exempt.  The multi-fill half of a _UNIQUE join (<UNIQUE, DEDUP>) therefore runs
+// with ONE probe vector per lane and without the build-row prefetch (what fits 128 VGPRs), and the geometries that
+// spill (512,13,1 and 512,13,4 without _UNIQUE) are not built.
 static const struct { int block, log2slots, batch; bool unique; } JOIN_BUILT[] = {
     {512, 13, 2, true}, {1024, 14, 2, true}, {256, 12, 2, false},
 };
@@ -535,11 +552,19 @@ bool hj_join_config_built(const JoinConfig &c, bool unique)
     return false;
 }
 
-// the _UNIQUE instance of a geometry: one vector per lane (see above)
+// the two launches of a _UNIQUE join (see join_kernel): single-fill items at the default geometry, then the multi-fill
+// items (their own work counter and worker slots) at one vector per lane
 #define JOIN_CASE_UNIQUE(B, L)                                                                    \
     if (c.block == B && c.log2slots == L && b.unique) {                                           \
-        if (b.packed) hipLaunchKernelGGL((join_kernel<B, L, 1, true, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
-        else hipLaunchKernelGGL((join_kernel<B, L, 1, false, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);          \
+        JoinArgs d = b;                                                                           \
+        d.work_counter = b.work_counter2; d.worker_base = (uint32_t)(join_grid(cus, c) * (B / 64)); \
+        if (b.packed) {                                                                           \
+            hipLaunchKernelGGL((join_kernel<B, L, 2, true, true, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
+            hipLaunchKernelGGL((join_kernel<B, L, 1, true, true, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, d);   \
+        } else {                                                                                  \
+            hipLaunchKernelGGL((join_kernel<B, L, 2, false, true, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b); \
+            hipLaunchKernelGGL((join_kernel<B, L, 1, false, true, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, d);  \
+        }                                                                                         \
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
     }
 
@@ -550,6 +575,11 @@ int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t st
     JoinArgs b = a;
     b.force_chained = t.force_chained ? 1u : 0u;       // tests: exercise the fallback table everywhere
     b.unique = (a.unique || t.unique) ? 1u : 0u;
+    b.worker_base = 0;
+    if (b.unique && !b.work_counter2) return HJGPU_EINVAL;
+    // materialising joins: the worker slots of a launch that does not happen (or returns at once) read "no open block"
+    if (b.ok && b.unique && hipMemsetAsync(b.final_offsets, 0xFF, (size_t)hj_join_workers(t, cus, a.big_tables != 0, true) * sizeof(u64), stream) != hipSuccess)
+        return HJGPU_EHIP;
     JOIN_CASE_UNIQUE(512, 13)
     JOIN_CASE_UNIQUE(1024, 14)
     JOIN_CASE(512, 13, 2, false)

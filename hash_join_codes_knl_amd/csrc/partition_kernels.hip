@@ -727,10 +727,14 @@ __device__ __forceinline__ void plan_items_body(const PlanArgs &a)
     };
     u64 run = 0;
     int parity = 0;
+    uint32_t multi = 0;                             // my partitions with work whose build rows take more than one table fill
     for (uint32_t tile = 0; tile < P; tile += 2 * PLAN_BLOCK, parity ^= 1) {
         const uint32_t q0 = tile + 2 * threadIdx.x, q1 = q0 + 1;
-        const u64 s0 = q0 < P ? shape_of(rows_of(cr, q0), rows_of(cs, q0)) : 0;
-        const u64 s1 = q1 < P ? shape_of(rows_of(cr, q1), rows_of(cs, q1)) : 0;
+        const u64 r0 = q0 < P ? rows_of(cr, q0) : 0, r1 = q1 < P ? rows_of(cr, q1) : 0;
+        const u64 s0 = q0 < P ? shape_of(r0, rows_of(cs, q0)) : 0;
+        const u64 s1 = q1 < P ? shape_of(r1, rows_of(cs, q1)) : 0;
+        multi += ((s0 & 0xFFFFFFFFull) && r0 > cap) ? 1u : 0u;
+        multi += ((s1 & 0xFFFFFFFFull) && r1 > cap) ? 1u : 0u;
         const u64 n0 = (s0 & 0xFFFFFFFFull) * (s0 >> 32), n1 = (s1 & 0xFFFFFFFFull) * (s1 >> 32);
         u64 first = n0 + n1, unused = 0, total, t2;
         plan_scan2(first, unused, total, t2, scratch2, parity);
@@ -749,6 +753,8 @@ __device__ __forceinline__ void plan_items_body(const PlanArgs &a)
         run += total;
     }
     if (threadIdx.x == 0) a.slice_prefix[P] = run;
+    // the multi-fill half of a _UNIQUE join (join_kernel<.., UNIQUE, DEDUP>) returns at once when this stays 0
+    if (a.multi_fill && multi) atomicAdd(a.multi_fill, multi);
 }
 
 __global__ __launch_bounds__(PLAN_BLOCK) void plan_items_kernel(PlanArgs a) { plan_items_body(a); }
@@ -1331,10 +1337,10 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             // all partition bases of a group are requested before the first is used (one LDS round trip per group, not one
             // per tuple).  Pass 2 at 4 vectors per thread takes two groups of 8: with all 16 bases live next to the 16 ranks
             // and the 32 registers of the next tile's loads the kernel needed 134 VGPRs, i.e. 6 spilled to SCRATCH at the
-            // 128-register cap of a 1024-thread workgroup - and a kernel with scratch must not run next to other streams'
-            // kernels: round 3's multi-GPU stress runs (tools/stress_cpra.py: prep / exchange / join streams of a rank
-            // side by side) lost a few hundred tuples in ~5 % of the steps with the spilling instance and none in 150
-            // steps without scratch.  tests/test_kernel_resources.py keeps every shipped instance free of scratch.
+            // 128-register cap of a 1024-thread workgroup - and a K6 launch with a private segment loses stores when
+            // kernels of another stream run beside it (DESIGN section 3 "Round 3 / 4", profiles/r04_scratch_repro.txt: the
+            // private values themselves are never wrong; same machine code with and without the descriptor bit).
+            // tests/test_kernel_resources.py keeps every shipped instance free of scratch.
 #if HJ_SCRATCH_EXPERIMENT == 1
             constexpr int GROUP = VPT * 4;                          // as before d8b72d0: all 16 bases live -> spills in pass 2
 #else

@@ -1,10 +1,12 @@
-"""CPU test (hipcc cross-compiles without a GPU): NO kernel instance of the library may use scratch memory.
+"""CPU test (hipcc cross-compiles without a GPU): NO kernel instance of the library may have a private segment (scratch).
 
-Round 3 found why: the multi-GPU CPRA runs a rank's partitioning, exchange and join streams side by side, and while
-K6's pass-2 instance spilled 6 VGPRs to scratch those runs lost a few hundred tuples in ~5 % of the steps
-(tools/stress_cpra.py; none in 600 steps once the instance was free of scratch; the same kernel alone on the device
-was always right).  A wave's scratch slot is evidently not safe when kernels of several queues share the CUs, so the
-rule is structural: zero scratch bytes per lane in every instance, checked from the compiler's own remarks."""
+Round 3's multi-GPU stress runs (a rank's partitioning, exchange and join streams side by side) lost matches in ~5 % of
+the steps while K6's pass-2 instance spilled 6 VGPRs.  Round 4 (DESIGN section 3 "Round 3 / 4",
+profiles/r04_scratch_repro.txt) narrowed it down: a K6 launch with a private segment - even one word that is written once
+and never read, the machine code otherwise identical - leaves ~10^-5 of its output slots unwritten when kernels of another
+stream run beside it (tools/scratch_two_streams.py), never alone; the private values themselves are never wrong and the
+cause is below the ISA.  So the rule is structural and for every kernel: zero scratch bytes per lane in every instance,
+checked from the compiler's own remarks."""
 import os
 import re
 import subprocess
