@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 INNER_FACTOR, OUTER_FACTOR = 0x2545F491, 0x9E3779B1
 # PMC traffic of the kernels (tools/collect_traffic.py): THIS file, and only while its kernel hash is the
 # running library's (hjgpu_kernel_hash) and it was taken on the workload being run
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 MASK64 = (1 << 64) - 1
 
 
@@ -664,6 +664,20 @@ def main():
         table_bytes = 2 << 30
         scratch_t = torch.empty(table_bytes // 4, dtype=torch.int32, device=dev)
         rl_ms = min(hj.random_line_read_ms(scratch_t.data_ptr(), table_bytes, outer, stream) for _ in range(3))
+        # ... and for the build's: `inner` independent random 8-byte CAS into the same (zeroed) 2 GiB, four in flight per lane,
+        # without and with a look at the bucket first (the build looks: its table is line-hashed, every key of a line starts
+        # at the line's first bucket).  The clear of the table is part of the build phase (npj.cpp:865-868): timed apart.
+        cas_ms = min(hj.random_cas_ms(scratch_t.data_ptr(), table_bytes, inner, 4, False, stream) for _ in range(3))
+        cas_look_ms = min(hj.random_cas_ms(scratch_t.data_ptr(), table_bytes, inner, 4, True, stream) for _ in range(3))
+        clr = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            scratch_t.zero_()
+            e1.record()
+            e1.synchronize()
+            clr.append(e0.elapsed_time(e1))
+        clear_ms = min(clr)
         del scratch_t
         sec["npj"] = {"workload": "NPJ |R|=%d join |S|=%d, global line-hashed table, load %.2f (%d buckets)"
                                   % (inner, outer, 0.25, int(ph["buckets"])),
@@ -677,7 +691,14 @@ def main():
                       "random_line_read_ceiling": {"ms_per_1e9_lines": round(rl_ms * 1e9 / outer, 3),
                                                    "Glines_per_s": round(outer / rl_ms / 1e6, 2),
                                                    "probe_frac_of_it": round(rl_ms / ph["ms_join"], 4)},
-                      "roofline_build": roof(8 * inner + 8 * ph["buckets"] + 8 * inner, ph["ms_build"], 1, stream_read_gbs)}
+                      "roofline_build": roof(8 * inner + 8 * ph["buckets"] + 8 * inner, ph["ms_build"], 1, stream_read_gbs),
+                      # the build's own ceiling: the memory system serves ~17 G independent returning 8-byte atomics per
+                      # second whatever the number in flight per lane (tools/npj_build_ceiling.py); build phase = table
+                      # clear + one claim per build tuple
+                      "random_cas_ceiling": {"ms_per_build_side": round(cas_ms, 3), "Gcas_per_s": round(inner / cas_ms / 1e6, 2),
+                                             "ms_with_a_look_first": round(cas_look_ms, 3), "ms_table_clear": round(clear_ms, 3),
+                                             "build_claims_ms": round(ph["ms_build"] - clear_ms, 3),
+                                             "build_claims_frac_of_it": round(cas_ms / max(ph["ms_build"] - clear_ms, 1e-3), 4)}}
         # one-GPU CPRA: 8 chunks partitioned independently (cpra2.cpp:1757-1827), gathered in place
         cprm = H.PhjParams(chunks=8)
         ms, ph = time_steps(lambda: hj.cpra_async(*a, cprm, d_result.data_ptr(), stream))

@@ -36,7 +36,7 @@ EXPORTS = [
     "hjgpu_comm_get_info", "hjgpu_comm_preflight",
     "hjgpu_phj_multi", "hjgpu_npj_multi", "hjgpu_cpra_multi", "hjgpu_join_host_multi",
     "hjgpu_phj_multi_rows", "hjgpu_npj_multi_rows", "hjgpu_cpra_multi_rows", "hjgpu_join_host_rows_multi",
-    "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_generate_select", "hjgpu_column_sums", "hjgpu_stream_read_ms", "hjgpu_random_line_read_ms",
+    "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_generate_select", "hjgpu_column_sums", "hjgpu_stream_read_ms", "hjgpu_random_line_read_ms", "hjgpu_random_cas_ms",
 ]
 
 
@@ -201,6 +201,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_synchronize.argtypes = [vp, vp]
     L.hjgpu_stream_read_ms.argtypes = [vp, vp, sz, C.POINTER(C.c_float), vp]
     L.hjgpu_random_line_read_ms.argtypes = [vp, vp, sz, sz, C.POINTER(C.c_float), vp]
+    L.hjgpu_random_cas_ms.argtypes = [vp, vp, sz, sz, C.c_int, C.c_int, C.POINTER(C.c_float), vp]
     L.hjgpu_host_alloc.argtypes = [vp, C.POINTER(vp), sz]
     L.hjgpu_host_free.argtypes = [vp, vp]
     L.hjgpu_histogram.argtypes = [vp, vp, sz, u32, u32, vp, vp]
@@ -587,6 +588,12 @@ class HjGpu:
     def stream_read_ms(self, d_ptr, nbytes, stream=None):
         ms = C.c_float()
         self._check(self.lib.hjgpu_stream_read_ms(self.handle, self._ptr(d_ptr), nbytes, C.byref(ms), stream))
+        return ms.value
+
+    def random_cas_ms(self, d_ptr, nbytes, ops, in_flight=4, load_first=False, stream=None):
+        """hjgpu_random_cas_ms: ms for `ops` independent random 8-byte CAS into the (zeroed) buffer: the NPJ build's ceiling"""
+        ms = C.c_float()
+        self._check(self.lib.hjgpu_random_cas_ms(self.handle, self._ptr(d_ptr), nbytes, ops, in_flight, int(bool(load_first)), C.byref(ms), stream))
         return ms.value
 
     def random_line_read_ms(self, d_ptr, nbytes, reads, stream=None):

@@ -238,6 +238,56 @@ int hj_launch_random_line_read(const void *p, size_t bytes, size_t reads, void *
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
+// Random 8-byte compare-and-swaps (hjgpu_random_cas_ms): the access shape of the NPJ build (npj.cpp:196-210: one CAS of an
+// empty bucket per build tuple) without the join - `ops` independent pseudo-random buckets of a zeroed buffer, each claimed
+// with ONE 64-bit CAS (expected 0), U of them in flight per lane; LOAD: a plain load of the bucket first, as the build
+// does to skip taken buckets.  What it reaches is the memory system's rate for independent returning atomics.
+template <int U, bool LOAD>
+__global__ __launch_bounds__(256) void random_cas_kernel(u64 *__restrict__ table, u64 buckets, u64 ops, u64 *sink)
+{
+    u64 acc = 0;
+    const u64 stride = (u64)gridDim.x * 256 * U;
+    for (u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) * U; r < ops; r += stride) {
+        u64 at[U], seen[U], old[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const u64 x = (u64)(uint32_t)((uint32_t)(r + i) * 0x9E3779B1u) ^ ((r + i) >> 32);
+            at[i] = (u64)(((unsigned __int128)(x & 0xFFFFFFFFull) * buckets) >> 32);
+            seen[i] = 0;
+        }
+        if (LOAD) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) seen[i] = __builtin_nontemporal_load(&table[at[i]]);
+        }
+        // all U atomics are issued back to back (no predicate around them: an operation past `ops` or on a bucket that was
+        // seen taken compares with a value no bucket holds and changes nothing)
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const bool live = r + i < ops && (uint32_t)seen[i] == 0u;
+            old[i] = atomicCAS(&table[at[i]], live ? 0ull : ~0ull, live ? (((r + i) << 1) | 1ull) : ~0ull);
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) acc ^= old[i];
+    }
+    if (acc == 0x9E3779B97F4A7C15ull) *sink = acc;          // keeps the returns alive
+}
+
+int hj_launch_random_cas(void *p, size_t bytes, size_t ops, int in_flight, bool load_first, void *sink8, int cus, hipStream_t stream)
+{
+    const u64 buckets = bytes / 8;
+    if (buckets == 0 || ops == 0 || ((uintptr_t)p & 7)) return HJGPU_EINVAL;
+    u64 *t = (u64 *)p, *sk = (u64 *)sink8;
+    const dim3 grid(cus * 16), block(256);
+#define RC(U, L) hipLaunchKernelGGL((random_cas_kernel<U, L>), grid, block, 0, stream, t, buckets, (u64)ops, sk)
+    if (in_flight == 1) { if (load_first) RC(1, true); else RC(1, false); }
+    else if (in_flight == 2) { if (load_first) RC(2, true); else RC(2, false); }
+    else if (in_flight == 4) { if (load_first) RC(4, true); else RC(4, false); }
+    else if (in_flight == 8) { if (load_first) RC(8, true); else RC(8, false); }
+    else return HJGPU_EINVAL;
+#undef RC
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
 // Placement probe (hjgpu_api.hip, ensure_placed): a plain streaming fill of a freshly allocated buffer.  Its rate
 // differs by up to 26 % between allocations of the same size on one MI355X (physical placement; profiles/r02_placement.txt)
 // and predicts how fast K6 pass 1 will write into that buffer.

@@ -2365,4 +2365,21 @@ int hjgpu_random_line_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, s
     return HJGPU_OK;
 }
 
+int hjgpu_random_cas_ms(hjgpu_ctx *ctx, void *d_ptr, size_t bytes, size_t ops, int in_flight, int load_first, float *ms, void *stream_)
+{
+    if (!ctx || !d_ptr || !ms) return HJGPU_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure(ctx, ctx->moves, 64));
+    HIPCHK(ctx, hipMemsetAsync(d_ptr, 0, bytes, stream));              // every bucket empty: outside the timed span
+    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
+    record(ctx, EV_BEGIN, stream);
+    CHK(hj_launch_random_cas(d_ptr, bytes, ops, in_flight, load_first != 0, ctx->moves.p, ctx->cus, stream));
+    record(ctx, EV_GAPS, stream);
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[EV_BEGIN], ctx->ev[EV_GAPS]));
+    ctx->last_algo = 2;
+    return HJGPU_OK;
+}
+
 }  // extern "C"

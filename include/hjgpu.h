@@ -610,6 +610,11 @@ int  hjgpu_stream_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, float
  * out of a table that does not fit the L2 the limit is memory-side requests per second (53-59 G/s for any request size
  * from 16 to 128 bytes, profiles/r03_request_size.txt), not bytes. */
 int  hjgpu_random_line_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, size_t reads, float *ms, void *stream);
+/* Measurement helper: duration of `ops` independent pseudo-random 8-byte compare-and-swaps (expected 0) into the `bytes` at
+ * d_ptr, which are zeroed first (outside the timed span) - the NPJ build's access shape without the join (npj.cpp:196-210:
+ * one CAS of an empty bucket per build tuple).  in_flight = 1, 2, 4 or 8 CAS per lane; load_first: a plain load of the
+ * bucket before the CAS, as the build skips taken buckets.  The empirical ceiling bench.py prices the NPJ build against. */
+int  hjgpu_random_cas_ms(hjgpu_ctx *ctx, void *d_ptr, size_t bytes, size_t ops, int in_flight, int load_first, float *ms, void *stream);
 
 #ifdef __cplusplus
 }

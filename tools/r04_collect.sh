@@ -1,0 +1,25 @@
+#!/bin/bash
+# After tools/r04_round.sh on the GPU box: copy what is to be judged from gpurun_out/ into profiles/ - but only artefacts
+# produced by THIS tree's kernels (round 3 committed a validation sweep of an earlier library under the final commit's
+# title).  JSON artefacts carry "kernel_hash"; text artefacts are covered by gpurun_out/r04_rc.txt ("kernel hash ...",
+# written by the run before anything else, after it compared the library with the tree).
+cd "$(dirname "$0")/.."
+tree=$(python3 -c "from hash_join_codes_knl_amd import build; print(build.kernel_hash())")
+run=$(sed -n 's/^kernel hash //p' gpurun_out/r04_rc.txt | head -1)
+if [ "$run" != "$tree" ]; then echo "REFUSED: the evidence run used kernels $run, the tree is $tree"; exit 1; fi
+ok=1
+for f in r04_bench.json r04_bench_force_dist_configs4.json r04_bench_force_dist_cpra.json r04_bench_force_dist_cpra_4slices.json r04_bench_force_dist_cpra_8slices.json r04_bench_force_dist_npj.json r04_bench_rehearse_solo.json r04_traffic.json r04_npj_traffic.json r04_cpra_traffic.json r04_materialized_traffic.json; do
+  [ -s gpurun_out/$f ] || { echo "missing: $f"; ok=0; continue; }
+  h=$(python3 -c "import json,sys; print(json.load(open('gpurun_out/$f')).get('kernel_hash'))")
+  if [ "$h" != "$tree" ]; then echo "REFUSED: $f carries kernel hash $h, the tree is $tree"; ok=0; continue; fi
+  cp gpurun_out/$f profiles/$f
+done
+for f in r04_cpra_64M_1G_kernel_stats.csv r04_materialized_64M_1G_kernel_stats.csv r04_npj_64M_1G_kernel_stats.csv r04_phj_64M_1G_kernel_stats.csv r04_validation.txt r04_npj_build_ceiling.txt r04_report.md; do
+  [ -s gpurun_out/$f ] || { echo "missing: $f"; ok=0; continue; }
+  cp gpurun_out/$f profiles/$f
+done
+grep -q "$tree" profiles/r04_validation.txt || { echo "REFUSED: r04_validation.txt does not name kernel hash $tree"; rm -f profiles/r04_validation.txt; ok=0; }
+cp gpurun_out/pmc_sq_r04.csv profiles/r04_pmc_sq.csv && python tools/pmc_sq_summary.py profiles/r04_pmc_sq.csv > profiles/r04_pmc_sq_summary.txt
+{ echo "# tools/kernel_resources.py (hipcc -Rpass-analysis=kernel-resource-usage, gfx950) on the round-4 sources (kernel hash $tree): VGPRs, spills, scratch bytes per lane, waves per SIMD"; for f in partition_kernels join_kernels npj_kernels gen_kernels; do echo "## $f.hip"; python tools/kernel_resources.py hash_join_codes_knl_amd/csrc/$f.hip 2>&1; done; } > profiles/r04_kernel_resources.txt
+tail -3 gpurun_out/r04_pytest.log
+[ $ok = 1 ] && echo "collected for kernel hash $tree" || echo "collected WITH GAPS for kernel hash $tree"
