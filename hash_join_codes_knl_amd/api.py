@@ -31,6 +31,7 @@ EXPORTS = [
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
     "hjgpu_phj_build", "hjgpu_phj_probe", "hjgpu_phj_probe_async",
     "hjgpu_partition_packed_async", "hjgpu_partition_packed_own_last_async", "hjgpu_phj_build_prepartitioned", "hjgpu_phj_probe_prepartitioned_async",
+    "hjgpu_partition_packed_counted_async", "hjgpu_phj_probe_prepartitioned_counted_async", "hjgpu_prepartitioned_plan",
     "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
     "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
     "hjgpu_comm_get_info", "hjgpu_comm_preflight",
@@ -248,6 +249,9 @@ def load_library(build_if_missing=True):
     L.hjgpu_phj_probe_async.argtypes = [vp, vp, vp, sz, vp, vp]
     L.hjgpu_partition_packed_async.argtypes = [vp, vp, vp, sz, u32, u32, vp, vp, vp]
     L.hjgpu_partition_packed_own_last_async.argtypes = [vp, vp, vp, sz, u32, u32, u32, u32, vp, vp, vp]
+    L.hjgpu_partition_packed_counted_async.argtypes = [vp, vp, vp, sz, u32, u32, u32, u32, u32, u32, vp, vp, vp, vp]
+    L.hjgpu_phj_probe_prepartitioned_counted_async.argtypes = [vp, vp, C.POINTER(PrePartitioned), vp, vp, vp]
+    L.hjgpu_prepartitioned_plan.argtypes = [vp, sz, u32, C.POINTER(PhjParams), C.POINTER(u32), C.POINTER(u32)]
     L.hjgpu_phj_build_prepartitioned.argtypes = [vp, vp, C.POINTER(PrePartitioned), sz, C.POINTER(PhjParams), vp]
     L.hjgpu_phj_probe_prepartitioned_async.argtypes = [vp, vp, C.POINTER(PrePartitioned), vp, vp]
     L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
@@ -472,6 +476,23 @@ class HjGpu:
     def partition_packed_own_last_async(self, d_keys, d_vals, n, factor, fanout, own_first, own_count, d_tuples_out, d_offsets, stream=None):
         self._check(self.lib.hjgpu_partition_packed_own_last_async(self.handle, self._ptr(d_keys), self._ptr(d_vals), n, factor, fanout,
                                                                    own_first, own_count, self._ptr(d_tuples_out), self._ptr(d_offsets), stream))
+
+    def partition_packed_counted_async(self, d_keys, d_vals, n, factor, fanout, own_first, own_count, factor2, fanout2,
+                                       d_tuples_out, d_offsets, d_counts2, stream=None):
+        self._check(self.lib.hjgpu_partition_packed_counted_async(self.handle, self._ptr(d_keys), self._ptr(d_vals), n, factor, fanout,
+                                                                  own_first, own_count, factor2, fanout2, self._ptr(d_tuples_out),
+                                                                  self._ptr(d_offsets), self._ptr(d_counts2), stream))
+
+    def prepartitioned_plan(self, inner, fanout1, params=None):
+        """(fanout2, factor2) that hjgpu_phj_build_prepartitioned plans for `inner` build rows in `fanout1` pass-1 partitions"""
+        f2, m2 = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.hjgpu_prepartitioned_plan(self.handle, inner, fanout1, C.byref(params) if params is not None else None,
+                                                       C.byref(f2), C.byref(m2)))
+        return f2.value, m2.value
+
+    def phj_probe_prepartitioned_counted_async(self, d_tuples, layout, d_counts, d_result, stream=None):
+        self._check(self.lib.hjgpu_phj_probe_prepartitioned_counted_async(self.handle, self._ptr(d_tuples), C.byref(layout),
+                                                                          self._ptr(d_counts), self._ptr(d_result), stream))
 
     @staticmethod
     def prepartitioned(factor1, fanout1_total, first_partition, fanout1, chunk_offsets):

@@ -285,6 +285,7 @@ int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_
                        double zipf = 0.0, double selectivity = 1.0, u64 *d_expect = nullptr);
 int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hipStream_t stream);
 int hj_launch_copy_to_host(void *host_mapped, const void *d, size_t bytes, hipStream_t stream);
+int hj_launch_row_sums(const u64 *counts, uint32_t F1, uint32_t F2, u64 *out, hipStream_t stream);
 int hj_launch_random_line_read(const void *p, size_t bytes, size_t reads, void *sink16, int cus, hipStream_t stream);
 int hj_launch_random_cas(void *p, size_t bytes, size_t ops, int in_flight, bool load_first, void *sink8, int cus, hipStream_t stream);
 int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream);

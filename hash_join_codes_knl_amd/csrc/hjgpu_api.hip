@@ -444,6 +444,9 @@ static_assert(sizeof(PhjPlan) <= sizeof(hjgpu_ctx::prepared_plan), "prepared_pla
 struct PrePieces {
     const u64 *tuples[2] = {nullptr, nullptr};      // [0] build side, [1] probe side (packed: payload << 32 | key)
     HjChunks ch[2];
+    // [chunks][P] fused (piece, final partition) counts of the relation, counted by the SENDERS' histogram pass and
+    // delivered with the exchange (hjgpu_phj_probe_prepartitioned_counted_async): K4p is skipped
+    const u64 *counts[2] = {nullptr, nullptr};
 };
 enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
 
@@ -636,8 +639,10 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             // The relation arrives pass-1-partitioned (multi-GPU CPRA: the exchange-level partitioning of the senders'
             // chunks was pass 1, cpra2.cpp:1757-1827): K4p counts per (piece, final partition), K5 lays pass 2 out,
             // K6 pass 2 reads the pieces where they are.  16 + 8 bytes per tuple less than partitioning from scratch.
-            if (nn[r]) CHK(hj_launch_hist_packed(pre->tuples[r], pre->ch[r], pl.pre_f1, pl.pre_F1tot, pl.pre_base, pl.F1,
-                                                 pl.f2, pl.F2, m.counts[r], ctx->cus, stream));
+            if (nn[r] && pre->counts[r])
+                HIPCHK(ctx, hipMemcpyAsync(m.counts[r], pre->counts[r], (size_t)pl.C * pl.P * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+            else if (nn[r]) CHK(hj_launch_hist_packed(pre->tuples[r], pre->ch[r], pl.pre_f1, pl.pre_F1tot, pl.pre_base, pl.F1,
+                                                      pl.f2, pl.F2, m.counts[r], ctx->cus, stream));
             record(ctx, ev[0], stream);
             pa.mask = plan_mask;
             CHK(hj_launch_plan(pa, stream));
@@ -1621,8 +1626,11 @@ int hjgpu_phj_probe_async(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv
 // ---- relations that arrive pass-1-partitioned (the receiving side of the multi-GPU CPRA) --------------------
 static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
                             uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
-                            uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_)
+                            uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_,
+                            uint32_t factor2 = 0, uint32_t fanout2 = 0, uint64_t *d_counts2 = nullptr)
 {
+    if (d_counts2 && (fanout2 < 1 || !(factor2 & 1) || factor2 == factor || (u64)fanout * fanout2 > HJGPU_MAX_PARTS))
+        return fail(ctx, HJGPU_EINVAL, "fused counts: factor2 odd and different from factor, fanout * fanout2 <= 32768");
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if ((u64)own_first + own_count > fanout) return fail(ctx, HJGPU_EINVAL, "own_first + own_count must not exceed fanout");
     if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
@@ -1642,7 +1650,17 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
     ctx->last_algo = 2;                    // hjgpu_get_stats().ms_total = the whole operator
     record(ctx, EV_BEGIN, stream);
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
-    if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets, ctx->cus, stream));
+    if (d_counts2) {
+        // the same read of the keys also counts the RECEIVERS' second level (bin = p1 * fanout2 + p2, the join's fused
+        // histogram): they then need no histogram pass of their own over what arrives (K4p).  The pass-1 counts of this
+        // call are the row sums.
+        HIPCHK(ctx, hipMemsetAsync(d_counts2, 0, (size_t)fanout * fanout2 * sizeof(u64), stream));
+        if (n) {
+            u64 *fused = reinterpret_cast<u64 *>(d_counts2);
+            CHK(hj_launch_hist2(d_keys, geom, factor, fanout, factor2, fanout2, fused, m.range_counts[0], m.tickets, ctx->cus, stream));
+            CHK(hj_launch_row_sums(fused, fanout, fanout2, m.counts[0], stream));
+        }
+    } else if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets, ctx->cus, stream));
     PlanArgs pa;
     for (int r = 0; r < 2; ++r) {
         pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
@@ -1686,6 +1704,39 @@ int hjgpu_partition_packed_own_last_async(hjgpu_ctx *ctx, const uint32_t *d_keys
     return partition_packed(ctx, d_keys, d_vals, n, factor, fanout, own_first, own_count, d_tuples_out, d_offsets, stream);
 }
 
+int hjgpu_partition_packed_counted_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                                         uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
+                                         uint32_t factor2, uint32_t fanout2, uint64_t *d_tuples_out, uint64_t *d_offsets,
+                                         uint64_t *d_counts2, void *stream)
+{
+    if (!d_counts2) return fail(ctx, HJGPU_EINVAL, "null counts array");
+    return partition_packed(ctx, d_keys, d_vals, n, factor, fanout, own_first, own_count, d_tuples_out, d_offsets, stream,
+                            factor2, fanout2, d_counts2);
+}
+
+// what hjgpu_phj_build_prepartitioned plans for a build side of `inner` rows in `fanout1` pass-1 partitions
+static void prepartitioned_plan(const hjgpu_ctx *ctx, size_t inner, uint32_t k, const hjgpu_phj_params *prm, uint32_t *F2, bool *big)
+{
+    *big = false;
+    double parts = ceil((double)inner / (ctx->tune.join.cap() * 0.85));
+    if (parts > HJGPU_MAX_PARTS) { *big = true; parts = ceil((double)inner / (hj_join_config_big().cap() * 0.85)); }
+    uint32_t f2 = (prm && prm->fanout2) ? prm->fanout2 : (uint32_t)std::max(2.0, ceil(parts / k));
+    if (f2 < 2) f2 = 2;
+    if (f2 > HJGPU_MAX_FANOUT) f2 = HJGPU_MAX_FANOUT;
+    while ((u64)k * f2 > HJGPU_MAX_PARTS && f2 > 2) --f2;
+    *F2 = f2;
+}
+
+int hjgpu_prepartitioned_plan(hjgpu_ctx *ctx, size_t inner, uint32_t fanout1, const hjgpu_phj_params *params,
+                              uint32_t *fanout2, uint32_t *factor2)
+{
+    if (!ctx || !fanout1 || !fanout2 || !factor2) return HJGPU_EINVAL;
+    bool big = false;
+    prepartitioned_plan(ctx, inner, fanout1, params, fanout2, &big);
+    *factor2 = (params && params->factor2) ? params->factor2 : DEFAULT_F2;
+    return HJGPU_OK;
+}
+
 static int check_layout(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, HjChunks *ch, size_t *rows)
 {
     if (!lay) return fail(ctx, HJGPU_EINVAL, "null layout");
@@ -1722,12 +1773,8 @@ int hjgpu_phj_build_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, con
     if (prm) p2 = *prm;
     const uint32_t k = lay->fanout1;
     bool big = false;
-    double parts = ceil((double)inner / (ctx->tune.join.cap() * 0.85));
-    if (parts > HJGPU_MAX_PARTS) { big = true; parts = ceil((double)inner / (hj_join_config_big().cap() * 0.85)); }
-    uint32_t F2 = p2.fanout2 ? p2.fanout2 : (uint32_t)std::max(2.0, ceil(parts / k));
-    if (F2 < 2) F2 = 2;
-    if (F2 > HJGPU_MAX_FANOUT) F2 = HJGPU_MAX_FANOUT;
-    while ((u64)k * F2 > HJGPU_MAX_PARTS && F2 > 2) --F2;
+    uint32_t F2 = 0;
+    prepartitioned_plan(ctx, inner, k, &p2, &F2, &big);
     p2.fanout1 = k; p2.fanout2 = F2;
     PhjPlan pl;
     CHK(phj_prepare(ctx, inner, max_outer, &p2, lay->chunks, &pl, true, big ? 1 : 0));
@@ -1740,8 +1787,24 @@ int hjgpu_phj_build_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, con
     return HJGPU_OK;
 }
 
+static int probe_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, const uint64_t *d_counts,
+                                hjgpu_result *d_result, void *stream_);
+
 int hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay,
                                          hjgpu_result *d_result, void *stream_)
+{
+    return probe_prepartitioned(ctx, d_tuples, lay, nullptr, d_result, stream_);
+}
+
+int hjgpu_phj_probe_prepartitioned_counted_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay,
+                                                 const uint64_t *d_counts, hjgpu_result *d_result, void *stream_)
+{
+    if (ctx && !d_counts) return fail(ctx, HJGPU_EINVAL, "null counts array");
+    return probe_prepartitioned(ctx, d_tuples, lay, d_counts, d_result, stream_);
+}
+
+static int probe_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, const uint64_t *d_counts,
+                                hjgpu_result *d_result, void *stream_)
 {
     if (!ctx) return HJGPU_EINVAL;
     const hjgpu_output *out = take_async_output(ctx, nullptr);   // consumed by this call even if it fails below (see hjgpu_npj_async)
@@ -1757,6 +1820,7 @@ int hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuple
         return fail(ctx, HJGPU_EINVAL, "the probe batch's layout differs from the prepared build side's (pieces, factor1, fan-outs, first partition)");
     if (outer > ctx->prepared_max_outer) return fail(ctx, HJGPU_EINVAL, "batch larger than the max_outer given to hjgpu_phj_build_prepartitioned");
     pre.tuples[1] = reinterpret_cast<const u64 *>(d_tuples);
+    pre.counts[1] = reinterpret_cast<const u64 *>(d_counts);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->last_had_output = out && out->d_keys;

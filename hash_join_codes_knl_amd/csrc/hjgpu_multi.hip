@@ -131,6 +131,9 @@ struct Rank {
     hipEvent_t ev_xchg[2] = {nullptr, nullptr};       // receive buffers of slot b filled
     hipEvent_t ev_join[2] = {nullptr, nullptr};       // receive buffers of slot b joined (free again)
     hipEvent_t ev_rx = nullptr;                       // build side received (CPRA)
+    // fused counts (CpraStep::fused): per probe slot, this rank's fused histogram of its slice [fan-out * F2], everybody's
+    // [G][fan-out * F2], and the rows of it that describe what this rank received, in the order of its pieces [G][k * F2]
+    Buf cnt2[2], cnt2_all[2], cnt_recv[2];
     hipEvent_t ev_dbg = nullptr, ev_dbg2 = nullptr;   // option "debug_serialize"
 #if HJ_SCRATCH_EXPERIMENT
     u64 *dbg = nullptr;                               // [DBG_SLICES][DBG_STAGES][4] results + [DBG_SLICES][DBG_OFF] offsets of every slice
@@ -177,6 +180,8 @@ struct hjgpu_comm {
                                              // them (last) and receives the other ranks' pieces right behind: the message to itself is never copied
     int cpra_k = 0;                          // option "cpra_k": partitions per rank of the exchange-level pass (0 = 192 / ranks); measurements:
                                              // k = 24 at world 1 gives the receiver the per-GPU work of an 8-GPU join
+    bool cpra_fused_counts = true;           // option "cpra_fused_counts": the senders' histogram pass counts the receivers' final partitions
+                                             // too when G * k * F2 <= 32768 (build sides up to ~114 M rows): the receivers skip K4p
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
     char err[512];
     char why_broken[512];
@@ -647,7 +652,7 @@ void destroy_rank(Rank &r)
     Buf *bufs[] = {&r.rbuf, &r.send_k[0], &r.send_k[1], &r.send_v[0], &r.send_v[1], &r.recv_k[0], &r.recv_k[1],
                    &r.recv_v[0], &r.recv_v[1], &r.rsend_k, &r.rsend_v, &r.rrecv_k, &r.rrecv_v, &r.d_off, &r.d_cnt,
                    &r.d_res, &r.scratch, &r.pre, &r.shard[0], &r.shard[1], &r.shard[2], &r.shard[3], &r.rows_col[0],
-                   &r.rows_col[1], &r.rows_col[2]};
+                   &r.rows_col[1], &r.rows_col[2], &r.cnt2[0], &r.cnt2[1], &r.cnt2_all[0], &r.cnt2_all[1], &r.cnt_recv[0], &r.cnt_recv[1]};
     for (Buf *b : bufs) if (b->p) (void)hipFree(b->p);
     hipEvent_t evs[] = {r.ev_ready, r.ev_x0, r.ev_x1, r.ev_t0, r.ev_t1, r.ev_part[0], r.ev_part[1], r.ev_xchg[0],
                         r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.ev_dbg, r.ev_dbg2, r.ev_up_s, r.ev_up_r, r.lb_in, r.lb_out};
@@ -942,6 +947,14 @@ struct CpraStep {
     // they arrived (hjgpu_phj_build_prepartitioned).  k = 0: round 2's two-level plan (fan-out G, complete local PHJ).
     uint32_t k = 0;
     uint32_t fanout() const { return k ? (uint32_t)G * k : (uint32_t)G; }
+    // Counts published with the partitions (cpra2.cpp:1783-1840): when the whole fused histogram G * k * F2 fits K4's LDS
+    // (<= 32768 counters; F2 = what the largest receiver's build side needs, the same on every rank) the SENDER's
+    // histogram pass counts the receivers' final partitions in the same read of its keys, the histograms travel with the
+    // counts all-gather, and a receiver joins what arrived without a histogram pass of its own (K4p: 8 of the 52 bytes
+    // per tuple at world 1).  Probe slices only (the build side's K4p reads 1 / 16 of the bytes).
+    bool fused = false;
+    uint32_t F2 = 0, factor2 = 0;
+    std::vector<char> counts_usable = std::vector<char>(2, 0);   // [slot] the last exchange through the slot delivered counts
     CpraStep(hjgpu_comm *comm, hjgpu_multi_stats *st)
         : c(comm), L((int)comm->ranks.size()), G(comm->nranks), soff(L, std::vector<u64>(G)), scnt(L, std::vector<u64>(G)),
           roff(L, std::vector<u64>(G)), rcnt(L, std::vector<u64>(G)), recv_total(L), stats(st), pieces(L, std::vector<u64>(G + 1)),
@@ -997,7 +1010,18 @@ struct CpraStep {
             }
             // in place: the slot's previous slice has been joined (its own piece lives in this buffer)
             if (own_last && which) HIPM(c, hipStreamWaitEvent(r.prep, r.ev_join[slot], 0));
-            if (in[l].n && own_last)
+            const bool counted = fused && which;
+            if (counted) {
+                CHKM(ensure(c, r, r.cnt2[slot], F * F2 * sizeof(u64)));
+                CHKM(ensure(c, r, r.cnt2_all[slot], Gs * F * F2 * sizeof(u64)));
+                CHKM(ensure(c, r, r.cnt_recv[slot], Gs * k * F2 * sizeof(u64)));
+            }
+            if (in[l].n && counted)
+                JOINM(c, r.part, hjgpu_partition_packed_counted_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)F,
+                                                                      own_last ? (uint32_t)r.global * k : 0u, own_last ? k : 0u, factor2, F2,
+                                                                      static_cast<uint64_t *>(b.sk->p), reinterpret_cast<uint64_t *>(d_off),
+                                                                      static_cast<uint64_t *>(r.cnt2[slot].p), r.prep));
+            else if (in[l].n && own_last)
                 JOINM(c, r.part, hjgpu_partition_packed_own_last_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)F,
                                                                        (uint32_t)r.global * k, k, static_cast<uint64_t *>(b.sk->p),
                                                                        reinterpret_cast<uint64_t *>(d_off), r.prep));
@@ -1008,7 +1032,10 @@ struct CpraStep {
                 JOINM(c, r.part, hjgpu_partition_async(r.part, in[l].keys, in[l].vals, in[l].n, TOP_LEVEL_FACTOR, (uint32_t)G,
                                                        static_cast<uint32_t *>(b.sk->p), static_cast<uint32_t *>(b.sv->p),
                                                        reinterpret_cast<uint64_t *>(d_off), r.prep));
-            else HIPM(c, hipMemsetAsync(d_off, 0, (F + 1) * sizeof(u64), r.prep));
+            else {
+                HIPM(c, hipMemsetAsync(d_off, 0, (F + 1) * sizeof(u64), r.prep));
+                if (counted) HIPM(c, hipMemsetAsync(r.cnt2[slot].p, 0, F * F2 * sizeof(u64), r.prep));
+            }
             HIPM(c, hipMemcpyAsync(h_off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
 #if HJ_SCRATCH_EXPERIMENT
             if (c->debug_forensics && which && k && !own_last && G == 1 && dbg_slice >= 0 && dbg_slice < DBG_SLICES && r.dbg) {
@@ -1057,6 +1084,15 @@ struct CpraStep {
         }
         const std::vector<hipStream_t> comms = streams_of(c, &Rank::comm);
         CHKM(c->transport->all_gather(csend.data(), crecv.data(), Gs * sizeof(u64), comms.data()));
+        const bool counted = fused && which;
+        if (counted) {
+            // every rank's fused histogram of its slice to every rank (the partitioning streams have been waited for above)
+            std::vector<const void *> hs;
+            std::vector<void *> hr;
+            for (int l = 0; l < L; ++l) { hs.push_back(c->ranks[l].cnt2[slot].p); hr.push_back(c->ranks[l].cnt2_all[slot].p); }
+            CHKM(c->transport->all_gather(hs.data(), hr.data(), (size_t)fanout() * F2 * sizeof(u64), comms.data()));
+        }
+        if (which) counts_usable[slot] = counted;
         for (int l = 0; l < L; ++l) {
             Rank &r = c->ranks[l];
             HIPM(c, hipSetDevice(r.device));
@@ -1097,6 +1133,24 @@ struct CpraStep {
             so.push_back(soff[l].data()); sc.push_back(scnt[l].data()); ro.push_back(roff[l].data()); rc.push_back(rcnt[l].data());
             HIPM(c, hipStreamWaitEvent(r.comm, r.ev_part[slot], 0));
             if (which) HIPM(c, hipStreamWaitEvent(r.comm, r.ev_join[slot], 0));   // the slot's previous slice has been joined
+            if (counted) {
+                // the rows of the senders' histograms that describe MY partitions, in the order of my pieces (in place: the
+                // own piece first, then the other ranks in order; else rank order): what K4p would have counted
+                const size_t mine = (size_t)k * F2, all = (size_t)fanout() * F2;
+                int piece = 0;
+                auto take = [&](int sender) -> int {
+                    HIPM(c, hipMemcpyAsync(static_cast<u64 *>(r.cnt_recv[slot].p) + (size_t)piece * mine,
+                                           static_cast<const u64 *>(r.cnt2_all[slot].p) + (size_t)sender * all + (size_t)r.global * mine,
+                                           mine * sizeof(u64), hipMemcpyDeviceToDevice, r.comm));
+                    ++piece;
+                    return HJGPU_OK;
+                };
+                if (rx.in_place) {
+                    CHKM(take(r.global));
+                    for (int p = 0; p < G; ++p) if (p != r.global) CHKM(take(p));
+                } else
+                    for (int p = 0; p < G; ++p) CHKM(take(p));
+            }
             if (l == 0) HIPM(c, hipEventRecord(r.ev_x0, r.comm));
         }
         // packed tuples: keys and payloads travel together, ONE all-to-all-v per slice
@@ -1173,6 +1227,27 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     const std::vector<u64> inner_recv = step.recv_total;
     const std::vector<std::vector<u64>> inner_pieces = step.pieces;
     const std::vector<const void *> inner_base = step.base;
+    // counts published with the partitions (CpraStep::fused): every rank reads the same G x G matrix of the build exchange,
+    // so every rank arrives at the same F2 - what the receiver with the largest build side needs
+    hjgpu_phj_params prm_fused;
+    if (K && c->cpra_fused_counts) {
+        const u64 *mx = hp_matrix(c->ranks[0], G);
+        u64 most = 0;
+        for (size_t dst = 0; dst < G; ++dst) {
+            u64 rows_of_dst = 0;
+            for (size_t src = 0; src < G; ++src) rows_of_dst += mx[src * G + dst];
+            most = most > rows_of_dst ? most : rows_of_dst;
+        }
+        uint32_t f2 = 0, m2 = 0;
+        if (most && hjgpu_prepartitioned_plan(c->ranks[0].join, (size_t)most, K, prm, &f2, &m2) == HJGPU_OK &&
+            (u64)G * K * f2 <= 32768 && m2 != TOP_LEVEL_FACTOR) {
+            step.fused = true; step.F2 = f2; step.factor2 = m2;
+            memset(&prm_fused, 0, sizeof(prm_fused));
+            if (prm) prm_fused = *prm;
+            prm_fused.fanout2 = f2;                         // every receiver plans the same second level
+            prm = &prm_fused;
+        }
+    }
     std::vector<size_t> max_outer(L);
     for (int l = 0; l < L; ++l) {
         Rank &r = c->ranks[l];
@@ -1255,6 +1330,12 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                         // a batch = rows [b, b + m) of what arrived: a contiguous piece of the pieces (still sorted by partition)
                         const u64 first = got_pieces[l][0];
                         const hjgpu_prepartitioned lay = layout_of(l, got_pieces[l], first + b, first + b + m);
+                        // the senders' counts describe WHOLE pieces: a slice that is joined in one batch needs no K4p
+                        if (step.fused && step.counts_usable[slot] && b == 0 && m == got[l])
+                            JOINM(c, r.join, hjgpu_phj_probe_prepartitioned_counted_async(r.join, static_cast<const uint64_t *>(got_base[l]), &lay,
+                                                                                          static_cast<const uint64_t *>(r.cnt_recv[slot].p),
+                                                                                          reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
+                        else
                         JOINM(c, r.join, hjgpu_phj_probe_prepartitioned_async(r.join, static_cast<const uint64_t *>(got_base[l]), &lay,
                                                                               reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
                     } else
@@ -1574,6 +1655,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
     if (strcmp(name, "exchange_in_place") == 0) { c->exchange_in_place = x != 0; return HJGPU_OK; }
     if (strcmp(name, "cpra_k") == 0) { if (x < 0 || x > 192) return cfail(c, HJGPU_EINVAL, "cpra_k: 0 ... 192"); c->cpra_k = (int)x; return HJGPU_OK; }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
+    if (strcmp(name, "cpra_fused_counts") == 0) { c->cpra_fused_counts = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }
     if (strcmp(name, "debug_forensics") == 0) { c->debug_forensics = (int)x; return HJGPU_OK; }
     if (strcmp(name, "self_via_rccl") == 0) { c->self_via_rccl = x != 0; return HJGPU_OK; }

@@ -432,6 +432,22 @@ int hj_launch_hist_packed(const u64 *tuples, const HjChunks &ch, uint32_t f1, ui
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
+// Row sums of a fused histogram: out[p1] = sum over p2 of counts[p1 * F2 + p2] (hjgpu_partition_packed_counted_async: the
+// pass-1 counts of a partitioning call whose histogram pass counted the receivers' second level as well).
+__global__ __launch_bounds__(64) void row_sums_kernel(const u64 *__restrict__ counts, uint32_t F2, u64 *__restrict__ out)
+{
+    u64 s = 0;
+    for (uint32_t j = threadIdx.x; j < F2; j += 64) s += counts[(u64)blockIdx.x * F2 + j];
+    s = wave_reduce_sum(s);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+int hj_launch_row_sums(const u64 *counts, uint32_t F1, uint32_t F2, u64 *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(row_sums_kernel, dim3(F1), dim3(64), 0, stream, counts, F2, out);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
 // --------------------------------------------------------------------------
 // K5b: per-range write bases of pass 1.  One workgroup per (chunk, partition):
 // base[range][p] = off1[chunk][p] + sum of the counts of earlier ranges of the chunk.

@@ -349,6 +349,24 @@ int  hjgpu_phj_build_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, co
                                     void *stream);
 int  hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *layout,
                                           hjgpu_result *d_result, void *stream);
+/* Counts published with the partitions (cpra2.cpp:1783-1840: every worker's histogram of its chunk is what the owners'
+ * gather is planned from).  The SENDER's histogram pass can count the receivers' second level in the same read of its keys:
+ * hjgpu_partition_packed_counted_async = hjgpu_partition_packed(_own_last)_async (own_count = 0: plain order) that also
+ * leaves d_counts2[p1 * fanout2 + p2] = rows of the chunk with H(key, factor, fanout) = p1 and H(key, factor2, fanout2) = p2
+ * (fanout * fanout2 <= 32768: the fused histogram lives in LDS).  A receiver that is handed, for every piece c, the rows
+ * [first_partition * fanout2, (first_partition + fanout1) * fanout2) of that piece's sender's d_counts2 - d_counts
+ * [c * fanout1 * fanout2 + ...], in the order of the pieces - joins the batch without a histogram pass of its own over what
+ * arrived (hjgpu_phj_probe_prepartitioned_counted_async; the batch must be whole pieces, as counted).  fanout2 / factor2
+ * have to be the prepared build side's: hjgpu_prepartitioned_plan says what hjgpu_phj_build_prepartitioned plans for a
+ * build side of `inner` rows (params->fanout2 forces it: all receivers of one exchange need the same). */
+int  hjgpu_partition_packed_counted_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                                          uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
+                                          uint32_t factor2, uint32_t fanout2, uint64_t *d_tuples_out, uint64_t *d_offsets,
+                                          uint64_t *d_counts2, void *stream);
+int  hjgpu_phj_probe_prepartitioned_counted_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *layout,
+                                                  const uint64_t *d_counts, hjgpu_result *d_result, void *stream);
+int  hjgpu_prepartitioned_plan(hjgpu_ctx *ctx, size_t inner, uint32_t fanout1, const hjgpu_phj_params *params,
+                               uint32_t *fanout2, uint32_t *factor2);
 
 /* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
  * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates.

@@ -752,3 +752,27 @@ def test_configs4_per_rank_work_at_rccl_world_one():
         assert st["join"]["fanout1"] == 24, st["join"]
         for c in cols:
             c.free()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_cpra_with_the_senders_counts_equals_cpra_with_k4p(worlds, oracle, world):
+    """Option cpra_fused_counts (default on): while G * k * F2 <= 32768 the senders' histogram pass counts the receivers'
+    final partitions, the histograms travel with the counts all-gather and the receivers skip K4p; beyond (or with the
+    option off) the receivers count what arrived.  Same result either way, in place and with the copying exchange, with
+    slices that are joined in several batches falling back to K4p."""
+    comm = worlds(world) if world > 1 else worlds(1, H.TRANSPORT_RCCL)
+    ik, iv, ok, ov = oracle.generate(250_003, 47_001, seed=90 + world)
+    want = numpy_join(ik, iv, ok, ov)
+    shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+    try:
+        for fused in (1, 0):
+            for in_place in (1, 0):
+                comm.set_option("cpra_fused_counts", fused)
+                comm.set_option("exchange_in_place", in_place)
+                for slices in (1, 3):
+                    assert comm.cpra_multi(shards, None, slices)[0] == want, (fused, in_place, slices)
+    finally:
+        comm.set_option("cpra_fused_counts", 1)
+        comm.set_option("exchange_in_place", 1)
+    for c in cols:
+        c.free()

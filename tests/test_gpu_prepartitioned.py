@@ -143,3 +143,72 @@ def test_own_partitions_last_refuses_a_range_beyond_the_fanout(hj):
     assert e.value.status == H.api.EINVAL
     for c in (dk, dv, dt, do):
         c.free()
+
+
+# ---- round 4: counts published with the partitions (cpra2.cpp:1783-1840) --------------------------------------------
+def send_counted(hj, keys, vals, chunks, fanout, factor2, fanout2):
+    """like send(), with the fused histogram of every chunk: counts[p1 * fanout2 + p2]"""
+    out = []
+    for b, e in bounds(len(keys), chunks):
+        n = e - b
+        dk, dv = hj.column(np.concatenate([keys[b:e], np.zeros(1, np.uint32)])), hj.column(np.concatenate([vals[b:e], np.zeros(1, np.uint32)]))
+        dt, do, dc = hj.column(n + 16, np.uint64), hj.column(fanout + 1, np.uint64), hj.column(fanout * fanout2, np.uint64)
+        hj.partition_packed_counted_async(dk, dv, n, FACTOR1, fanout, 0, 0, factor2, fanout2, dt, do, dc)
+        hj.synchronize()
+        t, o, cnt = dt.download(n), do.download().astype(np.int64), dc.download().astype(np.int64)
+        k32 = (t & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        p1, p2 = mulhi_hash(k32, FACTOR1, fanout), mulhi_hash(k32, factor2, fanout2)
+        # the operator's contract: the same partitions as the plain operator, and the fused histogram of the chunk
+        assert np.array_equal(p1, np.repeat(np.arange(fanout), np.diff(o)))
+        assert np.array_equal(cnt, np.bincount(p1.astype(np.int64) * fanout2 + p2, minlength=fanout * fanout2))
+        out.append((t, o, cnt.reshape(fanout, fanout2)))
+        for c in (dk, dv, dt, do, dc):
+            c.free()
+    return out
+
+
+@pytest.mark.parametrize("ranks", [1, 3, 8])
+@pytest.mark.parametrize("kind", ["unique", "dups", "tiny"])
+def test_a_receiver_with_the_senders_counts_needs_no_histogram_pass(hj, oracle, ranks, kind):
+    """hjgpu_partition_packed_counted_async + hjgpu_phj_probe_prepartitioned_counted_async: the receiver is handed the rows
+    of every sender's fused histogram that describe its partitions (in the order of its pieces) and joins what arrived
+    without counting it again; the result is the whole relations' join."""
+    ik, iv, ok, ov = {"unique": lambda: oracle.generate(300_007, 61_003, seed=ranks),
+                      "dups": lambda: oracle.generate(40_000, 250_000, seed=ranks),
+                      "tiny": lambda: oracle.generate(37, 5, seed=ranks)}[kind]()
+    want = numpy_join(ik, iv, ok, ov)
+    k = max(1, 192 // ranks)
+    fanout = ranks * k
+    sent_r = send(hj, ik, iv, ranks, fanout)
+    # every receiver plans the same second level: what the largest received build side needs
+    most = max(sum(int(o[(g + 1) * k] - o[g * k]) for _, o in sent_r) for g in range(ranks))
+    fanout2, factor2 = hj.prepartitioned_plan(most, k)
+    assert fanout * fanout2 <= 32768
+    sent_s = send_counted(hj, ok, ov, ranks, fanout, factor2, fanout2)
+    total = [0, 0, 0, 0]
+    d_res = hj.column(4, np.uint64)
+    prm = H.PhjParams(fanout2=fanout2)
+    for g in range(ranks):
+        tr, offr = received(sent_r, g, k)
+        ts, offs = received([(t, o) for t, o, _ in sent_s], g, k)
+        counts = np.concatenate([c[g * k:(g + 1) * k].ravel() for _, _, c in sent_s]).astype(np.uint64)
+        dr, ds = hj.column(np.concatenate([tr, np.zeros(2, np.uint64)]), np.uint64), hj.column(np.concatenate([ts, np.zeros(2, np.uint64)]), np.uint64)
+        dc = hj.column(counts, np.uint64)
+        hj.phj_build_prepartitioned(dr, hj.prepartitioned(FACTOR1, fanout, g * k, k, offr), max(len(ts), 1 << 16), prm)
+        hj.phj_probe_prepartitioned_counted_async(ds, hj.prepartitioned(FACTOR1, fanout, g * k, k, offs), dc, d_res)
+        hj.get_async_status()
+        total = [(a + int(b)) & ((1 << 64) - 1) for a, b in zip(total, d_res.download())]
+        for c in (dr, ds, dc):
+            c.free()
+    d_res.free()
+    assert tuple(total) == want, (ranks, kind)
+
+
+def test_counted_partitions_refuse_what_the_lds_histogram_cannot_hold(hj):
+    dk, dv, dt, do, dc = hj.column(64), hj.column(64), hj.column(80, np.uint64), hj.column(193, np.uint64), hj.column(16, np.uint64)
+    for factor2, fanout2 in ((0x85EBCA6B, 171), (FACTOR1, 4), (0x85EBCA6A, 4)):      # 192 x 171 > 32768; the same factor; an even factor
+        with pytest.raises(H.HjGpuError) as e:
+            hj.partition_packed_counted_async(dk, dv, 64, FACTOR1, 192, 0, 0, factor2, fanout2, dt, do, dc)
+        assert e.value.status == H.api.EINVAL
+    for c in (dk, dv, dt, do, dc):
+        c.free()
