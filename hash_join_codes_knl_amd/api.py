@@ -37,7 +37,7 @@ EXPORTS = [
     "hjgpu_comm_get_info", "hjgpu_comm_preflight",
     "hjgpu_phj_multi", "hjgpu_npj_multi", "hjgpu_cpra_multi", "hjgpu_join_host_multi",
     "hjgpu_phj_multi_rows", "hjgpu_npj_multi_rows", "hjgpu_cpra_multi_rows", "hjgpu_join_host_rows_multi",
-    "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_generate_select", "hjgpu_column_sums", "hjgpu_stream_read_ms", "hjgpu_random_line_read_ms", "hjgpu_random_cas_ms",
+    "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_join_host_rows_shared", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_generate_select", "hjgpu_column_sums", "hjgpu_stream_read_ms", "hjgpu_random_line_read_ms", "hjgpu_random_cas_ms",
 ]
 
 
@@ -258,6 +258,8 @@ def load_library(build_if_missing=True):
                                   C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(Stats)]
     L.hjgpu_join_host_rows.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
                                        C.POINTER(NpjParams), C.POINTER(HostRows), C.POINTER(Result), C.POINTER(Stats)]
+    L.hjgpu_join_host_rows_shared.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),
+                                              C.POINTER(NpjParams), C.POINTER(HostRows), u64p, C.POINTER(Result), C.POINTER(Stats)]
     L.hjgpu_generate.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
     L.hjgpu_generate_range.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, vp, vp, vp, vp, vp]
     L.hjgpu_generate_zipf.argtypes = [vp, C.c_uint64, sz, sz, sz, sz, sz, sz, u32, u32, C.c_double, vp, vp, vp, vp, vp]

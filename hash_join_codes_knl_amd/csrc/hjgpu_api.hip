@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 
 #include "hj_internal.hpp"
 
@@ -99,6 +100,34 @@ int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess
         hipError_t e_ = (call);                                                 \
         if (e_ != hipSuccess) return fail((ctx), HJGPU_EHIP, #call, e_);        \
     } while (0)
+
+// hipEventSynchronize / hipStreamSynchronize of the host pipelines.  The multi-GPU host call runs one host thread per rank,
+// each deep inside the runtime (staged uploads, copies, joins); there the runtime once answered a plain
+// hipEventSynchronize with hipErrorStreamCaptureUnsupported ("operation not permitted when stream is capturing") although
+// no stream of the process was capturing (this library refuses capturing streams: refuse_capture).  The answer is
+// transient: asked again, the wait proceeds.
+static hipError_t hj_event_synchronize(hipEvent_t ev)
+{
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 200; ++attempt) {
+        e = hipEventSynchronize(ev);
+        if (e != hipErrorStreamCaptureUnsupported) return e;
+        (void)hipGetLastError();
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    return e;
+}
+static hipError_t hj_stream_synchronize(hipStream_t st)
+{
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 200; ++attempt) {
+        e = hipStreamSynchronize(st);
+        if (e != hipErrorStreamCaptureUnsupported) return e;
+        (void)hipGetLastError();
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    return e;
+}
 
 #define CHK(call)                                                               \
     do {                                                                        \
@@ -1876,7 +1905,7 @@ static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, h
     for (size_t at_ = 0; at_ < bytes; at_ += stage_bytes) {
         const size_t n = bytes - at_ < stage_bytes ? bytes - at_ : stage_bytes;
         const int b = *next; *next ^= 1;
-        HIPCHK(ctx, hipEventSynchronize(stage_free[b]));           // the DMA that last used this buffer is done
+        HIPCHK(ctx, hj_event_synchronize(stage_free[b]));           // the DMA that last used this buffer is done
         memcpy(stage[b], (const char *)h + at_, n);
         HIPCHK(ctx, hipMemcpyAsync((char *)d + at_, stage[b], n, hipMemcpyHostToDevice, copy));
         HIPCHK(ctx, hipEventRecord(stage_free[b], copy));
@@ -1914,7 +1943,7 @@ static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes,
     HIPCHK(ctx, fetch(0));
     for (size_t c = 0; c < chunks; ++c) {
         if (c + 1 < chunks) HIPCHK(ctx, fetch(c + 1));            // the other buffer: emptied one round ago
-        HIPCHK(ctx, hipEventSynchronize(stage_done[c & 1]));
+        HIPCHK(ctx, hj_event_synchronize(stage_done[c & 1]));
         memcpy((char *)h + c * stage_bytes, stage[c & 1], len(c));
     }
     return HJGPU_OK;
@@ -1924,7 +1953,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
                           const uint32_t *ik, const uint32_t *iv, size_t inner,
                           const uint32_t *ok, const uint32_t *ov, size_t outer,
                           const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
-                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats);
+                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats, uint64_t *cursor = nullptr);
 
 int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
                     const uint32_t *ik, const uint32_t *iv, size_t inner,
@@ -1948,6 +1977,19 @@ int hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm,
     return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result, stats);
 }
 
+int hjgpu_join_host_rows_shared(hjgpu_ctx *ctx, int algorithm,
+                                const uint32_t *ik, const uint32_t *iv, size_t inner,
+                                const uint32_t *ok, const uint32_t *ov, size_t outer,
+                                const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
+                                const hjgpu_host_rows *rows, uint64_t *cursor, hjgpu_result *result, hjgpu_stats *stats)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (!rows || !result || !cursor) return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows_shared: rows, cursor and result are required");
+    if (rows->capacity && (!rows->keys || !rows->outer_vals || !rows->inner_vals))
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows_shared: null result column");
+    return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result, stats, cursor);
+}
+
 
 // Joins from host columns, aggregates only: the probe side never exists on the device as a whole.  R is uploaded and
 // prepared (PHJ / CPRA: hjgpu_phj_build's passes; NPJ: the table, npj.cpp:865-877), then the probe side travels in
@@ -1961,9 +2003,14 @@ int hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm,
 static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, const uint32_t *iv, size_t inner,
                              const uint32_t *ok, const uint32_t *ov, size_t outer, const hjgpu_phj_params *pp,
                              const hjgpu_npj_params *np, const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats,
-                             bool *done)
+                             bool *done, uint64_t *cursor = nullptr)
 {
+    // `cursor` (hjgpu_join_host_rows_shared): the caller's columns are shared by several contexts' calls; a batch's rows go
+    // where an atomic fetch-add on *cursor puts them.  Nothing is ever started over then (other calls have appended in
+    // between): a batch that does not fit - its device columns or the shared capacity - is counted, not written, and the
+    // call returns HJGPU_EOVERFLOW with its exact count.
     *done = false;
+    bool shared_overflow = false;
     long long want_batch = ctx->tune.host_batch;
     if (want_batch < 0) {
         // default: rows in batches; aggregates in batches only when whole columns plus their workspace (two packed twins of
@@ -2041,14 +2088,19 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     // batch j's rows -> the caller's columns (its dense count is on the host once `joined` has fired)
     auto download_batch = [&](size_t j) {
         const int slot = (int)(j & 1);
-        hip_ok(hipEventSynchronize(joined[slot]), "hipEventSynchronize(joined)");
+        hip_ok(hj_event_synchronize(joined[slot]), "hipEventSynchronize(joined)");
         if (rc != HJGPU_OK) return;
         const DevState &hs = h_state[j];
-        if (hs.overflow || rows_at + hs.dense > rows->capacity) { abandon = true; return; }
+        u64 at = rows_at;
+        if (cursor) {
+            if (hs.overflow) { shared_overflow = true; hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord"); return; }
+            at = __atomic_fetch_add(cursor, (uint64_t)hs.dense, __ATOMIC_RELAXED);
+            if (at + hs.dense > rows->capacity) { shared_overflow = true; hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord"); return; }
+        } else if (hs.overflow || rows_at + hs.dense > rows->capacity) { abandon = true; return; }
         const auto d0 = std::chrono::steady_clock::now();
         uint32_t *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
         for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
-            rc = download_column(ctx, hcol[i] + rows_at, d_rows[slot][i], hs.dense * sizeof(uint32_t), down, true);
+            rc = download_column(ctx, hcol[i] + at, d_rows[slot][i], hs.dense * sizeof(uint32_t), down, true);
         hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord");
         rows_at += hs.dense;
         ms_download += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - d0).count();
@@ -2132,22 +2184,22 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             if (abandon) break;
         }
         if (rows && rc == HJGPU_OK && !abandon) download_batch(nb - 1);
-        if (rows && rc == HJGPU_OK && !abandon) hip_ok(hipStreamSynchronize(down), "hipStreamSynchronize(down)");
+        if (rows && rc == HJGPU_OK && !abandon) hip_ok(hj_stream_synchronize(down), "hipStreamSynchronize(down)");
         if (rc == HJGPU_OK) {
-            hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
+            hip_ok(hj_stream_synchronize(copy), "hipStreamSynchronize(copy)");
             ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (npj && !abandon) {
                 // one accumulated result; key 0 in R -> HJGPU_EZEROKEY (the output counters are the last batch's: not checked here)
                 DevState hs;
                 hip_ok(hipMemcpyAsync(&hs, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");
-                hip_ok(hipStreamSynchronize(run), "hipStreamSynchronize(run)");
+                hip_ok(hj_stream_synchronize(run), "hipStreamSynchronize(run)");
                 if (rc == HJGPU_OK) {
                     if (result) *result = hs.result;
                     if (hs.zero_key) rc = fail(ctx, HJGPU_EZEROKEY, "NPJ: a build key is 0, the empty-bucket sentinel");
                 }
             } else if (!abandon) {
                 hip_ok(hipMemcpyAsync(parts.data(), d_res, nb * sizeof(hjgpu_result), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(results)");
-                hip_ok(hipStreamSynchronize(run), "hipStreamSynchronize(run)");
+                hip_ok(hj_stream_synchronize(run), "hipStreamSynchronize(run)");
             }
         }
     }
@@ -2175,6 +2227,8 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             stats->batches = (uint32_t)nb;
         }
         *done = true;
+        if (shared_overflow && rc == HJGPU_OK)
+            rc = fail(ctx, HJGPU_EOVERFLOW, "hjgpu_join_host_rows_shared: rows of this call did not fit (a batch's device columns or the shared capacity); result->count is exact");
     }
     (void)hipDeviceSynchronize();
     ctx->prepared = false;                             // the build columns are about to be freed with everything else
@@ -2200,17 +2254,21 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
                           const uint32_t *ik, const uint32_t *iv, size_t inner,
                           const uint32_t *ok, const uint32_t *ov, size_t outer,
                           const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
-                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats)
+                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats, uint64_t *cursor)
 {
     if (!ctx || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
     if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return fail(ctx, HJGPU_EINVAL, "null column");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     {
-        // the probe side in batches behind the DMA (join_host_batched); not taken: small probe sides, NPJ with rows, a
-        // batch whose rows outgrow their share of the capacity
+        // the probe side in batches behind the DMA (join_host_batched), all three algorithms, with or without rows; not taken
+        // (done = false): probe sides below two batches, host_batch = 0, and - after part of the work - a materialising call
+        // in which one batch's rows outgrow their share of the capacity (x 1.25) or the result outgrows rows->capacity: the
+        // call then starts over on the whole-column path below, which knows how to report the needed capacity.  (Skewed
+        // probe sides: pass host_batch = 0 to go there directly.)  CPRA in batches: every batch is ONE chunk (the reference
+        // partitions every chunk of S on its own, cpra2.cpp:1757-1827: a batch is such a chunk); stats->batches says so.
         bool done = false;
         hjgpu_result batched_result;
-        const int brc = join_host_batched(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result ? result : &batched_result, stats, &done);
+        const int brc = join_host_batched(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result ? result : &batched_result, stats, &done, cursor);
         if (brc != HJGPU_OK || done) return brc;
     }
     // materialised result: device columns of the caller's capacity plus one open block per worker
@@ -2280,7 +2338,7 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
             }
         }
         if (rc == HJGPU_OK) {
-            hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
+            hip_ok(hj_stream_synchronize(copy), "hipStreamSynchronize(copy)");
             ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             rc = finish_blocking(ctx, result, out, run);
         }
@@ -2288,14 +2346,16 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     // the dense prefix [0, J) of the three result columns -> the caller's host columns
     float ms_download = 0;
     if (rc == HJGPU_OK && rows) {
-        if (result->count > rows->capacity) {
+        // shared columns (hjgpu_join_host_rows_shared): this call's rows go where the cursor puts them
+        const u64 at = cursor ? __atomic_fetch_add(cursor, (uint64_t)result->count, __ATOMIC_RELAXED) : 0;
+        if (at + result->count > rows->capacity) {
             rc = fail(ctx, HJGPU_EOVERFLOW, "hjgpu_join_host_rows: the result has more rows than rows->capacity (see result->count)");
         } else if (result->count) {
             const auto t0 = std::chrono::steady_clock::now();
-            void *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
+            uint32_t *hcol[3] = {rows->keys + at, rows->outer_vals + at, rows->inner_vals + at};
             for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
                 rc = download_column(ctx, hcol[i], d_rows[i], result->count * sizeof(uint32_t), copy);
-            if (rc == HJGPU_OK) hip_ok(hipStreamSynchronize(copy), "hipStreamSynchronize(copy)");
+            if (rc == HJGPU_OK) hip_ok(hj_stream_synchronize(copy), "hipStreamSynchronize(copy)");
             ms_download = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     }

@@ -180,6 +180,7 @@ struct hjgpu_comm {
                                              // them (last) and receives the other ranks' pieces right behind: the message to itself is never copied
     int cpra_k = 0;                          // option "cpra_k": partitions per rank of the exchange-level pass (0 = 192 / ranks); measurements:
                                              // k = 24 at world 1 gives the receiver the per-GPU work of an 8-GPU join
+    bool host_rows_batched = true;           // option "host_rows_batched": hjgpu_join_host_rows_multi (PHJ / NPJ) = the one-GPU batched host pipeline per rank
     bool cpra_fused_counts = true;           // option "cpra_fused_counts": the senders' histogram pass counts the receivers' final partitions
                                              // too when G * k * F2 <= 32768 (build sides up to ~114 M rows): the receivers skip K4p
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
@@ -1656,6 +1657,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
     if (strcmp(name, "cpra_k") == 0) { if (x < 0 || x > 192) return cfail(c, HJGPU_EINVAL, "cpra_k: 0 ... 192"); c->cpra_k = (int)x; return HJGPU_OK; }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
     if (strcmp(name, "cpra_fused_counts") == 0) { c->cpra_fused_counts = x != 0; return HJGPU_OK; }
+    if (strcmp(name, "host_rows_batched") == 0) { c->host_rows_batched = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }
     if (strcmp(name, "debug_forensics") == 0) { c->debug_forensics = (int)x; return HJGPU_OK; }
     if (strcmp(name, "self_via_rccl") == 0) { c->self_via_rccl = x != 0; return HJGPU_OK; }
@@ -1881,8 +1883,51 @@ static int join_host_multi_impl(hjgpu_comm *c, int algorithm,
     if (host_rows && (!result || (host_rows->capacity && (!host_rows->keys || !host_rows->outer_vals || !host_rows->inner_vals))))
         return cfail(c, HJGPU_EINVAL, "hjgpu_join_host_rows_multi: result and the three result columns are required");
     const int G = c->nranks;
-    std::vector<hjgpu_shard> shards((size_t)G);
     const auto t0 = std::chrono::steady_clock::now();
+    if (host_rows && algorithm != 2 && c->host_rows_batched && inner && outer) {
+        // Replicated build side with rows: every rank runs the ONE-GPU host pipeline on its probe shard (npj.cpp:1013-1039
+        // reads the columns, 997-1000 sizes the output: here per GPU) - the build side read from the host by every GPU
+        // (SURVEY 8e), the shard in batches behind the DMA, a batch's dense rows going home while the next is joined and the
+        // one after it uploaded - and all ranks append to the caller's columns through one atomic cursor: the concatenation
+        // is the result, in the order the batches finish.  A rank whose rows do not fit (a skewed batch, or the capacity)
+        // counts them: the call then reports the needed rows, or starts over on the whole-shard path below.
+        uint64_t cursor = 0;
+        std::vector<hjgpu_result> res((size_t)G);
+        std::vector<hjgpu_stats> st((size_t)G);
+        std::vector<int> rcs((size_t)G, HJGPU_OK);
+        (void)each_rank(G, [&](int g) -> int {
+            Rank &r = c->ranks[(size_t)g];
+            size_t sb, se;
+            range_of(outer, 16, (size_t)g, (size_t)G, &sb, &se);
+            memset(&res[(size_t)g], 0, sizeof(hjgpu_result));
+            rcs[(size_t)g] = hjgpu_join_host_rows_shared(r.join, algorithm, ik, iv, inner, ok + sb, ov + sb, se - sb, pp, np, host_rows, &cursor,
+                                                        &res[(size_t)g], &st[(size_t)g]);
+            return HJGPU_OK;
+        });
+        bool overflow = false;
+        hjgpu_result sum;
+        memset(&sum, 0, sizeof(sum));
+        for (int g = 0; g < G; ++g) {
+            const int rg = rcs[(size_t)g];
+            if (rg == HJGPU_EOVERFLOW) overflow = true;
+            else if (rg != HJGPU_OK) return cfail(c, rg, "hjgpu_join_host_rows_shared", hjgpu_last_error(c->ranks[(size_t)g].join));
+            sum.count += res[(size_t)g].count; sum.sum_keys += res[(size_t)g].sum_keys;
+            sum.sum_outer_vals += res[(size_t)g].sum_outer_vals; sum.sum_inner_vals += res[(size_t)g].sum_inner_vals;
+        }
+        if (!overflow || sum.count > host_rows->capacity) {
+            *result = sum;
+            if (stats) {
+                memset(stats, 0, sizeof(*stats));
+                stats->join = st[0]; stats->ms_upload = st[0].ms_upload; stats->joins = st[0].batches ? st[0].batches : 1;
+                stats->tuples_joined = inner + outer / (size_t)G;
+                stats->ms_wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (overflow) return cfail(c, HJGPU_EOVERFLOW, "hjgpu_join_host_rows_multi: the result has more rows than rows->capacity (see result->count)");
+            return HJGPU_OK;
+        }
+        // a batch outgrew its device columns although the whole fits the capacity (skew): whole shards, below
+    }
+    std::vector<hjgpu_shard> shards((size_t)G);
     for (int g = 0; g < G; ++g) {
         Rank &r = c->ranks[(size_t)g];
         hjgpu_shard &s = shards[(size_t)g];

@@ -380,7 +380,10 @@ int  hjgpu_prepartitioned_plan(hjgpu_ctx *ctx, size_t inner, uint32_t fanout1, c
  * and the phase times are the last batch's scaled to that sum (NPJ: ms_build = the table's build).  hjgpu_join_host_rows works the
  * same way: every batch's rows are made dense on the device and go home - into page-locked columns by a copy kernel, so
  * that the DMA engines carry the upload only - while the next batch is joined; a batch that outgrows its share of
- * rows->capacity sends the call down the whole-column path.
+ * rows->capacity (x 1.25) sends the call down the whole-column path: it starts over, the caller's columns may have been
+ * partly written (a caller that expects a skewed probe side sets host_batch = 0).  In batches algorithm 2 (CPRA) joins
+ * every batch as ONE chunk of the probe side (cpra2.cpp:1757-1827 partitions every chunk on its own: a batch is one);
+ * params->chunks applies to calls without batches.
  * Otherwise (small probe sides, host_batch = 0) the columns are uploaded whole on their own
  * stream, probe side first, build side behind it; PHJ / CPRA partition the probe side while the build side is still
  * arriving.  Page-locked columns (hjgpu_host_alloc) are DMA'd where they are, pageable ones staged
@@ -408,6 +411,17 @@ int  hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm /* 0 npj, 1 phj, 2 cpra 
                           const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
                           const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
                           const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats);
+/* hjgpu_join_host_rows into result columns that SEVERAL calls share (one per GPU of a node, each on its own context and
+ * host thread: what hjgpu_join_host_rows_multi does for PHJ / NPJ): the rows of this call are appended where an atomic
+ * fetch-add on *cursor puts them - a batch's dense rows as soon as they exist, so the calls' rows interleave and
+ * [0, *cursor) is dense when all calls have returned (every reference worker appends its blocks to the shared output
+ * the same way: npj.cpp:244-246, 312-316).  result = THIS call's aggregates.  Rows that do not fit (rows->capacity, or a
+ * skewed batch's device columns) are counted, not written: HJGPU_EOVERFLOW, result->count exact, nothing starts over. */
+int  hjgpu_join_host_rows_shared(hjgpu_ctx *ctx, int algorithm,
+                                 const uint32_t *inner_keys, const uint32_t *inner_vals, size_t inner,
+                                 const uint32_t *outer_keys, const uint32_t *outer_vals, size_t outer,
+                                 const hjgpu_phj_params *phj_params, const hjgpu_npj_params *npj_params,
+                                 const hjgpu_host_rows *rows, uint64_t *cursor, hjgpu_result *result, hjgpu_stats *stats);
 
 /* ---- multi-GPU joins ------------------------------------------------------------------------------
  * The reference's cross-worker exchange is part of run_hj itself: phj.cpp:1715-1770 (thread-level pass: both

@@ -776,3 +776,47 @@ def test_cpra_with_the_senders_counts_equals_cpra_with_k4p(worlds, oracle, world
         comm.set_option("exchange_in_place", 1)
     for c in cols:
         c.free()
+
+
+@pytest.mark.parametrize("algorithm", [0, 1])
+def test_the_multi_gpu_host_rows_call_is_the_batched_pipeline_per_rank(worlds, algorithm):
+    """hjgpu_join_host_rows_multi for PHJ / NPJ: every rank runs the one-GPU host pipeline on its probe shard - batches
+    behind the DMA, a batch's dense rows going home while the next one is joined (option host_batch on the ranks' contexts
+    makes the batches small here) - and all ranks append to the caller's columns through one cursor
+    (hjgpu_join_host_rows_shared; npj.cpp:244-246: every worker claims its blocks of the shared output).  Row for row against
+    numpy; too small a capacity reports the rows needed; a batch that outgrows its device columns (all matches in one
+    batch) starts over on the whole-shard path."""
+    comm = worlds(3)
+    for g in range(3):
+        comm.ctx[g].set_option("host_batch", 100_000)
+    try:
+        rng = np.random.default_rng(41 + algorithm)
+        base = np.unique(rng.integers(1, 2**32, size=150_000, dtype=np.uint64).astype(np.uint32))
+        ik = np.concatenate([base, base[:30_000]])
+        iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+        ok = base[rng.integers(0, len(base), size=2_100_007)]
+        ov = rng.integers(0, 2**32, size=len(ok), dtype=np.uint64).astype(np.uint32)
+        want = numpy_join(ik, iv, ok, ov)
+        got, st, rows = comm.join_host_rows_multi(algorithm, ik, iv, ok, ov, want[0] + 4321)
+        assert got == want and len(rows[0]) == want[0]
+        assert st["join"]["batches"] == 7 and st["join"]["ms_download"] > 0      # 700 K probe rows per rank in batches of 100 K
+        for a, b in zip(sort_rows(*rows), materialised_rows(ik, iv, ok, ov)):
+            assert np.array_equal(a, b)
+        with pytest.raises(H.HjGpuError) as e:
+            comm.join_host_rows_multi(algorithm, ik, iv, ok, ov, want[0] // 2)
+        assert e.value.status == H.api.EOVERFLOW and e.value.result[0] == want[0]
+        # all matches of rank 0's shard in its first batch: that batch outgrows its device columns, the call starts over
+        ok2 = ok.copy()
+        ok2[100_000:] = (ok2[100_000:] ^ np.uint32(0x5a5a5a5a)) | np.uint32(1)
+        want2 = numpy_join(ik, iv, ok2, ov)
+        got2, _, rows2 = comm.join_host_rows_multi(algorithm, ik, iv, ok2, ov, want2[0] + 10)
+        assert got2 == want2
+        for a, b in zip(sort_rows(*rows2), materialised_rows(ik, iv, ok2, ov)):
+            assert np.array_equal(a, b)
+        comm.set_option("host_rows_batched", 0)                                   # the whole-shard path, same answer
+        got3, _, rows3 = comm.join_host_rows_multi(algorithm, ik, iv, ok, ov, want[0])
+        assert got3 == want and len(rows3[0]) == want[0]
+    finally:
+        comm.set_option("host_rows_batched", 1)
+        for g in range(3):
+            comm.ctx[g].set_option("host_batch", -1)
