@@ -101,11 +101,10 @@ int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess
         if (e_ != hipSuccess) return fail((ctx), HJGPU_EHIP, #call, e_);        \
     } while (0)
 
-// hipEventSynchronize / hipStreamSynchronize of the host pipelines.  The multi-GPU host call runs one host thread per rank,
-// each deep inside the runtime (staged uploads, copies, joins); there the runtime once answered a plain
-// hipEventSynchronize with hipErrorStreamCaptureUnsupported ("operation not permitted when stream is capturing") although
-// no stream of the process was capturing (this library refuses capturing streams: refuse_capture).  The answer is
-// transient: asked again, the wait proceeds.
+// hipEventSynchronize / hipStreamSynchronize of the host pipelines: a wait that the runtime refuses with
+// hipErrorStreamCaptureUnsupported although no stream captures (this library refuses capturing streams: refuse_capture)
+// is asked again.  (The refusals seen in round 4 had a cause - staging events recorded on per-call streams that were
+// destroyed, see join_host_impl - and are gone with it; the retry stays as a guard.)
 static hipError_t hj_event_synchronize(hipEvent_t ev)
 {
     hipError_t e = hipSuccess;
@@ -1009,11 +1008,11 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-    for (hipStream_t s : ctx->host_streams) if (s) (void)hipStreamDestroy(s);
     for (int b = 0; b < 4; ++b) {
         if (ctx->host_stage[b]) (void)hipHostFree(ctx->host_stage[b]);
-        if (ctx->host_stage_ev[b]) (void)hipEventDestroy(ctx->host_stage_ev[b]);
+        if (ctx->host_stage_ev[b]) (void)hipEventDestroy(ctx->host_stage_ev[b]);      // (the events go before the streams they were recorded on)
     }
+    for (hipStream_t s : ctx->host_streams) if (s) (void)hipStreamDestroy(s);
     delete ctx;
     return HJGPU_OK;
 }
@@ -2300,8 +2299,14 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     // the upload stream in the high-priority queue pool: its copies never share a hardware queue with the join's kernels
     int least = 0, greatest = 0;
     hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    hip_ok(hipStreamCreateWithPriority(&copy, hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
-    hip_ok(hipStreamCreateWithFlags(&run, hipStreamNonBlocking), "hipStreamCreate(run)");
+    // The context's OWN streams, made once and kept (as in the batched path): the page-locked staging buffers' events
+    // (host_stage_ev) outlive a call, and an event that was last recorded on a stream which has since been destroyed made
+    // the runtime's next hipEventSynchronize on it fail at random ("operation not permitted when stream is capturing" /
+    // "... on an event last recorded in a capturing stream": it looks at the dead stream) - round 4, seen once the
+    // multi-GPU host call ran this path on the ranks' contexts again and again.
+    if (!ctx->host_streams[0]) hip_ok(hipStreamCreateWithPriority(&ctx->host_streams[0], hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
+    if (!ctx->host_streams[1]) hip_ok(hipStreamCreateWithFlags(&ctx->host_streams[1], hipStreamNonBlocking), "hipStreamCreate(run)");
+    copy = ctx->host_streams[0]; run = ctx->host_streams[1];
     hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
     hip_ok(hipEventCreateWithFlags(&s_ready, hipEventDisableTiming), "hipEventCreate");
     PhjPlan pl;
@@ -2369,8 +2374,6 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     for (int i = 0; i < 3; ++i) if (d_rows[i]) (void)hipFree(d_rows[i]);
     if (r_ready) (void)hipEventDestroy(r_ready);
     if (s_ready) (void)hipEventDestroy(s_ready);
-    if (copy) (void)hipStreamDestroy(copy);
-    if (run) (void)hipStreamDestroy(run);
     return rc;
 }
 
