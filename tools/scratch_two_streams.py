@@ -20,12 +20,16 @@ def main():
     ap.add_argument("--n", type=int, default=125_000_000, help="tuples partitioned per step (one slice of the pipeline)")
     ap.add_argument("--fanout", type=int, default=192)
     ap.add_argument("--neighbour", type=int, default=1, help="0: nothing runs next to the partitioning")
+    ap.add_argument("--option", action="append", default=[], help="name=value, hjgpu_set_option on the PARTITIONING context (e.g. scatter_cfg=512,4,1)")
     a = ap.parse_args()
     import numpy as np
     import torch
     import hash_join_codes_knl_amd as H
     dev = torch.device("cuda", 0)
     A, B = H.HjGpu(0), H.HjGpu(0)
+    for o in a.option:
+        name, _, value = o.partition("=")
+        A.set_option(name, value)
     sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
     inner, outer = 64_000_000, 1_000_000_000
     ik, iv, ok, ov = B.column(inner), B.column(inner), B.column(outer), B.column(outer)
@@ -81,8 +85,8 @@ def main():
                       % (sorted(lens.items()), [(r, r % 16, ln) for r, ln in runs[:12]]), flush=True)
         if a.neighbour and [int(x) & ((1 << 64) - 1) for x in d_res.tolist()] != want_join:
             bad_join += 1
-    print("library %s (%s), neighbour %d: %d of %d partition outputs wrong, %d of %d neighbour joins wrong"
-          % (os.path.basename(os.environ.get("HJGPU_LIBRARY", "libhjgpu.so")), H.kernel_hash(), a.neighbour, bad_part, a.steps,
+    print("library %s (%s), options %s, neighbour %d: %d of %d partition outputs wrong, %d of %d neighbour joins wrong"
+          % (os.path.basename(os.environ.get("HJGPU_LIBRARY", "libhjgpu.so")), H.kernel_hash(), a.option, a.neighbour, bad_part, a.steps,
              bad_join, a.steps if a.neighbour else 0), flush=True)
 
 
