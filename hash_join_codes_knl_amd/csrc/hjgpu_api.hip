@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1527,6 +1528,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     ja.s_align = align_of(sk); ja.packed = 0;
     ja.broadcast = 1; ja.sentinel = bm.sentinel; ja.big_tables = big ? 1u : 0u; ja.unique = unique ? 1u : 0u;
     ja.result = &st->result; ja.work_counter = &st->work_counter; ja.work_counter2 = &st->work_counter2;
+    ja.multi_fill = &st->pad;                           // always 0: a broadcast join's build side is one table fill by construction
     if (bs) {
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
@@ -2084,6 +2086,12 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
         }
     }
     down = ctx->host_streams[2];
+    // A batch whose rows outgrew its device columns (a skewed probe side: most matches in few batches) is joined once more
+    // ALONE, into columns made for exactly its rows (its count is exact also when its rows overflowed), and its rows go
+    // home from there; returns false when that cannot be done (set below, once the plan exists).
+    std::function<bool(size_t, const DevState &, u64)> retry_alone;
+    u64 npj_count_before[2] = {0, 0};                                // NPJ: the accumulated count in front of the batch in each slot
+    uint32_t retries = 0;
     // batch j's rows -> the caller's columns (its dense count is on the host once `joined` has fired)
     auto download_batch = [&](size_t j) {
         const int slot = (int)(j & 1);
@@ -2095,7 +2103,11 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             if (hs.overflow) { shared_overflow = true; hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord"); return; }
             at = __atomic_fetch_add(cursor, (uint64_t)hs.dense, __ATOMIC_RELAXED);
             if (at + hs.dense > rows->capacity) { shared_overflow = true; hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord"); return; }
-        } else if (hs.overflow || rows_at + hs.dense > rows->capacity) { abandon = true; return; }
+        } else if (hs.overflow) {
+            const u64 need = npj ? hs.result.count - npj_count_before[slot] : hs.result.count;
+            if (rows_at + need > rows->capacity || !retry_alone || !retry_alone(j, hs, need)) abandon = true;
+            return;
+        } else if (rows_at + hs.dense > rows->capacity) { abandon = true; return; }
         const auto d0 = std::chrono::steady_clock::now();
         uint32_t *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
         for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
@@ -2116,6 +2128,52 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
     const bool line = !ctx->tune.npj_refhash, unique = npj && npj_unique(ctx, np);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 *table = reinterpret_cast<u64 *>(ctx->table.p);
+    if (rows && !cursor) retry_alone = [&](size_t j, const DevState &hs, u64 need) -> bool {
+        (void)hs;
+        const int slot = (int)(j & 1);
+        const size_t b = j * B, m = outer - b < B ? outer - b : B;
+        const size_t cap = (size_t)((need / row_bs + 1 + workers) * row_bs);
+        void *big[3] = {nullptr, nullptr, nullptr};
+        hjgpu_result *saved = nullptr;
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i) ok = hjgpu_malloc(ctx, &big[i], cap * sizeof(uint32_t)) == HJGPU_OK;
+        if (ok && npj) ok = hjgpu_malloc(ctx, reinterpret_cast<void **>(&saved), sizeof(hjgpu_result)) == HJGPU_OK;
+        hjgpu_output o;
+        memset(&o, 0, sizeof(o));
+        o.d_keys = (uint32_t *)big[0]; o.d_outer_vals = (uint32_t *)big[1]; o.d_inner_vals = (uint32_t *)big[2];
+        o.capacity = cap; o.block_size = row_bs;
+        DevState again;
+        memset(&again, 0, sizeof(again));
+        if (ok && npj) {
+            // the accumulated result already holds this batch (counts are exact when rows overflow): what the second run adds is dropped
+            ok = hipMemcpyAsync(saved, &st->result, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess &&
+                 hipMemsetAsync(&st->block_counter, 0, 3 * sizeof(u64), run) == hipSuccess &&
+                 hipMemsetAsync(&st->overflow, 0, sizeof(uint32_t), run) == hipSuccess &&
+                 hipMemsetAsync(&st->nmoves, 0, sizeof(uint32_t), run) == hipSuccess &&
+                 npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor, &o, run, line, unique) == HJGPU_OK &&
+                 hipMemcpyAsync(&again, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run) == hipSuccess &&
+                 hipMemcpyAsync(&st->result, saved, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess;
+        } else if (ok) {
+            ok = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, &o, run, nullptr, PHJ_PROBE_ONLY) == HJGPU_OK &&
+                 hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + j, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess &&
+                 hipMemcpyAsync(&again, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run) == hipSuccess;
+        }
+        // the slot's probe rows are needed until here: the next upload into the slot waits for THIS record
+        if (hipEventRecord(s_free[slot], run) != hipSuccess) ok = false;
+        if (ok) ok = hj_stream_synchronize(run) == hipSuccess;
+        if (ok) ok = !again.overflow && again.dense == need;
+        if (ok) {
+            uint32_t *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
+            for (int i = 0; i < 3 && ok; ++i) ok = download_column(ctx, hcol[i] + rows_at, big[i], need * sizeof(uint32_t), down, true) == HJGPU_OK;
+            if (ok) ok = hj_stream_synchronize(down) == hipSuccess;
+            if (ok) { rows_at += need; ++retries; }
+        }
+        (void)hipGetLastError();
+        hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord");
+        for (void *p : big) if (p) (void)hipFree(p);
+        if (saved) (void)hipFree(saved);
+        return ok;
+    };
     float ms_upload = 0;
     if (rc == HJGPU_OK) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -2179,7 +2237,10 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             hip_ok(hipEventRecord(bev[2 * i + 1], run), "hipEventRecord");
             hip_ok(hipEventRecord(s_free[slot], run), "hipEventRecord");
             // the previous batch's rows go home while this one is joined (its count is on the host by now, or soon)
-            if (rows && i >= 1 && rc == HJGPU_OK && !abandon) download_batch(i - 1);
+            if (rows && i >= 1 && rc == HJGPU_OK && !abandon) {
+                download_batch(i - 1);
+                if (npj) npj_count_before[(int)(i & 1)] = h_state[i - 1].result.count;       // what batch i starts from
+            }
             if (abandon) break;
         }
         if (rows && rc == HJGPU_OK && !abandon) download_batch(nb - 1);
@@ -2261,9 +2322,9 @@ static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
     {
         // the probe side in batches behind the DMA (join_host_batched), all three algorithms, with or without rows; not taken
         // (done = false): probe sides below two batches, host_batch = 0, and - after part of the work - a materialising call
-        // in which one batch's rows outgrow their share of the capacity (x 1.25) or the result outgrows rows->capacity: the
-        // call then starts over on the whole-column path below, which knows how to report the needed capacity.  (Skewed
-        // probe sides: pass host_batch = 0 to go there directly.)  CPRA in batches: every batch is ONE chunk (the reference
+        // whose result outgrows rows->capacity: the call then starts over on the whole-column path below, which knows how
+        // to report the needed capacity.  (A batch whose rows outgrow their share of the capacity x 1.25 - a skewed probe
+        // side - is joined once more alone, into device columns made for exactly its rows: nothing starts over.)  CPRA in batches: every batch is ONE chunk (the reference
         // partitions every chunk of S on its own, cpra2.cpp:1757-1827: a batch is such a chunk); stats->batches says so.
         bool done = false;
         hjgpu_result batched_result;

@@ -380,8 +380,8 @@ int  hjgpu_prepartitioned_plan(hjgpu_ctx *ctx, size_t inner, uint32_t fanout1, c
  * and the phase times are the last batch's scaled to that sum (NPJ: ms_build = the table's build).  hjgpu_join_host_rows works the
  * same way: every batch's rows are made dense on the device and go home - into page-locked columns by a copy kernel, so
  * that the DMA engines carry the upload only - while the next batch is joined; a batch that outgrows its share of
- * rows->capacity (x 1.25) sends the call down the whole-column path: it starts over, the caller's columns may have been
- * partly written (a caller that expects a skewed probe side sets host_batch = 0).  In batches algorithm 2 (CPRA) joins
+ * rows->capacity (x 1.25: a skewed probe side) is joined once more alone, into device columns made for exactly its rows;
+ * only a result beyond rows->capacity sends the call down the whole-column path (it starts over and reports the rows needed).  In batches algorithm 2 (CPRA) joins
  * every batch as ONE chunk of the probe side (cpra2.cpp:1757-1827 partitions every chunk on its own: a batch is one);
  * params->chunks applies to calls without batches.
  * Otherwise (small probe sides, host_batch = 0) the columns are uploaded whole on their own

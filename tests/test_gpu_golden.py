@@ -196,5 +196,10 @@ def test_full_size_64m_1g_equals_the_cpu_oracle(hj, oracle):
     assert hj.phj(ik, iv, inner, ok, ov, outer) == want
     assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=8)) == want
     assert hj.npj(ik, iv, inner, ok, ov, outer) == want
+    # the reference's -D_UNIQUE build (phj.cpp:635-637, npj.cpp:288-290): with unique build keys the first match is the only
+    # one, so the two-launch _UNIQUE join (round 4) and the _UNIQUE NPJ walk must return the same aggregates at full size
+    assert hj.phj(ik, iv, inner, ok, ov, outer, H.PhjParams(flags=H.FLAG_UNIQUE)) == want
+    assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=8, flags=H.FLAG_UNIQUE)) == want
+    assert hj.npj(ik, iv, inner, ok, ov, outer, H.NpjParams(flags=H.FLAG_UNIQUE)) == want
     for c in (ik, iv, ok, ov):
         c.free()

@@ -571,8 +571,9 @@ def test_join_host_rows_in_batches_go_home_behind_the_upload(hj, algorithm, pinn
     """hjgpu_join_host_rows with the probe side in batches (option "host_batch"): every batch's rows are made dense on the
     device and copied into the caller's columns while the next batch is joined; the batches' rows follow each other,
     the whole is the join row for row.  Duplicates on the build side (J != |S|); then a probe side whose matches sit
-    in ONE batch; then too small a capacity (the batched attempt is abandoned, the whole-column path reports
-    HJGPU_EOVERFLOW with the count, as without batches)."""
+    in ONE batch (that batch outgrows its device columns and is joined once more alone, into columns made for its rows);
+    then too small a capacity (the batched attempt is abandoned, the whole-column path reports HJGPU_EOVERFLOW with the
+    count, as without batches)."""
     with H.HjGpu() as ctx:
         ctx.set_option("host_batch", 300_000)
         rng = np.random.default_rng(177 + algorithm)
@@ -595,6 +596,7 @@ def test_join_host_rows_in_batches_go_home_behind_the_upload(hj, algorithm, pinn
         assert want2[0] > 0 and hit[300_000:].sum() < want2[0] // 4
         got2, st2, rows2 = ctx.join_host_rows(algorithm, ik, iv, ok2, ov, want2[0], pinned=pinned)
         assert got2 == want2 and len(rows2[0]) == want2[0]
+        assert st2["batches"] == 10      # round 4: the batch that outgrew its device columns was joined once more alone, nothing started over
         for a, b in zip(sort_rows(*rows2), materialised_rows(ik, iv, ok2, ov)):
             assert np.array_equal(a, b)
         with pytest.raises(H.HjGpuError) as e:
