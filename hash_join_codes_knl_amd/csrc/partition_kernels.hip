@@ -48,6 +48,8 @@
 //  12  pass 1: one private word re-read per tile by every thread (its value, 0, is added to a bin index), nothing else
 //  13  nothing changed in any kernel (control for the forensic instrumentation of hjgpu_multi.hip)
 //  14  variant 9 + s_waitcnt vmcnt(0) at the end of pass 1: no store is in flight when a wave ends
+//  17  K4 (hist2_kernel) carries the private word instead; 18 (join_kernels.hip): the join kernel does; 19: pass 2 does
+//      (variant 5 again, for tools/scratch_two_streams.py --what)
 //  15  variant 9 + the longest time between two tiles of a workgroup (was a wave ever switched out?); 16: the same without
 //      the private word
 // hjgpu_debug_scratch() returns the counters of variants 2-4.
@@ -146,6 +148,10 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
     for (int q = 0; q < 8; ++q) if (q == (int)chunk) { cb = geom.b[q]; ce = geom.b[q + 1]; }
     const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(keys - geom.align);
 
+#if HJ_SCRATCH_EXPERIMENT == 17
+    volatile uint32_t sy17[2];                          // variant 17: K4 carries one private word, written once, never read
+    sy17[0] = 0; sy17[1] = threadIdx.x;
+#endif
     for (uint32_t i = threadIdx.x; i < P + F1; i += BLOCK) lds_hist[i] = 0;     // fused histogram + range_hist
 
     // ranges are claimed from a per-chunk ticket counter (see K6: whoever runs, works); the next
@@ -1056,7 +1062,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         return c == 0 ? vq[j].x : c == 1 ? vq[j].y : c == 2 ? vq[j].z : vq[j].w;
     };
 
-#if HJ_SCRATCH_EXPERIMENT == 5 || HJ_SCRATCH_EXPERIMENT == 6
+#if HJ_SCRATCH_EXPERIMENT == 5 || HJ_SCRATCH_EXPERIMENT == 6 || HJ_SCRATCH_EXPERIMENT == 19
     volatile uint32_t sy[2];
     if (!RANGED) { sy[0] = 0; sy[1] = (uint32_t)tid; }
 #endif

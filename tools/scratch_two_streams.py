@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--n", type=int, default=125_000_000, help="tuples partitioned per step (one slice of the pipeline)")
     ap.add_argument("--fanout", type=int, default=192)
     ap.add_argument("--neighbour", type=int, default=1, help="0: nothing runs next to the partitioning")
+    ap.add_argument("--unpacked", action="store_true", help="hjgpu_partition_async (separate key / payload columns out: another stream-out path of K6) instead of the packed operator")
     ap.add_argument("--option", action="append", default=[], help="name=value, hjgpu_set_option on the PARTITIONING context (e.g. scatter_cfg=512,4,1)")
     a = ap.parse_args()
     import numpy as np
@@ -60,10 +61,19 @@ def main():
         with torch.cuda.stream(sA):
             for _ in range(4):                                    # several partition calls inside the neighbour's run
                 out.zero_()                                       # a slot that is not written stays 0
-                A.partition_packed_async(ok, ov, n, factor, F, out.data_ptr(), off.data_ptr(), sA.cuda_stream)
-            t = out[:n]
-            got_k = int(t.bitwise_and(0xFFFFFFFF).sum().item())
-            got_v = int((t >> 32).bitwise_and(0xFFFFFFFF).sum().item())
+                if a.unpacked:
+                    A.partition_async(ok, ov, n, factor, F, out.data_ptr(), out.data_ptr() + 4 * (n + 32), off.data_ptr(), sA.cuda_stream)
+                else:
+                    A.partition_packed_async(ok, ov, n, factor, F, out.data_ptr(), off.data_ptr(), sA.cuda_stream)
+            if a.unpacked:
+                o32 = out.view(torch.int32)
+                kk, vv = o32[:n].to(torch.int64).bitwise_and(0xFFFFFFFF), o32[n + 32:2 * n + 32].to(torch.int64).bitwise_and(0xFFFFFFFF)
+                got_k, got_v = int(kk.sum().item()), int(vv.sum().item())
+                t = kk + (vv << 32)
+            else:
+                t = out[:n]
+                got_k = int(t.bitwise_and(0xFFFFFFFF).sum().item())
+                got_v = int((t >> 32).bitwise_and(0xFFFFFFFF).sum().item())
             unwritten = int((t == 0).sum().item())
             where = (t == 0).nonzero().flatten()[:4096].tolist() if unwritten else []
         torch.cuda.synchronize()
