@@ -212,3 +212,41 @@ def test_counted_partitions_refuse_what_the_lds_histogram_cannot_hold(hj):
         assert e.value.status == H.api.EINVAL
     for c in (dk, dv, dt, do, dc):
         c.free()
+
+
+def test_partitioning_keeps_every_tuple_while_joins_run_on_another_stream():
+    """The condition under which a K6 pass-1 instance WITH a private segment lost ~1e-5 of its stores (DESIGN section 3,
+    profiles/r04_scratch_repro.txt: tools/scratch_two_streams.py, 23 of 40 steps wrong with one private word, 0 alone):
+    two independent contexts on one device, one partitioning on its stream while the other runs whole joins on a
+    second stream.  The shipped library has no private segment (tests/test_kernel_resources.py) and must lose
+    nothing: every output's 32-bit word sum equals the input's and no slot stays unwritten."""
+    import torch
+    a, b = H.HjGpu(0), H.HjGpu(0)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    inner, outer, n, fanout = 16_000_000, 256_000_000, 48_000_000, 192
+    ik, iv, ok, ov = b.column(inner), b.column(inner), b.column(outer), b.column(outer)
+    b.generate(1, inner, outer, 0, outer, 0x2545F491, 0x9E3779B1, ik, iv, ok, ov)
+    want_join = [outer, *b.column_sums(ok, outer, 0x9E3779B1, 0x2545F491)]
+    want_words = a.column_sums(ok, n, 1, 1)[0] + a.column_sums(ov, n, 1, 1)[0]
+    d_res = b.column(4, np.uint64)
+    off = a.column(fanout + 1, np.uint64)
+    out = torch.zeros(n + 64, dtype=torch.int64, device="cuda:0")       # zeroed before every call: a lost store stays 0
+    torch.cuda.synchronize()
+    for step in range(12):
+        for _ in range(2):
+            b.phj_async(ik, iv, inner, ok, ov, outer, None, d_res, sb.cuda_stream)
+        for _ in range(3):
+            with torch.cuda.stream(sa):
+                out.zero_()
+            a.partition_packed_async(ok, ov, n, FACTOR1, fanout, out.data_ptr(), off, sa.cuda_stream)
+        got_words = a.column_sums(out.data_ptr(), 2 * n, 1, 1, sa.cuda_stream)[0]
+        a.synchronize(sa.cuda_stream)
+        b.synchronize(sb.cuda_stream)
+        assert got_words == want_words, f"step {step}: the partitioned relation lost or changed tuples"
+        assert [int(x) for x in d_res.download()] == want_join, f"step {step}: the neighbouring join"
+        o = off.download().astype(np.int64)
+        assert o[0] == 0 and o[-1] == n and np.all(np.diff(o) >= 0)
+    for c in (ik, iv, ok, ov, d_res, off):
+        c.free()
+    a.close()
+    b.close()
