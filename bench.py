@@ -63,6 +63,8 @@ def parse(argv=None):
                     help="multi-GPU: CUs the partitioning kernels leave to RCCL's kernels (-1 = the library's default: 16 with > 1 rank)")
     ap.add_argument("--comm-option", action="append", default=[], metavar="NAME=VALUE",
                     help="communicator options for measurements (hjgpu_comm_set_option), e.g. cpra_k=24, cpra_two_level=1")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="context options for measurements (hjgpu_set_option), e.g. group_from=0, placement=12")
     ap.add_argument("--exchange-slices", type=int, default=0,
                     help="multi-GPU CPRA: pieces the probe side travels in (partition / all-to-all / join overlap); "
                          "0 = the library's choice: 4, or 1 in a world of one (nothing to overlap)")
@@ -394,6 +396,9 @@ def main():
         hj = comm.ctx[0]
     else:
         hj = H.HjGpu(local_rank)
+    for o in args.option:
+        name, _, value = o.partition("=")
+        hj.set_option(name, value)
     info = hj.device_info()
     inner, outer = args.inner, args.outer
     outer_total = outer * n_gpus
@@ -461,7 +466,7 @@ def main():
         torch.cuda.synchronize()
 
     phases = ["ms_total", "ms_histogram", "ms_plan", "ms_scatter1", "ms_scatter2", "ms_join",
-              "ms_build", "ms_close_gaps", "ms_inner_wait"]
+              "ms_build", "ms_close_gaps", "ms_inner_wait", "ms_scatter0"]
     per_step = {p: [] for p in phases}
     multi_steps = []
     preflight = None
@@ -526,11 +531,16 @@ def main():
     kernels = {}
     if args.algo in ("phj", "cpra"):
         two = st["fanout2"] > 1
+        groups = int(st.get("groups", 0))       # a grouped plan: pass 0 over both relations, then `groups` two-pass joins
         # a prepared build side (co-partitioned CPRA) is one call for R and one per probe slice: one launch each
         per_call = 1 if copart else 2
-        kernels["hist2_kernel"] = roof(4 * n_tuples, avg["ms_histogram"], per_call * jps, stream_read_gbs)
-        kernels["scatter_kernel"] = roof((2 if two else 1) * 16 * n_tuples, avg["ms_scatter1"] + avg["ms_scatter2"],
-                                         (2 if two else 1) * per_call * jps, stream_read_gbs)
+        kernels["hist2_kernel"] = roof(4 * n_tuples, avg["ms_histogram"], 2 * groups if groups else per_call * jps, stream_read_gbs)
+        if groups:       # (ms_scatter0 is the whole pass-0 operator, its histogram included: the fraction errs low)
+            kernels["scatter_kernel"] = roof(3 * 16 * n_tuples, avg["ms_scatter0"] + avg["ms_scatter1"] + avg["ms_scatter2"],
+                                             2 + 4 * groups, stream_read_gbs)
+        else:
+            kernels["scatter_kernel"] = roof((2 if two else 1) * 16 * n_tuples, avg["ms_scatter1"] + avg["ms_scatter2"],
+                                             (2 if two else 1) * per_call * jps, stream_read_gbs)
         kernels["join_kernel"] = roof(8 * n_tuples, avg["ms_join"], max(1, jps - 1) if copart else jps, stream_read_gbs)
     else:
         kernels["npj_build_kernel"] = roof(8 * inner + 8 * st["buckets"] + 8 * inner, avg["ms_build"], 1, stream_read_gbs)
@@ -561,12 +571,13 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s end-to-end (histogram + %s + LDS build/probe, aggregate output), "
                                "%s unique 32-bit keys, |R|=%d %s, |S|=%d per GPU, selectivity 1"
-                               % (args.algo.upper(), "2 scatter passes" if st["fanout2"] > 1 else "1 scatter pass",
+                               % (args.algo.upper(), ("3 scatter passes (%d groups)" % st["groups"]) if st.get("groups") else
+                                  "2 scatter passes" if st["fanout2"] > 1 else "1 scatter pass",
                                   "uniform" if args.zipf <= 0 else "Zipf(%g) probe side," % args.zipf, inner,
                                   "per GPU (co-partitioned)" if copart else "replicated", outer),
                    "algorithm": args.algo, "inner_tuples": inner, "outer_tuples_per_gpu": outer,
                    "outer_tuples_total": outer_total,
-                   "fanout": [st["fanout1"], st["fanout2"]],
+                   "fanout": [st["fanout1"], st["fanout2"]], "groups": int(st.get("groups", 0)),
                    "parallelism": parallelism},
         "roofline": roofline,
         "roofline_kernels": kernels,

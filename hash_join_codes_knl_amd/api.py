@@ -75,7 +75,8 @@ class Stats(C.Structure):
                 ("ms_scatter1", C.c_float), ("ms_scatter2", C.c_float), ("ms_join", C.c_float),
                 ("ms_build", C.c_float), ("ms_close_gaps", C.c_float),
                 ("ms_inner_wait", C.c_float), ("ms_upload", C.c_float), ("ms_download", C.c_float),
-                ("ms_reserve", C.c_float), ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("batches", C.c_uint32), ("buckets", C.c_uint64)]
+                ("ms_reserve", C.c_float), ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("batches", C.c_uint32), ("buckets", C.c_uint64),
+                ("ms_scatter0", C.c_float), ("groups", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

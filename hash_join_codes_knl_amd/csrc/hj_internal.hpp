@@ -67,6 +67,14 @@ struct HjTuning {
     // sum of fifteen 64 Mi-row joins - the wall clock is the upload's either way) and falls back to batches when they do not.
     // 0: never batch; n > 0: always, n rows per batch.
     long long host_batch = -1;
+    // Grouped plans (a third partitioning pass, hjgpu_api.hip phj_grouped): a build side of "group_from" tuples and more is
+    // first split, with the probe side, into key-disjoint groups of about "group_inner" build tuples (64 M: 8 K-slot tables well
+    // below their capacity; 1 G x 4 G: 68.1 ms against 72.4 at 100 M and 71.6 at 200 M, profiles/r04_grouped_sweep.txt), each joined by the
+    // two-pass plan (the reference plans up to four passes from the partition count, phj.cpp:1791-1808).  group_from 0 = never.
+    // "group_always" 1: every build side of group_from tuples and more (tests); 0: only where the cost estimate in
+    // grouped_groups() says the extra pass pays (several table fills per partition AND a probe side large enough).
+    long long group_from = 300000000, group_inner = 64000000;
+    bool group_always = false;
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned
@@ -214,9 +222,17 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     u64 *counts, uint32_t *range_counts, uint32_t *work_counter /* [chunks], zeroed */,
                     int cus, hipStream_t stream);
 // own_count > 0 (chunks == 1): partitions [own_first, own_first + own_count) are laid out behind all others
+// group_bins > 0 (chunks == 1, own_count == 0): groups of group_bins neighbouring partitions, each group on a 128-byte
+// line: group g (whose dense start is row `dense`) starts at row dense + hj_group_shift(dense, g)
 int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
                          uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream,
-                         uint32_t own_first = 0, uint32_t own_count = 0);
+                         uint32_t own_first = 0, uint32_t own_count = 0, uint32_t group_bins = 0);
+// 32 rows = one 128-byte line of a uint32 column.  Rounding the dense start up and adding one line per group keeps the
+// groups apart whatever their sizes: start(g + 1) - start(g) >= rows(g) - 31 + 32.
+__host__ __device__ inline u64 hj_group_shift(u64 dense_start, uint32_t g)
+{
+    return ((dense_start + 31) & ~(u64)31) - dense_start + (u64)32 * g;
+}
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream);
 // Batched partitioning of ONE relation (single chunk): the relation's pass-1 ranges are cut into batches of
 // `ranges_per_batch`; pass 1 of a batch writes into a small REUSED buffer (dense layout starting at 0) and pass 2 of

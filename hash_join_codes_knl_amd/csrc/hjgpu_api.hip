@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <vector>
 
 #include "hj_internal.hpp"
 
@@ -75,6 +76,10 @@ struct hjgpu_ctx {
     hjgpu_output pending_out;
     bool has_pending_out = false;
     bool last_had_output = false;   // hjgpu_get_async_status: the last enqueued join wrote result columns
+    // grouped plans (phj_grouped): pass-0 twins of the four columns, the groups' offsets, and the call's accumulated phase
+    // times (hjgpu_get_stats returns those while stats_override is set; any later operation's first event clears it)
+    DevBuf grp[4], grp_off;
+    bool stats_override = false;
     hipStream_t aux = nullptr;      // private non-blocking stream: placement probes of the workspace allocator
     float ms_reserve = 0;           // wall clock of the workspace growth so far (allocations + placement probes)
 };
@@ -222,6 +227,49 @@ struct ReserveClock {
     }
 };
 
+// grouped plans (phj_grouped below): how many groups, their pass-0 layout, the pass-0 twins
+const uint32_t DEFAULT_F0 = 0x7FEB352Du;
+
+uint32_t grouped_groups(const hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm)
+{
+    if (prm && (prm->fanout1 || prm->fanout2)) return 0;            // an explicit plan is honoured
+    const size_t from = (size_t)ctx->tune.group_from, per = (size_t)ctx->tune.group_inner;
+    if (!from || inner < from) return 0;
+    if (!ctx->tune.group_always) {
+        // Does the extra pass pay?  Measured on one MI355X (profiles/r04_grouped_sweep.txt): beyond two passes' reach
+        // (HJGPU_MAX_PARTS 16 K-slot tables at 0.85 of their capacity) every further table fill of a partition probes the
+        // partition's probe tuples again, ~3.2 ms per 10^9 probe tuples and fill; pass 0 plus what G smaller joins lose to
+        // their shorter launches is ~5 ms per 10^9 tuples of BOTH relations.  (The build itself - 6-8 ms per 10^9 build
+        // tuples, small work items bound by latency - costs the same either way.)
+        const double reach = (double)HJGPU_MAX_PARTS * hj_join_config_big().cap() * 0.85;
+        const double fills = (double)inner / reach;
+        if ((fills - 1.0) * 3.2 * (double)outer < 1.1 * 5.0 * ((double)inner + (double)outer)) return 0;
+    }
+    return (uint32_t)std::min<size_t>((inner + per - 1) / per, 192);
+}
+
+struct GroupLayout { uint32_t G, bins, F0; };
+GroupLayout group_layout(uint32_t G)
+{
+    GroupLayout l;
+    l.G = G;
+    l.bins = (64 + G - 1) / G;          // never fewer than 64 bins in K4 / K6 (choose_fanout)
+    l.F0 = G * l.bins;                  // <= 255: pass 0 keeps the whole-line carry and its large tiles
+    return l;
+}
+
+int grouped_twins(hjgpu_ctx *ctx, const GroupLayout &l, size_t inner, size_t outer)
+{
+    const size_t pad = (size_t)32 * (l.G + 2) + 64;
+    CHK(ensure_placed(ctx, ctx->grp[0], (inner + pad) * sizeof(uint32_t)));
+    CHK(ensure_placed(ctx, ctx->grp[1], (inner + pad) * sizeof(uint32_t)));
+    CHK(ensure_placed(ctx, ctx->grp[2], (outer + pad) * sizeof(uint32_t)));
+    CHK(ensure_placed(ctx, ctx->grp[3], (outer + pad) * sizeof(uint32_t)));
+    CHK(ensure(ctx, ctx->grp_off, (size_t)2 * (l.F0 + 1) * sizeof(u64)));
+    return HJGPU_OK;
+}
+
+
 // K6 occupies a CU completely (one 1024-thread workgroup with ~155 KiB of LDS that lives until the pass ends): a kernel
 // that arrives during a pass - RCCL's, on the multi-GPU path - finds no CU until the pass is over.  "reserve_cus" keeps
 // some CUs out of K6's grid (work is claimed from a ticket counter, so any grid size finishes the pass).
@@ -341,6 +389,7 @@ void choose_fanout(const HjTuning &tune, size_t inner, const hjgpu_phj_params *p
 
 void record(hjgpu_ctx *ctx, int which, hipStream_t s)
 {
+    if (which == EV_BEGIN) ctx->stats_override = false;
     ctx->ev_valid[which] = (hipEventRecord(ctx->ev[which], s) == hipSuccess);
 }
 
@@ -1005,7 +1054,7 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     (void)hipDeviceSynchronize();
     DevBuf *all[] = {&ctx->tmp[0], &ctx->tmp[1], &ctx->tmp[2], &ctx->tmp[3], &ctx->tmp[4], &ctx->tmp[5],
                      &ctx->tmp[6], &ctx->tmp[7], &ctx->meta, &ctx->table, &ctx->state, &ctx->moves,
-                     &ctx->final_offsets};
+                     &ctx->final_offsets, &ctx->grp[0], &ctx->grp[1], &ctx->grp[2], &ctx->grp[3], &ctx->grp_off};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
@@ -1054,7 +1103,14 @@ int hjgpu_reserve(hjgpu_ctx *ctx, size_t inner, size_t outer)
     PhjPlan pl;
     hjgpu_phj_params prm;
     memset(&prm, 0, sizeof(prm));
-    CHK(phj_prepare(ctx, inner, outer, &prm, 8, &pl));     // 8 chunks = largest meta
+    const uint32_t groups = grouped_groups(ctx, inner, outer, nullptr);
+    if (groups > 1 && outer) {
+        // a grouped plan: the pass-0 twins, and the two-pass workspace for ONE group (10 % above the mean group)
+        ReserveClock clock(ctx);
+        CHK(grouped_twins(ctx, group_layout(groups), inner, outer));
+        CHK(phj_prepare(ctx, inner / groups + inner / groups / 10, outer / groups + outer / groups / 10, &prm, 8, &pl));
+    } else
+        CHK(phj_prepare(ctx, inner, outer, &prm, 8, &pl));     // 8 chunks = largest meta
     size_t buckets; uint32_t factor;
     CHK(npj_prepare(ctx, inner, nullptr, &buckets, &factor));
     return HJGPU_OK;
@@ -1063,6 +1119,11 @@ int hjgpu_reserve(hjgpu_ctx *ctx, size_t inner, size_t outer)
 int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
 {
     if (!ctx || !s) return HJGPU_EINVAL;
+    if (ctx->stats_override) {               // a grouped plan: the sums over pass 0 and the groups' joins, taken as they finished
+        *s = ctx->stats;
+        s->ms_reserve = ctx->ms_reserve;
+        return HJGPU_OK;
+    }
     if (ctx->ev_valid[EV_GAPS]) HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
     auto span = [&](int a, int b) -> float {
         float ms = 0;
@@ -1095,6 +1156,7 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
         r.ms_build = 0;
     }
     r.ms_close_gaps = span(EV_JOIN, EV_GAPS);
+    r.ms_scatter0 = 0; r.groups = 0;
     *s = r;
     return HJGPU_OK;
 }
@@ -1236,9 +1298,11 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
     return HJGPU_OK;
 }
 
-int hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                          uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
-                          uint64_t *d_offsets, void *stream_)
+// group_bins > 0: the partitions in groups of group_bins neighbours, every group on a 128-byte line (hj_group_shift; the
+// columns then need room for n + 32 * (groups + 1) rows); d_offsets stay the dense prefix of the counts
+static int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                             uint32_t factor, uint32_t fanout, uint32_t group_bins, uint32_t *d_keys_out, uint32_t *d_vals_out,
+                             uint64_t *d_offsets, void *stream_)
 {
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
@@ -1275,7 +1339,7 @@ int hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t
     CHK(hj_launch_plan(pa, stream));
     if (n) {
         CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
-                                 geom.ranges_per_chunk, fanout, stream));
+                                 geom.ranges_per_chunk, fanout, stream, 0, 0, group_bins));
         ScatterArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
@@ -1289,6 +1353,13 @@ int hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t
                                hipMemcpyDeviceToDevice, stream));
     record(ctx, EV_GAPS, stream);
     return HJGPU_OK;
+}
+
+int hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
+                          uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
+                          uint64_t *d_offsets, void *stream_)
+{
+    return partition_columns(ctx, d_keys, d_vals, n, factor, fanout, 0, d_keys_out, d_vals_out, d_offsets, stream_);
 }
 
 int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
@@ -1547,6 +1618,97 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     return HJGPU_OK;
 }
 
+// ---- grouped plans: a third partitioning pass in front of the two-pass join ------------------------------------------
+// Two passes end at HJGPU_MAX_PARTS partitions (K4's LDS histogram): with 16 K-slot tables that is a build side of ~228 M
+// tuples; beyond it every partition's table is filled several times and the partition's probe tuples are probed once per
+// fill (1 G x 1 G: join phase 22 ms of 36, profiles/r04_big_build_before.txt).  The reference adds passes instead
+// (1-4 passes of equal fan-out from the partition count, phj.cpp:1791-1808).  Here: PASS 0 splits both relations by an
+// independent hash into G key-disjoint groups (the partition operator, fan-out >= 64 in G groups of neighbouring bins, every
+// group on a 128-byte line so that its columns can be handed to the two-pass plan as they are), then the groups are joined
+// one after the other by the plain plan, and their aggregates (and rows) added up.  One more read + write of both
+// relations buys single-fill tables in every group.
+static int phj_grouped(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks,
+                       const uint32_t *rk, const uint32_t *rv, size_t inner,
+                       const uint32_t *sk, const uint32_t *sv, size_t outer,
+                       const hjgpu_phj_params *prm, const hjgpu_output *out, hipStream_t stream)
+{
+    const GroupLayout l = group_layout(G);
+    {
+        ReserveClock clock(ctx);
+        CHK(grouped_twins(ctx, l, inner, outer));
+    }
+    uint32_t *g_rk = (uint32_t *)ctx->grp[0].p, *g_rv = (uint32_t *)ctx->grp[1].p;
+    uint32_t *g_sk = (uint32_t *)ctx->grp[2].p, *g_sv = (uint32_t *)ctx->grp[3].p;
+    u64 *d_off = (u64 *)ctx->grp_off.p;
+    hjgpu_stats sum, one;
+    memset(&sum, 0, sizeof(sum));
+    // pass 0: the probe side first, like the join itself (a build side that is still arriving is not supported here)
+    CHK(partition_columns(ctx, sk, sv, outer, DEFAULT_F0, l.F0, l.bins, g_sk, g_sv, reinterpret_cast<uint64_t *>(d_off + (l.F0 + 1)), stream));
+    CHK(hjgpu_get_stats(ctx, &one));
+    sum.ms_scatter0 += one.ms_total;
+    CHK(partition_columns(ctx, rk, rv, inner, DEFAULT_F0, l.F0, l.bins, g_rk, g_rv, reinterpret_cast<uint64_t *>(d_off), stream));
+    std::vector<u64> off((size_t)2 * (l.F0 + 1));
+    HIPCHK(ctx, hipMemcpyAsync(off.data(), d_off, off.size() * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    CHK(hjgpu_get_stats(ctx, &one));                        // waits for the operator's last event
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    sum.ms_scatter0 += one.ms_total;
+    const u64 *roff = off.data(), *soff = off.data() + (l.F0 + 1);
+    struct Piece { u64 r0, rn, s0, sn; };
+    std::vector<Piece> pc(G);
+    size_t max_r = 0, max_s = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        const u64 rb = roff[(size_t)g * l.bins], re = roff[(size_t)(g + 1) * l.bins];
+        const u64 sb = soff[(size_t)g * l.bins], se = soff[(size_t)(g + 1) * l.bins];
+        pc[g] = Piece{rb + hj_group_shift(rb, g), re - rb, sb + hj_group_shift(sb, g), se - sb};
+        max_r = std::max<size_t>(max_r, pc[g].rn); max_s = std::max<size_t>(max_s, pc[g].sn);
+    }
+    // one workspace for the largest group (no growth, and no placement search, from group to group)
+    PhjPlan pl;
+    CHK(phj_prepare(ctx, max_r, max_s, prm, chunks, &pl));
+    DevState acc;
+    memset(&acc, 0, sizeof(acc));
+    bool out_on = out && out->d_keys;
+    const u64 bs = out_on ? (out->block_size ? out->block_size : 65536) : 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        if (pc[g].sn == 0 || pc[g].rn == 0) continue;       // nothing can match
+        hjgpu_output view;
+        const hjgpu_output *vout = nullptr;
+        if (out_on) {
+            // the group's rows go behind the rows so far: its close_gaps makes [0, count) of the view dense
+            const u64 left = out->capacity > acc.dense ? out->capacity - acc.dense : 0;
+            if (left / bs == 0) { acc.overflow = 1; out_on = false; }
+            else {
+                view = *out;
+                view.d_keys += acc.dense; view.d_outer_vals += acc.dense; view.d_inner_vals += acc.dense;
+                view.capacity = left / bs * bs; view.block_size = bs;
+                vout = &view;
+            }
+        }
+        CHK(phj_prepare(ctx, pc[g].rn, pc[g].sn, prm, chunks, &pl));
+        CHK(phj_enqueue(ctx, pl, g_rk + pc[g].r0, g_rv + pc[g].r0, pc[g].rn, g_sk + pc[g].s0, g_sv + pc[g].s0, pc[g].sn,
+                        vout, stream));
+        DevState h;
+        HIPCHK(ctx, hipMemcpyAsync(&h, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+        HIPCHK(ctx, hipStreamSynchronize(stream));
+        CHK(hjgpu_get_stats(ctx, &one));
+        sum.ms_histogram += one.ms_histogram; sum.ms_plan += one.ms_plan; sum.ms_scatter1 += one.ms_scatter1;
+        sum.ms_scatter2 += one.ms_scatter2; sum.ms_join += one.ms_join; sum.ms_close_gaps += one.ms_close_gaps;
+        sum.fanout1 = one.fanout1; sum.fanout2 = one.fanout2;
+        acc.result.count += h.result.count; acc.result.sum_keys += h.result.sum_keys;
+        acc.result.sum_outer_vals += h.result.sum_outer_vals; acc.result.sum_inner_vals += h.result.sum_inner_vals;
+        if (h.overflow) { acc.overflow = 1; out_on = false; }          // the counts stay exact; no rows from here on
+        else if (vout) acc.dense += h.dense;
+    }
+    // the call's result where every entry point looks for it
+    HIPCHK(ctx, hipMemcpy(ctx->state.p, &acc, sizeof(DevState), hipMemcpyHostToDevice));
+    sum.ms_total = sum.ms_scatter0 + sum.ms_histogram + sum.ms_plan + sum.ms_scatter1 + sum.ms_scatter2 + sum.ms_join + sum.ms_close_gaps;
+    sum.groups = G;
+    ctx->stats = sum;
+    ctx->stats_override = true;
+    ctx->last_algo = 1;
+    return HJGPU_OK;
+}
+
 static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
                     const uint32_t *rk, const uint32_t *rv, size_t inner,
                     const uint32_t *sk, const uint32_t *sv, size_t outer,
@@ -1562,7 +1724,12 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
     ctx->last_had_output = out && out->d_keys;
-    if (broadcast_applies(ctx->tune, inner, outer, chunks, prm)) {
+    const uint32_t groups = inner_ready ? 0 : grouped_groups(ctx, inner, outer, prm);
+    if (groups > 1 && outer) {
+        // (the host waits for pass 0 and for every group inside this call, also in the *_async forms: the groups' sizes
+        // are known on the device only)
+        CHK(phj_grouped(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, stream));
+    } else if (broadcast_applies(ctx->tune, inner, outer, chunks, prm)) {
         CHK(broadcast_enqueue(ctx, rk, rv, inner, sk, sv, outer, prm, out, stream, (hipEvent_t)inner_ready));
     } else {
         PhjPlan pl;

@@ -457,12 +457,14 @@ int hj_launch_row_sums(const u64 *counts, uint32_t F1, uint32_t F2, u64 *out, hi
 // --------------------------------------------------------------------------
 // K5b: per-range write bases of pass 1.  One workgroup per (chunk, partition):
 // base[range][p] = off1[chunk][p] + sum of the counts of earlier ranges of the chunk.
+// group_bins > 0 (one chunk; the grouped plans' pass 0, hjgpu_api.hip): the partitions are laid out in GROUPS of group_bins
+// neighbours, dense inside a group, every group starting on a 128-byte line: group g moves up by hj_group_shift().
 // own_count > 0 (one chunk; hjgpu_partition_packed_own_last_async): partitions [own_first, own_first + own_count) are
 // laid out LAST, behind all others (which keep their order) - off1 stays the plain prefix of the counts.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void range_base_kernel(
     const uint32_t *__restrict__ range_counts, const u64 *__restrict__ off1,
-    u64 *__restrict__ range_base, uint32_t Rc, uint32_t F1, uint32_t own_first, uint32_t own_count)
+    u64 *__restrict__ range_base, uint32_t Rc, uint32_t F1, uint32_t own_first, uint32_t own_count, uint32_t group_bins)
 {
     __shared__ u64 scratch[256 / 64 + 1];
     const uint32_t c = blockIdx.x / F1, p = blockIdx.x - c * F1;
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256) void range_base_kernel(
         if (p >= own_first + own_count) first -= oe - ob;
         else if (p >= own_first) first = n - (oe - ob) + (first - ob);
     }
+    if (group_bins) first += hj_group_shift(off1[p / group_bins * group_bins], p / group_bins);
     u64 run = first + block_exclusive_scan<256, u64>(sum, scratch);
     for (uint32_t j = lo; j < hi; ++j) {
         range_base[(row0 + j) * F1 + p] = run;
@@ -486,11 +489,12 @@ __global__ __launch_bounds__(256) void range_base_kernel(
 
 int hj_launch_range_base(const uint32_t *range_counts, const u64 *off1, u64 *range_base,
                          uint32_t chunks, uint32_t ranges_per_chunk, uint32_t F1, hipStream_t stream,
-                         uint32_t own_first, uint32_t own_count)
+                         uint32_t own_first, uint32_t own_count, uint32_t group_bins)
 {
     if (own_count && (chunks != 1 || (u64)own_first + own_count > F1)) return HJGPU_EINVAL;
+    if (group_bins && (chunks != 1 || own_count)) return HJGPU_EINVAL;
     hipLaunchKernelGGL(range_base_kernel, dim3(chunks * F1), dim3(256), 0, stream, range_counts,
-                       off1, range_base, ranges_per_chunk, F1, own_first, own_count);
+                       off1, range_base, ranges_per_chunk, F1, own_first, own_count, group_bins);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
@@ -1640,6 +1644,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("unique")) return parse_flag(value, &t->unique);
     if (is("merged_plan")) return parse_flag(value, &t->merged_plan);
     if (is("piece_interleave")) return parse_flag(value, &t->piece_interleave);
+    if (is("group_always")) return parse_flag(value, &t->group_always);
     if (is("placement")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1659,6 +1664,13 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
         const long long x = strtoll(value, &end, 10);
         if (end == value || *end || x < -1) return false;
         t->host_batch = x;
+        return true;
+    }
+    if (is("group_from") || is("group_inner")) {
+        char *end = nullptr;
+        const long long x = strtoll(value, &end, 10);
+        if (end == value || *end || x < 0 || (is("group_inner") && x < 1)) return false;
+        (is("group_from") ? t->group_from : t->group_inner) = x;
         return true;
     }
     if (is("batch_tuples")) {
@@ -1696,7 +1708,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "host_batch", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

@@ -120,6 +120,11 @@ typedef struct {
                                   back to back, its intermediate copy kept in the Infinity Cache; their
                                   time is reported as ms_scatter1, ms_scatter2 = 0); 0 = unbatched    */
     uint64_t buckets;          /* NPJ table size                                             */
+    float    ms_scatter0;      /* grouped plans (a build side of option "group_from" tuples and more, the reference's
+                                  third pass, phj.cpp:1791-1808): pass 0, both relations split into `groups`
+                                  key-disjoint groups; every other phase is then the SUM over the groups' joins,
+                                  ms_total the sum of all of it                                              */
+    uint32_t groups;           /* 0 = the plain two-pass plan                                */
 } hjgpu_stats;
 
 typedef struct {
@@ -147,7 +152,8 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * including the operator-level hjgpu_npj_probe), "force_chained", "no_broadcast", "dense2", "npj_refhash",
  * "scatter_prof" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
  * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
- * twin, 1..16); "batch_tuples" (n, 0 = off).  Unknown names and malformed values: HJGPU_EINVAL. */
+ * twin, 1..16); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples) and "group_always" (0 / 1): the
+ * grouped plans of hjgpu_phj / hjgpu_cpra (below).  Unknown names and malformed values: HJGPU_EINVAL. */
 int  hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value);
 /* Pre-size the internal workspace (partition scratch twins = hj.h's [1]
  * columns, NPJ table) so that no allocation happens inside a timed join. */
@@ -220,7 +226,12 @@ int  hjgpu_npj(hjgpu_ctx *ctx,
                const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,
                const hjgpu_npj_params *params,
                hjgpu_result *result, const hjgpu_output *out, void *stream);
-/* run_hj(), phj.cpp:1646-1949 */
+/* run_hj(), phj.cpp:1646-1949.  Passes (phj.cpp:1791-1808 plans 1-4 of equal fan-out from the partition count): one
+ * or two passes up to HJGPU_MAX_PARTS partitions; a build side beyond their reach (~228 M tuples) whose probe side is
+ * large enough for a further pass to pay is joined by a GROUPED plan - pass 0 splits both relations into key-disjoint
+ * groups of about "group_inner" (64 M) build tuples, each joined by the two-pass plan, aggregates and rows added up
+ * (hjgpu_stats.groups / ms_scatter0).  A grouped call waits on the host for pass 0 and for every group, also in its
+ * *_async form; explicit fan-outs in params are never grouped; option "group_from" = 0 turns the plan off. */
 int  hjgpu_phj(hjgpu_ctx *ctx,
                const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
                const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,

@@ -1,0 +1,153 @@
+"""GPU tests of the grouped plans (a third partitioning pass: hjgpu_api.hip phj_grouped; the reference plans up to four
+passes from the partition count, phj.cpp:1791-1808).  The options "group_from" / "group_inner" bring the plan down to
+test sizes: both relations are split into key-disjoint groups by pass 0, every group is joined by the two-pass plan,
+and aggregates and rows must equal the oracle's / the definition's - the same bar as the plain plan (bit-exact)."""
+import numpy as np
+import pytest
+
+import hash_join_codes_knl_amd as H
+from helpers import numpy_join, materialised_rows, sort_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def grouped(hj):
+    """a context whose plans are grouped from 1000 build tuples on (after the session's context: torch, where it is
+    installed, has to initialise the GPU first - conftest.py)"""
+    ctx = H.HjGpu()
+    ctx.set_option("group_from", "1000")
+    ctx.set_option("group_always", "1")
+    yield ctx
+    ctx.close()
+
+
+def _cols(hj, *arrays):
+    return [hj.column(a) for a in arrays]
+
+
+def _free(*cols):
+    for c in cols:
+        c.free()
+
+
+SHAPES = {
+    # name: (outer, inner, selectivity, seed)
+    "unique": (400_000, 120_000, 1.0, 11),
+    "build_dups": (30_000, 240_000, 1.0, 12),           # 8 copies of every build key
+    "half": (250_000, 90_000, 0.5, 13),
+    "none": (50_000, 20_000, 0.0, 14),
+    "probe_small": (900, 60_000, 1.0, 15),
+}
+
+
+@pytest.mark.parametrize("groups", [2, 7, 64, 192])
+@pytest.mark.parametrize("shape", list(SHAPES))
+@pytest.mark.parametrize("algo", ["phj", "cpra"])
+def test_grouped_aggregates_equal_the_definition(grouped, oracle, algo, shape, groups):
+    outer, inner, sel, seed = SHAPES[shape]
+    ik, iv, ok, ov = oracle.generate(outer, inner, selectivity=sel, seed=seed)
+    want = numpy_join(ik, iv, ok, ov)
+    per = -(-len(ik) // groups)
+    groups = -(-len(ik) // per)
+    grouped.set_option("group_inner", str(per))
+    rk, rv, sk, sv = _cols(grouped, ik, iv, ok, ov)
+    got = getattr(grouped, algo)(rk, rv, len(ik), sk, sv, len(ok))
+    st = grouped.stats()
+    _free(rk, rv, sk, sv)
+    assert got == want
+    assert st["groups"] == groups and st["ms_scatter0"] > 0 and st["ms_total"] >= st["ms_scatter0"] + st["ms_join"]
+
+
+def test_the_plain_plan_reports_no_groups(hj, oracle):
+    ik, iv, ok, ov = oracle.generate(20_000, 5_000, seed=3)
+    rk, rv, sk, sv = _cols(hj, ik, iv, ok, ov)
+    assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == numpy_join(ik, iv, ok, ov)
+    st = hj.stats()
+    _free(rk, rv, sk, sv)
+    assert st["groups"] == 0 and st["ms_scatter0"] == 0
+
+
+@pytest.mark.parametrize("groups", [3, 40])
+@pytest.mark.parametrize("shape", ["unique", "build_dups", "half"])
+def test_grouped_rows_equal_the_definition(grouped, oracle, shape, groups):
+    outer, inner, sel, seed = SHAPES[shape]
+    ik, iv, ok, ov = oracle.generate(outer, inner, selectivity=sel, seed=seed)
+    want = numpy_join(ik, iv, ok, ov)
+    wk, wo, wi = materialised_rows(ik, iv, ok, ov)
+    grouped.set_option("group_inner", str(-(-len(ik) // groups)))
+    block = 256
+    capacity = grouped.output_capacity(1, len(ok), want[0], block)
+    rk, rv, sk, sv = _cols(grouped, ik, iv, ok, ov)
+    jk, jo, ji = grouped.column(capacity), grouped.column(capacity), grouped.column(capacity)
+    got = grouped.phj(rk, rv, len(ik), sk, sv, len(ok), None, out=(jk, jo, ji, capacity, block))
+    assert got == want
+    n = got[0]
+    gk, go, gi = sort_rows(jk.download(n), jo.download(n), ji.download(n))
+    _free(rk, rv, sk, sv, jk, jo, ji)
+    assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi)
+
+
+def test_grouped_rows_that_do_not_fit_are_reported_with_exact_counts(grouped, oracle):
+    ik, iv, ok, ov = oracle.generate(200_000, 50_000, seed=21)
+    want = numpy_join(ik, iv, ok, ov)
+    grouped.set_option("group_inner", "10000")
+    rk, rv, sk, sv = _cols(grouped, ik, iv, ok, ov)
+    cap = 256 * 300                                        # room for the first group or two only
+    jk, jo, ji = grouped.column(cap), grouped.column(cap), grouped.column(cap)
+    with pytest.raises(H.HjGpuError) as e:
+        grouped.phj(rk, rv, len(ik), sk, sv, len(ok), None, out=(jk, jo, ji, cap, 256))
+    assert e.value.status == H.api.EOVERFLOW
+    # the same call through the asynchronous form: the device-side result holds the exact aggregates
+    d_res = grouped.column(4, np.uint64)
+    grouped.set_async_output((jk, jo, ji, cap, 256))
+    grouped.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, d_res)
+    with pytest.raises(H.HjGpuError) as e:
+        grouped.get_async_status()
+    assert e.value.status == H.api.EOVERFLOW
+    assert tuple(int(x) for x in d_res.download()) == want
+    _free(rk, rv, sk, sv, jk, jo, ji, d_res)
+
+
+def test_grouped_first_match_only(grouped, oracle):
+    """HJGPU_FLAG_UNIQUE (-D_UNIQUE, phj.cpp:635-637): the groups are key-disjoint, so first-match-only inside every
+    group is first-match-only of the whole join: every probe tuple with a partner counts once"""
+    ik, iv, ok, ov = oracle.generate(40_000, 320_000, seed=31)          # 8 copies per build key
+    grouped.set_option("group_inner", "40000")
+    rk, rv, sk, sv = _cols(grouped, ik, iv, ok, ov)
+    count, sum_keys, sum_outer, _ = grouped.phj(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(flags=H.api.FLAG_UNIQUE))
+    _free(rk, rv, sk, sv)
+    hit = np.isin(ok, ik)
+    assert count == int(hit.sum())
+    assert sum_keys == int(ok[hit].astype(np.uint64).sum()) and sum_outer == int(ov[hit].astype(np.uint64).sum())
+
+
+def test_an_explicit_plan_is_never_grouped(grouped, oracle):
+    ik, iv, ok, ov = oracle.generate(60_000, 20_000, seed=41)
+    grouped.set_option("group_inner", "5000")
+    rk, rv, sk, sv = _cols(grouped, ik, iv, ok, ov)
+    assert grouped.phj(rk, rv, len(ik), sk, sv, len(ok), H.PhjParams(fanout1=8, fanout2=4)) == numpy_join(ik, iv, ok, ov)
+    st = grouped.stats()
+    _free(rk, rv, sk, sv)
+    assert st["groups"] == 0 and (st["fanout1"], st["fanout2"]) == (8, 4)
+
+
+def test_grouped_plan_at_a_size_it_is_chosen_for_by_default(hj):
+    """|R| = 900 M unique build keys (four table fills per partition in two passes), |S| = 2.6 G: the default options
+    group this join (15 groups of about 64 M build tuples); aggregates are analytic (selectivity 1: every probe tuple matches once).  The same build
+    side with |S| = 500 M stays with the two-pass plan: the extra pass would cost more than the fills it saves."""
+    hj = H.HjGpu()                                         # its own context: the workspace goes away with it
+    inner, outer = 900_000_000, 2_600_000_000
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(7, inner, outer, 0, outer, 0x2545F491, 0x9E3779B1, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, 0x9E3779B1, 0x2545F491)
+    got = hj.phj(ik, iv, inner, ok, ov, outer)
+    st = hj.stats()
+    small = 500_000_000
+    sums_small = hj.column_sums(ok, small, 0x9E3779B1, 0x2545F491)
+    got_small = hj.phj(ik, iv, inner, ok, ov, small)
+    st_small = hj.stats()
+    _free(ik, iv, ok, ov)
+    hj.close()
+    assert got == (outer, sums[0], sums[1], sums[2]) and st["groups"] == 15
+    assert got_small == (small, sums_small[0], sums_small[1], sums_small[2]) and st_small["groups"] == 0

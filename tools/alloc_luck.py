@@ -2,7 +2,7 @@
 """K6 pass 1 takes 2.9 or 3.3-3.4 ms on the same data depending on WHICH allocation its output twin lives in (the
 virtual offset inside an allocation does not matter: profiles/r02_shift_sweep.txt).  This looks at the distribution:
 contexts created one after the other (each frees its workspace before the next is made: `serial`) or kept alive
-(`stacked`: every new workspace lands somewhere else).  usage: python tools/alloc_luck.py [serial|stacked] [n] [phj|npj|cpra]"""
+(`stacked`: every new workspace lands somewhere else).  usage: python tools/alloc_luck.py [serial|stacked] [n] [phj|npj|cpra]; HJGPU_PLACEMENT=<n>: option "placement" of every context"""
 import os
 import sys
 
@@ -21,6 +21,8 @@ want = (outer, sums[0], sums[1], sums[2])
 keep = []
 for i in range(n):
     c = H.HjGpu(0)
+    if os.environ.get("HJGPU_PLACEMENT"):
+        c.set_option("placement", os.environ["HJGPU_PLACEMENT"])
     best = None
     for _ in range(4):
         assert getattr(c, algo)(ik, iv, inner, ok, ov, outer) == want
@@ -28,8 +30,8 @@ for i in range(n):
         key = "ms_scatter1" if algo != "npj" else "ms_total"
         if best is None or st[key] < best[key]:
             best = st
-    print("%s context %d: scatter1 %.3f scatter2 %.3f hist %.3f join %.3f build %.3f total %.3f"
-          % (mode, i, best["ms_scatter1"], best["ms_scatter2"], best["ms_histogram"], best["ms_join"], best["ms_build"], best["ms_total"]), flush=True)
+    print("%s context %d: scatter1 %.3f scatter2 %.3f hist %.3f join %.3f build %.3f total %.3f reserve %.1f"
+          % (mode, i, best["ms_scatter1"], best["ms_scatter2"], best["ms_histogram"], best["ms_join"], best["ms_build"], best["ms_total"], best["ms_reserve"]), flush=True)
     if mode == "stacked" and i < 6:
         keep.append(c)
     else:

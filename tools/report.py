@@ -21,6 +21,10 @@ ROWS = [
     ("PHJ 1 M x 1 G (one pass)", ["--inner", "1000000", "--outer", "1000000000"]),
     ("PHJ 8 M x 1 G (two passes)", ["--inner", "8000000", "--outer", "1000000000"]),
     ("PHJ 200 M x 1 G (two table fills per partition)", ["--inner", "200000000", "--outer", "1000000000", "--steps", "5"]),
+    ("PHJ 1 G x 4 G (grouped plan: pass 0 into 16 groups, then 16 two-pass joins)",
+     ["--inner", "1000000000", "--outer", "4000000000", "--steps", "3", "--warmup", "1"]),
+    ("PHJ 1 G x 4 G, option group_from=0 (two passes, 4-5 table fills per partition)",
+     ["--inner", "1000000000", "--outer", "4000000000", "--steps", "3", "--warmup", "1", "--option", "group_from=0"]),
     ("PHJ 128 M x 2.2 G (16 K-slot tables)", ["--inner", "128000000", "--outer", "2200000000", "--steps", "5"]),
     ("CPRA 128 M x 2 G, 8 chunks (one GPU's share of configs[4] after the exchange)",
      ["--algo", "cpra", "--inner", "128000000", "--outer", "2000000000", "--steps", "5"]),
@@ -28,26 +32,28 @@ ROWS = [
 
 
 def row(name, ms, outer, ok, fan, ph, join_ms):
-    print("| %s | %.2f | %.1f | %s | %s | %.2f | %.2f | %.2f | %.2f | %.2f |" % (
-        name, ms, outer / ms / 1e6, ok, fan, ph.get("ms_histogram", 0), ph.get("ms_plan", 0), ph.get("ms_scatter1", 0),
-        ph.get("ms_scatter2", 0), join_ms), flush=True)
+    print("| %s | %.2f | %.1f | %s | %s | %.2f | %.2f | %.2f | %.2f | %.2f | %.2f |" % (
+        name, ms, outer / ms / 1e6, ok, fan, ph.get("ms_scatter0", 0), ph.get("ms_histogram", 0), ph.get("ms_plan", 0),
+        ph.get("ms_scatter1", 0), ph.get("ms_scatter2", 0), join_ms), flush=True)
 
 
 def main():
-    print("| Workload | ms / step | Gtuples/s | checksum | fan-out | hist | plan | scatter 1 | scatter 2 | join |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
+    print("| Workload | ms / step | Gtuples/s | checksum | fan-out | pass 0 | hist | plan | scatter 1 | scatter 2 | join |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     for name, extra in ROWS:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--cpu-outer", "0"]
         cmd += ["--no-secondary"] + extra if extra is not None else []
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if p.returncode != 0 or not lines:
-            print("| %s | FAILED (%d) | | | | | | | | |" % (name, p.returncode), flush=True)
+            print("| %s | FAILED (%d) | | | | | | | | | |" % (name, p.returncode), flush=True)
             continue
         b = json.loads(lines[-1])
         ph = b["phase_ms"]
         outer = b["config"]["outer_tuples_per_gpu"]
         fan = "x".join(str(f) for f in b["config"]["fanout"])
+        if b["config"].get("groups"):
+            fan = "%d groups, each %s" % (b["config"]["groups"], fan)
         row(name, b["ms_per_step"], outer, b["checksum_ok"], fan, ph, ph["ms_join"] + ph["ms_build"])
         if extra is None:
             m, sec = b["materialized"], b["secondary"]
