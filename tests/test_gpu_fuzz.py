@@ -96,7 +96,30 @@ def test_random_join_matches_numpy(hj, case):
                 assert np.array_equal(a, b)
             for c in (jk, jo, ji):
                 c.free()
+        # the same join by a grouped plan (pass 0 + one planned join per group, phj.cpp:1791-1808): aggregates, and rows
+        groups = int(rng.integers(2, 41))
+        hj.set_option("group_from", 1)
+        hj.set_option("group_always", 1)
+        hj.set_option("group_inner", max(1, -(-len(ik) // groups)))
+        gprm = H.PhjParams(chunks=case["chunks"])
+        assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == want
+        assert hj.stats()["groups"] >= 2 or len(ik) < 2
+        assert hj.cpra(rk, rv, len(ik), sk, sv, len(ok), gprm) == want
+        if 0 < want[0] <= 3_000_000:
+            block = int(rng.choice([256, 4096]))
+            cap = hj.output_capacity(1, len(ok), want[0], block)
+            jk, jo, ji = hj.column(cap), hj.column(cap), hj.column(cap)
+            got = hj.phj(rk, rv, len(ik), sk, sv, len(ok), None, out=(jk, jo, ji, cap, block))
+            assert got == want
+            rows = sort_rows(jk.download()[:got[0]], jo.download()[:got[0]], ji.download()[:got[0]])
+            for a, b in zip(rows, materialised_rows(ik, iv, ok, ov)):
+                assert np.array_equal(a, b)
+            for c in (jk, jo, ji):
+                c.free()
     finally:
         hj.set_option("dense2", 0)
+        hj.set_option("group_always", 0)
+        hj.set_option("group_from", 300_000_000)
+        hj.set_option("group_inner", 64_000_000)
         for c in (rk, rv, sk, sv):
             c.free()
