@@ -15,7 +15,7 @@ for inner in inners:
         hj.generate(3, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
         sums = hj.column_sums(ok, outer, fo, fi)
         want = (outer, sums[0], sums[1], sums[2])
-        for per in (0, 60_000_000, 100_000_000, 114_000_000, 200_000_000):
+        for per in (0, 64_000_000, 100_000_000, 200_000_000):
             hj.set_option("group_from", "0" if per == 0 else "1")
             hj.set_option("group_always", "1")
             if per:

@@ -45,4 +45,6 @@ bash tools/pmc_sq.sh r04 > $out/r04_pmc_sq.log 2>&1; note "pmc rc=$?"
 # 5. the NPJ build's ceiling, all quoted workload shapes
 python tools/npj_build_ceiling.py 2>&1 | grep -v amdgpu.ids > $out/r04_npj_build_ceiling.txt
 python tools/report.py > $out/r04_report.md 2> $out/r04_report.err; note "report rc=$?"
+# 6. grouped plans against two passes with multi-fill tables (the sizes the cost estimate in grouped_groups() was fitted on)
+{ timeout -k 10 300 python tools/grouped_sweep.py 1000000000 512000000 1000000000; timeout -k 10 300 python tools/grouped_sweep.py 4000000000 700000000 1000000000; } 2>&1 | grep -v amdgpu.ids > $out/r04_grouped_sweep.txt; note "grouped sweep done"
 cat $out/r04_rc.txt
