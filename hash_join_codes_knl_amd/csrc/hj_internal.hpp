@@ -57,9 +57,12 @@ struct HjTuning {
     bool unique = false;            // "unique": stop a probe at its first match (_UNIQUE, npj.cpp:288-290)
     bool piece_interleave = true;   // "piece_interleave": pass 2 over arrived pieces takes its tiles partition by partition (PlanArgs::seg_interleave)
     bool merged_plan = true;        // "merged_plan": whole joins on resident columns plan both relations with one set of K5 launches
-    int placement = 4;              // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first; round 4:
-                                    // capped at 4 by default - what makes a block fast is its physical pages' spread over the memory
-                                    // channels (L2 tag / DRAM-credit stalls, profiles/r04_placement_counters.txt): nothing to choose, only to measure)
+    int placement = 12;             // "placement": candidate allocations tried for a large pass-1 twin (1 = take the first).  What makes a
+                                    // block fast is its physical pages' spread over the memory channels (L2 tag / DRAM-credit stalls,
+                                    // profiles/r04_placement_counters.txt): nothing to choose, only to measure.  A cap of 4 was tried in round 4
+                                    // and left 3 of 12 fresh processes without a fast block (profiles/r04_placement_log.txt: 10 of 32
+                                    // candidates are fast); the search stops at the first fast one, 3 candidates on average.
+    bool placement_log = false;     // "placement_log": the search prints every candidate's fill time and its choice to stderr (diagnostics)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
     // "host_batch": probe rows per batch of the host calls.  -1 (default): the materialising call in batches of 64 Mi rows
     // (its rows go home behind the upload); the aggregate call uploads whole columns while they fit the device's free

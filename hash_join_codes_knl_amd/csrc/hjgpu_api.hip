@@ -167,6 +167,8 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return HJGPU_OK;
     const int tries = ctx->tune.placement;
+    // (twins below 1 GiB - the headline's 512 MB build-side twin, a grouped plan's per-group twins - gain nothing from the
+    // search: profiles/r04_ab_placed_min.txt)
     if (tries <= 1 || bytes < ((size_t)1 << 30)) return ensure(ctx, b, bytes);
     if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     const size_t want = (bytes + 255) / 256 * 256 + 256;
@@ -201,6 +203,11 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (best < 0) return fail(ctx, HJGPU_ENOMEM, "hipMalloc(workspace)");
+    if (ctx->tune.placement_log) {
+        fprintf(stderr, "hjgpu placement: %zu bytes,", want);
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f ms%s", ms[i], i == best ? "*" : "");
+        fprintf(stderr, " (%.2f TB/s taken)\n", (double)want / (ms[best] * 1e-3) / 1e12);
+    }
     for (int i = 0; i < n; ++i) if (i != best) (void)hipFree(cand[i]);
     b.p = cand[best]; b.cap = want;
     return HJGPU_OK;
@@ -1700,7 +1707,9 @@ static int phj_grouped(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks,
         else if (vout) acc.dense += h.dense;
     }
     // the call's result where every entry point looks for it
-    HIPCHK(ctx, hipMemcpy(ctx->state.p, &acc, sizeof(DevState), hipMemcpyHostToDevice));
+    // (on the caller's stream, like everything else: nothing is issued on the legacy NULL stream)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->state.p, &acc, sizeof(DevState), hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, hipStreamSynchronize(stream));
     sum.ms_total = sum.ms_scatter0 + sum.ms_histogram + sum.ms_plan + sum.ms_scatter1 + sum.ms_scatter2 + sum.ms_join + sum.ms_close_gaps;
     sum.groups = G;
     ctx->stats = sum;

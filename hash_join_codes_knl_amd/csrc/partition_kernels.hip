@@ -1645,6 +1645,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("merged_plan")) return parse_flag(value, &t->merged_plan);
     if (is("piece_interleave")) return parse_flag(value, &t->piece_interleave);
     if (is("group_always")) return parse_flag(value, &t->group_always);
+    if (is("placement_log")) return parse_flag(value, &t->placement_log);
     if (is("placement")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1708,7 +1709,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "placement_log", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);
