@@ -214,13 +214,13 @@ def test_counted_partitions_refuse_what_the_lds_histogram_cannot_hold(hj):
         c.free()
 
 
-def test_partitioning_keeps_every_tuple_while_joins_run_on_another_stream():
+def test_partitioning_keeps_every_tuple_while_joins_run_on_another_stream(hj):
     """The condition under which a K6 pass-1 instance WITH a private segment lost ~1e-5 of its stores (DESIGN section 3,
     profiles/r04_scratch_repro.txt: tools/scratch_two_streams.py, 23 of 40 steps wrong with one private word, 0 alone):
     two independent contexts on one device, one partitioning on its stream while the other runs whole joins on a
     second stream.  The shipped library has no private segment (tests/test_kernel_resources.py) and must lose
     nothing: every output's 32-bit word sum equals the input's and no slot stays unwritten."""
-    import torch
+    import torch                                            # (initialised by the session's context fixture, before any library call)
     a, b = H.HjGpu(0), H.HjGpu(0)
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     inner, outer, n, fanout = 16_000_000, 256_000_000, 48_000_000, 192
