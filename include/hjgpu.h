@@ -150,7 +150,7 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * nothing else in the library looks at the environment, and nothing on a launch path reads mutable
  * process-wide state.  Names: "unique" (as HJGPU_FLAG_UNIQUE, for every join of the context,
  * including the operator-level hjgpu_npj_probe), "force_chained", "no_broadcast", "dense2", "npj_refhash",
- * "scatter_prof" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
+ * "scatter_prof", "merged_plan", "piece_interleave" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
  * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
  * twin, 1..16; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples) and "group_always" (0 / 1): the
  * grouped plans of hjgpu_phj / hjgpu_cpra (below).  Unknown names and malformed values: HJGPU_EINVAL. */

@@ -96,3 +96,17 @@ def test_product_package_never_uses_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 for pat in banned:
                     assert not re.search(pat, src, flags=re.M), (f, pat)
+
+
+def test_every_option_is_documented():
+    """hjgpu_set_option's names (the list hjgpu_create reads from the environment, csrc/partition_kernels.hip) all appear
+    in README.md's option table and in include/hjgpu.h's comment on hjgpu_set_option"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "hash_join_codes_knl_amd", "csrc", "partition_kernels.hip")).read()
+    names = re.findall(r'"(\w+)"', re.search(r"static const char \*const names\[\] = \{(.*?)\};", src, re.S).group(1))
+    assert len(names) >= 20
+    readme = open(os.path.join(root, "README.md")).read()
+    header = open(os.path.join(root, "include", "hjgpu.h")).read()
+    assert [n for n in names if "`" + n not in readme] == []
+    assert [n for n in names if '"' + n + '"' not in header] == []
