@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "lib")
 ARCH = "gfx950"
 
 KERNEL_SOURCES = ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip",
-                  "gen_kernels.hip", "hjgpu_api.hip", "hjgpu_multi.hip"]
+                  "gen_kernels.hip", "audit_kernels.hip", "hjgpu_api.hip", "hjgpu_multi.hip"]
 HOST_PROGRAMS = {"npj": "npj_main.cpp", "phj": "phj_main.cpp", "cpra": "cpra_main.cpp",
                  "write": "write_main.cpp"}
 

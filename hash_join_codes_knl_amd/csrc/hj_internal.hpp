@@ -63,6 +63,8 @@ struct HjTuning {
                                     // and left 3 of 12 fresh processes without a fast block (profiles/r04_placement_log.txt: 10 of 32
                                     // candidates are fast); the search stops at the first fast one, 3 candidates on average.
     bool placement_log = false;     // "placement_log": the search prints every candidate's fill time and its choice to stderr (diagnostics)
+    bool audit = false;             // "audit" (diagnostics): every stage leaves a checksum of its output (audit_kernels.hip, hjgpu_audit_read)
+    int hist_min_lds = 0;           // "hist_min_lds" (diagnostics): K4 asks for at least this many bytes of LDS per workgroup (nothing else then shares its CU)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)
     // "host_batch": probe rows per batch of the host calls.  -1 (default): the materialising call in batches of 64 Mi rows
     // (its rows go home behind the upload); the aggregate call uploads whole columns while they fit the device's free
@@ -223,7 +225,7 @@ int hj_launch_hist_packed(const u64 *tuples, const HjChunks &ch, uint32_t f1, ui
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
                     u64 *counts, uint32_t *range_counts, uint32_t *work_counter /* [chunks], zeroed */,
-                    int cus, hipStream_t stream);
+                    int cus, hipStream_t stream, size_t min_lds = 0);
 // own_count > 0 (chunks == 1): partitions [own_first, own_first + own_count) are laid out behind all others
 // group_bins > 0 (chunks == 1, own_count == 0): groups of group_bins neighbouring partitions, each group on a 128-byte
 // line: group g (whose dense start is row `dense`) starts at row dense + hj_group_shift(dense, g)
@@ -297,6 +299,21 @@ struct BroadcastMeta {
 int hj_launch_broadcast_meta(const uint32_t *inner_keys, size_t inner, size_t outer, uint32_t nslices,
                              uint32_t groups, const BroadcastMeta &m, hipStream_t stream);
 int hj_npj_probe_grid(int cus, size_t n);
+
+// option "audit" (audit_kernels.hip): read-only checks of a stage's output, on the stage's stream.  A record is
+// HJ_AUDIT_STAGES x {misplaced tuples, sum of keys, sum of payloads, tuples}; a context keeps its last HJ_AUDIT_RING records.
+// PHJ / CPRA calls: stage 0 probe side as read, 1 after pass 1, 2 final partitions; 3-5 the same for the build side (5 is
+// checked again by every probe of a prepared build side); 6 the join's result (count, three sums); 7 {sequence number, kind
+// (0 whole join, 1 build only, 2 probe only, 3 hjgpu_partition_packed*), build rows, probe rows}.  Partitioning calls: 0 input, 1 output.
+constexpr int HJ_AUDIT_STAGES = 8, HJ_AUDIT_RING = 256;
+struct HjAuditHash { uint32_t f1, F1, p1_base, f2, F2, modulo; };   // partition of a key: ((H(key, f1, F1) - p1_base) * F2 + H(key, f2, F2)); entry i holds partition i % modulo
+int hj_audit_partitions(const u64 *tuples, const u64 *beg, const u64 *end /* NULL: beg + 1 */, uint32_t parts, const HjAuditHash &h,
+                        u64 *rec, int cus, hipStream_t stream);
+int hj_audit_sums_packed(const u64 *tuples, u64 b, u64 e, u64 *rec, int cus, hipStream_t stream);
+int hj_audit_sums_columns(const uint32_t *k, const uint32_t *v, u64 n, u64 *rec, int cus, hipStream_t stream);
+int hj_audit_own_last(const u64 *prefix, uint32_t F, uint32_t own_first, uint32_t own_count, u64 n, u64 *beg, u64 *end, hipStream_t stream);
+int hj_audit_copy(const u64 *src, u64 *dst, uint32_t words, hipStream_t stream);
+int hj_audit_meta(u64 *dst, u64 a, u64 b, u64 c, u64 d, hipStream_t stream);
 
 // generator / checksums
 int hj_launch_generate(u64 seed, size_t inner, size_t inner_begin, size_t inner_count,

@@ -81,6 +81,10 @@ struct hjgpu_ctx {
     DevBuf grp[4], grp_off;
     bool stats_override = false;
     hipStream_t aux = nullptr;      // private non-blocking stream: placement probes of the workspace allocator
+    // option "audit": the last HJ_AUDIT_RING calls' stage records (audit_kernels.hip), the next call's sequence number, and the
+    // explicit partition bounds of an own-last layout
+    DevBuf audit, audit_lay;
+    uint64_t audit_seq = 0;
     float ms_reserve = 0;           // wall clock of the workspace growth so far (allocations + placement probes)
 };
 
@@ -400,6 +404,22 @@ void record(hjgpu_ctx *ctx, int which, hipStream_t s)
     ctx->ev_valid[which] = (hipEventRecord(ctx->ev[which], s) == hipSuccess);
 }
 
+// option "audit": this call's record - zeroed on `stream`, its last stage = {sequence number, kind, build rows, probe rows} -
+// or nullptr when the option is off.  Stage s of the record is rec + 4 * s.
+int audit_begin(hjgpu_ctx *ctx, int kind, size_t inner, size_t outer, hipStream_t stream, u64 **rec)
+{
+    *rec = nullptr;
+    if (!ctx->tune.audit) return HJGPU_OK;
+    const size_t words = (size_t)HJ_AUDIT_STAGES * 4;
+    CHK(ensure(ctx, ctx->audit, (size_t)HJ_AUDIT_RING * words * sizeof(u64)));
+    u64 *r = reinterpret_cast<u64 *>(ctx->audit.p) + (size_t)(ctx->audit_seq % HJ_AUDIT_RING) * words;
+    HIPCHK(ctx, hipMemsetAsync(r, 0, words * sizeof(u64), stream));
+    CHK(hj_audit_meta(r + 4 * (HJ_AUDIT_STAGES - 1), ctx->audit_seq, (u64)kind, (u64)inner, (u64)outer, stream));
+    ctx->audit_seq += 1;
+    *rec = r;
+    return HJGPU_OK;
+}
+
 // The enqueue paths are not valid inside a HIP stream capture: a replayed graph of one PHJ step faulted on
 // gfx950 / ROCm 7.0 (kernels with > 64 KiB of dynamic LDS among the nodes), so a capturing stream is refused
 // instead of handing the caller a graph that may corrupt memory.
@@ -624,6 +644,8 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables, pl.unique), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
+    u64 *audit = nullptr;                // option "audit": this call's record (else NULL: nothing below is enqueued)
+    CHK(audit_begin(ctx, (int)mode, inner, outer, stream, &audit));
     // counts[0] | counts[1] | tickets are contiguous: a whole join zeroes all, a prepared build its own
     // histogram and the tickets, a probe of a prepared build the probe side's histogram and the tickets
     {
@@ -684,6 +706,25 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.cap = (uint32_t)hj_join_config_of(ctx->tune, pl.big_tables).cap();
 
     uint32_t batches_used = 0;
+    // option "audit" (audit_kernels.hip): stage 0 / 3 the relation as it is read, 1 / 4 its pass-1 output, 2 / 5 its final partitions
+    auto audit_input = [&](int r) -> int {
+        if (!audit || !nn[r]) return HJGPU_OK;
+        u64 *rec = audit + 4 * (r ? 0 : 3);
+        if (pre) return pre->tuples[r] ? hj_audit_sums_packed(pre->tuples[r], pre->ch[r].b[0], pre->ch[r].b[pl.C], rec, ctx->cus, stream) : HJGPU_OK;
+        return in_k[r] ? hj_audit_sums_columns(in_k[r], in_v[r], nn[r], rec, ctx->cus, stream) : HJGPU_OK;
+    };
+    auto audit_pass1 = [&](int r) -> int {
+        if (!audit || !nn[r] || pre || pl.C != 1 || pl.F2 <= 1) return HJGPU_OK;
+        const HjAuditHash h = {pl.f1, pl.F1, 0u, 1u, 1u, pl.F1};
+        return hj_audit_partitions(reinterpret_cast<const u64 *>(ctx->tmp[2 * r].p), m.off1[r], nullptr, pl.F1, h, audit + 4 * (r ? 1 : 4), ctx->cus, stream);
+    };
+    auto audit_final = [&](int r) -> int {
+        if (!audit || !nn[r]) return HJGPU_OK;
+        const bool two = pl.F2 > 1;
+        const u64 *fin_r = reinterpret_cast<const u64 *>(two ? ctx->tmp[4 + 2 * r].p : ctx->tmp[2 * r].p);
+        const HjAuditHash h = {pre ? pl.pre_f1 : pl.f1, pre ? pl.pre_F1tot : pl.F1, pre ? pl.pre_base : 0u, pl.f2, pl.F2, pl.P};
+        return hj_audit_partitions(fin_r, m.off2[r], m.end2[r], (pad2 ? 1u : pl.C) * pl.P, h, audit + 4 * (r ? 2 : 5), ctx->cus, stream);
+    };
     // the stages of one relation's partitioning
     auto k4 = [&](int r) -> int {          // one read of the key column gives the histograms of both passes
         if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
@@ -745,6 +786,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
             }
             record(ctx, ev[3], stream);
+            CHK(audit_input(r)); CHK(audit_final(r));
             return HJGPU_OK;
         }
         CHK(k4(r));
@@ -796,6 +838,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             record(ctx, ev[2], stream);         // both passes interleaved: reported as pass 1, pass 2 = 0
             record(ctx, ev[3], stream);
             batches_used = batches;
+            CHK(audit_input(r)); CHK(audit_final(r));
             return HJGPU_OK;
         }
         CHK(k5b(r));
@@ -804,6 +847,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         record(ctx, ev[2], stream);
         CHK(pass2(r));
         record(ctx, ev[3], stream);
+        CHK(audit_input(r)); CHK(audit_pass1(r)); CHK(audit_final(r));
         return HJGPU_OK;
     };
     const int ev_s[4] = {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2};
@@ -827,6 +871,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         record(ctx, EV_S_SC2, stream);
         record(ctx, EV_WAITED, stream);
         for (int e : ev_r) record(ctx, e, stream);
+        for (int r = 0; r < 2; ++r) { CHK(audit_input(r)); CHK(audit_pass1(r)); CHK(audit_final(r)); }
     }
     if (!merged && mode != PHJ_BUILD_ONLY) CHK(partition_relation(1, 2u, ev_s));       // probe side first
     else if (!merged) for (int e : ev_s) record(ctx, e, stream);
@@ -840,6 +885,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         pa.mask = 4u;
         CHK(hj_launch_plan(pa, stream));
         for (int i = 1; i < 4; ++i) record(ctx, ev_r[i], stream);
+        CHK(audit_final(0));               // the prepared build side, as this probe finds it
     }
     const uint32_t *fin[4] = {t1[0], t1[1], t1[2], t1[3]};
     if (pl.F2 > 1) for (int i = 0; i < 4; ++i) fin[i] = t2[i];
@@ -873,6 +919,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             ja.overflow = &st->overflow;
         }
         CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
+        if (audit) CHK(hj_audit_copy(reinterpret_cast<const u64 *>(&st->result), audit + 4 * 6, 4, stream));
     }
     record(ctx, EV_JOIN, stream);
     if (bs && inner && outer && mode != PHJ_BUILD_ONLY) {
@@ -1061,7 +1108,7 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     (void)hipDeviceSynchronize();
     DevBuf *all[] = {&ctx->tmp[0], &ctx->tmp[1], &ctx->tmp[2], &ctx->tmp[3], &ctx->tmp[4], &ctx->tmp[5],
                      &ctx->tmp[6], &ctx->tmp[7], &ctx->meta, &ctx->table, &ctx->state, &ctx->moves,
-                     &ctx->final_offsets, &ctx->grp[0], &ctx->grp[1], &ctx->grp[2], &ctx->grp[3], &ctx->grp_off};
+                     &ctx->final_offsets, &ctx->grp[0], &ctx->grp[1], &ctx->grp[2], &ctx->grp[3], &ctx->grp_off, &ctx->audit, &ctx->audit_lay};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
@@ -1275,6 +1322,25 @@ int hjgpu_host_free(hjgpu_ctx *ctx, void *p)
     if (p) HIPCHK(ctx, hipHostFree(p));
     return HJGPU_OK;
 }
+int hjgpu_audit_read(hjgpu_ctx *ctx, uint64_t *next_seq, uint64_t first_seq, uint32_t count, uint64_t *records, void *stream_)
+{
+    if (!ctx) return HJGPU_EINVAL;
+    if (next_seq) *next_seq = ctx->audit_seq;
+    if (!count) return HJGPU_OK;
+    if (!records) return fail(ctx, HJGPU_EINVAL, "null records array");
+    if (first_seq + count > ctx->audit_seq || ctx->audit_seq - first_seq > (uint64_t)HJ_AUDIT_RING || !ctx->audit.p)
+        return fail(ctx, HJGPU_EINVAL, "hjgpu_audit_read: the context keeps the records of its last 256 calls made with option \"audit\"");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t words = (size_t)HJ_AUDIT_STAGES * 4;
+    for (uint32_t i = 0; i < count; ++i)
+        HIPCHK(ctx, hipMemcpyAsync(records + (size_t)i * words,
+                                   reinterpret_cast<const u64 *>(ctx->audit.p) + (size_t)((first_seq + i) % HJ_AUDIT_RING) * words,
+                                   words * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    HIPCHK(ctx, hj_stream_synchronize(stream));
+    return HJGPU_OK;
+}
+
 int hjgpu_synchronize(hjgpu_ctx *ctx, void *stream)
 {
     if (!ctx) return HJGPU_EINVAL;
@@ -1855,6 +1921,8 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
     for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
     ctx->last_algo = 2;                    // hjgpu_get_stats().ms_total = the whole operator
     record(ctx, EV_BEGIN, stream);
+    u64 *audit = nullptr;                  // option "audit": stage 0 the columns as read, stage 1 the packed output where it lies
+    CHK(audit_begin(ctx, 3, n, 0, stream, &audit));
     HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
     if (d_counts2) {
         // the same read of the keys also counts the RECEIVERS' second level (bin = p1 * fanout2 + p2, the join's fused
@@ -1863,7 +1931,7 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
         HIPCHK(ctx, hipMemsetAsync(d_counts2, 0, (size_t)fanout * fanout2 * sizeof(u64), stream));
         if (n) {
             u64 *fused = reinterpret_cast<u64 *>(d_counts2);
-            CHK(hj_launch_hist2(d_keys, geom, factor, fanout, factor2, fanout2, fused, m.range_counts[0], m.tickets, ctx->cus, stream));
+            CHK(hj_launch_hist2(d_keys, geom, factor, fanout, factor2, fanout2, fused, m.range_counts[0], m.tickets, ctx->cus, stream, (size_t)ctx->tune.hist_min_lds));
             CHK(hj_launch_row_sums(fused, fanout, fanout2, m.counts[0], stream));
         }
     } else if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets, ctx->cus, stream));
@@ -1893,6 +1961,14 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
         CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    if (audit && n) {
+        CHK(hj_audit_sums_columns(d_keys, d_vals, n, audit, ctx->cus, stream));
+        CHK(ensure(ctx, ctx->audit_lay, (size_t)2 * (HJGPU_MAX_FANOUT + 1) * sizeof(u64)));
+        u64 *beg = reinterpret_cast<u64 *>(ctx->audit_lay.p), *end = beg + HJGPU_MAX_FANOUT + 1;
+        CHK(hj_audit_own_last(m.off2[0], fanout, own_first, own_count, n, beg, end, stream));
+        const HjAuditHash h = {factor, fanout, 0u, 1u, 1u, fanout};
+        CHK(hj_audit_partitions(reinterpret_cast<const u64 *>(d_tuples_out), beg, end, fanout, h, audit + 4, ctx->cus, stream));
+    }
     record(ctx, EV_GAPS, stream);
     return HJGPU_OK;
 }

@@ -36,19 +36,6 @@
 
 typedef unsigned long long u64;
 
-#ifndef HJ_SCRATCH_EXPERIMENT
-#define HJ_SCRATCH_EXPERIMENT 0
-#endif
-#if HJ_SCRATCH_EXPERIMENT
-// Variant builds only (tools/build_variant.py -DHJ_SCRATCH_EXPERIMENT=n, see partition_kernels.hip): forensics of the
-// slice pipeline with option debug_forensics=1, world 1, exchange_in_place=0, <= 8 slices.  For every probe slice:
-// [0] the input columns' sums (partitioning stream), [1] the pass-1 output verified right behind pass 1 on the SAME
-// stream, [2] the received copy verified on the JOIN stream right before its join, [3] send and [4] receive buffer
-// verified once the step is over and the device quiet.  (misplaced tuples, sum of keys, sum of payloads, tuples seen)
-int hj_debug_verify(const u64 *tuples, const u64 *d_off, uint32_t F, uint32_t factor, u64 n, u64 *d_res, hipStream_t s);
-int hj_debug_sums(const uint32_t *k, const uint32_t *v, u64 n, u64 *d_res, hipStream_t s);
-constexpr int DBG_SLICES = 8, DBG_STAGES = 5, DBG_OFF = 1032;
-#endif
 
 namespace {
 
@@ -135,10 +122,6 @@ struct Rank {
     // [G][fan-out * F2], and the rows of it that describe what this rank received, in the order of its pieces [G][k * F2]
     Buf cnt2[2], cnt2_all[2], cnt_recv[2];
     hipEvent_t ev_dbg = nullptr, ev_dbg2 = nullptr;   // option "debug_serialize"
-#if HJ_SCRATCH_EXPERIMENT
-    u64 *dbg = nullptr;                               // [DBG_SLICES][DBG_STAGES][4] results + [DBG_SLICES][DBG_OFF] offsets of every slice
-    u64 dbg_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // tuples of every slice
-#endif
     hipEvent_t ev_up_s = nullptr, ev_up_r = nullptr;  // host path: probe shard / build columns uploaded
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;      // host path: first kernel of the join started / upload finished (timing)
     hipEvent_t lb_in = nullptr, lb_out = nullptr;     // loopback transport
@@ -172,7 +155,9 @@ struct hjgpu_comm {
     int stall_rank = -1, stall_ms = 0;       // loopback fault injection (options "stall_rank", "stall_ms")
     bool self_via_rccl = false;              // option "self_via_rccl": a rank's message to itself goes through ncclSend / ncclRecv too (tests:
                                              // grouped point-to-point RCCL calls run on a one-GPU box that way)
-    int debug_forensics = 0;                 // option "debug_forensics" (variant builds only)
+    int debug_forensics = 0;                 // option "debug_forensics": option "audit" on every rank's two contexts; a CPRA step keeps the
+                                             // records of its partitioning calls and joins (hjgpu_comm_get_forensics)
+    std::vector<u64> forensics;              // per local rank: {global rank, partitioning records, join records}, then the records (32 words each)
     int debug_serialize = 0;                 // option "debug_serialize" (diagnostics): bit 0 host waits after every slice's join, bit 1 the
                                              // partitioning waits for the joins enqueued so far, bit 2 the exchange waits for them,
                                              // bit 3 a join waits for the partitioning enqueued so far (with bit 1: the two never overlap)
@@ -938,7 +923,6 @@ struct CpraStep {
     // rank's SEND buffer - its own partitions were written last (hjgpu_partition_packed_own_last_async), the other ranks'
     // pieces are received right behind them: piece 0 = the own one, never copied; pieces 1.. = the other ranks in order.
     std::vector<const void *> base;
-    int dbg_slice = -1;                                       // variant builds, option debug_forensics: the probe slice being partitioned
     bool exchange_in_flight = false;                          // local rank 0's ev_x0 / ev_x1 hold an unread exchange
     bool from_host = false;                                   // the inputs are being uploaded (hjgpu_join_host_multi)
     float exchange_ms = 0;
@@ -1038,16 +1022,6 @@ struct CpraStep {
                 if (counted) HIPM(c, hipMemsetAsync(r.cnt2[slot].p, 0, F * F2 * sizeof(u64), r.prep));
             }
             HIPM(c, hipMemcpyAsync(h_off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
-#if HJ_SCRATCH_EXPERIMENT
-            if (c->debug_forensics && which && k && !own_last && G == 1 && dbg_slice >= 0 && dbg_slice < DBG_SLICES && r.dbg) {
-                u64 *res = r.dbg + (size_t)dbg_slice * DBG_STAGES * 4;
-                u64 *off = r.dbg + (size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)dbg_slice * DBG_OFF;
-                r.dbg_n[dbg_slice] = in[l].n;
-                HIPM(c, hipMemcpyAsync(off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToDevice, r.prep));
-                CHKM(hj_debug_sums(in[l].keys, in[l].vals, in[l].n, res + 0, r.prep));
-                CHKM(hj_debug_verify(static_cast<const u64 *>(b.sk->p), off, (uint32_t)F, TOP_LEVEL_FACTOR, in[l].n, res + 4, r.prep));
-            }
-#endif
             HIPM(c, hipEventRecord(r.ev_part[slot], r.prep));
             return HJGPU_OK;
         });
@@ -1187,16 +1161,13 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             return cfail(c, HJGPU_EINVAL, "null column in a shard");
     }
     CpraStep step(c, stats);
-#if HJ_SCRATCH_EXPERIMENT
+    // option "debug_forensics": where this step's audit records start in every rank's two contexts
+    std::vector<uint64_t> seq_part((size_t)L, 0), seq_join((size_t)L, 0);
     if (c->debug_forensics)
-        for (Rank &r : c->ranks) {
-            const size_t bytes = ((size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)DBG_SLICES * DBG_OFF) * sizeof(u64);
-            HIPM(c, hipSetDevice(r.device));
-            if (!r.dbg) HIPM(c, hipMalloc(reinterpret_cast<void **>(&r.dbg), bytes));
-            HIPM(c, hipDeviceSynchronize());
-            HIPM(c, hipMemset(r.dbg, 0, bytes));
+        for (int l = 0; l < L; ++l) {
+            (void)hjgpu_audit_read(c->ranks[l].part, &seq_part[(size_t)l], 0, 0, nullptr, nullptr);
+            (void)hjgpu_audit_read(c->ranks[l].join, &seq_join[(size_t)l], 0, 0, nullptr, nullptr);
         }
-#endif
     // one-level plan while the receiver can take one piece per source rank (<= 8 pieces): fan-out G * k with G * k <= 192,
     // the widest pass 1 whose whole-line carry still fits beside a 16 K-tuple tile
     if (c->nranks <= 8 && !c->cpra_two_level) step.k = (uint32_t)(c->cpra_k > 0 && c->cpra_k * c->nranks <= 192 ? c->cpra_k : 192 / c->nranks);
@@ -1295,11 +1266,6 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             HIPM(c, hipEventRecord(r.ev_w[2 * (size_t)i + 1], r.main));
             const uint32_t *sk = static_cast<const uint32_t *>(r.recv_k[slot].p), *sv = static_cast<const uint32_t *>(r.recv_v[slot].p);
             u64 *acc = static_cast<u64 *>(r.d_res.p);
-#if HJ_SCRATCH_EXPERIMENT
-            if (c->debug_forensics && K && !c->exchange_in_place && G == 1 && i < DBG_SLICES && r.dbg && got[l] == r.dbg_n[i])
-                CHKM(hj_debug_verify(static_cast<const u64 *>(got_base[l]) + got_pieces[l][0], r.dbg + (size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)i * DBG_OFF,
-                                     (uint32_t)c->nranks * K, TOP_LEVEL_FACTOR, got[l], r.dbg + ((size_t)i * DBG_STAGES + 2) * 4, r.main));
-#endif
             if (inner_recv[l])
                 for (u64 b = 0; b < got[l]; b += max_outer[l]) {
                     const size_t m = got[l] - b < max_outer[l] ? (size_t)(got[l] - b) : max_outer[l];
@@ -1371,7 +1337,6 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         // and only then does the host wait for partition(i)'s counts: the device works on join(i-1) and partition(i)
         // while the host and the ranks settle the sizes of exchange(i) (with the join enqueued after that wait, every
         // slice cost a world of one ~0.15-0.2 ms of idle device: 4 slices 13.0 -> 12.2-12.6 ms, 8 slices 16.7 -> 14.9-15.0 ms)
-        step.dbg_slice = i;
         CHKM(step.begin_exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr));
         if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
         CHKM(step.finish_exchange(in, 1 + slot, slot));
@@ -1390,46 +1355,22 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
     const int status = reduce_results(c, result);
     if (status != HJGPU_OK && status != HJGPU_EOVERFLOW) return status;
-#if HJ_SCRATCH_EXPERIMENT
-    if (c->debug_forensics && K && !c->exchange_in_place && G == 1 && slices <= 2) {
-        // two slices = both slots used once: their buffers still hold the slices
-        Rank &r = c->ranks[0];
-        HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipDeviceSynchronize());
-        for (int i = 0; i < slices && r.dbg; ++i) {
-            const u64 *off = r.dbg + (size_t)DBG_SLICES * DBG_STAGES * 4 + (size_t)i * DBG_OFF;
-            u64 *res = r.dbg + (size_t)i * DBG_STAGES * 4;
-            CHKM(hj_debug_verify(static_cast<const u64 *>(r.send_k[i & 1].p), off, (uint32_t)K, TOP_LEVEL_FACTOR, r.dbg_n[i], res + 12, r.main));
-            CHKM(hj_debug_verify(static_cast<const u64 *>(r.recv_k[i & 1].p), off, (uint32_t)K, TOP_LEVEL_FACTOR, r.dbg_n[i], res + 16, r.main));
-        }
-        HIPM(c, hipDeviceSynchronize());
-    }
-    if (c->debug_forensics && c->ranks[0].dbg) {
-        Rank &r = c->ranks[0];
-        u64 h[DBG_SLICES * DBG_STAGES * 4];
-        HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipDeviceSynchronize());
-        HIPM(c, hipMemcpy(h, r.dbg, sizeof(h), hipMemcpyDeviceToHost));
-        static const char *stage[DBG_STAGES] = {"input columns", "pass-1 output, same stream", "received copy, join stream", "send buffer, quiet", "receive buffer, quiet"};
-        for (int i = 0; i < slices && i < DBG_SLICES; ++i) {
-            const u64 *in0 = h + (size_t)i * DBG_STAGES * 4;
-            bool any = false;
-            for (int st = 1; st < DBG_STAGES; ++st) {
-                const u64 *x = in0 + st * 4;
-                if (x[3] && (x[0] || x[1] != in0[1] || x[2] != in0[2] || x[3] != in0[3])) any = true;
-            }
-            if (!any) continue;
-            fprintf(stderr, "forensics slice %d (%llu tuples):", i, (unsigned long long)in0[3]);
-            for (int st = 1; st < DBG_STAGES; ++st) {
-                const u64 *x = in0 + st * 4;
-                if (!x[3]) { fprintf(stderr, " [%s: -]", stage[st]); continue; }
-                fprintf(stderr, " [%s: %llu misplaced, key sum %+lld, payload sum %+lld]", stage[st], (unsigned long long)x[0],
-                        (long long)(x[1] - in0[1]), (long long)(x[2] - in0[2]));
-            }
-            fprintf(stderr, "\n");
+    if (c->debug_forensics) {
+        // every stage's checksum of this step (the streams are idle: reduce_results waited for them)
+        c->forensics.clear();
+        for (int l = 0; l < L; ++l) {
+            Rank &r = c->ranks[l];
+            uint64_t end_part = 0, end_join = 0;
+            (void)hjgpu_audit_read(r.part, &end_part, 0, 0, nullptr, nullptr);
+            (void)hjgpu_audit_read(r.join, &end_join, 0, 0, nullptr, nullptr);
+            const uint32_t np = (uint32_t)(end_part - seq_part[(size_t)l]), nj = (uint32_t)(end_join - seq_join[(size_t)l]);
+            const size_t at = c->forensics.size();
+            c->forensics.resize(at + 3 + ((size_t)np + nj) * 32, 0);
+            c->forensics[at] = (u64)r.global; c->forensics[at + 1] = np; c->forensics[at + 2] = nj;
+            JOINM(c, r.part, hjgpu_audit_read(r.part, nullptr, seq_part[(size_t)l], np, reinterpret_cast<uint64_t *>(c->forensics.data() + at + 3), r.prep));
+            JOINM(c, r.join, hjgpu_audit_read(r.join, nullptr, seq_join[(size_t)l], nj, reinterpret_cast<uint64_t *>(c->forensics.data() + at + 3 + (size_t)np * 32), r.main));
         }
     }
-#endif
     bool rows_fit = true;
     if (rows) for (int l = 0; l < L; ++l) {
         rows[l].rows = hp_local(c->ranks[l], G)[0];
@@ -1659,7 +1600,13 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
     if (strcmp(name, "cpra_fused_counts") == 0) { c->cpra_fused_counts = x != 0; return HJGPU_OK; }
     if (strcmp(name, "host_rows_batched") == 0) { c->host_rows_batched = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }
-    if (strcmp(name, "debug_forensics") == 0) { c->debug_forensics = (int)x; return HJGPU_OK; }
+    if (strcmp(name, "debug_forensics") == 0) {
+        for (Rank &r : c->ranks)
+            for (hjgpu_ctx *ctx : {r.join, r.part})
+                if (ctx && hjgpu_set_option(ctx, "audit", x ? "1" : "0") != HJGPU_OK) return cfail(c, HJGPU_EINVAL, "debug_forensics: option audit");
+        c->debug_forensics = (int)x;
+        return HJGPU_OK;
+    }
     if (strcmp(name, "self_via_rccl") == 0) { c->self_via_rccl = x != 0; return HJGPU_OK; }
     if (strcmp(name, "timeout_ms") == 0) {
         if (x < 0 || x > (1 << 30)) return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: timeout_ms outside 0..2^30");
@@ -1677,6 +1624,15 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
         return HJGPU_OK;
     }
     return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: unknown option");
+}
+
+int hjgpu_comm_get_forensics(hjgpu_comm *c, uint64_t *words, size_t capacity, size_t *count)
+{
+    if (!c || !count) return HJGPU_EINVAL;
+    *count = c->forensics.size();
+    if (!words || capacity < c->forensics.size()) return HJGPU_OK;       // the caller asks again with room for *count words
+    if (!c->forensics.empty()) memcpy(words, c->forensics.data(), c->forensics.size() * sizeof(u64));
+    return HJGPU_OK;
 }
 
 int hjgpu_comm_barrier(hjgpu_comm *c)

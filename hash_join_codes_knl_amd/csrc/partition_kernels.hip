@@ -306,12 +306,14 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
 
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-                    u64 *counts, uint32_t *range_counts, uint32_t *work_counter, int cus, hipStream_t stream)
+                    u64 *counts, uint32_t *range_counts, uint32_t *work_counter, int cus, hipStream_t stream, size_t min_lds)
 {
     constexpr int BLOCK = 1024;
     const uint32_t P = F1 * F2;
-    const size_t lds = ((size_t)P + F1) * sizeof(uint32_t);
+    size_t lds = ((size_t)P + F1) * sizeof(uint32_t);
     if (geom.chunks == 0 || geom.chunks > 8 || lds > 140 * 1024) return HJGPU_EINVAL;
+    // option "hist_min_lds" (diagnostics): the workgroup asks for at least this much LDS, so that nothing else fits the CU beside it
+    if (min_lds > lds && min_lds <= 140 * 1024) lds = min_lds;
     static HjPerDeviceOnce once;
     if (hj_allow_dynamic_lds(reinterpret_cast<const void *>(&hist2_kernel<BLOCK>), 140 * 1024, &once) != HJGPU_OK)
         return HJGPU_EHIP;
@@ -1646,6 +1648,14 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("piece_interleave")) return parse_flag(value, &t->piece_interleave);
     if (is("group_always")) return parse_flag(value, &t->group_always);
     if (is("placement_log")) return parse_flag(value, &t->placement_log);
+    if (is("audit")) return parse_flag(value, &t->audit);
+    if (is("hist_min_lds")) {
+        char *end = nullptr;
+        const long x = strtol(value, &end, 10);
+        if (end == value || *end || x < 0 || x > 140 * 1024) return false;
+        t->hist_min_lds = (int)x;
+        return true;
+    }
     if (is("placement")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1709,7 +1719,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "placement_log", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "placement_log", "audit", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

@@ -153,8 +153,21 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * "scatter_prof", "merged_plan", "piece_interleave" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
  * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
  * twin, 1..16; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples) and "group_always" (0 / 1): the
- * grouped plans of hjgpu_phj / hjgpu_cpra (below).  Unknown names and malformed values: HJGPU_EINVAL. */
+ * grouped plans of hjgpu_phj / hjgpu_cpra (below); diagnostics: "audit" (0 / 1: every stage of a join leaves a checksum of its output,
+ * hjgpu_audit_read below), "hist_min_lds" (bytes of LDS a histogram workgroup asks for at least: nothing else then shares its CU).
+ * Unknown names and malformed values: HJGPU_EINVAL. */
 int  hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value);
+/* Option "audit" (diagnostics; the reference's workers meet at barriers between their phases, phj.cpp:1715-1770,
+ * cpra2.cpp:1834-1840 - here the phases are kernels on several streams, and when a step of a pipeline comes out wrong the
+ * aggregates do not say which kernel's output lacked the tuples): every PHJ / CPRA / partitioning call of the context is
+ * followed, stage by stage and on the call's stream, by read-only kernels that check the stage's output where it lies.
+ * A record is 8 stages x {tuples lying in a partition their key does not hash to, sum of keys, sum of payloads, tuples}:
+ * 0 probe side as read, 1 after pass 1, 2 final partitions; 3-5 the same for the build side (5 again at every probe of a
+ * prepared build side); 6 the join's result; 7 {sequence number, kind (0 whole join, 1 build only, 2 probe only,
+ * 3 hjgpu_partition_packed*), build rows, probe rows}.  The context keeps its last 256 records.  *next_seq (may be NULL) =
+ * the sequence number the next call will get; records[count][32] = the calls first_seq .. first_seq + count - 1 (waits for
+ * `stream`). */
+int  hjgpu_audit_read(hjgpu_ctx *ctx, uint64_t *next_seq, uint64_t first_seq, uint32_t count, uint64_t *records, void *stream);
 /* Pre-size the internal workspace (partition scratch twins = hj.h's [1]
  * columns, NPJ table) so that no allocation happens inside a timed join. */
 int  hjgpu_reserve(hjgpu_ctx *ctx, size_t inner_tuples, size_t outer_tuples);
@@ -487,7 +500,8 @@ hjgpu_ctx *hjgpu_comm_ctx(hjgpu_comm *comm, int local_rank);
  * the process can exit.  "stall_rank" (k) / "stall_ms" (n): fault injection for tests, loopback transport only - rank
  * k arrives n ms late at every collective.  "exchange_in_place" (0 / 1, default 1): a CPRA rank keeps its own partitions
  * where its partitioning wrote them and receives the others' pieces behind them (no copy of the message to itself);
- * "cpra_two_level" (0 / 1): round 2's CPRA plan (used automatically beyond 8 ranks); "self_via_rccl" (tests). */
+ * "cpra_two_level" (0 / 1): round 2's CPRA plan (used automatically beyond 8 ranks); "self_via_rccl" (tests);
+ * "debug_forensics" (0 / 1, hjgpu_comm_get_forensics below). */
 int  hjgpu_comm_set_option(hjgpu_comm *comm, const char *name, const char *value);
 /* What the communicator really is: the transport's own view of the world (ncclCommCount / ncclCommUserRank /
  * ncclCommCuDevice of local rank 0, ncclGetVersion), so that a result line can prove that N ranks talked over RCCL. */
@@ -517,6 +531,13 @@ typedef struct {
     float    all_to_all_GBs;   /* bytes this rank SENDS per second when every rank sends link_bytes to every peer at once */
 } hjgpu_preflight;
 int  hjgpu_comm_preflight(hjgpu_comm *comm, size_t link_bytes, hjgpu_preflight *report);
+/* Communicator option "debug_forensics" (0 / 1; diagnostics): option "audit" (hjgpu_audit_read above) on both contexts of
+ * every local rank; hjgpu_cpra_multi then keeps the records of the step's exchange-level partitioning calls and of its
+ * joins.  words[] = for every local rank {global rank, np, nj} followed by np + nj records of 32 words (the rank's
+ * partitioning calls in order: build side, probe slices; then its joins: build, probe batches).  *count = the words there
+ * are; nothing is copied when capacity is smaller.  tools/stress_cpra.py --forensics prints them for every wrong step:
+ * the stage whose sums differ from its input's is the kernel that lost the tuples. */
+int  hjgpu_comm_get_forensics(hjgpu_comm *comm, uint64_t *words, size_t capacity, size_t *count);
 /* every local rank's streams drained, then a collective over all ranks */
 int  hjgpu_comm_barrier(hjgpu_comm *comm);
 

@@ -31,6 +31,8 @@ def main():
     want = (a.outer, sums[0], sums[1], sums[2])
     bad = 0
     for s in range(a.steps):
+        if s and s % 2000 == 0:
+            print("... %d steps, %d wrong so far" % (s, bad), flush=True)
         got = getattr(hj, a.algo)(ik, iv, a.inner, ok, ov, a.outer)
         if tuple(got) != want:
             bad += 1
@@ -45,7 +47,8 @@ def main():
         lib.hjgpu_debug_scratch(d, 0)
         print("private segment: %d values re-read and compared in the kernel, %d MISMATCHES" % (d[1], d[0]), flush=True)
     hj.close()
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
