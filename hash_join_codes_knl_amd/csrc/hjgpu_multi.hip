@@ -198,15 +198,23 @@ int cfail(hjgpu_comm *c, int status, const char *what, const char *detail = null
 // The enqueue work of the local ranks - about 25 kernel launches per rank and join - runs on one host thread per rank:
 // issued from a single thread, rank 7 of an 8-GPU host started a millisecond after rank 0 on an 8 ms step (round 2).
 // RCCL's grouped calls stay on the calling thread.  fn(l) returns an HJGPU_* status; the first failure is returned.
+// (HJ_HOST_FORK / HJ_HOST_JOIN: nothing in the product; tests/cpp_pipeline_ordering.cpp, which runs this file on a CPU under a
+// recorder of stream and event order, learns through them which host thread knows what about finished streams)
+#ifndef HJ_HOST_FORK
+#define HJ_HOST_FORK() ((void)0)
+#define HJ_HOST_JOIN() ((void)0)
+#endif
 template <typename F>
 int each_rank(int L, F fn)
 {
     if (L == 1) return fn(0);
     std::vector<int> rc((size_t)L, HJGPU_OK);
     std::vector<std::thread> workers;
+    HJ_HOST_FORK();
     for (int l = 1; l < L; ++l) workers.emplace_back([&rc, &fn, l] { rc[(size_t)l] = fn(l); });
     rc[0] = fn(0);
     for (std::thread &t : workers) t.join();
+    HJ_HOST_JOIN();
     for (int l = 0; l < L; ++l) if (rc[(size_t)l] != HJGPU_OK) return rc[(size_t)l];
     return HJGPU_OK;
 }

@@ -97,10 +97,6 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     const u64 *__restrict__ r64 = reinterpret_cast<const u64 *>(a.rk);
     const uint32_t tf0 = a.tf0, tf1 = a.tf1;
 
-#if defined(HJ_SCRATCH_EXPERIMENT) && HJ_SCRATCH_EXPERIMENT == 18
-    volatile uint32_t sy18[2];                   // variant 18 (see partition_kernels.hip): the join kernel carries one private word
-    sy18[0] = 0; sy18[1] = (uint32_t)tid;
-#endif
     Emitter em;
     em.init(a.ok, a.oov, a.oiv, a.block_size, a.block_limit, a.block_counter, a.overflow,
             &wave_cursor[wave]);

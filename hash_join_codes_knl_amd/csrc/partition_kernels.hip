@@ -26,102 +26,43 @@
 #include <type_traits>
 
 // --------------------------------------------------------------------------
-// HJ_SCRATCH_EXPERIMENT (tools/build_variant.py <name> -DHJ_SCRATCH_EXPERIMENT=n; never defined in the product build):
-// variants that put the PRIVATE SEGMENT (scratch) back into one kernel, for the question round 3 left open - did the
-// spilling pass-2 instance lose tuples next to other queues' kernels because scratch is unsafe there, or did its
-// timing expose a race of the slice pipeline (DESIGN section 3 "Round 4")?
-//   1  pass 2 as it was before d8b72d0: addresses hoisted out of the tile loop, 16 partition bases live -> register spills
-//   2  pass 2: three per-thread addresses kept in a volatile private array (scratch by construction), re-read every
-//      tile, USED for the tile's claims, and compared with their recomputed values (hj_scratch_dbg counts mismatches)
-//   3  pass 1: the same with the range-base address (re-read at every new range and every tile)
-//   4  K4p (hist_packed_kernel): the same with the tuple and counter addresses
-//   5  pass 2: a private array exists and is written before the tile loop, never touched inside it (does the mere
-//      presence of a private segment in the dispatch matter?)
-//   6  pass 2: one private word re-read per tile by the bin-owner threads, folded into the claim index (it is 0), no
-//      comparison, no extra atomics
-//   7  pass 2: NO private segment; the bin-owner threads sleep (s_sleep) before their claims - timing only
-//   8  pass 2: NO private segment; every thread drains its vector-memory counter (s_waitcnt vmcnt(0)) before the claims
-//   9  pass 1: a private word exists (written before the tile loop), never touched inside it
-//  10  pass 1: NO private segment; every tile starts with s_waitcnt vmcnt(0) and one global atomic by thread 0 (the timing
-//      of variant 3 without its private segment)
-//  11  pass 1: NO private segment; the range bases are read through a generic pointer (flat_load instead of global_load)
-//  12  pass 1: one private word re-read per tile by every thread (its value, 0, is added to a bin index), nothing else
-//  13  nothing changed in any kernel (control for the forensic instrumentation of hjgpu_multi.hip)
-//  14  variant 9 + s_waitcnt vmcnt(0) at the end of pass 1: no store is in flight when a wave ends
-//  17  K4 (hist2_kernel) carries the private word instead; 18 (join_kernels.hip): the join kernel does; 19: pass 2 does
-//      (variant 5 again, for tools/scratch_two_streams.py --what)
-//  15  variant 9 + the longest time between two tiles of a workgroup (was a wave ever switched out?); 16: the same without
-//      the private word
-// hjgpu_debug_scratch() returns the counters of variants 2-4.
+// How K6's stores leave the CU (HJ_K6_STORE, a build-time choice; tools/build_variant.py <name> -DHJ_K6_STORE=n):
+//   0  plain stores (write-back in the XCD's L2)
+//   1  non-temporal stores (global_store ... nt)
+//   2  system-scope stores (global_store ... sc0 sc1: written through to memory)
+// Round 5 (DESIGN section 3 "Round 5"): with plain stores a K6 launch loses stores - output slots keep what the
+// previous use of the buffer left there - about once in 10^4 pipeline steps when kernels of ANOTHER stream start and end
+// beside it (tools/stress_cpra.py --forensics names the stage; never on one stream).  Rounds 3-4 saw the same
+// signature at a far higher rate with a private segment in the kernel and studied it with -DHJ_SCRATCH_EXPERIMENT=n
+// variants of this file (profiles/r04_scratch_repro.txt; the variants are in the history before round 5, not here).
 // --------------------------------------------------------------------------
-#ifndef HJ_SCRATCH_EXPERIMENT
-#define HJ_SCRATCH_EXPERIMENT 0
+#ifndef HJ_K6_STORE
+#define HJ_K6_STORE 0
 #endif
-#if HJ_SCRATCH_EXPERIMENT
-__device__ u64 hj_scratch_dbg[40];   // [0] mismatches, [1] values re-read, [8 + 4 i ..], i < 8: (block << 32 | thread), slot, expected, got
-__device__ __forceinline__ void hj_scratch_check(u64 got, u64 want, uint32_t slot)
+__device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
 {
-    if (got != want) {
-        const u64 at = atomicAdd(&hj_scratch_dbg[0], 1ull);
-        if (at < 8) {
-            hj_scratch_dbg[8 + 4 * at] = ((u64)blockIdx.x << 32) | threadIdx.x; hj_scratch_dbg[9 + 4 * at] = slot;
-            hj_scratch_dbg[10 + 4 * at] = want; hj_scratch_dbg[11 + 4 * at] = got;
-        }
-    }
-}
-// an index the compiler cannot see through: the "expected" side of a check is recomputed, never kept
-__device__ __forceinline__ uint32_t hj_scratch_opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
-// Forensics of the slice pipeline (hjgpu_multi.hip, variant builds): is a slice's pass-1 output right where it was
-// written, where it is read, and in memory once everything is quiet?  res[0] += tuples lying in a partition their key
-// does not hash to, res[1] += sum of keys, res[2] += sum of payloads, res[3] += tuples seen.
-__global__ __launch_bounds__(1024) void hj_debug_verify_kernel(const u64 *__restrict__ tuples, const u64 *__restrict__ off, uint32_t F,
-                                                               uint32_t factor, u64 n, u64 *__restrict__ res)
-{
-    __shared__ u64 s_off[1026];
-    for (uint32_t i = threadIdx.x; i <= F; i += 1024) s_off[i] = off[i];
-    __syncthreads();
-    u64 bad = 0, sk = 0, sv = 0, seen = 0;
-    for (u64 j = (u64)blockIdx.x * 1024 + threadIdx.x; j < n; j += (u64)gridDim.x * 1024) {
-        const u64 t = tuples[j];
-        const uint32_t key = (uint32_t)t;
-        uint32_t lo = 0, hi = F;                                    // largest p with s_off[p] <= j
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (s_off[mid] <= j) lo = mid; else hi = mid; }
-        if (hj_hash(key, factor, F) != lo) ++bad;
-        sk += key; sv += t >> 32; ++seen;
-    }
-    bad = wave_reduce_sum(bad); sk = wave_reduce_sum(sk); sv = wave_reduce_sum(sv); seen = wave_reduce_sum(seen);
-    if (hj_lane() == 0) { atomicAdd(&res[0], bad); atomicAdd(&res[1], sk); atomicAdd(&res[2], sv); atomicAdd(&res[3], seen); }
-}
-__global__ __launch_bounds__(1024) void hj_debug_sums_kernel(const uint32_t *__restrict__ k, const uint32_t *__restrict__ v, u64 n,
-                                                             u64 *__restrict__ res)
-{
-    u64 sk = 0, sv = 0, seen = 0;
-    for (u64 j = (u64)blockIdx.x * 1024 + threadIdx.x; j < n; j += (u64)gridDim.x * 1024) { sk += k[j]; sv += v[j]; ++seen; }
-    sk = wave_reduce_sum(sk); sv = wave_reduce_sum(sv); seen = wave_reduce_sum(seen);
-    if (hj_lane() == 0) { atomicAdd(&res[1], sk); atomicAdd(&res[2], sv); atomicAdd(&res[3], seen); }
-}
-int hj_debug_verify(const u64 *tuples, const u64 *d_off, uint32_t F, uint32_t factor, u64 n, u64 *d_res, hipStream_t s)
-{
-    if (n) hipLaunchKernelGGL(hj_debug_verify_kernel, dim3(64), dim3(1024), 0, s, tuples, d_off, F, factor, n, d_res);
-    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
-}
-int hj_debug_sums(const uint32_t *k, const uint32_t *v, u64 n, u64 *d_res, hipStream_t s)
-{
-    if (n) hipLaunchKernelGGL(hj_debug_sums_kernel, dim3(64), dim3(1024), 0, s, k, v, n, d_res);
-    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
-}
-
-extern "C" int hjgpu_debug_scratch(unsigned long long *out40, int reset)
-{
-    if (out40 && hipMemcpyFromSymbol(out40, HIP_SYMBOL(hj_scratch_dbg), sizeof(u64) * 40) != hipSuccess) return HJGPU_EHIP;
-    if (reset) {
-        u64 zero[40];
-        memset(zero, 0, sizeof(zero));
-        if (hipMemcpyToSymbol(HIP_SYMBOL(hj_scratch_dbg), zero, sizeof(zero)) != hipSuccess) return HJGPU_EHIP;
-    }
-    return HJGPU_OK;
-}
+#if HJ_K6_STORE == 1
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    v4u_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4u_t *>(p));
+#elif HJ_K6_STORE == 2
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    v4u_t t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(t) : "memory");
+#else
+    *reinterpret_cast<uint4 *>(p) = v;
 #endif
+}
+__device__ __forceinline__ void k6_store8(u64 *p, u64 v)
+{
+#if HJ_K6_STORE == 1
+    __builtin_nontemporal_store(v, p);
+#elif HJ_K6_STORE == 2
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
 
 // --------------------------------------------------------------------------
 // K4: fused two-level histogram + per-range pass-1 counts.
@@ -148,10 +89,6 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
     for (int q = 0; q < 8; ++q) if (q == (int)chunk) { cb = geom.b[q]; ce = geom.b[q + 1]; }
     const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(keys - geom.align);
 
-#if HJ_SCRATCH_EXPERIMENT == 17
-    volatile uint32_t sy17[2];                          // variant 17: K4 carries one private word, written once, never read
-    sy17[0] = 0; sy17[1] = threadIdx.x;
-#endif
     for (uint32_t i = threadIdx.x; i < P + F1; i += BLOCK) lds_hist[i] = 0;     // fused histogram + range_hist
 
     // ranges are claimed from a per-chunk ticket counter (see K6: whoever runs, works); the next
@@ -348,11 +285,7 @@ __global__ __launch_bounds__(BLOCK) void hist_packed_kernel(const u64 *__restric
     counts += (u64)chunk * P;
     for (uint32_t i = threadIdx.x; i < P; i += BLOCK) lds_hist[i] = 0;
     __syncthreads();
-#if HJ_SCRATCH_EXPERIMENT == 4
-    const uint4 *t4 = reinterpret_cast<const uint4 *>(tuples);
-#else
     const uint4 *__restrict__ t4 = reinterpret_cast<const uint4 *>(tuples);     // two tuples per 16 bytes
-#endif
     constexpr int U = 4;                                // vectors per lane in flight
     const u64 first = cb & ~1ull;                       // the 16-byte vector that holds the chunk's first tuple
     const u64 step = (u64)BLOCK * 2 * U;
@@ -384,20 +317,8 @@ __global__ __launch_bounds__(BLOCK) void hist_packed_kernel(const u64 *__restric
     uint4 va[U], vb[U];
     u64 base = first + (u64)blockIdx.x * step;
     bool wa = whole_at(base), wb = false;
-#if HJ_SCRATCH_EXPERIMENT == 4
-    volatile u64 sx[2];
-    sx[0] = (u64)(tuples + threadIdx.x); sx[1] = (u64)(counts + threadIdx.x);
-#endif
     if (base < ce) fetch(base, va, wa);
     while (base < ce) {
-#if HJ_SCRATCH_EXPERIMENT == 4
-        {   // re-read per batch, used for the next batch's loads
-            const u64 got = sx[0];
-            hj_scratch_check(got, (u64)(tuples + hj_scratch_opaque(threadIdx.x)), 40);
-            atomicAdd(&hj_scratch_dbg[1], threadIdx.x == 0 ? (u64)BLOCK : 0ull);
-            t4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const u64 *>(got) - threadIdx.x);
-        }
-#endif
         wb = whole_at(base + stride);
         if (base + stride < ce) fetch(base + stride, vb, wb);
         count(base, va, wa);
@@ -409,13 +330,6 @@ __global__ __launch_bounds__(BLOCK) void hist_packed_kernel(const u64 *__restric
         base += stride;
     }
     __syncthreads();
-#if HJ_SCRATCH_EXPERIMENT == 4
-    {
-        const u64 got = sx[1];
-        hj_scratch_check(got, (u64)(counts + hj_scratch_opaque(threadIdx.x)), 41);
-        counts = reinterpret_cast<u64 *>(got) - threadIdx.x;
-    }
-#endif
     for (uint32_t i = threadIdx.x; i < P; i += BLOCK) {
         const uint32_t c = lds_hist[i];
         if (c) atomicAdd(&counts[i], (u64)c);
@@ -973,19 +887,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         asm volatile("v_mov_b32 %0, 0" : "=v"(z));
         return z;
     };
-#if HJ_SCRATCH_EXPERIMENT == 1
-    uint32_t opaque_zero_once;                                      // as before d8b72d0: hoisted, kept (and spilled) across the tile loop
-    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero_once));
-#endif
     auto take_ticket = [&]() -> uint32_t {                          // uniform; at most once between two deposits
         const uint32_t t = claim[claim_parity];
-#if HJ_SCRATCH_EXPERIMENT == 1
-        if (!RANGED) {
-            if (tid == 0) { pending_ticket = atomicAdd(a.work_counter + opaque_zero_once, 1u); pending_slot = claim_parity; }
-            claim_parity ^= 1;
-            return t;
-        }
-#endif
         if (tid == 0) { pending_ticket = atomicAdd(a.work_counter + opaque_zero_now(), 1u); pending_slot = claim_parity; }
         claim_parity ^= 1;
         return t;
@@ -1068,19 +971,6 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         return c == 0 ? vq[j].x : c == 1 ? vq[j].y : c == 2 ? vq[j].z : vq[j].w;
     };
 
-#if HJ_SCRATCH_EXPERIMENT == 5 || HJ_SCRATCH_EXPERIMENT == 6 || HJ_SCRATCH_EXPERIMENT == 19
-    volatile uint32_t sy[2];
-    if (!RANGED) { sy[0] = 0; sy[1] = (uint32_t)tid; }
-#endif
-#if HJ_SCRATCH_EXPERIMENT == 9 || HJ_SCRATCH_EXPERIMENT == 12 || HJ_SCRATCH_EXPERIMENT == 14 || HJ_SCRATCH_EXPERIMENT == 15
-    volatile uint32_t sy[2];
-    if (RANGED) { sy[0] = 0; sy[1] = (uint32_t)tid; }
-#endif
-#if HJ_SCRATCH_EXPERIMENT == 2 || HJ_SCRATCH_EXPERIMENT == 3
-    volatile u64 sx[4];                                             // the private segment: scratch_store / scratch_load
-    if (HJ_SCRATCH_EXPERIMENT == 2 && !RANGED) { sx[0] = (u64)(a.cursors + tid); sx[1] = (u64)(a.part_start + tid); sx[2] = (u64)(a.part_end + tid); }
-    if (HJ_SCRATCH_EXPERIMENT == 3 && RANGED) sx[3] = (u64)(a.range_base + tid);
-#endif
     Tile cur = next_tile();
     deposit_ticket();                                               // the loop's first take needs its slot refilled
     __syncthreads();
@@ -1106,65 +996,12 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             for (uint32_t u = 0; u < extra; ++u) heavy[at + u] = bin | ((u + 1) << 16);
         }
     };
-#if HJ_SCRATCH_EXPERIMENT == 15 || HJ_SCRATCH_EXPERIMENT == 16
-    u64 gap_prev = 0;
-#endif
     for (;;) {
-#if HJ_SCRATCH_EXPERIMENT == 3
-        const u64 *rb_private = a.range_base;
-        if (RANGED) {                                               // re-read every tile, used at every new range
-            const u64 got = sx[3];
-            hj_scratch_check(got, (u64)(a.range_base + hj_scratch_opaque(tid)), 30);
-            if (tid == 0) atomicAdd(&hj_scratch_dbg[1], (u64)BLOCK);
-            rb_private = reinterpret_cast<const u64 *>(got) - tid;
-        }
-#endif
-#if HJ_SCRATCH_EXPERIMENT == 15 || HJ_SCRATCH_EXPERIMENT == 16
-        // was this wave ever off its CU (context save / restore)?  Thread 0 of every workgroup keeps the longest time between
-        // two of its tiles (100 MHz wall clock): a tile takes ~13 us, a wave that was switched out would be gone for far longer
-        if (RANGED && tid == 0) {
-            const u64 now = wall_clock64();
-            if (gap_prev) {
-                const u64 gap = now - gap_prev;
-                atomicMax(&hj_scratch_dbg[2], gap);
-                if (gap > 100000) atomicAdd(&hj_scratch_dbg[3], 1ull);          // > 1 ms
-                if (gap > 10000) atomicAdd(&hj_scratch_dbg[4], 1ull);           // > 100 us
-                atomicAdd(&hj_scratch_dbg[5], 1ull);
-            }
-            gap_prev = now;
-        }
-#endif
-#if HJ_SCRATCH_EXPERIMENT == 10
-        if (RANGED) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == 0) atomicAdd(&hj_scratch_dbg[1], (u64)BLOCK);
-        }
-#endif
-#if HJ_SCRATCH_EXPERIMENT == 11
-        const u64 *rb_generic = a.range_base;
-        if (RANGED) {                                               // the same address, its address space hidden from the compiler
-            u64 bits = (u64)a.range_base;
-            asm volatile("" : "+v"(bits));
-            rb_generic = reinterpret_cast<const u64 *>(bits);
-        }
-#endif
-#if HJ_SCRATCH_EXPERIMENT == 12
-        uint32_t private_zero = 0;
-        if (RANGED) private_zero = sy[0];
-#endif
         if (RANGED && cur.new_range) {
 #pragma unroll
             for (int i = 0; i < BPT; ++i) {
                 const uint32_t bin = tid * bpt + i;
-#if HJ_SCRATCH_EXPERIMENT == 11
-                if ((uint32_t)i < bpt && bin < F) mycur[i] = rb_generic[(u64)cur.range * F + bin];
-#elif HJ_SCRATCH_EXPERIMENT == 12
-                if ((uint32_t)i < bpt && bin < F) mycur[i] = a.range_base[(u64)cur.range * F + bin + private_zero];
-#elif HJ_SCRATCH_EXPERIMENT == 3
-                if ((uint32_t)i < bpt && bin < F) mycur[i] = rb_private[(u64)cur.range * F + bin];
-#else
                 if ((uint32_t)i < bpt && bin < F) mycur[i] = a.range_base[(u64)cur.range * F + bin];
-#endif
                 mycc[i] = 0;                                        // the previous range flushed its carry
             }
         }
@@ -1294,39 +1131,11 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     // one returning atomic carries both claims (lines | tail tuples << 32)
                     const uint32_t front = cnt[i] & ~(LINE - 1), tail = cnt[i] & (LINE - 1);
                     // (the index is laundered per tile: no per-thread address lives across the tile loop, see opaque_zero_now)
-#if HJ_SCRATCH_EXPERIMENT == 1
-                    // as before d8b72d0: `cursors + tid`, `part_start + tid`, `part_end + tid` are hoisted by the compiler
-                    dst[i] = atomicAdd(&a.cursors[cur.cursor_row + bin], ((u64)tail << 32) | (u64)(front / LINE));
-                    pstart[i] = a.part_start[cur.cursor_row + bin];
-                    pend[i] = a.part_end[cur.cursor_row + bin];
-#elif HJ_SCRATCH_EXPERIMENT == 2
-                    {
-                        // the three addresses come back from the private segment and are used as they come
-                        const u64 g0 = sx[0], g1 = sx[1], g2 = sx[2];
-                        const uint32_t t_op = hj_scratch_opaque(tid);
-                        hj_scratch_check(g0, (u64)(a.cursors + t_op), 20);
-                        hj_scratch_check(g1, (u64)(a.part_start + t_op), 21);
-                        hj_scratch_check(g2, (u64)(a.part_end + t_op), 22);
-                        atomicAdd(&hj_scratch_dbg[1], 3ull);
-                        const uint32_t rel = cur.cursor_row + bin - tid;
-                        dst[i] = atomicAdd(reinterpret_cast<u64 *>(g0) + rel, ((u64)tail << 32) | (u64)(front / LINE));
-                        pstart[i] = reinterpret_cast<const u64 *>(g1)[rel];
-                        pend[i] = reinterpret_cast<const u64 *>(g2)[rel];
-                    }
-#else
                     uint32_t at = cur.cursor_row + bin;
-#if HJ_SCRATCH_EXPERIMENT == 6
-                    at += sy[0];                                    // 0, from the private segment
-#elif HJ_SCRATCH_EXPERIMENT == 7
-                    __builtin_amdgcn_s_sleep(60); __builtin_amdgcn_s_sleep(60); __builtin_amdgcn_s_sleep(60); __builtin_amdgcn_s_sleep(60);
-#elif HJ_SCRATCH_EXPERIMENT == 8
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                     asm volatile("" : "+v"(at));                    // an index the compiler cannot take apart
                     dst[i] = atomicAdd(&a.cursors[at], ((u64)tail << 32) | (u64)(front / LINE));
                     pstart[i] = a.part_start[at];
                     pend[i] = a.part_end[at];
-#endif
                 } else {
                     uint32_t at = cur.cursor_row + bin;
                     asm volatile("" : "+v"(at));                    // an index the compiler cannot take apart (see opaque_zero_now)
@@ -1369,11 +1178,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             // kernels of another stream run beside it (DESIGN section 3 "Round 3 / 4", profiles/r04_scratch_repro.txt: the
             // private values themselves are never wrong; same machine code with and without the descriptor bit).
             // tests/test_kernel_resources.py keeps every shipped instance free of scratch.
-#if HJ_SCRATCH_EXPERIMENT == 1
-            constexpr int GROUP = VPT * 4;                          // as before d8b72d0: all 16 bases live -> spills in pass 2
-#else
             constexpr int GROUP = (!RANGED && VPT == 4) ? 8 : VPT * 4;
-#endif
 #pragma unroll
             for (int k0 = 0; k0 < VPT * 4; k0 += GROUP) {
                 uint32_t pbase[GROUP];
@@ -1456,10 +1261,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                         const bool v0 = s >= off, v1 = s + 1 >= off && s + 1 < lim;
                         if (v0 && v1) {
                             const u64 t0 = fetch(s - off), t1 = fetch(s + 1 - off);
-                            *reinterpret_cast<uint4 *>(out64 + base + s) =
-                                make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
-                        } else if (v0) out64[base + s] = fetch(s - off);
-                        else if (v1) out64[base + s + 1] = fetch(s + 1 - off);
+                            k6_store16(out64 + base + s, make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32)));
+                        } else if (v0) k6_store8(out64 + base + s, fetch(s - off));
+                        else if (v1) k6_store8(out64 + base + s + 1, fetch(s + 1 - off));
                     }
                     s += 32;
                 }
@@ -1468,10 +1272,9 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 const u64 *__restrict__ src = stage + src0 - off - fc;
                 for (; s + 1 < s_end; s += 32) {
                     const u64 t0 = src[s], t1 = src[s + 1];
-                    *reinterpret_cast<uint4 *>(out64 + base + s) =
-                        make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32));
+                    k6_store16(out64 + base + s, make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32)));
                 }
-                if (s < s_end) out64[base + s] = src[s];            // the run ends on an even slot
+                if (s < s_end) k6_store8(out64 + base + s, src[s]);            // the run ends on an even slot
             };
             const uint32_t nunits = F + wsum[NW + 1];
             for (uint32_t u = gid; u < nunits; u += NG) {
@@ -1483,7 +1286,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 for (uint32_t idx = tid; idx < F * LINE; idx += BLOCK) {
                     const uint32_t p = idx / LINE, j = idx % LINE;
                     const u64 ti = tinfo[p];
-                    if (j < ((uint32_t)ti & (LINE - 1))) out64[(ti >> 4) + j] = stage[hist[p] + (meta[p] & 0xFFFFu) + j];
+                    if (j < ((uint32_t)ti & (LINE - 1))) k6_store8(out64 + (ti >> 4) + j, stage[hist[p] + (meta[p] & 0xFFFFu) + j]);
                 }
             }
         } else {
@@ -1502,10 +1305,6 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         have_left = true;
         have_left_or_prev = true;
     }
-#if HJ_SCRATCH_EXPERIMENT == 14
-    // variant 9 + the wave does not end before its stores have been acknowledged
-    if (RANGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 }
 
 // ---- geometry of a pass: workgroup size, vectors per thread, whole-line mode -------
