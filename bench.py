@@ -31,7 +31,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 INNER_FACTOR, OUTER_FACTOR = 0x2545F491, 0x9E3779B1
 # PMC traffic of the kernels (tools/collect_traffic.py): THIS file, and only while its kernel hash is the
 # running library's (hjgpu_kernel_hash) and it was taken on the workload being run
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+# the other legs of the N = 1 line: PMC traffic of the same kernels measured through `tools/collect_traffic.py <args>` (the file
+# records the arguments); attached under the same rule as the headline's - same kernel hash, same workload - or null with the reason
+SECONDARY_TRAFFIC = {"npj": ("r05_npj_traffic.json", ["--algo", "npj"]),
+                     "cpra": ("r05_cpra_traffic.json", ["--algo", "cpra"]),
+                     "phj_unique": ("r05_unique_traffic.json", ["--option", "unique=1"]),
+                     "materialized": ("r05_materialized_traffic.json", ["--materialized"])}
 MASK64 = (1 << 64) - 1
 
 
@@ -269,6 +275,43 @@ def attach_traffic(H, kernels, args, n_gpus):
             entry["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["launches_seen"] for h in hit)
                                    / max(1, sum(h["launches_seen"] for h in hit)))
     return "%s (kernels %s)" % (name, t["kernel_hash"])
+
+
+def workspace_report(hj):
+    """what the context spent growing its workspace before the timed region, and its placement search for the probe side's
+    pass-1 twin (hjgpu_stats.ms_reserve / placement_*): candidates allocated and filled, the kept block's fill rate, whether
+    the search's budget (option placement_ms, 500 ms) ended it"""
+    st = hj.stats()
+    fill = st["placement_fill_ms"]
+    return {"ms_reserve": round(st["ms_reserve"], 1), "candidates_tried": int(st["placement_tried"]),
+            "chosen_fill_ms": round(fill, 3), "chosen_fill_TBs": round(st["placement_bytes"] / (fill * 1e-3) / 1e12, 2) if fill > 0 else None,
+            "chosen_is_fast_kind": bool(fill > 0 and st["placement_bytes"] / (fill * 1e-3) >= 5.5e12),
+            "search_timeboxed": bool(st["placement_timeboxed"]), "search_budget_ms": 500}
+
+
+def attach_secondary_traffic(H, leg, entries):
+    """entries: {roofline object: (kernel name prefix, "mean" | "sum" over the template instances)}; returns the source text"""
+    fname, want_args = SECONDARY_TRAFFIC[leg]
+    path = os.path.join(ROOT, "profiles", fname)
+    for entry, _ in entries:
+        if entry is not None:
+            entry["traffic"] = None
+    if not os.path.exists(path):
+        return "none: profiles/%s is missing" % fname
+    t = json.load(open(path))
+    if t.get("kernel_hash") != H.kernel_hash():
+        return "refused: profiles/%s was measured with kernels %s, this library is %s" % (fname, t.get("kernel_hash"), H.kernel_hash())
+    if list(t.get("bench_args") or []) != want_args:
+        return "refused: profiles/%s was measured with %r, this leg is %r" % (fname, t.get("bench_args"), want_args)
+    for entry, (prefix, how) in entries:
+        hit = [v for k, v in t["kernels"].items() if k.startswith(prefix)]
+        if entry is None or not hit:
+            continue
+        if how == "sum":          # every instance runs once per join (the two launches of a _UNIQUE join)
+            entry["traffic"] = int(sum(h["hbm_bytes_per_launch"] for h in hit))
+        else:
+            entry["traffic"] = int(sum(h["hbm_bytes_per_launch"] * h["launches_seen"] for h in hit) / max(1, sum(h["launches_seen"] for h in hit)))
+    return "profiles/%s (kernels %s)" % (fname, t["kernel_hash"])
 
 
 def cpra_multi_leg(args, H, torch, dist, comm, hj, dev, rank, n_gpus):
@@ -595,7 +638,7 @@ def main():
         "device": info["name"], "arch": info["arch"],
         # wall clock this context spent growing its workspace before the timed region (allocations + the placement search
         # for the probe side's pass-1 twin: up to 12 candidate blocks of 8.5 GB held and filled twice, hjgpu_stats.ms_reserve)
-        "workspace": {"ms_reserve": round(hj.stats()["ms_reserve"], 1)},
+        "workspace": workspace_report(hj),
     }
     if args.rehearse_solo:
         out["rehearsal"] = "--rehearse-solo: %d processes on ONE GPU, each with a one-rank RCCL communicator; the numbers mean nothing" % world
@@ -651,8 +694,9 @@ def main():
     extras = (not multi and rank == 0 and not args.no_secondary and args.algo == "phj" and args.zipf <= 0
               and (args.inner, args.outer) == (64_000_000, 1_000_000_000))
     if extras:
-        def time_steps(fn, warm=1, steps=5):
+        def time_steps(fn, warm=1, steps=5, ctx=None):
             """ms per call (host clock over `steps` back-to-back enqueues + one synchronise) and the per-phase stats"""
+            ctx = ctx or hj
             for _ in range(warm):
                 fn()
             torch.cuda.synchronize()
@@ -660,7 +704,7 @@ def main():
             acc = {}
             for _ in range(steps):
                 fn()
-                for key, val in hj.stats().items():          # waits for this call's last event
+                for key, val in ctx.stats().items():          # waits for this call's last event
                     acc[key] = acc.get(key, 0.0) + val
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / steps * 1e3, {key: val / steps for key, val in acc.items()}
@@ -729,6 +773,27 @@ def main():
                              "ms_join": round(ph["ms_join"], 4),
                              "join_vs_default_instance": round(ph["ms_join"] / join_ms, 4) if join_ms > 0 else None,
                              "roofline_join": roof(8 * (inner + outer), ph["ms_join"], 1, stream_read_gbs)}
+        # the headline WITHOUT the placement search (option placement=1: the first allocation is taken): what a step costs when
+        # the probe side's pass-1 twin is whatever block hipMalloc returns (a context of its own, closed afterwards)
+        hj1 = H.HjGpu(local_rank)
+        try:
+            hj1.set_option("placement", "1")
+            hj1.reserve(inner, outer)
+            ms, ph = time_steps(lambda: hj1.phj_async(*a, prm, d_result.data_ptr(), stream), warm=2, steps=min(args.steps, 10), ctx=hj1)
+            ok_ = [int(x) & MASK64 for x in d_result.tolist()] == expect_local
+            ws1 = hj1.stats()
+            sec["phj_unplaced"] = {"workload": "the headline with option placement=1 (no search: the first allocation holds the probe side's pass-1 twin)",
+                                   "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2), "checksum_ok": ok_,
+                                   "ms_scatter1": round(ph["ms_scatter1"], 4), "ms_scatter1_headline": round(avg["ms_scatter1"], 4),
+                                   "ms_reserve": round(ws1["ms_reserve"], 1)}
+        finally:
+            hj1.close()
+        sec["npj"]["traffic_source"] = attach_secondary_traffic(H, "npj", [(sec["npj"]["roofline_probe"], ("npj_probe", "mean")),
+                                                                             (sec["npj"]["roofline_probe_line_granular"], ("npj_probe", "mean")),
+                                                                             (sec["npj"]["roofline_build"], ("npj_build", "mean"))])
+        sec["cpra"]["traffic_source"] = attach_secondary_traffic(H, "cpra", [(sec["cpra"]["roofline_scatter"], ("scatter_kernel", "mean")),
+                                                                               (sec["cpra"]["roofline_join"], ("join_kernel", "mean"))])
+        sec["phj_unique"]["traffic_source"] = attach_secondary_traffic(H, "phj_unique", [(sec["phj_unique"]["roofline_join"], ("join_kernel", "sum"))])
         out["secondary"] = sec
         # rows (key, outer payload, inner payload) written through the block
         # protocol, compacted by close_gaps; priced against read + written bytes.
@@ -769,7 +834,9 @@ def main():
                                "join_phase_rw_frac": round(rw / (tj * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "join_phase_rw_frac_min_max": [round(rw / (max(tj_each) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                                               round(rw / (min(tj_each) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)],
+                               "roofline_join": roof(rw, tj, 1, stream_read_gbs),
                                "block_size": block, "rows_checksum_ok": bool(ok_rows)}
+        out["materialized"]["traffic_source"] = attach_secondary_traffic(H, "materialized", [(out["materialized"]["roofline_join"], ("join_kernel", "mean"))])
         del jk, jo, ji
         for c in jcols:
             c.free()

@@ -84,20 +84,30 @@ def build_library(force=False, verbose=True):
     return so
 
 
-def build_host(force=False, verbose=True):
+def build_host(force=False, verbose=True, sanitize=False):
     """The reference's four programs (./npj ./phj ./cpra ./write) as thin C++ hosts
-    over the C-ABI.  Plain g++: they do not include HIP headers."""
+    over the C-ABI.  Plain g++: they do not include HIP headers.
+    sanitize=True: the same sources with -fsanitize=address,undefined into lib/asan/ (CPU-side checks of argv handling,
+    file I/O and the generator, tests/test_sanitizers.py; the library they link stays the product's)."""
     os.makedirs(LIB, exist_ok=True)
+    if sanitize:
+        return _build_host_into(os.path.join(LIB, "asan"), force, verbose,
+                                ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"])
+    return _build_host_into(LIB, force, verbose, ["-O2"])
+
+
+def _build_host_into(out_dir, force, verbose, flags):
+    os.makedirs(out_dir, exist_ok=True)
     built = []
     common = [os.path.join(HOST, "host_common.hpp"), os.path.join(ROOT, "include", "hjgpu.h")]
     for name, src in HOST_PROGRAMS.items():
         srcp = os.path.join(HOST, src)
         if not os.path.exists(srcp):
             continue
-        exe = os.path.join(LIB, name)
+        exe = os.path.join(out_dir, name)
         if force or _newer(exe, [srcp, lib_path()] + common):
-            cmd = ["g++", "-O2", "-std=c++20", "-Wall", "-I", os.path.join(ROOT, "include"),
-                   srcp, "-o", exe, "-L", LIB, "-lhjgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+            cmd = ["g++"] + flags + ["-std=c++20", "-Wall", "-I", os.path.join(ROOT, "include"),
+                   srcp, "-o", exe, "-L", LIB, "-lhjgpu", "-Wl,-rpath," + ("$ORIGIN" if out_dir == LIB else "$ORIGIN/.."), "-lpthread"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -62,6 +62,8 @@ struct HjTuning {
                                     // profiles/r04_placement_counters.txt): nothing to choose, only to measure.  A cap of 4 was tried in round 4
                                     // and left 3 of 12 fresh processes without a fast block (profiles/r04_placement_log.txt: 10 of 32
                                     // candidates are fast); the search stops at the first fast one, 3 candidates on average.
+    int placement_ms = 500;         // "placement_ms": wall-clock budget of one placement search (0 = none): when it is spent the best block so far is
+                                    // taken (round 4's driver run spent 3.07 s in a search that found no fast block among twelve)
     bool placement_log = false;     // "placement_log": the search prints every candidate's fill time and its choice to stderr (diagnostics)
     bool audit = false;             // "audit" (diagnostics): every stage leaves a checksum of its output (audit_kernels.hip, hjgpu_audit_read)
     int hist_min_lds = 0;           // "hist_min_lds" (diagnostics): K4 asks for at least this many bytes of LDS per workgroup (nothing else then shares its CU)
@@ -99,8 +101,22 @@ int hj_allow_dynamic_lds(const void *kernel, int bytes, HjPerDeviceOnce *once);
 // tiles.  K4 counts per range, K5 turns the counts into per-range write bases,
 // and K6 pass 1 walks the same ranges with private cursors - no global atomics.
 constexpr uint32_t HJ_MAX_RANGE_ENTRIES = 1u << 24;   // ranges * F1 kept below this (64 MiB of counts)
+// Independently partitioned chunks of a relation (CPRA: the reference's #threads, cpra2.cpp:1757-1827, 2023; its runs used up
+// to 129+ threads, the result does not depend on the number).  Beyond 8 chunks the plan is always two passes with
+// line-aligned final partitions: the join then sees ONE region per partition whatever the number of chunks.
+constexpr uint32_t HJ_MAX_CHUNKS = 64;
+// work-claim counters inside MetaLayout::tickets (uint32 words, zeroed per join)
+constexpr uint32_t HJ_TICKET_K4 = 0;                          // K4: [r * HJ_MAX_CHUNKS + chunk]
+constexpr uint32_t HJ_TICKET_K6 = 2 * HJ_MAX_CHUNKS;          // K6: [2 * r + pass - 1]
+constexpr uint32_t HJ_TICKET_MULTI_FILL = 2 * HJ_MAX_CHUNKS + 8;
+constexpr uint32_t HJ_TICKET_WORDS = 2 * HJ_MAX_CHUNKS + 16;
 struct Pass1Geom {
-    u64 b[9];                       // chunk boundaries b[0..chunks]
+    u64 n, part;                    // chunk c = rows [part * c, c + 1 == chunks ? n : part * (c + 1)): thread_beg / thread_end with
+                                    // alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742) - computed, not stored: any number of chunks
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    u64 beg(uint32_t c) const { return c >= chunks ? n : part * c; }
     uint32_t chunks;
     uint32_t align;                 // (address of the key column / 4) % 4
     uint32_t ranges_per_chunk;      // ceil(tiles of the largest chunk / tiles per range)
@@ -169,17 +185,21 @@ struct JoinArgs {
     const uint32_t *sentinel;
     uint32_t force_chained;              // tests: skip the cuckoo fast path (option "force_chained")
     uint32_t unique;                     // _UNIQUE (npj.cpp:288-290): a probe key reports its first match only
-    // a _UNIQUE join is two launches (join_kernel<.., UNIQUE, DEDUP>): the multi-fill half has its own work counter and
-    // worker slots and returns at once when the plan counted no multi-fill partition (multi_fill, may be NULL = unknown)
+    // a _UNIQUE join is two launches (join_kernel<.., UNIQUE, DEDUP>): the multi-fill half has its own work counter, goes on
+    // in the open output blocks of the single-fill half (same grid, same final_offsets slots) and returns at once when the
+    // plan counted no multi-fill partition (multi_fill, may be NULL = unknown)
     u64 *work_counter2;
     const uint32_t *multi_fill;
-    uint32_t worker_base;                // first final_offsets entry of this launch's waves
 };
 
 struct PlanArgs {
     const u64 *counts[2];     // [chunks*P] fused two-level histograms of R (0) and S (1)
     u64 n[2];                 // relation sizes
-    u64 chunk_beg[2][9];      // first row of every chunk (host-known: sizes only)
+    u64 chunk_beg[2][9];      // first row of every chunk (host-known: sizes only) - read when the chunks are pieces of any size
+                              // (pre-partitioned relations, <= 8 pieces); regular chunks are computed:
+    u64 *more[2] = {nullptr, nullptr};   // chunks > 8: [P] the counters of chunks 8 ... chunks - 1 added up (written by hj_launch_plan)
+    uint32_t regular[2];      // 1: chunk c of relation r starts at row chunk_part[r] * c (Pass1Geom::part; up to HJ_MAX_CHUNKS chunks)
+    u64 chunk_part[2];
     u64 *off2[2];             // [chunks*P + 1] first row of every final partition
     u64 *end2[2];             // [chunks*P] one past its last row
     uint32_t pad2;            // 1: final partitions start on 128-byte lines (two-pass plans)

@@ -86,6 +86,11 @@ struct hjgpu_ctx {
     DevBuf audit, audit_lay;
     uint64_t audit_seq = 0;
     float ms_reserve = 0;           // wall clock of the workspace growth so far (allocations + placement probes)
+    // the last placement search (ensure_placed): candidate blocks it allocated and filled, the kept block's fill time and size,
+    // whether the budget (option "placement_ms") ended it
+    uint32_t placement_tried = 0, placement_timeboxed = 0;
+    float placement_fill_ms = 0;
+    size_t placement_bytes = 0;
 };
 
 namespace {
@@ -191,8 +196,17 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     size_t free0 = 0, total0 = 0;
     if (hipMemGetInfo(&free0, &total0) != hipSuccess) free0 = 0;
     const size_t budget = free0 / 2;
+    const auto search_began = std::chrono::steady_clock::now();
+    bool timeboxed = false;
     for (; n < tries; ++n) {
         if (n && (size_t)(n + 1) * want > budget) break;                     // no room for another candidate
+        // the search's wall-clock budget (option "placement_ms"): the best block so far is good enough (a block of the slow kind
+        // costs pass 1 ~15 %; round 4's driver run looked at twelve 8.5 GB candidates for 3 s and found no fast one)
+        if (n && ctx->tune.placement_ms > 0 &&
+            std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - search_began).count() >= (float)ctx->tune.placement_ms) {
+            timeboxed = true;
+            break;
+        }
         if (hipMalloc(&cand[n], want) != hipSuccess) { (void)hipGetLastError(); break; }
         ms[n] = 1e30f;
         for (int rep = 0; rep < 2; ++rep) {                                  // the first touch of fresh memory is slower
@@ -214,6 +228,8 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     }
     for (int i = 0; i < n; ++i) if (i != best) (void)hipFree(cand[i]);
     b.p = cand[best]; b.cap = want;
+    ctx->placement_tried = (uint32_t)n; ctx->placement_timeboxed = timeboxed ? 1u : 0u;
+    ctx->placement_fill_ms = ms[best]; ctx->placement_bytes = want;
     return HJGPU_OK;
 }
 
@@ -296,8 +312,9 @@ inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) 
 struct MetaLayout {
     u64 *counts[2], *off2[2], *end2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
     u64 *seg2[2];                // [F1 + 1] partition-major pass-1 layout of a chunked relation: bounds of the pass-1 partitions
+    u64 *more[2];                // [P] more than 8 chunks: the counters of chunks 8 ... C - 1 added up (PlanArgs::more), else NULL
     u64 *slice_prefix, *slices;
-    uint32_t *tickets;           // [64] work-claim counters of K4 / K6 (inside the block zeroed per join)
+    uint32_t *tickets;           // [HJ_TICKET_WORDS] work-claim counters of K4 / K6, the multi-fill count (inside the block zeroed per join)
     uint32_t *item_part;         // [P + items_extra] partition of every join work item
     uint4 *tdesc[2];             // [tdesc_cap][2] pass-2 tile descriptors (K5 -> K6 pass 2)
     size_t tdesc_cap;
@@ -322,7 +339,7 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
     auto take = [&](size_t n) { u64 *r = p ? p + at : nullptr; at += (n + 1) & ~size_t(1); return r; };
     m.counts[0] = take((size_t)C * P);
     m.counts[1] = take((size_t)C * P);
-    m.tickets = reinterpret_cast<uint32_t *>(take(32));      // K4: [r * 8 + chunk]; K6: [16 + 2 * r + pass - 1]
+    m.tickets = reinterpret_cast<uint32_t *>(take(HJ_TICKET_WORDS / 2));     // HJ_TICKET_K4 / _K6 / _MULTI_FILL (hj_internal.hpp)
     m.counts_bytes = at * sizeof(u64);
     for (int r = 0; r < 2; ++r) {
         m.off2[r] = take((size_t)C * P + 1);
@@ -334,6 +351,7 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
         m.seg1[r] = take(C + 1);
         m.tp2[r] = take((size_t)C * F1 + 1);
         m.seg2[r] = take((size_t)F1 + 1);
+        m.more[r] = C > 8 ? take(P) : nullptr;
     }
     m.slice_prefix = take((size_t)P + 1);
     m.slices = take(P);
@@ -501,15 +519,14 @@ Pass1Geom make_geom(const HjTuning &tune, const void *keys, size_t n, uint32_t C
     // chunk ranges = thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
     Pass1Geom g;
     const size_t part = (n / C) & ~size_t(15);
-    for (uint32_t c = 0; c < C; ++c) g.b[c] = part * c;
-    for (uint32_t c = C; c < 9; ++c) g.b[c] = n;
+    g.n = n; g.part = part;
     g.chunks = C;
     g.align = align_of(keys);
     g.tile = (uint32_t)hj_scatter_tile(tune, 1, F1, out_packed);
     u64 max_tiles = 1;
     for (uint32_t c = 0; c < C; ++c) {
         // sizing (keys == nullptr): any alignment of the column may follow, one more tile per chunk
-        const u64 t = hj_tiles_of(g.b[c], g.b[c + 1], g.align, g.tile) + (keys ? 0 : 1);
+        const u64 t = hj_tiles_of(g.beg(c), g.beg(c + 1), g.align, g.tile) + (keys ? 0 : 1);
         if (t > max_tiles) max_tiles = t;
     }
     g.ranges_per_chunk = capacity ? ranges_capacity(tune, max_tiles, F1) : ranges_of(tune, max_tiles, F1);
@@ -565,6 +582,17 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
     pl->unique = ctx->tune.unique || (prm && (prm->flags & HJGPU_FLAG_UNIQUE));
     choose_fanout(ctx->tune, inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
     if (big_override >= 0) pl->big_tables = big_override != 0;
+    if (chunks > 8 && !pre) {
+        // More than 8 chunks (the reference takes any #threads, cpra2.cpp:2023): always two passes with line-aligned final
+        // partitions - every chunk's pass-2 tiles then write ONE shared region per final partition and the join sees a single
+        // piece per partition, as after PHJ's passes (it walks at most 8 pieces of a partition in place).
+        if (ctx->tune.dense2) return fail(ctx, HJGPU_EINVAL, "more than 8 chunks need the line-aligned final layout (option dense2 is set)");
+        if (pl->F2 <= 1) {
+            if (prm && prm->fanout1) return fail(ctx, HJGPU_EINVAL, "more than 8 chunks need a two-pass plan (fanout2 >= 2)");
+            const uint32_t parts = pl->F1;              // what one pass would have made: 64 ... 640
+            pl->F2 = 2; pl->F1 = (parts + 1) / 2;
+        }
+    }
     if (pl->unique && !hj_join_config_built(hj_join_config_of(ctx->tune, pl->big_tables), true))
         return fail(ctx, HJGPU_EINVAL, "HJGPU_FLAG_UNIQUE: the join_cfg geometry of this context has no _UNIQUE instance "
                                        "(geometries with one: 512,13,2 and 1024,14,2)");
@@ -666,8 +694,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     if (pre)
         for (int r = 0; r < 2; ++r) {
             if (!pre->tuples[r]) continue;
-            for (uint32_t c = 0; c < 9; ++c) geom[r].b[c] = c <= pl.C ? pre->ch[r].b[c] : pre->ch[r].b[pl.C];
-            geom[r].align = 0;
+            geom[r].align = 0;                  // (the pieces' bounds go to the plan kernels as they are: pa.chunk_beg below)
         }
     for (int r = 0; r < 2; ++r)
         if (!pre && (size_t)geom[r].ranges_per_chunk * pl.C > pl.ranges)
@@ -682,10 +709,11 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
         pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r]; pa.tdesc[r] = m.tdesc[r];
         pa.seg2[r] = m.seg2[r];
+        pa.more[r] = m.more[r];
     }
     pa.tdesc_cap = (uint32_t)m.tdesc_cap;
     pa.unique = pl.unique ? 1u : 0u;
-    pa.multi_fill = m.tickets + 32;          // zeroed with the tickets; counted by the work-item plan, read by the _UNIQUE join
+    pa.multi_fill = m.tickets + HJ_TICKET_MULTI_FILL;          // zeroed with the tickets; counted by the work-item plan, read by the _UNIQUE join
     // two-pass plans: final partitions start on 128-byte lines (pass 2 claims whole lines); option "dense2": dense
     const bool pad2 = pl.F2 > 1 && !ctx->tune.dense2;
     pa.pad2 = pad2 ? 1u : 0u;
@@ -697,7 +725,11 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     pa.seg_interleave = (pre && pl.C > 1 && pad2 && ctx->tune.piece_interleave) ? 1u : 0u;
     // pre-partitioned pieces sit at absolute rows [b[0], b[C]) of the caller's array
     if (pre) for (int r = 0; r < 2; ++r) if (pre->tuples[r]) pa.n[r] = pre->ch[r].b[pl.C];
-    for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = geom[r].b[c];
+    for (int r = 0; r < 2; ++r) {
+        const bool pieces = pre && pre->tuples[r];
+        pa.regular[r] = pieces ? 0u : 1u; pa.chunk_part[r] = geom[r].part;
+        for (uint32_t c = 0; c < 9; ++c) pa.chunk_beg[r][c] = pieces ? pre->ch[r].b[c <= pl.C ? c : pl.C] : geom[r].beg(c);
+    }
     pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
     pa.chunks = pl.C; pa.F1 = pl.F1; pa.F2 = pl.F2;
     pa.in_align[0] = pre ? 0u : align_of(rk); pa.in_align[1] = pre ? 0u : align_of(sk);
@@ -728,7 +760,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     // the stages of one relation's partitioning
     auto k4 = [&](int r) -> int {          // one read of the key column gives the histograms of both passes
         if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
-                                       m.range_counts[r], m.tickets + 8 * r, ctx->cus, stream));
+                                       m.range_counts[r], m.tickets + HJ_TICKET_K4 + HJ_MAX_CHUNKS * r, ctx->cus, stream));
         return HJGPU_OK;
     };
     auto k5b = [&](int r) -> int {
@@ -743,7 +775,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         sa.kin = in_k[r]; sa.vin = in_v[r]; sa.kout = t1[2 * r]; sa.vout = t1[2 * r + 1];
         sa.seg_off = m.seg1[r]; sa.tile_prefix = m.tp1[r]; sa.cursors = m.cur1[r];
         sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
-        sa.ranged = 1; sa.work_counter = m.tickets + 16 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
+        sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
         sa.in_packed = 0; sa.out_packed = 1;
         return hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream);
     };
@@ -754,7 +786,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         sa.kin = t1[2 * r]; sa.vin = t1[2 * r + 1]; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
         sa.seg_off = p_major ? m.seg2[r] : m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
         sa.nseg = p_major ? pl.F1 : pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
-        sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
+        sa.ranged = 0; sa.work_counter = m.tickets + HJ_TICKET_K6 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
         sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
         sa.in_packed = 1; sa.out_packed = 1;
         return hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream);
@@ -780,7 +812,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 sa.kin = reinterpret_cast<const uint32_t *>(pre->tuples[r]); sa.vin = nullptr; sa.kout = t2[2 * r]; sa.vout = t2[2 * r + 1];
                 sa.seg_off = m.off1[r]; sa.tile_prefix = m.tp2[r]; sa.cursors = m.cur2[r]; sa.tile_desc = m.tdesc[r];
                 sa.nseg = pl.C * pl.F1; sa.F = pl.F2; sa.factor = pl.f2; sa.in_align = 0;
-                sa.ranged = 0; sa.work_counter = m.tickets + 16 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
+                sa.ranged = 0; sa.work_counter = m.tickets + HJ_TICKET_K6 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
                 sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
                 sa.in_packed = 1; sa.out_packed = 1;
                 CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
@@ -910,7 +942,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.result = &st->result;
         ja.work_counter = &st->work_counter;
         ja.work_counter2 = &st->work_counter2;
-        ja.multi_fill = m.tickets + 32;
+        ja.multi_fill = m.tickets + HJ_TICKET_MULTI_FILL;
         if (bs) {
             ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
             ja.block_size = bs; ja.block_limit = bl;
@@ -1170,12 +1202,20 @@ int hjgpu_reserve(hjgpu_ctx *ctx, size_t inner, size_t outer)
     return HJGPU_OK;
 }
 
+// the workspace's side of hjgpu_stats: what the context has spent growing it, and its last placement search
+static void fill_reserve(const hjgpu_ctx *ctx, hjgpu_stats *s)
+{
+    s->ms_reserve = ctx->ms_reserve;
+    s->placement_tried = ctx->placement_tried; s->placement_timeboxed = ctx->placement_timeboxed;
+    s->placement_fill_ms = ctx->placement_fill_ms; s->placement_bytes = (uint64_t)ctx->placement_bytes;
+}
+
 int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
 {
     if (!ctx || !s) return HJGPU_EINVAL;
     if (ctx->stats_override) {               // a grouped plan: the sums over pass 0 and the groups' joins, taken as they finished
         *s = ctx->stats;
-        s->ms_reserve = ctx->ms_reserve;
+        fill_reserve(ctx, s);
         return HJGPU_OK;
     }
     if (ctx->ev_valid[EV_GAPS]) HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
@@ -1188,11 +1228,11 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
     hjgpu_stats r = ctx->stats;
     r.ms_total = span(EV_BEGIN, EV_GAPS);
     r.ms_inner_wait = 0;
-    r.ms_reserve = ctx->ms_reserve;
+    fill_reserve(ctx, &r);
     if (ctx->last_algo == 2) {                 // hjgpu_column_sums: one kernel
         memset(&r, 0, sizeof(r));
         r.ms_total = span(EV_BEGIN, EV_GAPS);
-        r.ms_reserve = ctx->ms_reserve;
+        fill_reserve(ctx, &r);
         *s = r;
         return HJGPU_OK;
     }
@@ -1405,7 +1445,8 @@ static int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint3
     }
     pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = 0;
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
-    for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
+    for (uint32_t c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
+    pa.regular[0] = pa.regular[1] = 0; pa.chunk_part[0] = pa.chunk_part[1] = 0;
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
     pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 7u;
@@ -1418,7 +1459,7 @@ static int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint3
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
         sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
-        sa.ranged = 1; sa.work_counter = m.tickets + 16; sa.geom = geom; sa.range_base = m.range_base[0];
+        sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6; sa.geom = geom; sa.range_base = m.range_base[0];
         sa.in_packed = 0; sa.out_packed = 0;
         CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }
@@ -1496,7 +1537,8 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     }
     pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = unique ? 1u : 0u;
     pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
-    for (int r = 0; r < 2; ++r) for (int c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
+    for (int r = 0; r < 2; ++r) for (uint32_t c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
+    pa.regular[0] = pa.regular[1] = 0; pa.chunk_part[0] = pa.chunk_part[1] = 0;
     pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
     pa.tile1 = pa.tile2 = (uint32_t)hj_scatter_tile(ctx->tune, 2, 1, true); pa.slice = HJ_JOIN_SLICE;
     pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 7u;
@@ -1794,7 +1836,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
     CHK(check_columns(ctx, rk, rv, inner));
     CHK(check_columns(ctx, sk, sv, outer));
-    if (chunks < 1 || chunks > 8) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 8]");
+    if (chunks < 1 || chunks > HJ_MAX_CHUNKS) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 64]");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
@@ -1943,7 +1985,8 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
     }
     pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = 0;
     pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
-    for (int c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
+    for (uint32_t c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
+    pa.regular[0] = pa.regular[1] = 0; pa.chunk_part[0] = pa.chunk_part[1] = 0;
     pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
     pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
     pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 1u;
@@ -1956,7 +1999,7 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
         sa.kin = d_keys; sa.vin = d_vals; sa.kout = reinterpret_cast<uint32_t *>(d_tuples_out); sa.vout = nullptr;
         sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
-        sa.ranged = 1; sa.work_counter = m.tickets + 16; sa.geom = geom; sa.range_base = m.range_base[0];
+        sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6; sa.geom = geom; sa.range_base = m.range_base[0];
         sa.in_packed = 0; sa.out_packed = 1;
         CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }

@@ -100,7 +100,10 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     Emitter em;
     em.init(a.ok, a.oov, a.oiv, a.block_size, a.block_limit, a.block_counter, a.overflow,
             &wave_cursor[wave]);
-    if (hj_lane() == 0) wave_cursor[wave] = HJ_NO_CURSOR;
+    // (the multi-fill half of a _UNIQUE join runs behind the single-fill half on the same stream, with the same grid: wave w of
+    // workgroup b goes on in the block that wave w of workgroup b left open, and leaves its cursor in the same slot - one
+    // launch's worth of worker slots for close_gaps, not two)
+    if (hj_lane() == 0) wave_cursor[wave] = (DEDUP && a.ok) ? a.final_offsets[(u64)blockIdx.x * NW + wave] : HJ_NO_CURSOR;
 
     u64 acc_n = 0, acc_k = 0, acc_o = 0, acc_i = 0;
     uint32_t empty = 0;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
 
     // ---- per-wave cursors -> final offsets (close_gaps input) ---------------------
     if (a.ok && hj_lane() == 0)
-        a.final_offsets[(DEDUP ? (u64)a.worker_base : 0ull) + (u64)blockIdx.x * NW + wave] = wave_cursor[wave];
+        a.final_offsets[(u64)blockIdx.x * NW + wave] = wave_cursor[wave];
 
     // ---- workgroup reduction of the aggregates, 4 atomics per workgroup ---------
     acc_n = wave_reduce_sum(acc_n); acc_k = wave_reduce_sum(acc_k);
@@ -518,13 +521,13 @@ static int join_wgs_per_cu(const JoinConfig &c)
 }
 
 static int join_grid(int cus, const JoinConfig &c) { return cus * join_wgs_per_cu(c); }
-// Worker slots (final_offsets entries, one open output block each) of a join; a _UNIQUE join is two launches (see
-// join_kernel) and has two launches' worth: the slots of the half that returns at once hold HJ_NO_CURSOR
-// (hj_launch_join fills them in).
+// Worker slots (final_offsets entries, one open output block each) of a join: one per wave of ONE launch.  A _UNIQUE join is
+// two launches (see join_kernel) of the same grid; the second half's waves continue in the first half's open blocks.
 int hj_join_workers(const HjTuning &t, int cus, bool big_tables, bool unique)
 {
+    (void)unique;
     const JoinConfig &c = hj_join_config_of(t, big_tables);
-    return (unique || t.unique ? 2 : 1) * join_grid(cus, c) * (c.block / 64);
+    return join_grid(cus, c) * (c.block / 64);
 }
 
 #define JOIN_CASE(B, L, U, UNQ)                                                                   \
@@ -557,7 +560,7 @@ bool hj_join_config_built(const JoinConfig &c, bool unique)
 #define JOIN_CASE_UNIQUE(B, L)                                                                    \
     if (c.block == B && c.log2slots == L && b.unique) {                                           \
         JoinArgs d = b;                                                                           \
-        d.work_counter = b.work_counter2; d.worker_base = (uint32_t)(join_grid(cus, c) * (B / 64)); \
+        d.work_counter = b.work_counter2;                                                         \
         if (b.packed) {                                                                           \
             hipLaunchKernelGGL((join_kernel<B, L, 2, true, true, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
             hipLaunchKernelGGL((join_kernel<B, L, 1, true, true, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, d);   \
@@ -575,11 +578,7 @@ int hj_launch_join(const JoinArgs &a, const HjTuning &t, int cus, hipStream_t st
     JoinArgs b = a;
     b.force_chained = t.force_chained ? 1u : 0u;       // tests: exercise the fallback table everywhere
     b.unique = (a.unique || t.unique) ? 1u : 0u;
-    b.worker_base = 0;
     if (b.unique && !b.work_counter2) return HJGPU_EINVAL;
-    // materialising joins: the worker slots of a launch that does not happen (or returns at once) read "no open block"
-    if (b.ok && b.unique && hipMemsetAsync(b.final_offsets, 0xFF, (size_t)hj_join_workers(t, cus, a.big_tables != 0, true) * sizeof(u64), stream) != hipSuccess)
-        return HJGPU_EHIP;
     JOIN_CASE_UNIQUE(512, 13)
     JOIN_CASE_UNIQUE(1024, 14)
     JOIN_CASE(512, 13, 2, false)

@@ -28,16 +28,21 @@
 // --------------------------------------------------------------------------
 // How K6's stores leave the CU (HJ_K6_STORE, a build-time choice; tools/build_variant.py <name> -DHJ_K6_STORE=n):
 //   0  plain stores (write-back in the XCD's L2)
-//   1  non-temporal stores (global_store ... nt)
-//   2  system-scope stores (global_store ... sc0 sc1: written through to memory)
-// Round 5 (DESIGN section 3 "Round 5"): with plain stores a K6 launch loses stores - output slots keep what the
-// previous use of the buffer left there - about once in 10^4 pipeline steps when kernels of ANOTHER stream start and end
-// beside it (tools/stress_cpra.py --forensics names the stage; never on one stream).  Rounds 3-4 saw the same
-// signature at a far higher rate with a private segment in the kernel and studied it with -DHJ_SCRATCH_EXPERIMENT=n
-// variants of this file (profiles/r04_scratch_repro.txt; the variants are in the history before round 5, not here).
+//   1  non-temporal stores (global_store ... nt) - THE PRODUCT
+//   2  system-scope stores (two relaxed 8-byte __hip_atomic_store per 16 bytes: global_store_dwordx2 ... sc0 sc1, written through)
+// Round 5 (DESIGN section 3 "Round 5", profiles/r05_*.txt): with plain stores a K6 launch LOSES STORES - output slots keep what
+// the previous use of the buffer left there - in about 1.3 of 10^4 steps of the multi-GPU slice pipeline (11 wrong steps in
+// 82 000), i.e. when kernels and copies of ANOTHER stream start and end beside it; never on one stream (0 in 15 000), never
+// with partitioning and joins serialised (0 in 15 000).  Option "audit" named the kernel: the sums of pass 2's output differ
+// from its input's with nothing misplaced and the count intact.  The same machine code with the nt bit on its stores: 0 wrong
+// steps in 28 000 + (this build) tools/r05_round.sh's sweep; same speed (K6 is bound by the memory system either way).
+// Rounds 3-4 saw the same signature at a far higher rate with a private segment in the kernel and studied it with
+// -DHJ_SCRATCH_EXPERIMENT=n variants of this file (profiles/r04_scratch_repro.txt; the variants are in the history before
+// round 5, not here).  What is lost is data that sits dirty in an XCD's L2 while another queue's kernel boundary writes back
+// and invalidates that L2; non-temporal stores do not linger there.
 // --------------------------------------------------------------------------
 #ifndef HJ_K6_STORE
-#define HJ_K6_STORE 0
+#define HJ_K6_STORE 1
 #endif
 __device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
 {
@@ -46,9 +51,8 @@ __device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
     v4u_t t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<v4u_t *>(p));
 #elif HJ_K6_STORE == 2
-    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
-    v4u_t t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(t) : "memory");
+    __hip_atomic_store(p, (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(p + 1, (u64)v.z | ((u64)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
     *reinterpret_cast<uint4 *>(p) = v;
 #endif
@@ -58,7 +62,7 @@ __device__ __forceinline__ void k6_store8(u64 *p, u64 v)
 #if HJ_K6_STORE == 1
     __builtin_nontemporal_store(v, p);
 #elif HJ_K6_STORE == 2
-    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
     *p = v;
 #endif
@@ -84,9 +88,7 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
     const uint32_t chunk = blockIdx.y;                  // one grid row per chunk: a workgroup never mixes chunks
     counts += (u64)chunk * P;
     range_counts += (u64)chunk * Rc * F1;
-    u64 cb = 0, ce = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) if (q == (int)chunk) { cb = geom.b[q]; ce = geom.b[q + 1]; }
+    const u64 cb = geom.beg(chunk), ce = geom.beg(chunk + 1);
     const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(keys - geom.align);
 
     for (uint32_t i = threadIdx.x; i < P + F1; i += BLOCK) lds_hist[i] = 0;     // fused histogram + range_hist
@@ -248,7 +250,7 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
     constexpr int BLOCK = 1024;
     const uint32_t P = F1 * F2;
     size_t lds = ((size_t)P + F1) * sizeof(uint32_t);
-    if (geom.chunks == 0 || geom.chunks > 8 || lds > 140 * 1024) return HJGPU_EINVAL;
+    if (geom.chunks == 0 || geom.chunks > HJ_MAX_CHUNKS || lds > 140 * 1024) return HJGPU_EINVAL;
     // option "hist_min_lds" (diagnostics): the workgroup asks for at least this much LDS, so that nothing else fits the CU beside it
     if (min_lds > lds && min_lds <= 140 * 1024) lds = min_lds;
     static HjPerDeviceOnce once;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
     const u64 *__restrict__ cnt = a.counts[r] + (u64)c * P;
     u64 *off2 = a.off2[r] + (u64)c * P;
     u64 *end2 = a.end2[r] + (u64)c * P;
-    const u64 base = a.chunk_beg[r][c];
+    const u64 base = a.regular[r] ? a.chunk_part[r] * c : a.chunk_beg[r][c];
     if (!PAD) {
         // dense final layout: partition q occupies [off2[q], off2[q + 1])
         plan_scan(P, [&](uint32_t i) { return cnt[i]; }, off2, base, scratch,
@@ -540,16 +542,19 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
             __syncthreads();
         }
         auto padded = [](u64 n) { return (n + HJ_LINE_TUPLES - 1) & ~(u64)(HJ_LINE_TUPLES - 1); };
-        u64 drun = p_major ? a.chunk_beg[r][0] : base;                // dense offset of the tile's first partition
+        u64 drun = p_major ? (a.regular[r] ? 0 : a.chunk_beg[r][0]) : base;                // dense offset of the tile's first partition
         u64 prun = 0;                                                 // padded one (block 0; the relation starts at row 0)
         const uint32_t F2 = a.F2;
         const u64 *__restrict__ all = a.counts[r];
+        const u64 *__restrict__ more = a.more[r];
         u64 *fo = a.off2[r], *fe = a.end2[r], *fc = a.cur2[r];
         auto total_of = [&](uint32_t q) -> u64 {
-            u64 v[8];
+            u64 v[8];                                            // the first eight chunks' counters are requested before the first add
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) v[k] = k < C ? all[(u64)k * P + q] : 0;
-            return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            u64 t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            if (more) t += more[q];                              // chunks 8 ... C - 1, summed by chunk_tail_sums_kernel
+            return t;
         };
         int parity = 0;
         for (uint32_t tile = 0; tile < P; tile += 2 * PLAN_BLOCK, parity ^= 1) {
@@ -662,10 +667,13 @@ __device__ __forceinline__ void plan_items_body(const PlanArgs &a)
     // tiles of 2 * PLAN_BLOCK partitions, thread t takes partitions tile + 2t and tile + 2t + 1 (see plan_scan2)
     __shared__ u64 scratch2[4 * (PLAN_BLOCK / 64)];
     auto rows_of = [&](const u64 *__restrict__ cnt, uint32_t q) -> u64 {
-        u64 v[8];                                   // chunks <= 8: all loads are requested before the first add
+        u64 v[8];                                   // the first eight chunks: all loads are requested before the first add
 #pragma unroll
         for (uint32_t c = 0; c < 8; ++c) v[c] = c < C ? cnt[(u64)c * P + q] : 0;
-        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        u64 t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        const u64 *__restrict__ more = cnt == cr ? a.more[0] : a.more[1];
+        if (more) t += more[q];                     // chunks 8 ... C - 1 (chunk_tail_sums_kernel)
+        return t;
     };
     u64 run = 0;
     int parity = 0;
@@ -742,8 +750,26 @@ int hj_launch_batch_plan(const BatchPlanArgs &a, uint32_t batches, hipStream_t s
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
+// More than 8 chunks (the reference's larger thread counts): more[q] = the counters of chunks 8 ... C - 1 added up, so that the plan
+// kernels keep their eight loads per partition (a loop over the chunks there cost plan_offsets_kernel 17 VGPRs of spills).
+__global__ __launch_bounds__(256) void chunk_tail_sums_kernel(const u64 *__restrict__ counts, uint32_t C, uint32_t P, u64 *__restrict__ more)
+{
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= P) return;
+    u64 t = 0;
+    for (uint32_t c = 8; c < C; ++c) t += counts[(u64)c * P + q];
+    more[q] = t;
+}
+
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
 {
+    const uint32_t P_all = a.F1 * a.F2;
+    for (int r = 0; r < 2; ++r) {
+        if (a.chunks > 8 && !a.more[r]) return HJGPU_EINVAL;
+        // (bit 2, the join's work items, reads both relations' sums: a probe of a prepared build side has the build side's from its build)
+        if (a.more[r] && ((a.mask >> r) & 1u))
+            hipLaunchKernelGGL(chunk_tail_sums_kernel, dim3((P_all + 255) / 256), dim3(256), 0, stream, a.counts[r], a.chunks, P_all, a.more[r]);
+    }
     if (a.mask & 3u) {
         const unsigned rows = (a.mask & 4u) ? 3u : 2u;          // row 2 = the join's work items
         if ((a.mask & 4u) && ((a.cap & (a.cap - 1)) || a.slice != (uint32_t)HJ_JOIN_SLICE)) return HJGPU_EINVAL;
@@ -914,9 +940,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 if (r_cur >= nranges) { exhausted = true; return t; }
                 r_cur += a.range_begin;
                 const uint32_t c = r_cur / Rc, j = r_cur - c * Rc;
-                u64 cb = 0, ce = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (q == (int)c) { cb = a.geom.b[q]; ce = a.geom.b[q + 1]; }
+                const u64 cb = a.geom.beg(c), ce = a.geom.beg(c + 1);
                 r_gb = a.geom.align + cb; r_ge = a.geom.align + ce;
                 const u64 tiles = hj_tiles_of(cb, ce, a.geom.align, TILE);
                 rt = tiles * j / Rc; rt_end = tiles * (j + 1) / Rc;
@@ -1462,6 +1486,13 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
         t->placement = (int)x;
         return true;
     }
+    if (is("placement_ms")) {
+        char *end = nullptr;
+        const long x = strtol(value, &end, 10);
+        if (end == value || *end || x < 0 || x > 600000) return false;
+        t->placement_ms = (int)x;
+        return true;
+    }
     if (is("reserve_cus")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1518,7 +1549,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "placement_log", "audit", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "placement_ms", "placement_log", "audit", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

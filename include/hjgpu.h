@@ -85,8 +85,9 @@ typedef struct {
     uint32_t factor1, factor2; /* odd pass multipliers; 0 = library defaults                 */
     uint32_t table_factor[2];  /* odd table hash / step multipliers; 0 = defaults            */
     uint32_t chunks;           /* CPRA only: number of independently partitioned chunks
-                                  (the reference's #threads, cpra2.cpp:1757-1827); 0 = 8;
-                                  1..8 (HJGPU_EINVAL beyond: the result does not depend on it) */
+                                  (the reference's #threads, cpra2.cpp:1757-1827, 2023); 0 = 8;
+                                  1..64 (HJGPU_EINVAL beyond: the result does not depend on it;
+                                  beyond 8 the plan is always two passes)                    */
     uint32_t flags;            /* HJGPU_FLAG_*                                               */
 } hjgpu_phj_params;
 
@@ -125,6 +126,13 @@ typedef struct {
                                   key-disjoint groups; every other phase is then the SUM over the groups' joins,
                                   ms_total the sum of all of it                                              */
     uint32_t groups;           /* 0 = the plain two-pass plan                                */
+    /* the context's last placement search (option "placement": candidate blocks for a buffer of 1 GiB and more that K6's
+     * pass 1 scatters into; outside every timed join): blocks allocated and filled, 1 when the search's wall-clock budget
+     * (option "placement_ms", default 500) ended it before a fast block was found, the kept block's fill time and size
+     * (bytes / ms = its fill rate: >= 5.5 TB/s is the fast kind) */
+    uint32_t placement_tried, placement_timeboxed;
+    float    placement_fill_ms;
+    uint64_t placement_bytes;
 } hjgpu_stats;
 
 typedef struct {
@@ -152,7 +160,7 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * including the operator-level hjgpu_npj_probe), "force_chained", "no_broadcast", "dense2", "npj_refhash",
  * "scatter_prof", "merged_plan", "piece_interleave" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
  * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
- * twin, 1..16; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples) and "group_always" (0 / 1): the
+ * twin, 1..16; "placement_ms": the search's wall-clock budget, default 500, 0 = none; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples) and "group_always" (0 / 1): the
  * grouped plans of hjgpu_phj / hjgpu_cpra (below); diagnostics: "audit" (0 / 1: every stage of a join leaves a checksum of its output,
  * hjgpu_audit_read below), "hist_min_lds" (bytes of LDS a histogram workgroup asks for at least: nothing else then shares its CU).
  * Unknown names and malformed values: HJGPU_EINVAL. */

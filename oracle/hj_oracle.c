@@ -365,7 +365,9 @@ void hjo_npj_build(const uint32_t *keys, const uint32_t *vals, size_t size,
         uint64_t pair = ((uint64_t)vals[i] << 32) | key;
         size_t h = hash_wide(key * factor, buckets);
         for (;;) {
-            uint64_t tab = table[h];
+            /* (the reference reads the bucket through a volatile pointer, npj.cpp:202; a relaxed atomic load is the same
+             * instruction and says so to ThreadSanitizer: other workers CAS into the table meanwhile) */
+            uint64_t tab = __atomic_load_n(&table[h], __ATOMIC_RELAXED);
             if ((uint32_t)tab == empty &&
                 __sync_bool_compare_and_swap(&table[h], tab, pair))
                 break;

@@ -34,6 +34,9 @@ class Output(C.Structure):
 
 
 def build(force=False):
+    # HJ_ORACLE_LIB: another build of the same sources (oracle/Makefile asan / tsan; tests/test_sanitizers.py)
+    if os.environ.get("HJ_ORACLE_LIB"):
+        return os.environ["HJ_ORACLE_LIB"]
     so = os.path.join(HERE, "libhjoracle.so")
     srcs = [os.path.join(HERE, f) for f in ("hj_oracle.c", "hj_oracle_avx512.c", "hj_oracle.h")]
     if force or not os.path.exists(so) or any(

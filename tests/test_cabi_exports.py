@@ -63,7 +63,7 @@ def test_struct_layouts_match_header(tmp_path):
         got = [int(x) for x in line.split()[1:]]
         want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert got == want, (cname, got, want)
-    assert C.sizeof(H.Stats) == 80 and C.sizeof(api.HostRows) == 32
+    assert C.sizeof(H.Stats) == 104 and C.sizeof(api.HostRows) == 32
 
 
 def test_library_does_not_link_rccl():

@@ -458,3 +458,46 @@ def test_options_and_communicator_argument_errors(hj):
         assert comm.phj_multi(shards, 0)[0] == want
     for c in (rk, rv):
         c.free()
+
+
+@pytest.mark.parametrize("chunks", [9, 16, 33, 64])
+def test_cpra_with_more_chunks_than_eight(hj, chunks):
+    """CPRA's chunks are the reference's #threads (cpra2.cpp:1757-1827, 2023: any thread count; its runs used 129 and more).
+    Beyond 8 chunks the plan is always two passes with line-aligned final partitions (one region per partition whatever the
+    number of chunks): build sides small enough for one pass, ragged sizes, an empty chunk tail, rows, _UNIQUE."""
+    rng = np.random.default_rng(1000 + chunks)
+    for inner, outer in ((3000, 70_001), (250_000, 1_000_003), (chunks * 16 - 5, 5000)):
+        u = np.unique(rng.integers(1, 2**32, size=inner, dtype=np.uint64).astype(np.uint32))
+        ik = rng.permutation(u)
+        iv = rng.integers(0, 2**32, size=len(ik), dtype=np.uint64).astype(np.uint32)
+        ok = np.where(rng.random(outer) < 0.8, ik[rng.integers(0, len(ik), size=outer)], rng.integers(1, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)).astype(np.uint32)
+        ov = rng.integers(0, 2**32, size=outer, dtype=np.uint64).astype(np.uint32)
+        want = numpy_join(ik, iv, ok, ov)
+        rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+        assert hj.cpra(rk, rv, len(ik), sk, sv, outer, H.PhjParams(chunks=chunks)) == want
+        assert hj.cpra(rk, rv, len(ik), sk, sv, outer, H.PhjParams(chunks=chunks, flags=H.FLAG_UNIQUE)) == want
+        assert hj.cpra(rk, rv, len(ik), sk, sv, outer, H.PhjParams(chunks=chunks, fanout1=24, fanout2=7)) == want
+        for c in (rk, rv, sk, sv):
+            c.free()
+    # an explicit single-pass plan cannot hold more than 8 chunks; neither can the dense final layout
+    ik = np.arange(1, 2001, dtype=np.uint32)
+    rk = hj.column(ik)
+    with pytest.raises(H.HjGpuError):
+        hj.cpra(rk, rk, len(ik), rk, rk, len(ik), H.PhjParams(chunks=chunks, fanout1=64, fanout2=1))
+    with pytest.raises(H.HjGpuError):
+        hj.cpra(rk, rk, len(ik), rk, rk, len(ik), H.PhjParams(chunks=65))
+    rk.free()
+
+
+def test_full_size_cpra_in_64_chunks(hj):
+    """64 M x 1 G in 64 chunks (./cpra 64 ...): the same aggregates as in 8 chunks and as PHJ"""
+    inner, outer = 64_000_000, 1_000_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
+    hj.generate(5, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    sums = hj.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    for chunks in (8, 64, 37):
+        assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=chunks)) == want
+    for c in (ik, iv, ok, ov):
+        c.free()
