@@ -29,12 +29,13 @@ struct Emitter {
     u64 *block_counter;
     uint32_t *overflow;
     volatile hj_lds_u64 *cursor;   // this wave's cursor, in LDS (ds_read_b64 / ds_write_b64)
+    bool nt;                       // non-temporal row stores (uniform)
 
     __device__ __forceinline__ void init(uint32_t *k, uint32_t *ov, uint32_t *iv, u64 bs, u64 bl,
-                                         u64 *bc, uint32_t *ovf, u64 *lds_cursor)
+                                         u64 *bc, uint32_t *ovf, u64 *lds_cursor, bool nt_rows = false)
     {
         ok = k; oov = ov; oiv = iv; block_size = bs; block_limit = bl;
-        block_counter = bc; overflow = ovf; cursor = (volatile hj_lds_u64 *)lds_cursor;
+        block_counter = bc; overflow = ovf; cursor = (volatile hj_lds_u64 *)lds_cursor; nt = nt_rows;
     }
 
     // Called by the lanes that have a match (any subset of the wave).
@@ -67,8 +68,18 @@ struct Emitter {
             next = base + (n - room);
         }
         if (rank == 0) *cursor = next;
-        ok[pos] = key;
-        oov[pos] = outer_val;
-        oiv[pos] = inner_val;
+        // Row stores of a join that runs beside other streams' kernels and copies (enqueue-only joins, the batched host
+        // pipelines, the multi-GPU *_rows calls) are NON-TEMPORAL: plain stores that sit dirty in an XCD's L2 while another
+        // queue's kernel boundary writes back and invalidates it can be lost (round 5, DESIGN section 3: K6 lost stores that
+        // way in 1.3 of 10^4 pipeline steps).  A blocking join on its own stream keeps plain stores (4 % faster rows).
+        if (nt) {
+            __builtin_nontemporal_store(key, &ok[pos]);
+            __builtin_nontemporal_store(outer_val, &oov[pos]);
+            __builtin_nontemporal_store(inner_val, &oiv[pos]);
+        } else {
+            ok[pos] = key;
+            oov[pos] = outer_val;
+            oiv[pos] = inner_val;
+        }
     }
 };

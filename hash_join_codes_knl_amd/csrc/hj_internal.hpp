@@ -178,6 +178,7 @@ struct JoinArgs {
     u64 *block_counter;                  // device
     u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
     uint32_t *overflow;                  // device flag
+    uint32_t nt_rows;                    // 1: the rows leave through non-temporal stores (joins that run beside other streams' work, hj_emit.hpp)
     uint32_t big_tables;                 // hj_join_config_big() instead of hj_join_config()
     // broadcast join (tiny build side, nothing partitioned): P = 1, the relations are the caller's columns, the
     // empty sentinel is *sentinel (a value no build key equals, found by hj_launch_broadcast_meta)
@@ -298,6 +299,7 @@ struct NpjProbeArgs {
     u64 *block_counter;
     u64 *final_offsets;
     uint32_t *overflow;
+    uint32_t nt_rows;                    // as JoinArgs::nt_rows
 };
 int hj_launch_npj_probe(const NpjProbeArgs &a, int cus, hipStream_t stream, int *grid_out);
 

@@ -76,6 +76,7 @@ struct hjgpu_ctx {
     hjgpu_output pending_out;
     bool has_pending_out = false;
     bool last_had_output = false;   // hjgpu_get_async_status: the last enqueued join wrote result columns
+    bool rows_plain = false;        // the join being enqueued is a blocking call on its own: plain row stores (else non-temporal, hj_emit.hpp)
     // grouped plans (phj_grouped): pass-0 twins of the four columns, the groups' offsets, and the call's accumulated phase
     // times (hjgpu_get_stats returns those while stats_override is set; any later operation's first event clears it)
     DevBuf grp[4], grp_off;
@@ -109,6 +110,14 @@ int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess
     }
     return status;
 }
+
+// Result rows of a BLOCKING join (the caller waits for it: nothing of this context runs beside it) leave through plain stores;
+// every enqueue-only join and every pipeline (host batches, multi-GPU slices) writes its rows with non-temporal stores.
+struct PlainRows {
+    hjgpu_ctx *ctx;
+    PlainRows(hjgpu_ctx *c, bool blocking) : ctx(c) { if (ctx) ctx->rows_plain = blocking; }
+    ~PlainRows() { if (ctx) ctx->rows_plain = false; }
+};
 
 #define HIPCHK(ctx, call)                                                       \
     do {                                                                        \
@@ -949,6 +958,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             ja.block_counter = &st->block_counter;
             ja.final_offsets = (u64 *)ctx->final_offsets.p;
             ja.overflow = &st->overflow;
+            ja.nt_rows = ctx->rows_plain ? 0u : 1u;
         }
         CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
         if (audit) CHK(hj_audit_copy(reinterpret_cast<const u64 *>(&st->result), audit + 4 * 6, 4, stream));
@@ -1022,6 +1032,7 @@ int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, si
             pa.ok = out->d_keys; pa.oov = out->d_outer_vals; pa.oiv = out->d_inner_vals;
             pa.block_size = bs; pa.block_limit = bl; pa.block_counter = &st->block_counter;
             pa.final_offsets = (u64 *)ctx->final_offsets.p; pa.overflow = &st->overflow;
+            pa.nt_rows = ctx->rows_plain ? 0u : 1u;
         }
         CHK(hj_launch_npj_probe(pa, ctx->cus, stream, nullptr));
     }
@@ -1559,6 +1570,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
         ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
+        ja.nt_rows = ctx->rows_plain ? 0u : 1u;
     }
     CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     record(ctx, EV_JOIN, stream);
@@ -1640,6 +1652,7 @@ int hjgpu_npj(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inn
     CHK(refuse_capture(ctx, stream));
     CHK(npj_prepare(ctx, inner, prm, &buckets, &factor));
     ctx->last_had_output = out && out->d_keys;
+    PlainRows plain(ctx, true);
     CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream, npj_unique(ctx, prm)));
     return finish_blocking(ctx, result, out, stream);
 }
@@ -1719,6 +1732,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
         ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
+        ja.nt_rows = ctx->rows_plain ? 0u : 1u;
     }
     CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     record(ctx, EV_JOIN, stream);
@@ -1834,6 +1848,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
 {
     if (!ctx) return HJGPU_EINVAL;
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
+    PlainRows plain(ctx, blocking);
     CHK(check_columns(ctx, rk, rv, inner));
     CHK(check_columns(ctx, sk, sv, outer));
     if (chunks < 1 || chunks > HJ_MAX_CHUNKS) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 64]");
@@ -1906,6 +1921,7 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
 {
     if (!ctx) return HJGPU_EINVAL;
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
+    PlainRows plain(ctx, blocking);
     if (!ctx->prepared)
         return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe: no prepared build side (hjgpu_phj_build), or another "
                                        "entry point has used the workspace since");

@@ -123,6 +123,7 @@ struct Rank {
     Buf cnt2[2], cnt2_all[2], cnt_recv[2];
     hipEvent_t ev_dbg = nullptr, ev_dbg2 = nullptr;   // option "debug_serialize"
     hipEvent_t ev_up_s = nullptr, ev_up_r = nullptr;  // host path: probe shard / build columns uploaded
+    std::vector<hipEvent_t> ev_up_slice;              // host path, CPRA: probe slice i of the shard uploaded
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;      // host path: first kernel of the join started / upload finished (timing)
     hipEvent_t lb_in = nullptr, lb_out = nullptr;     // loopback transport
     Buf rbuf;                       // PHJ / NPJ: replicated build side (keys | payloads)
@@ -652,6 +653,7 @@ void destroy_rank(Rank &r)
                         r.ev_xchg[1], r.ev_join[0], r.ev_join[1], r.ev_rx, r.ev_dbg, r.ev_dbg2, r.ev_up_s, r.ev_up_r, r.lb_in, r.lb_out};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r.ev_w) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r.ev_up_slice) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : {r.main, r.comm, r.prep, r.up}) if (s) (void)hipStreamDestroy(s);
     if (r.h_pin) (void)hipHostFree(r.h_pin);
     if (r.join) (void)hjgpu_destroy(r.join);
@@ -969,12 +971,13 @@ struct CpraStep {
     // `ready`: which upload event of the rank the partitioning waits for (host path), or nullptr.
     int exchange(const std::vector<Slice> &in, int which, int slot, hipEvent_t Rank::*ready = nullptr)
     {
-        CHKM(begin_exchange(in, which, slot, ready));
+        CHKM(begin_exchange(in, which, slot, ready, -1));
         return finish_exchange(in, which, slot);
     }
 
     // first half: the partitioning of every local rank's slice is enqueued (nothing waits on the host)
-    int begin_exchange(const std::vector<Slice> &in, int which, int slot, hipEvent_t Rank::*ready = nullptr)
+    // `host_slice` >= 0 (host path): the upload event of that probe slice instead (Rank::ev_up_slice)
+    int begin_exchange(const std::vector<Slice> &in, int which, int slot, hipEvent_t Rank::*ready = nullptr, int host_slice = -1)
     {
         const size_t Gs = (size_t)G;
         const size_t F = fanout();                                  // partitions of the exchange-level pass
@@ -995,7 +998,8 @@ struct CpraStep {
             u64 *d_off = static_cast<u64 *>(r.d_off.p) + (size_t)slot * OFF_WORDS;
             u64 *h_off = hp_off(r, Gs, slot);
             HIPM(c, hipSetDevice(r.device));
-            if (ready) HIPM(c, hipStreamWaitEvent(r.prep, r.*ready, 0));
+            if (host_slice >= 0) HIPM(c, hipStreamWaitEvent(r.prep, r.ev_up_slice[(size_t)host_slice], 0));
+            else if (ready) HIPM(c, hipStreamWaitEvent(r.prep, r.*ready, 0));
             if (c->debug_serialize & 6) {
                 HIPM(c, hipEventRecord(r.ev_dbg, r.main));
                 if (c->debug_serialize & 2) HIPM(c, hipStreamWaitEvent(r.prep, r.ev_dbg, 0));
@@ -1149,8 +1153,11 @@ struct CpraStep {
     }
 };
 
+// from_host: the shards are being uploaded (hjgpu_join_host_multi): the build side's partitioning waits for ev_up_r, the probe
+// slices' for ev_up_s - or, with slice_events, slice i for its own upload event ev_up_slice[i] (the shard then arrives in the
+// same `slices` pieces, build side first: slice i is partitioned, exchanged and joined while the later slices are on the bus)
 int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, const hjgpu_phj_params *prm, int slices,
-              hjgpu_result *result, hjgpu_multi_stats *stats, bool from_host = false)
+              hjgpu_result *result, hjgpu_multi_stats *stats, bool from_host = false, bool slice_events = false)
 {
     if (!c || !shards) return HJGPU_EINVAL;
     CHKM(refuse_broken(c));
@@ -1345,7 +1352,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         // and only then does the host wait for partition(i)'s counts: the device works on join(i-1) and partition(i)
         // while the host and the ranks settle the sizes of exchange(i) (with the join enqueued after that wait, every
         // slice cost a world of one ~0.15-0.2 ms of idle device: 4 slices 13.0 -> 12.2-12.6 ms, 8 slices 16.7 -> 14.9-15.0 ms)
-        CHKM(step.begin_exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr));
+        CHKM(step.begin_exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr, from_host && slice_events ? i : -1));
         if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
         CHKM(step.finish_exchange(in, 1 + slot, slot));
         if (build_stats_pending && i == 0) {
@@ -1834,6 +1841,10 @@ int hjgpu_cpra_multi_rows(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_
 // buffers that the communicator keeps between calls (no hipMalloc / hipFree per call), probe side first, and the
 // joins are enqueued right behind: a rank partitions its probe shard while its (and the root's build) columns are
 // still arriving - the single-GPU host path's pipeline (hjgpu_join_host), per rank.
+// probe slices of the CPRA host call: the shard is uploaded, partitioned, exchanged and joined in this many pieces (a slice costs
+// ~0.6 ms of launches; the upload of 1 / 8 of a shard takes ~10 ms at the PCIe rate)
+constexpr int HOST_CPRA_SLICES = 8;
+
 static int join_host_multi_impl(hjgpu_comm *c, int algorithm,
                                 const uint32_t *ik, const uint32_t *iv, size_t inner,
                                 const uint32_t *ok, const uint32_t *ov, size_t outer,
@@ -1905,12 +1916,35 @@ static int join_host_multi_impl(hjgpu_comm *c, int algorithm,
         const size_t n[4] = {re - rb, re - rb, s.outer, s.outer};
         for (int i = 0; i < 4; ++i) CHKM(ensure(c, r, r.shard[i], (n[i] + 4) * sizeof(uint32_t)));
         HIPM(c, hipSetDevice(r.device));
-        // pinned columns (hjgpu_host_alloc) are DMA'd; the GPUs' uploads run side by side, probe side first
-        for (int i : {2, 3, 0, 1}) {
-            if (n[i]) HIPM(c, hipMemcpyAsync(r.shard[i].p, h[i], n[i] * sizeof(uint32_t), hipMemcpyHostToDevice, r.up));
-            if (i == 3) HIPM(c, hipEventRecord(r.ev_up_s, r.up));
+        // pinned columns (hjgpu_host_alloc) are DMA'd; the GPUs' uploads run side by side
+        if (algorithm == 2) {
+            // CPRA needs the build side first (its exchange and the prepared build come before any probe slice), then the
+            // probe shard arrives in the slices the join takes it in: slice i is partitioned, exchanged and joined while the
+            // later slices are still on the bus (the reference reads all four columns before its clock starts,
+            // cpra2.cpp:2110-2136; here the upload is most of a call: 8.5 GB at the PCIe rate against ~15 ms of join)
+            while (r.ev_up_slice.size() < (size_t)HOST_CPRA_SLICES) {
+                hipEvent_t e = nullptr;
+                HIPM(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                r.ev_up_slice.push_back(e);
+            }
+            for (int i : {0, 1}) if (n[i]) HIPM(c, hipMemcpyAsync(r.shard[i].p, h[i], n[i] * sizeof(uint32_t), hipMemcpyHostToDevice, r.up));
+            HIPM(c, hipEventRecord(r.ev_up_r, r.up));
+            for (int i = 0; i < HOST_CPRA_SLICES; ++i) {
+                size_t b, e;
+                range_of(s.outer, 16, (size_t)i, (size_t)HOST_CPRA_SLICES, &b, &e);       // the slices of cpra_join
+                for (int col : {2, 3})
+                    if (e > b) HIPM(c, hipMemcpyAsync(static_cast<uint32_t *>(r.shard[col].p) + b, h[col] + b, (e - b) * sizeof(uint32_t), hipMemcpyHostToDevice, r.up));
+                HIPM(c, hipEventRecord(r.ev_up_slice[(size_t)i], r.up));
+            }
+            HIPM(c, hipEventRecord(r.ev_up_s, r.up));
+        } else {
+            // PHJ / NPJ: probe side first - it is partitioned while the build side is still arriving
+            for (int i : {2, 3, 0, 1}) {
+                if (n[i]) HIPM(c, hipMemcpyAsync(r.shard[i].p, h[i], n[i] * sizeof(uint32_t), hipMemcpyHostToDevice, r.up));
+                if (i == 3) HIPM(c, hipEventRecord(r.ev_up_s, r.up));
+            }
+            HIPM(c, hipEventRecord(r.ev_up_r, r.up));
         }
-        HIPM(c, hipEventRecord(r.ev_up_r, r.up));
         HIPM(c, hipEventRecord(r.ev_t1, r.up));
         s.d_outer_keys = static_cast<const uint32_t *>(r.shard[2].p); s.d_outer_vals = static_cast<const uint32_t *>(r.shard[3].p);
         if (re > rb) { s.d_inner_keys = static_cast<const uint32_t *>(r.shard[0].p); s.d_inner_vals = static_cast<const uint32_t *>(r.shard[1].p); }
@@ -1934,12 +1968,12 @@ static int join_host_multi_impl(hjgpu_comm *c, int algorithm,
                 o.d_inner_vals = static_cast<uint32_t *>(r.rows_col[2].p);
                 o.capacity = cap; o.block_size = bs;
             }
-            if (algorithm == 2) rc = cpra_join(c, shards.data(), rows.data(), pp, 0, result, stats, attempt == 0);
+            if (algorithm == 2) rc = cpra_join(c, shards.data(), rows.data(), pp, HOST_CPRA_SLICES, result, stats, attempt == 0, attempt == 0);
             else rc = replicated_join(c, algorithm, shards.data(), rows.data(), 0, pp, np, result, stats, attempt == 0);
             if (rc != HJGPU_EOVERFLOW) break;
         }
     } else {
-        if (algorithm == 2) rc = cpra_join(c, shards.data(), nullptr, pp, 0, result, stats, true);
+        if (algorithm == 2) rc = cpra_join(c, shards.data(), nullptr, pp, HOST_CPRA_SLICES, result, stats, true, true);
         else rc = replicated_join(c, algorithm, shards.data(), nullptr, 0, pp, np, result, stats, true);
     }
     if (rc != HJGPU_OK) { if (!c->broken) (void)sync_all(c); return rc; }

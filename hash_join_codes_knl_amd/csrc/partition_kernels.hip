@@ -30,6 +30,7 @@
 //   0  plain stores (write-back in the XCD's L2)
 //   1  non-temporal stores (global_store ... nt) - THE PRODUCT
 //   2  system-scope stores (two relaxed 8-byte __hip_atomic_store per 16 bytes: global_store_dwordx2 ... sc0 sc1, written through)
+//   3 / 4  timing experiments only: 16-byte stores non-temporal and 8-byte stores plain / the other way round
 // Round 5 (DESIGN section 3 "Round 5", profiles/r05_*.txt): with plain stores a K6 launch LOSES STORES - output slots keep what
 // the previous use of the buffer left there - in about 1.3 of 10^4 steps of the multi-GPU slice pipeline (11 wrong steps in
 // 82 000), i.e. when kernels and copies of ANOTHER stream start and end beside it; never on one stream (0 in 15 000), never
@@ -46,7 +47,7 @@
 #endif
 __device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
 {
-#if HJ_K6_STORE == 1
+#if HJ_K6_STORE == 1 || HJ_K6_STORE == 3
     typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
     v4u_t t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<v4u_t *>(p));
@@ -59,7 +60,7 @@ __device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
 }
 __device__ __forceinline__ void k6_store8(u64 *p, u64 v)
 {
-#if HJ_K6_STORE == 1
+#if HJ_K6_STORE == 1 || HJ_K6_STORE == 4
     __builtin_nontemporal_store(v, p);
 #elif HJ_K6_STORE == 2
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -16,7 +16,7 @@
 //     that does not own its partition, a sender's count that differs from what arrived: an ERROR), joins really joined -
 //     so the result of every scenario is compared with a map-based join of the inputs;
 //   * fault injection: --drop-wait k ignores the k-th hipStreamWaitEvent of the run (the checker must then report).
-// usage: cpp_pipeline_ordering <algo cpra|phj|npj> <world> <slices> [--rows] [--no-fused] [--no-in-place] [--two-level]
+// usage: cpp_pipeline_ordering <algo cpra|cpra-host|phj|npj> <world> <slices> [--rows] [--no-fused] [--no-in-place] [--two-level]
 //                              [--drop-wait k] [--list-waits] [--inner n] [--outer n] [--seed s] [--steps n]
 // prints one line: "ok|FAIL waits=<hipStreamWaitEvent calls> ops=<n> violations=<n> ..."; exit status 0 = result right and no violation.
 #include <algorithm>
@@ -588,6 +588,36 @@ int main(int argc, char **argv)
         std::sort(c.begin(), c.end());
         return c;
     };
+    if (algo == "cpra-host") {
+        // hjgpu_join_host_multi / hjgpu_join_host_rows_multi, CPRA: host columns cut into the ranks' shares, the build side uploaded
+        // first, the probe shard slice by slice (an upload event per slice), the slice pipeline behind it
+        bool right = true;
+        for (int step = 0; step < steps; ++step) {
+            hjgpu_result got;
+            memset(&got, 0, sizeof(got));
+            std::vector<uint32_t> hk(outer + 1024), ho(outer + 1024), hi(outer + 1024);
+            hjgpu_host_rows hr = {hk.data(), ho.data(), hi.data(), hk.size()};
+            const int rc = rows ? hjgpu_join_host_rows_multi(comm, 2, ik.data(), iv.data(), inner, ok.data(), ov.data(), outer, nullptr, nullptr, &hr, &got, nullptr)
+                                : hjgpu_join_host_multi(comm, 2, ik.data(), iv.data(), inner, ok.data(), ov.data(), outer, nullptr, nullptr, &got, nullptr);
+            if (rc != HJGPU_OK) { fprintf(stderr, "step %d: status %d: %s\n", step, rc, hjgpu_comm_last_error(comm)); right = false; break; }
+            if (got.count != want[0] || got.sum_keys != want[1] || got.sum_outer_vals != want[2] || got.sum_inner_vals != want[3]) right = false;
+            if (rows) {
+                uint64_t sk = 0;
+                for (uint64_t i = 0; i < got.count && i < hk.size(); ++i) {
+                    auto it = truth.find(hk[i]);
+                    if (it == truth.end() || it->second != hi[i]) { right = false; break; }
+                    sk += hk[i];
+                }
+                if (sk != want[1]) right = false;
+            }
+        }
+        const bool ok_all = right && rec::violations == 0 && rec::errors == 0;
+        printf("%s waits=%ld ops=%zu violations=%d errors=%d result=%s\n", ok_all ? "ok" : "FAIL", rec::wait_calls, rec::ops.size(), rec::violations, rec::errors,
+               right ? "right" : "WRONG");
+        for (const std::string &m : rec::messages) printf("  %s\n", m.c_str());
+        if (rec::list_waits) { printf("waits:"); for (const std::string &w : rec::wait_list) printf(" %s", w.c_str()); printf("\n"); }
+        return ok_all ? 0 : 1;
+    }
     const bool replicated = algo != "cpra";
     const std::vector<size_t> ci = cuts(inner), co = cuts(outer);
     std::vector<hjgpu_shard> shards((size_t)G);
