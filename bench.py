@@ -58,6 +58,8 @@ def parse(argv=None):
                          "workload: ~1 s (~18 CPU-seconds) on the 16 CPUs of a GPU box with the AVX-512 operators")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota)")
+    ap.add_argument("--enqueue-only", action="store_true",
+                    help="N = 1: time the enqueue-only entry points (hjgpu_*_async: all K6 stores non-temporal) instead of the blocking ones")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra N = 1 measurements (NPJ, one-GPU CPRA, materialising PHJ, configs[0] on the CPU)")
     ap.add_argument("--materialize", action="store_true", help="kept for compatibility: the materialising PHJ is on by default")
@@ -495,12 +497,24 @@ def main():
             return
         s = torch.cuda.current_stream().cuda_stream
         a = (rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer)
+        # One step = one complete join through the BLOCKING entry point - the counterpart of the reference's run() / run_hj(), which
+        # return when the join is done (npj.cpp:861-918) - on this process's only stream: a solo join, whose partial-line and row
+        # stores stay plain (DESIGN section 3 "Round 5").  The enqueue-only forms, which may run beside other streams' work and
+        # therefore write everything non-temporal, are timed as secondary.phj_enqueue_only.
+        if args.enqueue_only:
+            if args.algo == "phj":
+                hj.phj_async(*a, prm, d_result.data_ptr(), s)
+            elif args.algo == "cpra":
+                hj.cpra_async(*a, prm, d_result.data_ptr(), s)
+            else:
+                hj.npj_async(*a, nprm, d_result.data_ptr(), s)
+            return
         if args.algo == "phj":
-            hj.phj_async(*a, prm, d_result.data_ptr(), s)
+            last["result"] = list(hj.phj(*a, prm, stream=s))
         elif args.algo == "cpra":
-            hj.cpra_async(*a, prm, d_result.data_ptr(), s)
+            last["result"] = list(hj.cpra(*a, prm, stream=s))
         else:
-            hj.npj_async(*a, nprm, d_result.data_ptr(), s)
+            last["result"] = list(hj.npj(*a, nprm, stream=s))
 
     def barrier():
         torch.cuda.synchronize()
@@ -554,9 +568,11 @@ def main():
             st = hj.stats()             # hipEvent spans of this step's kernels (same stream)
             for p in phases:
                 per_step[p].append(st[p])
+            if not args.enqueue_only:   # the blocking call returned this step's aggregates: every step is checked
+                results_ok = results_ok and last["result"] == expect_global
     barrier()
     elapsed = max_over_ranks(dist, torch, time.perf_counter() - t0)
-    got = last["result"] if multi else [int(x) & MASK64 for x in d_result.tolist()]
+    got = last["result"] if (multi or not args.enqueue_only) else [int(x) & MASK64 for x in d_result.tolist()]
     # the analytic aggregates assume unique build keys, i.e. at least as many probe as build tuples
     checksum_ok = (got == expect_global and results_ok) if outer_total >= inner_total else None
 
@@ -773,6 +789,13 @@ def main():
                              "ms_join": round(ph["ms_join"], 4),
                              "join_vs_default_instance": round(ph["ms_join"] / join_ms, 4) if join_ms > 0 else None,
                              "roofline_join": roof(8 * (inner + outer), ph["ms_join"], 1, stream_read_gbs)}
+        # the headline through the enqueue-only entry point: a join that may run beside other streams' work writes every K6 store
+        # non-temporal (partial lines included: +0.15-0.4 ms per pass, profiles/r05_ab_stores.txt), the price of never losing one
+        ms, ph = time_steps(lambda: hj.phj_async(*a, prm, d_result.data_ptr(), stream), warm=2, steps=min(args.steps, 10))
+        ok_ = [int(x) & MASK64 for x in d_result.tolist()] == expect_local
+        sec["phj_enqueue_only"] = {"workload": "the headline through hjgpu_phj_async (enqueue-only: partial-line stores non-temporal too)",
+                                   "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2), "checksum_ok": ok_,
+                                   "phase_ms": {k2: round(ph[k2], 4) for k2 in phases if k2 in ph}}
         # the headline WITHOUT the placement search (option placement=1: the first allocation is taken): what a step costs when
         # the probe side's pass-1 twin is whatever block hipMalloc returns (a context of its own, closed afterwards)
         hj1 = H.HjGpu(local_rank)

@@ -82,6 +82,8 @@ struct HjTuning {
     // grouped_groups() says the extra pass pays (several table fills per partition AND a probe side large enough).
     long long group_from = 300000000, group_inner = 64000000;
     bool group_always = false;
+    bool group_async = true;        // "group_async": a grouped plan through hjgpu_phj_async / hjgpu_cpra_async returns at once (a worker thread of the
+                                    // context plans the groups, the caller's stream waits for its last command); 0: the call waits itself
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned
@@ -153,6 +155,7 @@ struct ScatterArgs {
     uint32_t range_begin, range_count;   // pass 1: this launch covers ranges [range_begin, +range_count) (0, 0 = all)
     const u64 *range_base;          // [ranges][F] absolute output position of each (range, partition)
     u64 *prof;                      // diagnostics (HJGPU_SCATTER_PROF=1): s_memtime ticks per phase, else NULL
+    uint32_t nt_partial;            // 1: the 8-byte (partial-line) stores are non-temporal too (every launch that is not solo, see k6_store8)
 };
 
 struct JoinArgs {

@@ -76,12 +76,23 @@ struct hjgpu_ctx {
     hjgpu_output pending_out;
     bool has_pending_out = false;
     bool last_had_output = false;   // hjgpu_get_async_status: the last enqueued join wrote result columns
-    bool rows_plain = false;        // the join being enqueued is a blocking call on its own: plain row stores (else non-temporal, hj_emit.hpp)
+    bool rows_plain = false;        // the join being enqueued is SOLO - a blocking call, nothing of this context runs beside it: plain row stores
+                                    // (hj_emit.hpp) and plain partial-line stores in K6 (k6_store8); every other launch writes them non-temporal
     // grouped plans (phj_grouped): pass-0 twins of the four columns, the groups' offsets, and the call's accumulated phase
     // times (hjgpu_get_stats returns those while stats_override is set; any later operation's first event clears it)
     DevBuf grp[4], grp_off;
     bool stats_override = false;
     hipStream_t aux = nullptr;      // private non-blocking stream: placement probes of the workspace allocator
+    // Grouped plans through the enqueue-only forms (grouped_async below): the call returns at once; a worker thread of the context
+    // runs pass 0 and the groups on grp_stream (the groups' sizes are known on the device only: somebody has to wait for them,
+    // it need not be the caller) and the CALLER's stream waits for a counter in signal memory that the worker's last command
+    // raises.  Any later use of the context joins the worker first (settle).
+    std::thread grp_worker;
+    hipStream_t grp_stream = nullptr;
+    hipEvent_t grp_in = nullptr;
+    uint64_t *grp_flag = nullptr;   // hipExtMallocWithFlags(hipMallocSignalMemory): joins of this context finished so far
+    uint64_t grp_seq = 0;
+    int grp_status = HJGPU_OK;      // of the last asynchronous grouped join (hjgpu_get_async_status)
     // option "audit": the last HJ_AUDIT_RING calls' stage records (audit_kernels.hip), the next call's sequence number, and the
     // explicit partition bounds of an own-last layout
     DevBuf audit, audit_lay;
@@ -109,6 +120,13 @@ int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess
             snprintf(ctx->err, sizeof(ctx->err), "%s", what);
     }
     return status;
+}
+
+// an asynchronous grouped join of this context is still being enqueued by its worker thread: wait for the worker (never from the
+// worker itself, which calls the same planning functions)
+void settle(hjgpu_ctx *ctx)
+{
+    if (ctx && ctx->grp_worker.joinable() && ctx->grp_worker.get_id() != std::this_thread::get_id()) ctx->grp_worker.join();
 }
 
 // Result rows of a BLOCKING join (the caller waits for it: nothing of this context runs beside it) leave through plain stores;
@@ -584,6 +602,7 @@ enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
 int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm,
                 uint32_t chunks, PhjPlan *pl, bool pre = false, int big_override = -1)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     ctx->prepared = false;               // the workspace is about to be re-planned (hjgpu_phj_build sets it again)
     ReserveClock clock(ctx);
     pl->C = chunks;
@@ -786,6 +805,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         sa.nseg = pl.C; sa.F = pl.F1; sa.factor = pl.f1; sa.in_align = align_of(in_k[r]);
         sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
         sa.in_packed = 0; sa.out_packed = 1;
+        sa.nt_partial = ctx->rows_plain ? 0u : 1u;
         return hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream);
     };
     auto pass2 = [&](int r) -> int {       // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
@@ -798,6 +818,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         sa.ranged = 0; sa.work_counter = m.tickets + HJ_TICKET_K6 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
         sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
         sa.in_packed = 1; sa.out_packed = 1;
+        sa.nt_partial = ctx->rows_plain ? 0u : 1u;
         return hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream);
     };
     // K4 -> K5 -> K6 x2 for one relation; ev = {after hist, after plan, after pass 1, after pass 2}
@@ -824,6 +845,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 sa.ranged = 0; sa.work_counter = m.tickets + HJ_TICKET_K6 + 2 * r + 1; sa.geom = geom[r]; sa.range_base = nullptr;
                 sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = pad2 ? 1u : 0u;
                 sa.in_packed = 1; sa.out_packed = 1;
+                sa.nt_partial = ctx->rows_plain ? 0u : 1u;
                 CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
             }
             record(ctx, ev[3], stream);
@@ -864,6 +886,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 sa.range_begin = b * pl.batch_ranges;
                 sa.range_count = std::min(pl.batch_ranges, geom[r].ranges_per_chunk - sa.range_begin);
                 sa.in_packed = 0; sa.out_packed = 1;
+                sa.nt_partial = ctx->rows_plain ? 0u : 1u;
                 CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
                 // pass 2 of the batch: the batch buffer -> the relation's final, line-aligned partitions
                 memset(&sa, 0, sizeof(sa));
@@ -874,6 +897,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 sa.ranged = 0; sa.work_counter = m.btickets + 2 * b + 1; sa.geom = geom[r]; sa.range_base = nullptr;
                 sa.part_start = m.off2[r]; sa.part_end = m.end2[r]; sa.aligned_claims = 1u;
                 sa.in_packed = 1; sa.out_packed = 1;
+                sa.nt_partial = ctx->rows_plain ? 0u : 1u;
                 CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
             }
             record(ctx, ev[2], stream);         // both passes interleaved: reported as pass 1, pass 2 = 0
@@ -1000,6 +1024,7 @@ bool npj_unique(const hjgpu_ctx *ctx, const hjgpu_npj_params *prm)
 int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_t *buckets,
                 uint32_t *factor)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     ReserveClock clock(ctx);
     double load = (prm && prm->load > 0) ? prm->load : 0.25;
     if (load > 0.99) return fail(ctx, HJGPU_EINVAL, "load factor must be <= 0.99");
@@ -1147,6 +1172,7 @@ int hjgpu_create(int device, hjgpu_ctx **out)
 int hjgpu_destroy(hjgpu_ctx *ctx)
 {
     if (!ctx) return HJGPU_OK;
+    settle(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf *all[] = {&ctx->tmp[0], &ctx->tmp[1], &ctx->tmp[2], &ctx->tmp[3], &ctx->tmp[4], &ctx->tmp[5],
@@ -1155,6 +1181,9 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    if (ctx->grp_in) (void)hipEventDestroy(ctx->grp_in);
+    if (ctx->grp_stream) (void)hipStreamDestroy(ctx->grp_stream);
+    if (ctx->grp_flag) (void)hipFree(ctx->grp_flag);
     for (int b = 0; b < 4; ++b) {
         if (ctx->host_stage[b]) (void)hipHostFree(ctx->host_stage[b]);
         if (ctx->host_stage_ev[b]) (void)hipEventDestroy(ctx->host_stage_ev[b]);      // (the events go before the streams they were recorded on)
@@ -1168,6 +1197,7 @@ const char *hjgpu_last_error(const hjgpu_ctx *ctx) { return ctx ? ctx->err : "nu
 
 int hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !name || !value) return HJGPU_EINVAL;
     HjTuning t = ctx->tune;
     if (!hj_tuning_set(&t, name, value)) return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: unknown option or malformed value");
@@ -1223,6 +1253,7 @@ static void fill_reserve(const hjgpu_ctx *ctx, hjgpu_stats *s)
 
 int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !s) return HJGPU_EINVAL;
     if (ctx->stats_override) {               // a grouped plan: the sums over pass 0 and the groups' joins, taken as they finished
         *s = ctx->stats;
@@ -1268,7 +1299,9 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
 
 int hjgpu_get_async_status(hjgpu_ctx *ctx, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx) return HJGPU_EINVAL;
+    if (ctx->grp_status != HJGPU_OK) { const int rc = ctx->grp_status; ctx->grp_status = HJGPU_OK; return rc; }     // an asynchronous grouped join failed (text in hjgpu_last_error)
     if (!ctx->state.p) return HJGPU_OK;                  // nothing was ever enqueued
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1284,6 +1317,7 @@ int hjgpu_get_async_status(hjgpu_ctx *ctx, void *stream_)
 
 int hjgpu_accumulate_async_status(hjgpu_ctx *ctx, uint64_t *d_flags, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_flags) return HJGPU_EINVAL;
     if (!ctx->state.p) return HJGPU_OK;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1375,6 +1409,7 @@ int hjgpu_host_free(hjgpu_ctx *ctx, void *p)
 }
 int hjgpu_audit_read(hjgpu_ctx *ctx, uint64_t *next_seq, uint64_t first_seq, uint32_t count, uint64_t *records, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx) return HJGPU_EINVAL;
     if (next_seq) *next_seq = ctx->audit_seq;
     if (!count) return HJGPU_OK;
@@ -1403,6 +1438,7 @@ int hjgpu_synchronize(hjgpu_ctx *ctx, void *stream)
 int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t factor,
                     uint32_t fanout, uint64_t *d_counts, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_counts || (n && !d_keys)) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (fanout == 0 || fanout > HJGPU_MAX_PARTS || !(factor & 1))
         return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 32768] and factor odd");
@@ -1428,6 +1464,7 @@ static int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint3
                              uint32_t factor, uint32_t fanout, uint32_t group_bins, uint32_t *d_keys_out, uint32_t *d_vals_out,
                              uint64_t *d_offsets, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
         return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 1024] and factor odd");
@@ -1472,7 +1509,8 @@ static int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint3
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
         sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6; sa.geom = geom; sa.range_base = m.range_base[0];
         sa.in_packed = 0; sa.out_packed = 0;
-        CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
+        sa.nt_partial = ctx->rows_plain ? 0u : 1u;
+                CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
                                hipMemcpyDeviceToDevice, stream));
@@ -1502,6 +1540,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
                           const hjgpu_phj_params *passes, hjgpu_result *result,
                           const hjgpu_output *out, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !passes || !roff || !soff || !rk || !rv || !sk || !sv)
         return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (((uintptr_t)sk & 15) || ((uintptr_t)sv & 15))
@@ -1588,6 +1627,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
 int hjgpu_npj_build(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
                     uint64_t *d_table, size_t buckets, uint32_t factor, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_table || (n && (!d_keys || !d_vals))) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (!(factor & 1) || buckets <= n) return fail(ctx, HJGPU_EINVAL, "factor must be odd and buckets > n");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1604,6 +1644,7 @@ int hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
                     const uint64_t *d_table, size_t buckets, uint32_t factor,
                     hjgpu_result *result, const hjgpu_output *out, void *stream_)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_table || buckets == 0) return fail(ctx, HJGPU_EINVAL, "null pointer");
     CHK(check_columns(ctx, d_keys, d_vals, n));
     hipStream_t stream = (hipStream_t)stream_;
@@ -1683,6 +1724,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
                              const hjgpu_phj_params *prm, const hjgpu_output *out, hipStream_t stream,
                              hipEvent_t inner_ready)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     CHK(refuse_capture(ctx, stream));
     ctx->prepared = false;
     const uint32_t tf0 = (prm && prm->table_factor[0]) ? prm->table_factor[0] : DEFAULT_TF0;
@@ -1840,6 +1882,50 @@ static int phj_grouped(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks,
     return HJGPU_OK;
 }
 
+// A grouped plan enqueue-only (hjgpu_phj_async / hjgpu_cpra_async): the groups' sizes are known on the device only, so
+// somebody waits for pass 0 and plans every group from its size - the context's worker thread, on a stream of its own.  The
+// caller's stream is tied in on both ends: the worker's stream starts behind what the caller has enqueued so far (the input
+// columns), and the caller's stream goes on only when the worker's LAST command has raised the context's counter in signal
+// memory (hipStreamWaitValue64 / hipStreamWriteValue64) - the call itself returns at once.  phj.cpp:1791-1863 plans and runs
+// its passes inside run_hj, on the worker threads; nothing there is asynchronous to wait for.
+static int grouped_async(hjgpu_ctx *ctx, uint32_t groups, uint32_t chunks,
+                         const uint32_t *rk, const uint32_t *rv, size_t inner,
+                         const uint32_t *sk, const uint32_t *sv, size_t outer,
+                         const hjgpu_phj_params *prm, const hjgpu_output *out, hjgpu_result *d_result, hipStream_t stream)
+{
+    if (!ctx->grp_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->grp_stream, hipStreamNonBlocking));
+    if (!ctx->grp_in) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->grp_in, hipEventDisableTiming));
+    if (!ctx->grp_flag) {
+        HIPCHK(ctx, hipExtMallocWithFlags(reinterpret_cast<void **>(&ctx->grp_flag), sizeof(uint64_t), hipMallocSignalMemory));
+        HIPCHK(ctx, hipStreamWriteValue64(ctx->grp_stream, ctx->grp_flag, 0, 0));
+        HIPCHK(ctx, hj_stream_synchronize(ctx->grp_stream));
+    }
+    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
+    const uint64_t seq = ++ctx->grp_seq;
+    HIPCHK(ctx, hipEventRecord(ctx->grp_in, stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->grp_stream, ctx->grp_in, 0));
+    HIPCHK(ctx, hipStreamWaitValue64(stream, ctx->grp_flag, seq, hipStreamWaitValueGte, ~0ull));
+    const bool has_prm = prm != nullptr, has_out = out != nullptr;
+    hjgpu_phj_params prm_copy;
+    hjgpu_output out_copy;
+    memset(&prm_copy, 0, sizeof(prm_copy)); memset(&out_copy, 0, sizeof(out_copy));
+    if (prm) prm_copy = *prm;
+    if (out) out_copy = *out;
+    ctx->grp_status = HJGPU_OK;
+    ctx->grp_worker = std::thread([=]() {
+        hipStream_t ws = ctx->grp_stream;
+        int rc = hipSetDevice(ctx->device) == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+        if (rc == HJGPU_OK)
+            rc = phj_grouped(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, has_prm ? &prm_copy : nullptr, has_out ? &out_copy : nullptr, ws);
+        if (rc == HJGPU_OK && d_result && hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, ws) != hipSuccess)
+            rc = HJGPU_EHIP;
+        ctx->grp_status = rc;
+        // whatever happened, the caller's stream must not wait for ever
+        (void)hipStreamWriteValue64(ws, ctx->grp_flag, seq, 0);
+    });
+    return HJGPU_OK;
+}
+
 static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
                     const uint32_t *rk, const uint32_t *rv, size_t inner,
                     const uint32_t *sk, const uint32_t *sv, size_t outer,
@@ -1857,9 +1943,14 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
     ctx->last_had_output = out && out->d_keys;
     const uint32_t groups = inner_ready ? 0 : grouped_groups(ctx, inner, outer, prm);
+    if (groups > 1 && outer && !blocking && ctx->tune.group_async) {
+        // enqueue-only: the context's worker thread waits for the groups' sizes, not the caller (grouped_async)
+        settle(ctx);
+        return grouped_async(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, d_result, stream);
+    }
     if (groups > 1 && outer) {
-        // (the host waits for pass 0 and for every group inside this call, also in the *_async forms: the groups' sizes
-        // are known on the device only)
+        // (a blocking call, or option group_async = 0: this thread waits for pass 0 and for every group)
+        settle(ctx);
         CHK(phj_grouped(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, stream));
     } else if (broadcast_applies(ctx->tune, inner, outer, chunks, prm)) {
         CHK(broadcast_enqueue(ctx, rk, rv, inner, sk, sv, outer, prm, out, stream, (hipEvent_t)inner_ready));
@@ -1919,6 +2010,7 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
                               hjgpu_result *result, hjgpu_result *d_result, const hjgpu_output *out,
                               void *stream_, bool blocking)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx) return HJGPU_EINVAL;
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
     PlainRows plain(ctx, blocking);
@@ -1959,6 +2051,7 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
                             uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_,
                             uint32_t factor2 = 0, uint32_t fanout2 = 0, uint64_t *d_counts2 = nullptr)
 {
+    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (d_counts2 && (fanout2 < 1 || !(factor2 & 1) || factor2 == factor || (u64)fanout * fanout2 > HJGPU_MAX_PARTS))
         return fail(ctx, HJGPU_EINVAL, "fused counts: factor2 odd and different from factor, fanout * fanout2 <= 32768");
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
@@ -2017,7 +2110,8 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
         sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
         sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6; sa.geom = geom; sa.range_base = m.range_base[0];
         sa.in_packed = 0; sa.out_packed = 1;
-        CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
+        sa.nt_partial = ctx->rows_plain ? 0u : 1u;
+                CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
     if (audit && n) {
@@ -2147,6 +2241,7 @@ int hjgpu_phj_probe_prepartitioned_counted_async(hjgpu_ctx *ctx, const uint64_t 
 static int probe_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, const uint64_t *d_counts,
                                 hjgpu_result *d_result, void *stream_)
 {
+    settle(ctx);
     if (!ctx) return HJGPU_EINVAL;
     const hjgpu_output *out = take_async_output(ctx, nullptr);   // consumed by this call even if it fails below (see hjgpu_npj_async)
     if (!ctx->prepared) return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe_prepartitioned_async: no prepared build side, or another entry point has used the workspace since");

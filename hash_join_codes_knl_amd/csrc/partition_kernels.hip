@@ -58,13 +58,25 @@ __device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
     *reinterpret_cast<uint4 *>(p) = v;
 #endif
 }
-__device__ __forceinline__ void k6_store8(u64 *p, u64 v)
+// 8-byte stores write PARTIAL lines (the < 16 tail tuples of a pass-2 run, the edges of a pass-1 run).  Non-temporal they cost
+// 0.15-0.4 ms per pass (a partial line that leaves the L2 at once is a read-modify-write at the memory side; plain, the L2
+// waits for the rest of the line), while the 16-byte whole-line stores are FASTER non-temporal than plain
+// (profiles/r05_ab_stores.txt, ms pass 1 / pass 2 at 64 M x 1 G in the same allocations: all plain 2.99 / 3.07, 16-byte nt
+// 2.93 / 2.96, all nt 3.07 / 3.13, only 8-byte nt 3.37 / 3.20).  So: whole lines always non-temporal; partial lines non-temporal
+// unless the launch is SOLO (ScatterArgs::nt_partial = 0: a blocking join, nothing of its context runs beside it - the
+// condition under which no store was ever lost: 0 wrong steps in 15 000 on one stream with every store plain).
+__device__ __forceinline__ void k6_store8(u64 *p, u64 v, bool nt)
 {
-#if HJ_K6_STORE == 1 || HJ_K6_STORE == 4
+#if HJ_K6_STORE == 1
+    if (nt) __builtin_nontemporal_store(v, p); else *p = v;
+#elif HJ_K6_STORE == 4
+    (void)nt;
     __builtin_nontemporal_store(v, p);
 #elif HJ_K6_STORE == 2
+    (void)nt;
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
+    (void)nt;
     *p = v;
 #endif
 }
@@ -1269,6 +1281,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             constexpr uint32_t NG = BLOCK / 16;
             const uint32_t gid = tid >> 4, sub = tid & 15;
             u64 *__restrict__ out64 = reinterpret_cast<u64 *>(a.kout);
+            const bool nt8 = a.nt_partial != 0;                     // (uniform)
             auto move_unit = [&](uint32_t p, uint32_t c) {
                 const uint32_t m = meta[p], e = m & 0xFFFFu, fc = m >> 16;
                 if (e == 0) return;
@@ -1287,8 +1300,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                         if (v0 && v1) {
                             const u64 t0 = fetch(s - off), t1 = fetch(s + 1 - off);
                             k6_store16(out64 + base + s, make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32)));
-                        } else if (v0) k6_store8(out64 + base + s, fetch(s - off));
-                        else if (v1) k6_store8(out64 + base + s + 1, fetch(s + 1 - off));
+                        } else if (v0) k6_store8(out64 + base + s, fetch(s - off), nt8);
+                        else if (v1) k6_store8(out64 + base + s + 1, fetch(s + 1 - off), nt8);
                     }
                     s += 32;
                 }
@@ -1299,7 +1312,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     const u64 t0 = src[s], t1 = src[s + 1];
                     k6_store16(out64 + base + s, make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32)));
                 }
-                if (s < s_end) k6_store8(out64 + base + s, src[s]);            // the run ends on an even slot
+                if (s < s_end) k6_store8(out64 + base + s, src[s], nt8);            // the run ends on an even slot
             };
             const uint32_t nunits = F + wsum[NW + 1];
             for (uint32_t u = gid; u < nunits; u += NG) {
@@ -1311,7 +1324,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 for (uint32_t idx = tid; idx < F * LINE; idx += BLOCK) {
                     const uint32_t p = idx / LINE, j = idx % LINE;
                     const u64 ti = tinfo[p];
-                    if (j < ((uint32_t)ti & (LINE - 1))) k6_store8(out64 + (ti >> 4) + j, stage[hist[p] + (meta[p] & 0xFFFFu) + j]);
+                    if (j < ((uint32_t)ti & (LINE - 1))) k6_store8(out64 + (ti >> 4) + j, stage[hist[p] + (meta[p] & 0xFFFFu) + j], nt8);
                 }
             }
         } else {
@@ -1320,7 +1333,13 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 const u64 kv = stage[i];
                 const uint32_t k = (uint32_t)kv;
                 const u64 d = delta[hj_hash(k, factor, F)] + i;
+                // (separate output columns - hjgpu_partition, pass 0 of a grouped plan: consecutive lanes write consecutive words, whole
+                // lines leave a wave in one instruction; non-temporal like every whole-line store of K6)
+#if HJ_K6_STORE == 1
+                __builtin_nontemporal_store(k, &a.kout[d]); __builtin_nontemporal_store((uint32_t)(kv >> 32), &a.vout[d]);
+#else
                 a.kout[d] = k; a.vout[d] = (uint32_t)(kv >> 32);
+#endif
             }
         }
         hj_barrier_lds();
@@ -1471,6 +1490,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("merged_plan")) return parse_flag(value, &t->merged_plan);
     if (is("piece_interleave")) return parse_flag(value, &t->piece_interleave);
     if (is("group_always")) return parse_flag(value, &t->group_always);
+    if (is("group_async")) return parse_flag(value, &t->group_async);
     if (is("placement_log")) return parse_flag(value, &t->placement_log);
     if (is("audit")) return parse_flag(value, &t->audit);
     if (is("hist_min_lds")) {
@@ -1550,7 +1570,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "host_batch", "placement", "placement_ms", "placement_log", "audit", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "group_async", "host_batch", "placement", "placement_ms", "placement_log", "audit", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

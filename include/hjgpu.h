@@ -160,7 +160,7 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * including the operator-level hjgpu_npj_probe), "force_chained", "no_broadcast", "dense2", "npj_refhash",
  * "scatter_prof", "merged_plan", "piece_interleave" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
  * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
- * twin, 1..16; "placement_ms": the search's wall-clock budget, default 500, 0 = none; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples) and "group_always" (0 / 1): the
+ * twin, 1..16; "placement_ms": the search's wall-clock budget, default 500, 0 = none; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples), "group_always" and "group_async" (0 / 1): the
  * grouped plans of hjgpu_phj / hjgpu_cpra (below); diagnostics: "audit" (0 / 1: every stage of a join leaves a checksum of its output,
  * hjgpu_audit_read below), "hist_min_lds" (bytes of LDS a histogram workgroup asks for at least: nothing else then shares its CU).
  * Unknown names and malformed values: HJGPU_EINVAL. */
@@ -251,8 +251,12 @@ int  hjgpu_npj(hjgpu_ctx *ctx,
  * or two passes up to HJGPU_MAX_PARTS partitions; a build side beyond their reach (~228 M tuples) whose probe side is
  * large enough for a further pass to pay is joined by a GROUPED plan - pass 0 splits both relations into key-disjoint
  * groups of about "group_inner" (64 M) build tuples, each joined by the two-pass plan, aggregates and rows added up
- * (hjgpu_stats.groups / ms_scatter0).  A grouped call waits on the host for pass 0 and for every group, also in its
- * *_async form; explicit fan-outs in params are never grouped; option "group_from" = 0 turns the plan off. */
+ * (hjgpu_stats.groups / ms_scatter0).  Somebody has to wait for pass 0 and for every group (their sizes are known on the
+ * device only): in the blocking forms the caller; in the *_async forms (round 5) a worker thread of the context, on a stream
+ * of its own - the call returns at once, the CALLER's stream goes on when the worker's last command has raised a counter in
+ * signal memory (hipStreamWaitValue64), and any later use of the context joins the worker first; a failure there is what
+ * hjgpu_get_async_status returns (option "group_async" = 0: the call waits itself, as in round 4).  Explicit fan-outs in
+ * params are never grouped; option "group_from" = 0 turns the plan off. */
 int  hjgpu_phj(hjgpu_ctx *ctx,
                const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
                const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,

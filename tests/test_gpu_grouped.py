@@ -151,3 +151,39 @@ def test_grouped_plan_at_a_size_it_is_chosen_for_by_default(hj):
     hj.close()
     assert got == (outer, sums[0], sums[1], sums[2]) and st["groups"] == 15
     assert got_small == (small, sums_small[0], sums_small[1], sums_small[2]) and st_small["groups"] == 0
+
+
+@pytest.mark.parametrize("algo", ["phj", "cpra"])
+def test_grouped_plan_through_the_enqueue_only_form_returns_at_once(grouped, algo):
+    """hjgpu_phj_async / hjgpu_cpra_async with a grouped plan: the call returns before the join has run (the context's worker
+    thread waits for the groups' sizes; the caller's stream waits for the worker's last command), the result is in d_result once
+    the CALLER's stream is idle, calls queue up back to back, and the blocking form gives the same aggregates."""
+    import time
+    inner, outer = 20_000_000, 100_000_000
+    fi, fo = 0x2545F491, 0x9E3779B1
+    grouped.set_option("group_inner", "2500000")          # 8 groups
+    ik, iv, ok, ov = (grouped.column(n) for n in (inner, inner, outer, outer))
+    grouped.generate(7, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
+    sums = grouped.column_sums(ok, outer, fo, fi)
+    want = (outer, sums[0], sums[1], sums[2])
+    blocking = getattr(grouped, algo)(ik, iv, inner, ok, ov, outer)
+    assert blocking == want and grouped.stats()["groups"] == 8
+    t0 = time.perf_counter()
+    getattr(grouped, algo)(ik, iv, inner, ok, ov, outer)
+    t_blocking = time.perf_counter() - t0
+    d = [grouped.column(4, np.uint64) for _ in range(2)]
+    t0 = time.perf_counter()
+    getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[0])
+    t_call = time.perf_counter() - t0
+    getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[1])        # queues behind the first (joins its worker)
+    grouped.synchronize()
+    grouped.get_async_status()
+    for r in d:
+        assert tuple(int(x) for x in r.download()) == want
+    assert grouped.stats()["groups"] == 8
+    assert t_call < 0.5 * t_blocking, (t_call, t_blocking)
+    grouped.set_option("group_async", "0")                # round 4's behaviour: the call itself waits
+    getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[0])
+    grouped.synchronize()
+    assert tuple(int(x) for x in d[0].download()) == want
+    _free(ik, iv, ok, ov, *d)
