@@ -1814,10 +1814,18 @@ static int phj_grouped(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks,
     hjgpu_stats sum, one;
     memset(&sum, 0, sizeof(sum));
     // pass 0: the probe side first, like the join itself (a build side that is still arriving is not supported here)
-    CHK(partition_columns(ctx, sk, sv, outer, DEFAULT_F0, l.F0, l.bins, g_sk, g_sv, reinterpret_cast<uint64_t *>(d_off + (l.F0 + 1)), stream));
+    // pass 0 must split by a hash that is independent of the groups' own two passes: with the same multiplier every key of a
+    // group would fall into 1 / G of the pass-1 partitions (SURVEY appendix A "Factor independence")
+    uint32_t f0 = DEFAULT_F0;
+    {
+        const uint32_t f1 = (prm && prm->factor1) ? prm->factor1 : DEFAULT_F1, f2 = (prm && prm->factor2) ? prm->factor2 : DEFAULT_F2;
+        const uint32_t other[3] = {0x7FEB352Du, 0x846CA68Bu, 0xC6A4A793u};
+        for (uint32_t cand : other) if (cand != f1 && cand != f2) { f0 = cand; break; }
+    }
+    CHK(partition_columns(ctx, sk, sv, outer, f0, l.F0, l.bins, g_sk, g_sv, reinterpret_cast<uint64_t *>(d_off + (l.F0 + 1)), stream));
     CHK(hjgpu_get_stats(ctx, &one));
     sum.ms_scatter0 += one.ms_total;
-    CHK(partition_columns(ctx, rk, rv, inner, DEFAULT_F0, l.F0, l.bins, g_rk, g_rv, reinterpret_cast<uint64_t *>(d_off), stream));
+    CHK(partition_columns(ctx, rk, rv, inner, f0, l.F0, l.bins, g_rk, g_rv, reinterpret_cast<uint64_t *>(d_off), stream));
     std::vector<u64> off((size_t)2 * (l.F0 + 1));
     HIPCHK(ctx, hipMemcpyAsync(off.data(), d_off, off.size() * sizeof(u64), hipMemcpyDeviceToHost, stream));
     CHK(hjgpu_get_stats(ctx, &one));                        // waits for the operator's last event
@@ -2566,7 +2574,13 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
         }
         // the slot's probe rows are needed until here: the next upload into the slot waits for THIS record
         if (hipEventRecord(s_free[slot], run) != hipSuccess) ok = false;
-        if (ok) ok = hj_stream_synchronize(run) == hipSuccess;
+        // Whatever was enqueued above - a copy into the stack variable `again`, kernels that read `saved` and write `big` - has run
+        // before this lambda leaves (and frees them), on the failure paths too; NPJ's accumulated result is put back if the chain
+        // broke before its restore was enqueued.
+        const bool drained = hj_stream_synchronize(run) == hipSuccess;
+        if (!ok && npj && saved && drained)
+            (void)hipMemcpy(&st->result, saved, sizeof(hjgpu_result), hipMemcpyDeviceToDevice);
+        if (!drained) ok = false;
         if (ok) ok = !again.overflow && again.dense == need;
         if (ok) {
             uint32_t *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};

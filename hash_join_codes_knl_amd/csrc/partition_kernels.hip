@@ -32,15 +32,14 @@
 //   2  system-scope stores (two relaxed 8-byte __hip_atomic_store per 16 bytes: global_store_dwordx2 ... sc0 sc1, written through)
 //   3 / 4  timing experiments only: 16-byte stores non-temporal and 8-byte stores plain / the other way round
 // Round 5 (DESIGN section 3 "Round 5", profiles/r05_*.txt): with plain stores a K6 launch LOSES STORES - output slots keep what
-// the previous use of the buffer left there - in about 1.3 of 10^4 steps of the multi-GPU slice pipeline (11 wrong steps in
-// 82 000), i.e. when kernels and copies of ANOTHER stream start and end beside it; never on one stream (0 in 15 000), never
-// with partitioning and joins serialised (0 in 15 000).  Option "audit" named the kernel: the sums of pass 2's output differ
-// from its input's with nothing misplaced and the count intact.  The same machine code with the nt bit on its stores: 0 wrong
-// steps in 28 000 + (this build) tools/r05_round.sh's sweep; same speed (K6 is bound by the memory system either way).
-// Rounds 3-4 saw the same signature at a far higher rate with a private segment in the kernel and studied it with
-// -DHJ_SCRATCH_EXPERIMENT=n variants of this file (profiles/r04_scratch_repro.txt; the variants are in the history before
-// round 5, not here).  What is lost is data that sits dirty in an XCD's L2 while another queue's kernel boundary writes back
-// and invalidates that L2; non-temporal stores do not linger there.
+// the previous use of the buffer left there - in 1.5 of 10^4 steps of the multi-GPU slice pipeline (13 wrong steps in 84 000),
+// i.e. when kernels and copies of ANOTHER stream start and end beside it; never on one stream (0 in 15 000), never with
+// partitioning and joins serialised (0 in 15 000).  Option "audit" named the kernel: the sums of pass 2's output differ from its
+// input's with nothing misplaced and the count intact.  The same machine code with the nt bit on its stores: 0 wrong steps in
+// 73 000; written through (sc0 sc1): 0 in 15 000.  Rounds 3-4 saw the same signature at a far higher rate with a private segment in
+// the kernel and studied it with -DHJ_SCRATCH_EXPERIMENT=n variants of this file (profiles/r04_scratch_repro.txt; the variants
+// are in the history before round 5, not here).  What is lost is data that sits dirty in an XCD's L2 while another queue's
+// kernel boundary writes back and invalidates that L2; non-temporal stores do not linger there.
 // --------------------------------------------------------------------------
 #ifndef HJ_K6_STORE
 #define HJ_K6_STORE 1

@@ -187,3 +187,17 @@ def test_grouped_plan_through_the_enqueue_only_form_returns_at_once(grouped, alg
     grouped.synchronize()
     assert tuple(int(x) for x in d[0].download()) == want
     _free(ik, iv, ok, ov, *d)
+
+
+def test_pass_zero_is_independent_of_the_callers_pass_factors(grouped, oracle):
+    """A caller's factor1 (or factor2) equal to the library's default pass-0 multiplier must not line the groups' own first pass
+    up with pass 0 (every key of a group would land in 1 / G of its pass-1 partitions: correct through multi-fill tables, but
+    what the grouped plan exists to avoid): pass 0 then takes another multiplier.  Results equal the definition either way."""
+    ik, iv, ok, ov = oracle.generate(300_000, 100_000, seed=31)
+    want = numpy_join(ik, iv, ok, ov)
+    grouped.set_option("group_inner", "12500")            # 8 groups
+    rk, rv, sk, sv = _cols(grouped, ik, iv, ok, ov)
+    for prm in (H.PhjParams(factor1=0x7FEB352D), H.PhjParams(factor2=0x7FEB352D), H.PhjParams(factor1=0x7FEB352D, factor2=0x846CA68B)):
+        assert grouped.phj(rk, rv, len(ik), sk, sv, len(ok), prm) == want
+        assert grouped.stats()["groups"] == 8
+    _free(rk, rv, sk, sv)

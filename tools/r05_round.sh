@@ -28,7 +28,7 @@ stress() {   # every step of the slice pipeline checked; the tool exits 1 on a w
 }
 case $part in
 tests)
-  timeout -k 10 1100 python3 -m pytest tests -m gpu -q -x > $out/r05_pytest.log 2>&1; note "pytest rc=$? $(tail -1 $out/r05_pytest.log)"
+  PYTHONUNBUFFERED=1 timeout -k 10 1100 python3 -u -m pytest tests -m gpu -q -x > $out/r05_pytest.log 2>&1; note "pytest rc=$? $(tail -1 $out/r05_pytest.log)"
   ;;
 validation)
   sweep=r05_validation.txt; bad=0

@@ -23,6 +23,8 @@ ROWS = [
     ("PHJ 200 M x 1 G (two table fills per partition)", ["--inner", "200000000", "--outer", "1000000000", "--steps", "5"]),
     ("PHJ 1 G x 4 G (grouped plan: pass 0 into 16 groups, then 16 two-pass joins)",
      ["--inner", "1000000000", "--outer", "4000000000", "--steps", "3", "--warmup", "1"]),
+    ("PHJ 1 G x 4 G through hjgpu_phj_async (grouped plan enqueue-only: a worker thread of the context waits for the groups' sizes)",
+     ["--inner", "1000000000", "--outer", "4000000000", "--steps", "3", "--warmup", "1", "--enqueue-only"]),
     ("PHJ 1 G x 4 G, option group_from=0 (two passes, 4-5 table fills per partition)",
      ["--inner", "1000000000", "--outer", "4000000000", "--steps", "3", "--warmup", "1", "--option", "group_from=0"]),
     ("PHJ 128 M x 2.2 G (16 K-slot tables)", ["--inner", "128000000", "--outer", "2200000000", "--steps", "5"]),
