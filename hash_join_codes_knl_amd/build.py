@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "lib")
 ARCH = "gfx950"
 
 KERNEL_SOURCES = ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip",
-                  "gen_kernels.hip", "audit_kernels.hip", "hjgpu_api.hip", "hjgpu_multi.hip"]
+                  "gen_kernels.hip", "audit_kernels.hip", "hjgpu_api.hip", "hjgpu_ops.hip", "hjgpu_host.hip", "hjgpu_multi.hip"]
 HOST_PROGRAMS = {"npj": "npj_main.cpp", "phj": "phj_main.cpp", "cpra": "cpra_main.cpp",
                  "write": "write_main.cpp"}
 
@@ -30,7 +30,7 @@ def _hipcc():
 
 # the kernels AND the plan that launches them (fan-out defaults, grid geometry, placement, reserve_cus live in hjgpu_api.hip)
 KERNEL_HASH_FILES = ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip", "hj_device.hpp",
-                     "hj_emit.hpp", "hj_internal.hpp", "hjgpu_api.hip"]
+                     "hj_emit.hpp", "hj_internal.hpp", "hjgpu_ctx.hpp", "hjgpu_api.hip", "hjgpu_ops.hip"]
 
 
 def kernel_hash():

@@ -3,115 +3,16 @@
 // orchestration run()/run_hj() (npj.cpp:769-927, phj.cpp:1646-1949,
 // cpra2.cpp:1697-1986): phase order, pass planning, factor choice.  Barriers
 // between phases become stream order; there is no host round trip inside a join.
-#include <hip/hip_runtime.h>
-#include <algorithm>
-#include <chrono>
-#include <functional>
-#include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <thread>
-#include <vector>
+#include "hjgpu_ctx.hpp"
 
-#include "hj_internal.hpp"
+using namespace hjapi;
 
-namespace {
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
 
-// Small device-resident state of one join.
-struct DevState {
-    hjgpu_result result;
-    u64 block_counter;
-    u64 dense;
-    u64 work_counter;
-    uint32_t overflow;
-    uint32_t zero_key;
-    uint32_t nmoves;
-    uint32_t pad;
-    u64 work_counter2;      // the multi-fill half of a _UNIQUE join (hj_launch_join)
-};
+namespace hjapi {
 
-// probe side (S) is partitioned first, then the build side (R): a caller can overlap the
-// arrival of R (e.g. an RCCL broadcast) with the S passes through `inner_ready`
-enum { EV_BEGIN = 0, EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2, EV_WAITED,
-       EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2, EV_JOIN, EV_GAPS, EV_COUNT };
 
-}  // namespace
-
-struct hjgpu_ctx {
-    int device = 0;
-    int cus = 0;
-    hipDeviceProp_t prop;
-    char err[512];
-    DevBuf tmp[8];          // pass-1 / pass-2 twins of the 4 columns (hj.h's [1] scratch columns)
-    DevBuf meta;            // histograms, offsets, cursors, tile / work-item prefixes
-    DevBuf table;           // NPJ table
-    DevBuf state;           // DevState
-    DevBuf moves;           // close_gaps move list
-    DevBuf final_offsets;   // per-wave end cursors
-    hipEvent_t ev[EV_COUNT];
-    bool ev_valid[EV_COUNT];
-    hjgpu_stats stats;
-    int last_algo = -1;     // 0 npj, 1 phj/cpra
-    // hjgpu_phj_build: the partitioned build side (tmp[0] / tmp[4]) and its plan (meta) stay valid until
-    // another entry point uses the workspace
-    bool prepared = false;
-    size_t prepared_inner = 0, prepared_max_outer = 0;
-    unsigned char prepared_plan[128];
-    HjTuning tune;          // tuning / test switches: environment at hjgpu_create, hjgpu_set_option afterwards
-    // hjgpu_join_host*: two page-locked staging buffers for PAGEABLE host columns, made when the first one is seen and kept
-    // (hipHostMalloc + hipHostFree of 2 x 32 MiB cost 22 ms per call; page-locked columns never need them)
-    // the batched host calls' three streams (upload / join / download), made once: the runtime binds a stream's copies to a
-    // DMA engine when it first uses it, and fresh streams in every call ended up with upload and download on ONE engine
-    // from the second call on (one after the other: 430 ms instead of 275 for 8.5 GB up and 12 GB down)
-    hipStream_t host_streams[3] = {nullptr, nullptr, nullptr};
-    void *host_stage[4] = {nullptr, nullptr, nullptr, nullptr};          // [0..1] uploads, [2..3] downloads (both run at once
-    hipEvent_t host_stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // when result rows go home behind the upload)
-    // hjgpu_set_async_output: the next *_async join of this context materialises into these columns (one-shot)
-    hjgpu_output pending_out;
-    bool has_pending_out = false;
-    bool last_had_output = false;   // hjgpu_get_async_status: the last enqueued join wrote result columns
-    bool rows_plain = false;        // the join being enqueued is SOLO - a blocking call, nothing of this context runs beside it: plain row stores
-                                    // (hj_emit.hpp) and plain partial-line stores in K6 (k6_store8); every other launch writes them non-temporal
-    // grouped plans (phj_grouped): pass-0 twins of the four columns, the groups' offsets, and the call's accumulated phase
-    // times (hjgpu_get_stats returns those while stats_override is set; any later operation's first event clears it)
-    DevBuf grp[4], grp_off;
-    bool stats_override = false;
-    hipStream_t aux = nullptr;      // private non-blocking stream: placement probes of the workspace allocator
-    // Grouped plans through the enqueue-only forms (grouped_async below): the call returns at once; a worker thread of the context
-    // runs pass 0 and the groups on grp_stream (the groups' sizes are known on the device only: somebody has to wait for them,
-    // it need not be the caller) and the CALLER's stream waits for a counter in signal memory that the worker's last command
-    // raises.  Any later use of the context joins the worker first (settle).
-    std::thread grp_worker;
-    hipStream_t grp_stream = nullptr;
-    hipEvent_t grp_in = nullptr;
-    uint64_t *grp_flag = nullptr;   // hipExtMallocWithFlags(hipMallocSignalMemory): joins of this context finished so far
-    uint64_t grp_seq = 0;
-    int grp_status = HJGPU_OK;      // of the last asynchronous grouped join (hjgpu_get_async_status)
-    // option "audit": the last HJ_AUDIT_RING calls' stage records (audit_kernels.hip), the next call's sequence number, and the
-    // explicit partition bounds of an own-last layout
-    DevBuf audit, audit_lay;
-    uint64_t audit_seq = 0;
-    float ms_reserve = 0;           // wall clock of the workspace growth so far (allocations + placement probes)
-    // the last placement search (ensure_placed): candidate blocks it allocated and filled, the kept block's fill time and size,
-    // whether the budget (option "placement_ms") ended it
-    uint32_t placement_tried = 0, placement_timeboxed = 0;
-    float placement_fill_ms = 0;
-    size_t placement_bytes = 0;
-};
-
-namespace {
-
-const uint32_t DEFAULT_F1 = 0x9E3779B1u, DEFAULT_F2 = 0x85EBCA6Bu;
-const uint32_t DEFAULT_TF0 = 0xC2B2AE35u, DEFAULT_TF1 = 0x27D4EB2Fu;
-const uint32_t DEFAULT_NPJ_FACTOR = 0x9E3779B1u;
-
-int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess)
+int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e)
 {
     if (ctx) {
         if (e != hipSuccess)
@@ -129,25 +30,13 @@ void settle(hjgpu_ctx *ctx)
     if (ctx && ctx->grp_worker.joinable() && ctx->grp_worker.get_id() != std::this_thread::get_id()) ctx->grp_worker.join();
 }
 
-// Result rows of a BLOCKING join (the caller waits for it: nothing of this context runs beside it) leave through plain stores;
-// every enqueue-only join and every pipeline (host batches, multi-GPU slices) writes its rows with non-temporal stores.
-struct PlainRows {
-    hjgpu_ctx *ctx;
-    PlainRows(hjgpu_ctx *c, bool blocking) : ctx(c) { if (ctx) ctx->rows_plain = blocking; }
-    ~PlainRows() { if (ctx) ctx->rows_plain = false; }
-};
 
-#define HIPCHK(ctx, call)                                                       \
-    do {                                                                        \
-        hipError_t e_ = (call);                                                 \
-        if (e_ != hipSuccess) return fail((ctx), HJGPU_EHIP, #call, e_);        \
-    } while (0)
 
 // hipEventSynchronize / hipStreamSynchronize of the host pipelines: a wait that the runtime refuses with
 // hipErrorStreamCaptureUnsupported although no stream captures (this library refuses capturing streams: refuse_capture)
 // is asked again.  (The refusals seen in round 4 had a cause - staging events recorded on per-call streams that were
 // destroyed, see join_host_impl - and are gone with it; the retry stays as a guard.)
-static hipError_t hj_event_synchronize(hipEvent_t ev)
+hipError_t hj_event_synchronize(hipEvent_t ev)
 {
     hipError_t e = hipSuccess;
     for (int attempt = 0; attempt < 200; ++attempt) {
@@ -158,7 +47,7 @@ static hipError_t hj_event_synchronize(hipEvent_t ev)
     }
     return e;
 }
-static hipError_t hj_stream_synchronize(hipStream_t st)
+hipError_t hj_stream_synchronize(hipStream_t st)
 {
     hipError_t e = hipSuccess;
     for (int attempt = 0; attempt < 200; ++attempt) {
@@ -170,11 +59,6 @@ static hipError_t hj_stream_synchronize(hipStream_t st)
     return e;
 }
 
-#define CHK(call)                                                               \
-    do {                                                                        \
-        int s_ = (call);                                                        \
-        if (s_ != HJGPU_OK) return s_;                                          \
-    } while (0)
 
 int ensure(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
 {
@@ -260,29 +144,7 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     return HJGPU_OK;
 }
 
-// Wall clock of workspace growth (hjgpu_stats.ms_reserve): the placement search holds and fills up to 12 candidate
-// blocks of the probe side's pass-1 twin; it happens at hjgpu_reserve / the first join of a size, never in a timed join
-// afterwards, and its cost is reported instead of being invisible.
-struct ReserveClock {
-    hjgpu_ctx *ctx;
-    size_t before;
-    std::chrono::steady_clock::time_point t0;
-    static size_t held(const hjgpu_ctx *c)
-    {
-        size_t n = c->meta.cap + c->table.cap + c->state.cap;
-        for (const DevBuf &b : c->tmp) n += b.cap;
-        return n;
-    }
-    explicit ReserveClock(hjgpu_ctx *c) : ctx(c), before(held(c)), t0(std::chrono::steady_clock::now()) {}
-    ~ReserveClock()
-    {
-        if (held(ctx) != before)
-            ctx->ms_reserve += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    }
-};
 
-// grouped plans (phj_grouped below): how many groups, their pass-0 layout, the pass-0 twins
-const uint32_t DEFAULT_F0 = 0x7FEB352Du;
 
 uint32_t grouped_groups(const hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm)
 {
@@ -302,7 +164,6 @@ uint32_t grouped_groups(const hjgpu_ctx *ctx, size_t inner, size_t outer, const 
     return (uint32_t)std::min<size_t>((inner + per - 1) / per, 192);
 }
 
-struct GroupLayout { uint32_t G, bins, F0; };
 GroupLayout group_layout(uint32_t G)
 {
     GroupLayout l;
@@ -324,41 +185,10 @@ int grouped_twins(hjgpu_ctx *ctx, const GroupLayout &l, size_t inner, size_t out
 }
 
 
-// K6 occupies a CU completely (one 1024-thread workgroup with ~155 KiB of LDS that lives until the pass ends): a kernel
-// that arrives during a pass - RCCL's, on the multi-GPU path - finds no CU until the pass is over.  "reserve_cus" keeps
-// some CUs out of K6's grid (work is claimed from a ticket counter, so any grid size finishes the pass).
-inline int scatter_cus(const hjgpu_ctx *ctx)
-{
-    const int n = ctx->cus - ctx->tune.reserve_cus;
-    return n < 1 ? 1 : n;
-}
 
-inline uint32_t align_of(const void *p) { return (uint32_t)(((uintptr_t)p >> 2) & 3); }
 
-// Carves the meta buffer; must match between sizing and use.
-struct MetaLayout {
-    u64 *counts[2], *off2[2], *end2[2], *cur2[2], *off1[2], *cur1[2], *tp1[2], *seg1[2], *tp2[2];
-    u64 *seg2[2];                // [F1 + 1] partition-major pass-1 layout of a chunked relation: bounds of the pass-1 partitions
-    u64 *more[2];                // [P] more than 8 chunks: the counters of chunks 8 ... C - 1 added up (PlanArgs::more), else NULL
-    u64 *slice_prefix, *slices;
-    uint32_t *tickets;           // [HJ_TICKET_WORDS] work-claim counters of K4 / K6, the multi-fill count (inside the block zeroed per join)
-    uint32_t *item_part;         // [P + items_extra] partition of every join work item
-    uint4 *tdesc[2];             // [tdesc_cap][2] pass-2 tile descriptors (K5 -> K6 pass 2)
-    size_t tdesc_cap;
-    uint32_t *range_counts[2];   // [ranges][F1] pass-1 counts per range (K4 -> K5b)
-    u64 *range_base[2];          // [ranges][F1] pass-1 write bases per range (K5b -> K6)
-    // batched probe-side partitioning (hj_launch_batch_plan): per-batch pass-1 layout, pass-2 tile prefix,
-    // pass-2 tile descriptors, and one ticket word per launch (pass 1 / pass 2 of every batch)
-    u64 *boff, *tp2b;
-    uint4 *tdescb;
-    uint32_t *btickets;
-    size_t btickets_bytes;
-    size_t counts_bytes;    // both relations, contiguous (zeroed per join)
-    size_t total_bytes;
-};
-
-MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges, size_t items_extra = 0,
-                 size_t tiles2 = 0, size_t batches = 0, size_t tdesc_b_cap = 0)
+MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges, size_t items_extra, size_t tiles2, size_t batches,
+                 size_t tdesc_b_cap)
 {
     MetaLayout m;
     u64 *p = reinterpret_cast<u64 *>(base);
@@ -540,8 +370,7 @@ uint32_t ranges_capacity(const HjTuning &tune, u64 max_tiles, uint32_t F1)
     return best;
 }
 
-Pass1Geom make_geom(const HjTuning &tune, const void *keys, size_t n, uint32_t C, uint32_t F1, bool out_packed,
-                    bool capacity = false)
+Pass1Geom make_geom(const HjTuning &tune, const void *keys, size_t n, uint32_t C, uint32_t F1, bool out_packed, bool capacity)
 {
     // chunk ranges = thread_beg/thread_end with alignment 16 (npj.cpp:516-529; cpra2.cpp:1737-1742)
     Pass1Geom g;
@@ -571,36 +400,9 @@ Pass1Geom make_geom(const HjTuning &tune, const void *keys, size_t n, uint32_t C
 // ---------------------------------------------------------------------------
 // PHJ / CPRA: fused histogram -> plan -> scatter x2 -> LDS join
 // ---------------------------------------------------------------------------
-struct PhjPlan {
-    size_t ranges, items_extra, tiles2;
-    uint32_t C, F1, F2, P;
-    uint32_t f1, f2, tf0, tf1;
-    bool big_tables;
-    bool unique;             // HJGPU_FLAG_UNIQUE / option "unique"
-    // batched probe-side partitioning: 0 batches = off
-    uint32_t batch_ranges;   // pass-1 ranges per batch
-    uint32_t batch_cap;      // batches the tables hold
-    uint32_t batch_tile_cap; // tiles per range the batch buffers are sized for
-    size_t tdesc_b_cap;      // pass-2 tile descriptors per batch
-    size_t batch_bytes;      // one batch buffer (packed tuples)
-    // pre-partitioned relations (hjgpu_phj_build_prepartitioned): pass 1 was the exchange-level partitioning of the
-    // multi-GPU CPRA; F1 = this rank's share k of its fan-out pre_F1tot, partitions [pre_base, pre_base + k)
-    uint32_t pre;            // 1: the relations arrive pass-1-partitioned
-    uint32_t pre_f1, pre_F1tot, pre_base;
-};
-static_assert(sizeof(PhjPlan) <= sizeof(hjgpu_ctx::prepared_plan), "prepared_plan too small");
-// the pieces a pre-partitioned relation arrives in (one per source rank)
-struct PrePieces {
-    const u64 *tuples[2] = {nullptr, nullptr};      // [0] build side, [1] probe side (packed: payload << 32 | key)
-    HjChunks ch[2];
-    // [chunks][P] fused (piece, final partition) counts of the relation, counted by the SENDERS' histogram pass and
-    // delivered with the exchange (hjgpu_phj_probe_prepartitioned_counted_async): K4p is skipped
-    const u64 *counts[2] = {nullptr, nullptr};
-};
-enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
 
 int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm,
-                uint32_t chunks, PhjPlan *pl, bool pre = false, int big_override = -1)
+                uint32_t chunks, PhjPlan *pl, bool pre, int big_override)
 {
     settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     ctx->prepared = false;               // the workspace is about to be re-planned (hjgpu_phj_build sets it again)
@@ -689,8 +491,7 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
 int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *rk, const uint32_t *rv, size_t inner,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
-                const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready = nullptr,
-                PhjMode mode = PHJ_WHOLE, const PrePieces *pre = nullptr)
+                const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready, PhjMode mode, const PrePieces *pre)
 {
     CHK(refuse_capture(ctx, stream));
     if ((pre != nullptr) != (pl.pre != 0)) return fail(ctx, HJGPU_EINVAL, "internal: plan and relations disagree about pre-partitioning");
@@ -1042,7 +843,7 @@ int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_
 
 int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, size_t outer,
                       const u64 *table, size_t buckets, uint32_t factor, const hjgpu_output *out,
-                      hipStream_t stream, bool line_hash = false, bool unique = false)
+                      hipStream_t stream, bool line_hash, bool unique)
 {
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 bs = 0, bl = 0;
@@ -1109,7 +910,7 @@ const hjgpu_output *take_async_output(hjgpu_ctx *ctx, const hjgpu_output *given)
     return &ctx->pending_out;
 }
 
-}  // namespace
+}  // namespace hjapi
 
 // ===========================================================================
 // extern "C"
@@ -1432,229 +1233,6 @@ int hjgpu_synchronize(hjgpu_ctx *ctx, void *stream)
     if (!ctx) return HJGPU_EINVAL;
     HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream));
     return HJGPU_OK;
-}
-
-// ---- partition operators ------------------------------------------------------
-int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t factor,
-                    uint32_t fanout, uint64_t *d_counts, void *stream_)
-{
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
-    if (!ctx || !d_counts || (n && !d_keys)) return fail(ctx, HJGPU_EINVAL, "null pointer");
-    if (fanout == 0 || fanout > HJGPU_MAX_PARTS || !(factor & 1))
-        return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 32768] and factor odd");
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, (size_t)fanout * sizeof(u64), stream));
-    if (n) {
-        // the per-range counts are a by-product here; they go to scratch
-        const Pass1Geom g = make_geom(ctx->tune, d_keys, n, 1, 1, false);
-        CHK(ensure(ctx, ctx->moves, ((size_t)g.ranges_per_chunk + 16) * sizeof(uint32_t)));
-        uint32_t *ticket = (uint32_t *)ctx->moves.p + g.ranges_per_chunk;
-        HIPCHK(ctx, hipMemsetAsync(ticket, 0, 8 * sizeof(uint32_t), stream));
-        CHK(hj_launch_hist2(d_keys, g, 1u, 1u, factor, fanout, (u64 *)d_counts,
-                            (uint32_t *)ctx->moves.p, ticket, ctx->cus, stream));
-    }
-    HIPCHK(ctx, hipStreamSynchronize(stream));
-    return HJGPU_OK;
-}
-
-// group_bins > 0: the partitions in groups of group_bins neighbours, every group on a 128-byte line (hj_group_shift; the
-// columns then need room for n + 32 * (groups + 1) rows); d_offsets stay the dense prefix of the counts
-static int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                             uint32_t factor, uint32_t fanout, uint32_t group_bins, uint32_t *d_keys_out, uint32_t *d_vals_out,
-                             uint64_t *d_offsets, void *stream_)
-{
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
-    if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
-    if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
-        return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 1024] and factor odd");
-    if (n && (!d_keys_out || !d_vals_out)) return fail(ctx, HJGPU_EINVAL, "null output column");
-    CHK(check_columns(ctx, d_keys, d_vals, n));
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(refuse_capture(ctx, stream));
-    const Pass1Geom geom = make_geom(ctx->tune, d_keys, n, 1, fanout, false);
-    MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
-    ctx->prepared = false;                 // the workspace is re-planned below
-    CHK(ensure(ctx, ctx->meta, sz.total_bytes));
-    MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
-    // hjgpu_get_stats().ms_total afterwards = duration of the whole operator (histogram + plan + scatter)
-    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
-    ctx->last_algo = 2;
-    record(ctx, EV_BEGIN, stream);
-    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
-    if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets,
-                               ctx->cus, stream));
-    PlanArgs pa;
-    for (int r = 0; r < 2; ++r) {
-        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
-        pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
-        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
-    }
-    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = 0;
-    pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
-    for (uint32_t c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
-    pa.regular[0] = pa.regular[1] = 0; pa.chunk_part[0] = pa.chunk_part[1] = 0;
-    pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
-    pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
-    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 7u;
-    CHK(hj_launch_plan(pa, stream));
-    if (n) {
-        CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1,
-                                 geom.ranges_per_chunk, fanout, stream, 0, 0, group_bins));
-        ScatterArgs sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.kin = d_keys; sa.vin = d_vals; sa.kout = d_keys_out; sa.vout = d_vals_out;
-        sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
-        sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
-        sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6; sa.geom = geom; sa.range_base = m.range_base[0];
-        sa.in_packed = 0; sa.out_packed = 0;
-        sa.nt_partial = ctx->rows_plain ? 0u : 1u;
-                CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
-    }
-    HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
-                               hipMemcpyDeviceToDevice, stream));
-    record(ctx, EV_GAPS, stream);
-    return HJGPU_OK;
-}
-
-int hjgpu_partition_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                          uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
-                          uint64_t *d_offsets, void *stream_)
-{
-    return partition_columns(ctx, d_keys, d_vals, n, factor, fanout, 0, d_keys_out, d_vals_out, d_offsets, stream_);
-}
-
-int hjgpu_partition(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                    uint32_t factor, uint32_t fanout, uint32_t *d_keys_out, uint32_t *d_vals_out,
-                    uint64_t *d_offsets, void *stream_)
-{
-    CHK(hjgpu_partition_async(ctx, d_keys, d_vals, n, factor, fanout, d_keys_out, d_vals_out, d_offsets, stream_));
-    HIPCHK(ctx, hipStreamSynchronize((hipStream_t)stream_));
-    return HJGPU_OK;
-}
-
-int hjgpu_join_partitions(hjgpu_ctx *ctx,
-                          const uint32_t *rk, const uint32_t *rv, const uint64_t *roff,
-                          const uint32_t *sk, const uint32_t *sv, const uint64_t *soff,
-                          const hjgpu_phj_params *passes, hjgpu_result *result,
-                          const hjgpu_output *out, void *stream_)
-{
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
-    if (!ctx || !passes || !roff || !soff || !rk || !rv || !sk || !sv)
-        return fail(ctx, HJGPU_EINVAL, "null pointer");
-    if (((uintptr_t)sk & 15) || ((uintptr_t)sv & 15))
-        return fail(ctx, HJGPU_EALIGN, "probe columns must be 16-byte aligned");
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    PhjPlan pl;
-    pl.C = 1;
-    pl.F1 = passes->fanout1; pl.F2 = passes->fanout2 ? passes->fanout2 : 1;
-    pl.P = pl.F1 * pl.F2;
-    if (pl.F1 == 0 || pl.P < 2 || pl.P > HJGPU_MAX_PARTS) return fail(ctx, HJGPU_EINVAL, "fan-out out of range");
-    pl.f1 = passes->factor1 ? passes->factor1 : DEFAULT_F1;
-    pl.f2 = passes->factor2 ? passes->factor2 : DEFAULT_F2;
-    pl.tf0 = passes->table_factor[0] ? passes->table_factor[0] : DEFAULT_TF0;
-    pl.tf1 = passes->table_factor[1] ? passes->table_factor[1] : DEFAULT_TF1;
-    if (!(pl.f1 & 1) || !(pl.f2 & 1) || !(pl.tf0 & 1) || !(pl.tf1 & 1))
-        return fail(ctx, HJGPU_EINVAL, "hash factors must be odd");
-    // the work-item directory is sized from the probe rows, which only the device knows here
-    u64 s_ends[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(&s_ends[0], soff, sizeof(u64), hipMemcpyDeviceToHost, stream));
-    HIPCHK(ctx, hipMemcpyAsync(&s_ends[1], soff + pl.P, sizeof(u64), hipMemcpyDeviceToHost, stream));
-    HIPCHK(ctx, hipStreamSynchronize(stream));
-    const size_t items_extra = hj_join_items_capacity(pl.P, (size_t)(s_ends[1] - s_ends[0])) - pl.P;
-    MetaLayout sz = carve(nullptr, 1, pl.F1, pl.P, 1, items_extra);
-    ctx->prepared = false;                 // the workspace is re-planned below
-    CHK(ensure(ctx, ctx->meta, sz.total_bytes));
-    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
-    MetaLayout m = carve(ctx->meta.p, 1, pl.F1, pl.P, 1, items_extra);
-    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
-    u64 bs = 0, bl = 0;
-    const bool unique = ctx->tune.unique || (passes->flags & HJGPU_FLAG_UNIQUE);
-    CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, false, unique), &bs, &bl));
-    record(ctx, EV_BEGIN, stream);
-    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
-    // counts = adjacent differences of the caller's offsets, then the usual plan
-    // (re-derives identical offsets and the work-item prefix)
-    CHK(hj_launch_offsets_to_counts((const u64 *)roff, m.counts[0], pl.P, stream));
-    CHK(hj_launch_offsets_to_counts((const u64 *)soff, m.counts[1], pl.P, stream));
-    PlanArgs pa;
-    for (int r = 0; r < 2; ++r) {
-        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
-        pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
-        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
-    }
-    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = unique ? 1u : 0u;
-    pa.n[0] = pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
-    for (int r = 0; r < 2; ++r) for (uint32_t c = 0; c < 9; ++c) pa.chunk_beg[r][c] = 0;
-    pa.regular[0] = pa.regular[1] = 0; pa.chunk_part[0] = pa.chunk_part[1] = 0;
-    pa.chunks = 1; pa.F1 = pl.F1; pa.F2 = pl.F2; pa.in_align[0] = pa.in_align[1] = 0;
-    pa.tile1 = pa.tile2 = (uint32_t)hj_scatter_tile(ctx->tune, 2, 1, true); pa.slice = HJ_JOIN_SLICE;
-    pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 7u;
-    CHK(hj_launch_plan(pa, stream));
-    for (int e : {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2, EV_WAITED, EV_R_HIST, EV_R_PLAN, EV_R_SC1, EV_R_SC2}) record(ctx, e, stream);
-    JoinArgs ja;
-    memset(&ja, 0, sizeof(ja));
-    ja.rk = rk; ja.rv = rv; ja.sk = sk; ja.sv = sv;
-    ja.roff = (const u64 *)roff; ja.soff = (const u64 *)soff;    // caller's offsets (may start at non-zero)
-    ja.rend = ja.roff + 1; ja.send = ja.soff + 1;
-    ja.slice_prefix = m.slice_prefix; ja.slices = m.slices; ja.item_part = m.item_part;
-    ja.P = pl.P; ja.chunks = 1;
-    ja.f1 = pl.f1; ja.F1 = pl.F1; ja.f2 = pl.f2; ja.F2 = pl.F2; ja.tf0 = pl.tf0; ja.tf1 = pl.tf1;
-    ja.s_align = 0; ja.result = &st->result; ja.work_counter = &st->work_counter;
-    ja.work_counter2 = &st->work_counter2;       // (multi_fill stays NULL: the caller's partitions were not counted)
-    ja.unique = unique ? 1u : 0u;
-    if (bs) {
-        ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
-        ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
-        ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
-        ja.nt_rows = ctx->rows_plain ? 0u : 1u;
-    }
-    CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
-    record(ctx, EV_JOIN, stream);
-    if (bs)
-        CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
-                                    (const u64 *)ctx->final_offsets.p,
-                                    (uint32_t)hj_join_workers(ctx->tune, ctx->cus, false, unique), bs, &st->block_counter,
-                                    &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
-    record(ctx, EV_GAPS, stream);
-    ctx->last_algo = 1;
-    return finish_blocking(ctx, result, out, stream);
-}
-
-// ---- NPJ operators ------------------------------------------------------------
-int hjgpu_npj_build(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                    uint64_t *d_table, size_t buckets, uint32_t factor, void *stream_)
-{
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
-    if (!ctx || !d_table || (n && (!d_keys || !d_vals))) return fail(ctx, HJGPU_EINVAL, "null pointer");
-    if (!(factor & 1) || buckets <= n) return fail(ctx, HJGPU_EINVAL, "factor must be odd and buckets > n");
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
-    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
-    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
-    HIPCHK(ctx, hipMemsetAsync(d_table, 0, buckets * sizeof(u64), stream));
-    if (n) CHK(hj_launch_npj_build(d_keys, d_vals, n, (u64 *)d_table, buckets, factor, &st->zero_key, ctx->cus, stream));
-    return finish_blocking(ctx, nullptr, nullptr, stream);
-}
-
-int hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                    const uint64_t *d_table, size_t buckets, uint32_t factor,
-                    hjgpu_result *result, const hjgpu_output *out, void *stream_)
-{
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
-    if (!ctx || !d_table || buckets == 0) return fail(ctx, HJGPU_EINVAL, "null pointer");
-    CHK(check_columns(ctx, d_keys, d_vals, n));
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(DevState), stream));
-    record(ctx, EV_BEGIN, stream); record(ctx, EV_R_HIST, stream);
-    CHK(npj_probe_enqueue(ctx, d_keys, d_vals, n, (const u64 *)d_table, buckets, factor, out, stream, false, ctx->tune.unique));
-    ctx->last_algo = 0;
-    return finish_blocking(ctx, result, out, stream);
 }
 
 // ---- whole joins ----------------------------------------------------------------
@@ -2053,227 +1631,6 @@ int hjgpu_phj_probe_async(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv
     return phj_probe_prepared(ctx, sk, sv, outer, nullptr, d_result, nullptr, stream, false);
 }
 
-// ---- relations that arrive pass-1-partitioned (the receiving side of the multi-GPU CPRA) --------------------
-static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                            uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
-                            uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_,
-                            uint32_t factor2 = 0, uint32_t fanout2 = 0, uint64_t *d_counts2 = nullptr)
-{
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
-    if (d_counts2 && (fanout2 < 1 || !(factor2 & 1) || factor2 == factor || (u64)fanout * fanout2 > HJGPU_MAX_PARTS))
-        return fail(ctx, HJGPU_EINVAL, "fused counts: factor2 odd and different from factor, fanout * fanout2 <= 32768");
-    if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
-    if ((u64)own_first + own_count > fanout) return fail(ctx, HJGPU_EINVAL, "own_first + own_count must not exceed fanout");
-    if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
-        return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 1024] and factor odd");
-    if (n && !d_tuples_out) return fail(ctx, HJGPU_EINVAL, "null output array");
-    if ((uintptr_t)d_tuples_out & 127) return fail(ctx, HJGPU_EALIGN, "the packed output must be 128-byte aligned (whole-line writes)");
-    CHK(check_columns(ctx, d_keys, d_vals, n));
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(refuse_capture(ctx, stream));
-    const Pass1Geom geom = make_geom(ctx->tune, d_keys, n, 1, fanout, true);
-    MetaLayout sz = carve(nullptr, 1, fanout, fanout, geom.ranges_per_chunk);
-    ctx->prepared = false;                 // the workspace is re-planned below
-    CHK(ensure(ctx, ctx->meta, sz.total_bytes));
-    MetaLayout m = carve(ctx->meta.p, 1, fanout, fanout, geom.ranges_per_chunk);
-    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
-    ctx->last_algo = 2;                    // hjgpu_get_stats().ms_total = the whole operator
-    record(ctx, EV_BEGIN, stream);
-    u64 *audit = nullptr;                  // option "audit": stage 0 the columns as read, stage 1 the packed output where it lies
-    CHK(audit_begin(ctx, 3, n, 0, stream, &audit));
-    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
-    if (d_counts2) {
-        // the same read of the keys also counts the RECEIVERS' second level (bin = p1 * fanout2 + p2, the join's fused
-        // histogram): they then need no histogram pass of their own over what arrives (K4p).  The pass-1 counts of this
-        // call are the row sums.
-        HIPCHK(ctx, hipMemsetAsync(d_counts2, 0, (size_t)fanout * fanout2 * sizeof(u64), stream));
-        if (n) {
-            u64 *fused = reinterpret_cast<u64 *>(d_counts2);
-            CHK(hj_launch_hist2(d_keys, geom, factor, fanout, factor2, fanout2, fused, m.range_counts[0], m.tickets, ctx->cus, stream, (size_t)ctx->tune.hist_min_lds));
-            CHK(hj_launch_row_sums(fused, fanout, fanout2, m.counts[0], stream));
-        }
-    } else if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets, ctx->cus, stream));
-    PlanArgs pa;
-    for (int r = 0; r < 2; ++r) {
-        pa.counts[r] = m.counts[r]; pa.off2[r] = m.off2[r]; pa.end2[r] = m.end2[r]; pa.cur2[r] = m.cur2[r];
-        pa.off1[r] = m.off1[r]; pa.cur1[r] = m.cur1[r]; pa.tp1[r] = m.tp1[r];
-        pa.seg1[r] = m.seg1[r]; pa.tp2[r] = m.tp2[r];
-    }
-    pa.tdesc[0] = pa.tdesc[1] = nullptr; pa.tdesc_cap = 0; pa.pad2 = 0; pa.unique = 0;
-    pa.n[0] = n; pa.n[1] = 0; pa.slice_prefix = m.slice_prefix; pa.slices = m.slices; pa.item_part = m.item_part;
-    for (uint32_t c = 0; c < 9; ++c) { pa.chunk_beg[0][c] = c ? n : 0; pa.chunk_beg[1][c] = 0; }
-    pa.regular[0] = pa.regular[1] = 0; pa.chunk_part[0] = pa.chunk_part[1] = 0;
-    pa.chunks = 1; pa.F1 = fanout; pa.F2 = 1;
-    pa.in_align[0] = align_of(d_keys); pa.in_align[1] = 0;
-    pa.tile1 = pa.tile2 = geom.tile; pa.slice = HJ_JOIN_SLICE; pa.cap = (uint32_t)ctx->tune.join.cap(); pa.mask = 1u;
-    CHK(hj_launch_plan(pa, stream));
-    if (n) {
-        CHK(hj_launch_range_base(m.range_counts[0], m.off1[0], m.range_base[0], 1, geom.ranges_per_chunk, fanout, stream,
-                                 own_first, own_count));
-        ScatterArgs sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.kin = d_keys; sa.vin = d_vals; sa.kout = reinterpret_cast<uint32_t *>(d_tuples_out); sa.vout = nullptr;
-        sa.seg_off = m.seg1[0]; sa.tile_prefix = m.tp1[0]; sa.cursors = m.cur1[0];
-        sa.nseg = 1; sa.F = fanout; sa.factor = factor; sa.in_align = align_of(d_keys);
-        sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6; sa.geom = geom; sa.range_base = m.range_base[0];
-        sa.in_packed = 0; sa.out_packed = 1;
-        sa.nt_partial = ctx->rows_plain ? 0u : 1u;
-                CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
-    }
-    HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
-    if (audit && n) {
-        CHK(hj_audit_sums_columns(d_keys, d_vals, n, audit, ctx->cus, stream));
-        CHK(ensure(ctx, ctx->audit_lay, (size_t)2 * (HJGPU_MAX_FANOUT + 1) * sizeof(u64)));
-        u64 *beg = reinterpret_cast<u64 *>(ctx->audit_lay.p), *end = beg + HJGPU_MAX_FANOUT + 1;
-        CHK(hj_audit_own_last(m.off2[0], fanout, own_first, own_count, n, beg, end, stream));
-        const HjAuditHash h = {factor, fanout, 0u, 1u, 1u, fanout};
-        CHK(hj_audit_partitions(reinterpret_cast<const u64 *>(d_tuples_out), beg, end, fanout, h, audit + 4, ctx->cus, stream));
-    }
-    record(ctx, EV_GAPS, stream);
-    return HJGPU_OK;
-}
-
-int hjgpu_partition_packed_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                                 uint32_t factor, uint32_t fanout, uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream)
-{
-    return partition_packed(ctx, d_keys, d_vals, n, factor, fanout, 0, 0, d_tuples_out, d_offsets, stream);
-}
-
-int hjgpu_partition_packed_own_last_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                                          uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
-                                          uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream)
-{
-    return partition_packed(ctx, d_keys, d_vals, n, factor, fanout, own_first, own_count, d_tuples_out, d_offsets, stream);
-}
-
-int hjgpu_partition_packed_counted_async(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
-                                         uint32_t factor, uint32_t fanout, uint32_t own_first, uint32_t own_count,
-                                         uint32_t factor2, uint32_t fanout2, uint64_t *d_tuples_out, uint64_t *d_offsets,
-                                         uint64_t *d_counts2, void *stream)
-{
-    if (!d_counts2) return fail(ctx, HJGPU_EINVAL, "null counts array");
-    return partition_packed(ctx, d_keys, d_vals, n, factor, fanout, own_first, own_count, d_tuples_out, d_offsets, stream,
-                            factor2, fanout2, d_counts2);
-}
-
-// what hjgpu_phj_build_prepartitioned plans for a build side of `inner` rows in `fanout1` pass-1 partitions
-static void prepartitioned_plan(const hjgpu_ctx *ctx, size_t inner, uint32_t k, const hjgpu_phj_params *prm, uint32_t *F2, bool *big)
-{
-    *big = false;
-    double parts = ceil((double)inner / (ctx->tune.join.cap() * 0.85));
-    if (parts > HJGPU_MAX_PARTS) { *big = true; parts = ceil((double)inner / (hj_join_config_big().cap() * 0.85)); }
-    uint32_t f2 = (prm && prm->fanout2) ? prm->fanout2 : (uint32_t)std::max(2.0, ceil(parts / k));
-    if (f2 < 2) f2 = 2;
-    if (f2 > HJGPU_MAX_FANOUT) f2 = HJGPU_MAX_FANOUT;
-    while ((u64)k * f2 > HJGPU_MAX_PARTS && f2 > 2) --f2;
-    *F2 = f2;
-}
-
-int hjgpu_prepartitioned_plan(hjgpu_ctx *ctx, size_t inner, uint32_t fanout1, const hjgpu_phj_params *params,
-                              uint32_t *fanout2, uint32_t *factor2)
-{
-    if (!ctx || !fanout1 || !fanout2 || !factor2) return HJGPU_EINVAL;
-    bool big = false;
-    prepartitioned_plan(ctx, inner, fanout1, params, fanout2, &big);
-    *factor2 = (params && params->factor2) ? params->factor2 : DEFAULT_F2;
-    return HJGPU_OK;
-}
-
-static int check_layout(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, HjChunks *ch, size_t *rows)
-{
-    if (!lay) return fail(ctx, HJGPU_EINVAL, "null layout");
-    if (lay->chunks < 1 || lay->chunks > 8) return fail(ctx, HJGPU_EINVAL, "a pre-partitioned relation arrives in 1 to 8 pieces");
-    if (!(lay->factor1 & 1) || lay->fanout1 == 0 || lay->fanout1_total > HJGPU_MAX_FANOUT ||
-        (u64)lay->first_partition + lay->fanout1 > lay->fanout1_total)
-        return fail(ctx, HJGPU_EINVAL, "pre-partitioned layout: odd factor1, fanout1 >= 1, first_partition + fanout1 <= fanout1_total <= 1024");
-    ch->chunks = lay->chunks;
-    for (uint32_t c = 0; c < 9; ++c) {
-        ch->b[c] = lay->chunk_offsets[c <= lay->chunks ? c : lay->chunks];
-        if (c && ch->b[c] < ch->b[c - 1]) return fail(ctx, HJGPU_EINVAL, "pre-partitioned layout: chunk_offsets must not decrease");
-    }
-    *rows = (size_t)(ch->b[lay->chunks] - ch->b[0]);
-    if (*rows && !d_tuples) return fail(ctx, HJGPU_EINVAL, "null tuple array");
-    if ((uintptr_t)d_tuples & 15) return fail(ctx, HJGPU_EALIGN, "packed tuples must be 16-byte aligned");
-    return HJGPU_OK;
-}
-
-int hjgpu_phj_build_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay,
-                                   size_t max_outer, const hjgpu_phj_params *prm, void *stream_)
-{
-    if (!ctx) return HJGPU_EINVAL;
-    PrePieces pre;
-    size_t inner = 0;
-    CHK(check_layout(ctx, d_tuples, lay, &pre.ch[0], &inner));
-    pre.tuples[0] = reinterpret_cast<const u64 *>(d_tuples);
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(refuse_capture(ctx, stream));
-    // pass 1 is given (fan-out k = lay->fanout1 on this rank): pass 2 brings the build partitions down to one LDS table.
-    // Always a second pass (F2 >= 2): the final partitions are then ONE line-aligned region each, whatever the number of pieces.
-    hjgpu_phj_params p2;
-    memset(&p2, 0, sizeof(p2));
-    if (prm) p2 = *prm;
-    const uint32_t k = lay->fanout1;
-    bool big = false;
-    uint32_t F2 = 0;
-    prepartitioned_plan(ctx, inner, k, &p2, &F2, &big);
-    p2.fanout1 = k; p2.fanout2 = F2;
-    PhjPlan pl;
-    CHK(phj_prepare(ctx, inner, max_outer, &p2, lay->chunks, &pl, true, big ? 1 : 0));
-    pl.pre_f1 = lay->factor1; pl.pre_F1tot = lay->fanout1_total; pl.pre_base = lay->first_partition;
-    if (pl.f2 == pl.pre_f1) return fail(ctx, HJGPU_EINVAL, "factor2 must differ from the exchange-level factor1 (same factor: the second pass would not split)");
-    CHK(phj_enqueue(ctx, pl, nullptr, nullptr, inner, nullptr, nullptr, 0, nullptr, stream, nullptr, PHJ_BUILD_ONLY, &pre));
-    memcpy(ctx->prepared_plan, &pl, sizeof(pl));
-    ctx->prepared_inner = inner; ctx->prepared_max_outer = max_outer;
-    ctx->prepared = true;
-    return HJGPU_OK;
-}
-
-static int probe_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, const uint64_t *d_counts,
-                                hjgpu_result *d_result, void *stream_);
-
-int hjgpu_phj_probe_prepartitioned_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay,
-                                         hjgpu_result *d_result, void *stream_)
-{
-    return probe_prepartitioned(ctx, d_tuples, lay, nullptr, d_result, stream_);
-}
-
-int hjgpu_phj_probe_prepartitioned_counted_async(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay,
-                                                 const uint64_t *d_counts, hjgpu_result *d_result, void *stream_)
-{
-    if (ctx && !d_counts) return fail(ctx, HJGPU_EINVAL, "null counts array");
-    return probe_prepartitioned(ctx, d_tuples, lay, d_counts, d_result, stream_);
-}
-
-static int probe_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, const uint64_t *d_counts,
-                                hjgpu_result *d_result, void *stream_)
-{
-    settle(ctx);
-    if (!ctx) return HJGPU_EINVAL;
-    const hjgpu_output *out = take_async_output(ctx, nullptr);   // consumed by this call even if it fails below (see hjgpu_npj_async)
-    if (!ctx->prepared) return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe_prepartitioned_async: no prepared build side, or another entry point has used the workspace since");
-    PhjPlan pl;
-    memcpy(&pl, ctx->prepared_plan, sizeof(pl));
-    if (!pl.pre) return fail(ctx, HJGPU_EINVAL, "the prepared build side was not pre-partitioned (hjgpu_phj_build_prepartitioned)");
-    PrePieces pre;
-    size_t outer = 0;
-    CHK(check_layout(ctx, d_tuples, lay, &pre.ch[1], &outer));
-    if (lay->chunks != pl.C || lay->factor1 != pl.pre_f1 || lay->fanout1_total != pl.pre_F1tot ||
-        lay->first_partition != pl.pre_base || lay->fanout1 != pl.F1)
-        return fail(ctx, HJGPU_EINVAL, "the probe batch's layout differs from the prepared build side's (pieces, factor1, fan-outs, first partition)");
-    if (outer > ctx->prepared_max_outer) return fail(ctx, HJGPU_EINVAL, "batch larger than the max_outer given to hjgpu_phj_build_prepartitioned");
-    pre.tuples[1] = reinterpret_cast<const u64 *>(d_tuples);
-    pre.counts[1] = reinterpret_cast<const u64 *>(d_counts);
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    ctx->last_had_output = out && out->d_keys;
-    CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, nullptr, nullptr, outer, out, stream, nullptr, PHJ_PROBE_ONLY, &pre));
-    if (d_result)
-        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
-    return HJGPU_OK;
-}
-
 int hjgpu_cpra(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t inner,
                const uint32_t *sk, const uint32_t *sv, size_t outer,
                const hjgpu_phj_params *prm, hjgpu_result *result, const hjgpu_output *out, void *stream)
@@ -2288,706 +1645,6 @@ int hjgpu_cpra_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, siz
 {
     const uint32_t chunks = (prm && prm->chunks) ? prm->chunks : 8;
     return phj_like(ctx, chunks, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false);
-}
-
-// Host column -> HBM on `copy`.  Page-locked memory (hjgpu_host_alloc, hipHostRegister'ed, ...) is
-// DMA'd directly; pageable memory goes through two pinned staging buffers so that the CPU's copy
-// of chunk i+1 overlaps the DMA of chunk i.
-constexpr size_t HJ_HOST_STAGE = 32u << 20;
-static int host_stage(hjgpu_ctx *ctx, int first)
-{
-    for (int b = first; b < first + 2; ++b) {
-        if (!ctx->host_stage[b]) HIPCHK(ctx, hipHostMalloc(&ctx->host_stage[b], HJ_HOST_STAGE, hipHostMallocDefault));
-        if (!ctx->host_stage_ev[b]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->host_stage_ev[b], hipEventDisableTiming));
-    }
-    return HJGPU_OK;
-}
-
-static int upload_column(hjgpu_ctx *ctx, void *d, const void *h, size_t bytes, hipStream_t copy, int *next)
-{
-    if (!bytes) return HJGPU_OK;
-    hipPointerAttribute_t at;
-    const bool pinned = hipPointerGetAttributes(&at, h) == hipSuccess && at.type == hipMemoryTypeHost;
-    (void)hipGetLastError();                            // a pageable pointer reports an error: expected
-    if (pinned) {
-        HIPCHK(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, copy));
-        return HJGPU_OK;
-    }
-    CHK(host_stage(ctx, 0));
-    void **stage = ctx->host_stage;
-    hipEvent_t *stage_free = ctx->host_stage_ev;
-    const size_t stage_bytes = HJ_HOST_STAGE;
-    for (size_t at_ = 0; at_ < bytes; at_ += stage_bytes) {
-        const size_t n = bytes - at_ < stage_bytes ? bytes - at_ : stage_bytes;
-        const int b = *next; *next ^= 1;
-        HIPCHK(ctx, hj_event_synchronize(stage_free[b]));           // the DMA that last used this buffer is done
-        memcpy(stage[b], (const char *)h + at_, n);
-        HIPCHK(ctx, hipMemcpyAsync((char *)d + at_, stage[b], n, hipMemcpyHostToDevice, copy));
-        HIPCHK(ctx, hipEventRecord(stage_free[b], copy));
-    }
-    return HJGPU_OK;
-}
-
-// HBM column -> host column on `copy`: the mirror image of upload_column.  Pageable destinations are
-// filled from two pinned staging buffers, the CPU's copy of chunk i overlapping the DMA of chunk i+1.
-static int download_column(hjgpu_ctx *ctx, void *h, const void *d, size_t bytes, hipStream_t copy, bool by_kernel = false)
-{
-    if (!bytes) return HJGPU_OK;
-    hipPointerAttribute_t at;
-    const bool pinned = hipPointerGetAttributes(&at, h) == hipSuccess && at.type == hipMemoryTypeHost;
-    (void)hipGetLastError();
-    // (by_kernel: the DMA engines are busy with an upload in the other direction, see copy_to_host_kernel)
-    if (pinned && by_kernel && at.devicePointer && !(((uintptr_t)at.devicePointer | (uintptr_t)d | bytes) & 3)) {
-        if (hj_launch_copy_to_host(at.devicePointer, d, bytes, copy) != HJGPU_OK) return fail(ctx, HJGPU_EHIP, "copy_to_host_kernel");
-        return HJGPU_OK;
-    }
-    if (pinned) {
-        HIPCHK(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, copy));
-        return HJGPU_OK;
-    }
-    CHK(host_stage(ctx, 2));
-    void **stage = ctx->host_stage + 2;
-    hipEvent_t *stage_done = ctx->host_stage_ev + 2;
-    const size_t stage_bytes = HJ_HOST_STAGE;
-    const size_t chunks = (bytes + stage_bytes - 1) / stage_bytes;
-    auto len = [&](size_t c) { return c + 1 < chunks ? stage_bytes : bytes - c * stage_bytes; };
-    auto fetch = [&](size_t c) -> hipError_t {
-        hipError_t e = hipMemcpyAsync(stage[c & 1], (const char *)d + c * stage_bytes, len(c), hipMemcpyDeviceToHost, copy);
-        return e != hipSuccess ? e : hipEventRecord(stage_done[c & 1], copy);
-    };
-    HIPCHK(ctx, fetch(0));
-    for (size_t c = 0; c < chunks; ++c) {
-        if (c + 1 < chunks) HIPCHK(ctx, fetch(c + 1));            // the other buffer: emptied one round ago
-        HIPCHK(ctx, hj_event_synchronize(stage_done[c & 1]));
-        memcpy((char *)h + c * stage_bytes, stage[c & 1], len(c));
-    }
-    return HJGPU_OK;
-}
-
-static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
-                          const uint32_t *ik, const uint32_t *iv, size_t inner,
-                          const uint32_t *ok, const uint32_t *ov, size_t outer,
-                          const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
-                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats, uint64_t *cursor = nullptr);
-
-int hjgpu_join_host(hjgpu_ctx *ctx, int algorithm,
-                    const uint32_t *ik, const uint32_t *iv, size_t inner,
-                    const uint32_t *ok, const uint32_t *ov, size_t outer,
-                    const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
-                    hjgpu_result *result, hjgpu_stats *stats)
-{
-    return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, nullptr, result, stats);
-}
-
-int hjgpu_join_host_rows(hjgpu_ctx *ctx, int algorithm,
-                         const uint32_t *ik, const uint32_t *iv, size_t inner,
-                         const uint32_t *ok, const uint32_t *ov, size_t outer,
-                         const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
-                         const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats)
-{
-    if (!ctx) return HJGPU_EINVAL;
-    if (!rows || !result) return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows: rows and result are required");
-    if (rows->capacity && (!rows->keys || !rows->outer_vals || !rows->inner_vals))
-        return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows: null result column");
-    return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result, stats);
-}
-
-int hjgpu_join_host_rows_shared(hjgpu_ctx *ctx, int algorithm,
-                                const uint32_t *ik, const uint32_t *iv, size_t inner,
-                                const uint32_t *ok, const uint32_t *ov, size_t outer,
-                                const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
-                                const hjgpu_host_rows *rows, uint64_t *cursor, hjgpu_result *result, hjgpu_stats *stats)
-{
-    if (!ctx) return HJGPU_EINVAL;
-    if (!rows || !result || !cursor) return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows_shared: rows, cursor and result are required");
-    if (rows->capacity && (!rows->keys || !rows->outer_vals || !rows->inner_vals))
-        return fail(ctx, HJGPU_EINVAL, "hjgpu_join_host_rows_shared: null result column");
-    return join_host_impl(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result, stats, cursor);
-}
-
-
-// Joins from host columns, aggregates only: the probe side never exists on the device as a whole.  R is uploaded and
-// prepared (PHJ / CPRA: hjgpu_phj_build's passes; NPJ: the table, npj.cpp:865-877), then the probe side travels in
-// batches of `host_batch` rows through two device buffers: batch i is joined against the prepared build side (K4 .. K8,
-// or NPJ's probe, on `run`) while batch i + 1 is on the bus (`copy`).  R join S = union over the batches
-// (phj.cpp:1869-1924 runs per partition; the reference's CPRA partitions every chunk of S on its own,
-// cpra2.cpp:1757-1827: a batch is such a chunk; an NPJ worker probes its own range of S, npj.cpp:882-901).  What the
-// call costs is the upload plus the last batch's join; the device holds R, two batches and a workspace for ONE batch
-// (no 8.5 GB columns, no placement search of the twin; a probe side larger than the device's memory is fine).
-// Returns HJGPU_OK with *done = false when the call should take the monolithic path instead.
-static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, const uint32_t *iv, size_t inner,
-                             const uint32_t *ok, const uint32_t *ov, size_t outer, const hjgpu_phj_params *pp,
-                             const hjgpu_npj_params *np, const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats,
-                             bool *done, uint64_t *cursor = nullptr)
-{
-    // `cursor` (hjgpu_join_host_rows_shared): the caller's columns are shared by several contexts' calls; a batch's rows go
-    // where an atomic fetch-add on *cursor puts them.  Nothing is ever started over then (other calls have appended in
-    // between): a batch that does not fit - its device columns or the shared capacity - is counted, not written, and the
-    // call returns HJGPU_EOVERFLOW with its exact count.
-    *done = false;
-    bool shared_overflow = false;
-    long long want_batch = ctx->tune.host_batch;
-    if (want_batch < 0) {
-        // default: rows in batches; aggregates in batches only when whole columns plus their workspace (two packed twins of
-        // the probe side: 8 + 16 bytes per probe tuple, 8 + 24 per build tuple) would not fit what is free on the device
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        const double need = 24.0 * (double)outer + 32.0 * (double)inner + 4e9;
-        want_batch = (rows || need > (double)free_b) ? (64ll << 20) : 0;
-    }
-    const size_t B = ((size_t)want_batch + 15) & ~size_t(15);       // rows per batch (batches start 64-byte aligned)
-    if (!B || !inner || outer < 2 * B || ctx->tune.batch_tuples) return HJGPU_OK;
-    // Materialised rows: every batch's rows are made dense on the device (close_gaps per batch) and travel to
-    // the caller's host columns on a third stream while the next batch is joined and the one after it uploaded - PCIe is
-    // full duplex, the 12 bytes per result row hide behind the 8 bytes per probe tuple of the upload as far as they can.
-    // The per-batch device columns hold the batch's share of rows->capacity with a quarter of headroom: a batch that
-    // needs more (or a result beyond the caller's capacity) sends the call down the whole-column path, which knows how
-    // to report the needed capacity.
-    const size_t nb = (outer + B - 1) / B;
-    const u64 row_bs = 4096;
-    const size_t workers = !rows ? 0 : algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, B) * 4
-                         : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false, true), hj_join_workers(ctx->tune, ctx->cus, true, true));
-    const size_t want_b = rows ? (size_t)((double)rows->capacity * (double)B / (double)outer * 1.25) + row_bs : 0;
-    const size_t cap_b = rows ? (want_b / row_bs + 1 + workers) * row_bs : 0;
-    void *d_rows[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    hjgpu_output dev_out[2];
-    memset(dev_out, 0, sizeof(dev_out));
-    DevState *h_state = nullptr;                                     // page-locked: one per batch (dense count, overflow flag)
-    hipEvent_t joined[2] = {nullptr, nullptr}, rows_free[2] = {nullptr, nullptr};
-    hipStream_t down = nullptr;
-    u64 rows_at = 0;                                                 // rows in the caller's columns so far
-    bool abandon = false;                                            // take the whole-column path instead
-    float ms_download = 0;
-    void *d_r[2] = {nullptr, nullptr}, *d_s[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *d_res = nullptr;
-    hipEvent_t r_ready = nullptr, s_ready[2] = {nullptr, nullptr}, s_free[2] = {nullptr, nullptr}, b0 = nullptr, b1 = nullptr;
-    hipStream_t copy = nullptr, run = nullptr;
-    std::vector<hjgpu_result> parts(nb);
-    const bool npj = algorithm == 0;
-    int rc = HJGPU_OK;
-    auto hip_ok = [&](hipError_t e, const char *what) { if (rc == HJGPU_OK && e != hipSuccess) rc = fail(ctx, HJGPU_EHIP, what, e); };
-    for (int i = 0; i < 2 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_r[i], inner * sizeof(uint32_t));
-    for (int s = 0; s < 2; ++s) for (int i = 0; i < 2 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_s[s][i], B * sizeof(uint32_t));
-    if (rc == HJGPU_OK) rc = hjgpu_malloc(ctx, &d_res, nb * sizeof(hjgpu_result));
-    if (rows) {
-        for (int s = 0; s < 2; ++s) {
-            for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_rows[s][i], cap_b * sizeof(uint32_t));
-            dev_out[s].d_keys = (uint32_t *)d_rows[s][0]; dev_out[s].d_outer_vals = (uint32_t *)d_rows[s][1];
-            dev_out[s].d_inner_vals = (uint32_t *)d_rows[s][2];
-            dev_out[s].capacity = cap_b; dev_out[s].block_size = row_bs;
-        }
-        if (rc == HJGPU_OK && hipHostMalloc(reinterpret_cast<void **>(&h_state), nb * sizeof(DevState), hipHostMallocDefault) != hipSuccess)
-            rc = fail(ctx, HJGPU_ENOMEM, "hipHostMalloc(batch states)");
-    }
-    int least = 0, greatest = 0;
-    hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    // three priority classes = three hardware-queue pools: upload, join and download never share a queue
-    if (!ctx->host_streams[0]) hip_ok(hipStreamCreateWithPriority(&ctx->host_streams[0], hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
-    if (!ctx->host_streams[1]) hip_ok(hipStreamCreateWithFlags(&ctx->host_streams[1], hipStreamNonBlocking), "hipStreamCreate(run)");
-    if (!ctx->host_streams[2]) hip_ok(hipStreamCreateWithPriority(&ctx->host_streams[2], hipStreamNonBlocking, least), "hipStreamCreate(down)");
-    copy = ctx->host_streams[0]; run = ctx->host_streams[1];
-    hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
-    hip_ok(hipEventCreate(&b0), "hipEventCreate"); hip_ok(hipEventCreate(&b1), "hipEventCreate");     // around the build side's work
-    // one timed pair per batch: the call's device time is the SUM of the build and of every batch's join (what the
-    // reference's programs print is the time of the join, npj.cpp:1104-1114), read once after the pipeline
-    std::vector<hipEvent_t> bev(2 * nb, nullptr);
-    for (hipEvent_t &e : bev) hip_ok(hipEventCreate(&e), "hipEventCreate");
-    for (int b = 0; b < 2; ++b) {
-        hip_ok(hipEventCreateWithFlags(&s_ready[b], hipEventDisableTiming), "hipEventCreate");
-        hip_ok(hipEventCreateWithFlags(&s_free[b], hipEventDisableTiming), "hipEventCreate");
-        if (rows) {
-            hip_ok(hipEventCreateWithFlags(&joined[b], hipEventDisableTiming), "hipEventCreate");
-            hip_ok(hipEventCreateWithFlags(&rows_free[b], hipEventDisableTiming), "hipEventCreate");
-        }
-    }
-    down = ctx->host_streams[2];
-    // A batch whose rows outgrew its device columns (a skewed probe side: most matches in few batches) is joined once more
-    // ALONE, into columns made for exactly its rows (its count is exact also when its rows overflowed), and its rows go
-    // home from there; returns false when that cannot be done (set below, once the plan exists).
-    std::function<bool(size_t, const DevState &, u64)> retry_alone;
-    u64 npj_count_before[2] = {0, 0};                                // NPJ: the accumulated count in front of the batch in each slot
-    uint32_t retries = 0;
-    // batch j's rows -> the caller's columns (its dense count is on the host once `joined` has fired)
-    auto download_batch = [&](size_t j) {
-        const int slot = (int)(j & 1);
-        hip_ok(hj_event_synchronize(joined[slot]), "hipEventSynchronize(joined)");
-        if (rc != HJGPU_OK) return;
-        const DevState &hs = h_state[j];
-        u64 at = rows_at;
-        if (cursor) {
-            if (hs.overflow) { shared_overflow = true; hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord"); return; }
-            at = __atomic_fetch_add(cursor, (uint64_t)hs.dense, __ATOMIC_RELAXED);
-            if (at + hs.dense > rows->capacity) { shared_overflow = true; hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord"); return; }
-        } else if (hs.overflow) {
-            const u64 need = npj ? hs.result.count - npj_count_before[slot] : hs.result.count;
-            if (rows_at + need > rows->capacity || !retry_alone || !retry_alone(j, hs, need)) abandon = true;
-            return;
-        } else if (rows_at + hs.dense > rows->capacity) { abandon = true; return; }
-        const auto d0 = std::chrono::steady_clock::now();
-        uint32_t *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
-        for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
-            rc = download_column(ctx, hcol[i] + at, d_rows[slot][i], hs.dense * sizeof(uint32_t), down, true);
-        hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord");
-        rows_at += hs.dense;
-        ms_download += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - d0).count();
-    };
-    PhjPlan pl;
-    size_t buckets = 0; uint32_t factor = 0;
-    // the workspace (for ONE batch) before the clocks start, like the reference's mamalloc()s (npj.cpp:982-1000 vs 861-863)
-    if (rc == HJGPU_OK) {
-        const int placement = ctx->tune.placement;          // no placement search in a call that is bound by its upload
-        ctx->tune.placement = 1;
-        rc = npj ? npj_prepare(ctx, inner, np, &buckets, &factor) : phj_prepare(ctx, inner, B, pp, 1, &pl);
-        ctx->tune.placement = placement;
-    }
-    const bool line = !ctx->tune.npj_refhash, unique = npj && npj_unique(ctx, np);
-    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
-    u64 *table = reinterpret_cast<u64 *>(ctx->table.p);
-    if (rows && !cursor) retry_alone = [&](size_t j, const DevState &hs, u64 need) -> bool {
-        (void)hs;
-        const int slot = (int)(j & 1);
-        const size_t b = j * B, m = outer - b < B ? outer - b : B;
-        const size_t cap = (size_t)((need / row_bs + 1 + workers) * row_bs);
-        void *big[3] = {nullptr, nullptr, nullptr};
-        hjgpu_result *saved = nullptr;
-        bool ok = true;
-        for (int i = 0; i < 3 && ok; ++i) ok = hjgpu_malloc(ctx, &big[i], cap * sizeof(uint32_t)) == HJGPU_OK;
-        if (ok && npj) ok = hjgpu_malloc(ctx, reinterpret_cast<void **>(&saved), sizeof(hjgpu_result)) == HJGPU_OK;
-        hjgpu_output o;
-        memset(&o, 0, sizeof(o));
-        o.d_keys = (uint32_t *)big[0]; o.d_outer_vals = (uint32_t *)big[1]; o.d_inner_vals = (uint32_t *)big[2];
-        o.capacity = cap; o.block_size = row_bs;
-        DevState again;
-        memset(&again, 0, sizeof(again));
-        if (ok && npj) {
-            // the accumulated result already holds this batch (counts are exact when rows overflow): what the second run adds is dropped
-            ok = hipMemcpyAsync(saved, &st->result, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess &&
-                 hipMemsetAsync(&st->block_counter, 0, 3 * sizeof(u64), run) == hipSuccess &&
-                 hipMemsetAsync(&st->overflow, 0, sizeof(uint32_t), run) == hipSuccess &&
-                 hipMemsetAsync(&st->nmoves, 0, sizeof(uint32_t), run) == hipSuccess &&
-                 npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor, &o, run, line, unique) == HJGPU_OK &&
-                 hipMemcpyAsync(&again, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run) == hipSuccess &&
-                 hipMemcpyAsync(&st->result, saved, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess;
-        } else if (ok) {
-            ok = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, &o, run, nullptr, PHJ_PROBE_ONLY) == HJGPU_OK &&
-                 hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + j, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess &&
-                 hipMemcpyAsync(&again, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run) == hipSuccess;
-        }
-        // the slot's probe rows are needed until here: the next upload into the slot waits for THIS record
-        if (hipEventRecord(s_free[slot], run) != hipSuccess) ok = false;
-        // Whatever was enqueued above - a copy into the stack variable `again`, kernels that read `saved` and write `big` - has run
-        // before this lambda leaves (and frees them), on the failure paths too; NPJ's accumulated result is put back if the chain
-        // broke before its restore was enqueued.
-        const bool drained = hj_stream_synchronize(run) == hipSuccess;
-        if (!ok && npj && saved && drained)
-            (void)hipMemcpy(&st->result, saved, sizeof(hjgpu_result), hipMemcpyDeviceToDevice);
-        if (!drained) ok = false;
-        if (ok) ok = !again.overflow && again.dense == need;
-        if (ok) {
-            uint32_t *hcol[3] = {rows->keys, rows->outer_vals, rows->inner_vals};
-            for (int i = 0; i < 3 && ok; ++i) ok = download_column(ctx, hcol[i] + rows_at, big[i], need * sizeof(uint32_t), down, true) == HJGPU_OK;
-            if (ok) ok = hj_stream_synchronize(down) == hipSuccess;
-            if (ok) { rows_at += need; ++retries; }
-        }
-        (void)hipGetLastError();
-        hip_ok(hipEventRecord(rows_free[slot], down), "hipEventRecord");
-        for (void *p : big) if (p) (void)hipFree(p);
-        if (saved) (void)hipFree(saved);
-        return ok;
-    };
-    float ms_upload = 0;
-    if (rc == HJGPU_OK) {
-        const auto t0 = std::chrono::steady_clock::now();
-        int next = 0;
-        rc = upload_column(ctx, d_r[0], ik, inner * sizeof(uint32_t), copy, &next);
-        if (rc == HJGPU_OK) rc = upload_column(ctx, d_r[1], iv, inner * sizeof(uint32_t), copy, &next);
-        hip_ok(hipEventRecord(r_ready, copy), "hipEventRecord");
-        hip_ok(hipStreamWaitEvent(run, r_ready, 0), "hipStreamWaitEvent");
-        if (rc == HJGPU_OK && npj) {
-            // K1 set() npj.cpp:865-868 ; K2 build() 871-877; the probes of all batches add to ONE result (atomics on the state)
-            rc = refuse_capture(ctx, run);
-            hip_ok(hipEventRecord(b0, run), "hipEventRecord");
-            hip_ok(hipMemsetAsync(st, 0, sizeof(DevState), run), "hipMemsetAsync(state)");
-            hip_ok(hipMemsetAsync(table, 0, buckets * sizeof(u64), run), "hipMemsetAsync(table)");
-            if (rc == HJGPU_OK) rc = hj_launch_npj_build((const uint32_t *)d_r[0], (const uint32_t *)d_r[1], inner, table, buckets, factor,
-                                                        &st->zero_key, ctx->cus, run, line);
-            hip_ok(hipEventRecord(b1, run), "hipEventRecord");
-        } else if (rc == HJGPU_OK) {
-            hip_ok(hipEventRecord(b0, run), "hipEventRecord");
-            rc = phj_enqueue(ctx, pl, (const uint32_t *)d_r[0], (const uint32_t *)d_r[1], inner, nullptr, nullptr, 0, nullptr, run, nullptr, PHJ_BUILD_ONLY);
-            hip_ok(hipEventRecord(b1, run), "hipEventRecord");
-        }
-        for (size_t i = 0; i < nb && rc == HJGPU_OK; ++i) {
-            const int slot = (int)(i & 1);
-            const size_t b = i * B, m = outer - b < B ? outer - b : B;
-            if (i >= 2) hip_ok(hipStreamWaitEvent(copy, s_free[slot], 0), "hipStreamWaitEvent");      // batch i - 2 has been joined
-            if (rc == HJGPU_OK) rc = upload_column(ctx, d_s[slot][0], ok + b, m * sizeof(uint32_t), copy, &next);
-            if (rc == HJGPU_OK) rc = upload_column(ctx, d_s[slot][1], ov + b, m * sizeof(uint32_t), copy, &next);
-            hip_ok(hipEventRecord(s_ready[slot], copy), "hipEventRecord");
-            hip_ok(hipStreamWaitEvent(run, s_ready[slot], 0), "hipStreamWaitEvent");
-            if (rows && i >= 2) hip_ok(hipStreamWaitEvent(run, rows_free[slot], 0), "hipStreamWaitEvent");   // batch i - 2's rows have left
-            hip_ok(hipEventRecord(bev[2 * i], run), "hipEventRecord");
-            if (rc == HJGPU_OK && npj) {
-                // the phase events describe the LAST batch's probe (the build has its own pair)
-                for (int e = 0; e < EV_COUNT; ++e) ctx->ev_valid[e] = false;
-                record(ctx, EV_BEGIN, run);
-                record(ctx, EV_R_HIST, run);
-                if (rows) {
-                    // the output protocol's counters start over with every batch; the result and the zero-key flag add up
-                    hip_ok(hipMemsetAsync(&st->block_counter, 0, 3 * sizeof(u64), run), "hipMemsetAsync(counters)");
-                    hip_ok(hipMemsetAsync(&st->overflow, 0, sizeof(uint32_t), run), "hipMemsetAsync(overflow)");
-                    hip_ok(hipMemsetAsync(&st->nmoves, 0, sizeof(uint32_t), run), "hipMemsetAsync(nmoves)");
-                }
-                rc = npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor,
-                                       rows ? &dev_out[slot] : nullptr, run, line, unique);
-                ctx->stats.fanout1 = ctx->stats.fanout2 = 0; ctx->stats.buckets = buckets; ctx->last_algo = 0;
-                if (rows) {
-                    hip_ok(hipMemcpyAsync(&h_state[i], ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");
-                    hip_ok(hipEventRecord(joined[slot], run), "hipEventRecord");
-                }
-            } else if (rc == HJGPU_OK) {
-                rc = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m,
-                                 rows ? &dev_out[slot] : nullptr, run, nullptr, PHJ_PROBE_ONLY);
-                hip_ok(hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + i, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run),
-                       "hipMemcpyAsync(result)");
-                if (rows) {
-                    hip_ok(hipMemcpyAsync(&h_state[i], ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");
-                    hip_ok(hipEventRecord(joined[slot], run), "hipEventRecord");
-                }
-            }
-            hip_ok(hipEventRecord(bev[2 * i + 1], run), "hipEventRecord");
-            hip_ok(hipEventRecord(s_free[slot], run), "hipEventRecord");
-            // the previous batch's rows go home while this one is joined (its count is on the host by now, or soon)
-            if (rows && i >= 1 && rc == HJGPU_OK && !abandon) {
-                download_batch(i - 1);
-                if (npj) npj_count_before[(int)(i & 1)] = h_state[i - 1].result.count;       // what batch i starts from
-            }
-            if (abandon) break;
-        }
-        if (rows && rc == HJGPU_OK && !abandon) download_batch(nb - 1);
-        if (rows && rc == HJGPU_OK && !abandon) hip_ok(hj_stream_synchronize(down), "hipStreamSynchronize(down)");
-        if (rc == HJGPU_OK) {
-            hip_ok(hj_stream_synchronize(copy), "hipStreamSynchronize(copy)");
-            ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (npj && !abandon) {
-                // one accumulated result; key 0 in R -> HJGPU_EZEROKEY (the output counters are the last batch's: not checked here)
-                DevState hs;
-                hip_ok(hipMemcpyAsync(&hs, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");
-                hip_ok(hj_stream_synchronize(run), "hipStreamSynchronize(run)");
-                if (rc == HJGPU_OK) {
-                    if (result) *result = hs.result;
-                    if (hs.zero_key) rc = fail(ctx, HJGPU_EZEROKEY, "NPJ: a build key is 0, the empty-bucket sentinel");
-                }
-            } else if (!abandon) {
-                hip_ok(hipMemcpyAsync(parts.data(), d_res, nb * sizeof(hjgpu_result), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(results)");
-                hip_ok(hj_stream_synchronize(run), "hipStreamSynchronize(run)");
-            }
-        }
-    }
-    if (!abandon && (rc == HJGPU_OK || (npj && rc == HJGPU_EZEROKEY))) {
-        if (!npj) {
-            hjgpu_result sum;
-            memset(&sum, 0, sizeof(sum));
-            for (const hjgpu_result &p : parts) { sum.count += p.count; sum.sum_keys += p.sum_keys; sum.sum_outer_vals += p.sum_outer_vals; sum.sum_inner_vals += p.sum_inner_vals; }
-            if (result) *result = sum;
-        }
-        if (stats) {
-            const int rs = hjgpu_get_stats(ctx, stats);          // the phase times of the LAST batch's join ...
-            if (rc == HJGPU_OK) rc = rs;
-            // ... scaled to the sum over all batches (the batches have one shape; the last may be shorter), plus the
-            // build side's work: ms_total is the device time of the whole join, as after a call without batches
-            float build_ms = 0, sum = 0, last = 0;
-            (void)hipEventElapsedTime(&build_ms, b0, b1);
-            for (size_t i = 0; i < nb; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, bev[2 * i], bev[2 * i + 1]) == hipSuccess) { sum += ms; last = ms; } }
-            const float k = last > 0 ? sum / last : 1.0f;
-            stats->ms_histogram *= k; stats->ms_plan *= k; stats->ms_scatter1 *= k; stats->ms_scatter2 *= k;
-            stats->ms_join *= k; stats->ms_close_gaps *= k;
-            if (npj) stats->ms_build = build_ms;
-            stats->ms_total = build_ms + sum;
-            stats->ms_upload = ms_upload; stats->ms_download = ms_download;
-            stats->batches = (uint32_t)nb;
-        }
-        *done = true;
-        if (shared_overflow && rc == HJGPU_OK)
-            rc = fail(ctx, HJGPU_EOVERFLOW, "hjgpu_join_host_rows_shared: rows of this call did not fit (a batch's device columns or the shared capacity); result->count is exact");
-    }
-    (void)hipDeviceSynchronize();
-    ctx->prepared = false;                             // the build columns are about to be freed with everything else
-    for (int s2 = 0; s2 < 2; ++s2) for (int i = 0; i < 3; ++i) if (d_rows[s2][i]) (void)hipFree(d_rows[s2][i]);
-    if (h_state) (void)hipHostFree(h_state);
-    for (int b = 0; b < 2; ++b) { if (joined[b]) (void)hipEventDestroy(joined[b]); if (rows_free[b]) (void)hipEventDestroy(rows_free[b]); }
-
-    for (int i = 0; i < 2; ++i) if (d_r[i]) (void)hipFree(d_r[i]);
-    for (int s = 0; s < 2; ++s) for (int i = 0; i < 2; ++i) if (d_s[s][i]) (void)hipFree(d_s[s][i]);
-    if (d_res) (void)hipFree(d_res);
-    for (int b = 0; b < 2; ++b) {
-        if (s_ready[b]) (void)hipEventDestroy(s_ready[b]);
-        if (s_free[b]) (void)hipEventDestroy(s_free[b]);
-    }
-    if (r_ready) (void)hipEventDestroy(r_ready);
-    if (b0) (void)hipEventDestroy(b0);
-    if (b1) (void)hipEventDestroy(b1);
-    for (hipEvent_t e : bev) if (e) (void)hipEventDestroy(e);
-    return rc;
-}
-
-static int join_host_impl(hjgpu_ctx *ctx, int algorithm,
-                          const uint32_t *ik, const uint32_t *iv, size_t inner,
-                          const uint32_t *ok, const uint32_t *ov, size_t outer,
-                          const hjgpu_phj_params *pp, const hjgpu_npj_params *np,
-                          const hjgpu_host_rows *rows, hjgpu_result *result, hjgpu_stats *stats, uint64_t *cursor)
-{
-    if (!ctx || algorithm < 0 || algorithm > 2) return HJGPU_EINVAL;
-    if ((inner && (!ik || !iv)) || (outer && (!ok || !ov))) return fail(ctx, HJGPU_EINVAL, "null column");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    {
-        // the probe side in batches behind the DMA (join_host_batched), all three algorithms, with or without rows; not taken
-        // (done = false): probe sides below two batches, host_batch = 0, and - after part of the work - a materialising call
-        // whose result outgrows rows->capacity: the call then starts over on the whole-column path below, which knows how
-        // to report the needed capacity.  (A batch whose rows outgrow their share of the capacity x 1.25 - a skewed probe
-        // side - is joined once more alone, into device columns made for exactly its rows: nothing starts over.)  CPRA in batches: every batch is ONE chunk (the reference
-        // partitions every chunk of S on its own, cpra2.cpp:1757-1827: a batch is such a chunk); stats->batches says so.
-        bool done = false;
-        hjgpu_result batched_result;
-        const int brc = join_host_batched(ctx, algorithm, ik, iv, inner, ok, ov, outer, pp, np, rows, result ? result : &batched_result, stats, &done, cursor);
-        if (brc != HJGPU_OK || done) return brc;
-    }
-    // materialised result: device columns of the caller's capacity plus one open block per worker
-    // (the reference sizes its output the same way: 1.05 J + 2T blocks, npj.cpp:997-1000)
-    hjgpu_output dev_out;
-    memset(&dev_out, 0, sizeof(dev_out));
-    void *d_rows[3] = {nullptr, nullptr, nullptr};
-    const hjgpu_output *out = nullptr;
-    hjgpu_result local_result;
-    if (rows && !result) result = &local_result;
-    void *d[4] = {nullptr, nullptr, nullptr, nullptr};
-    const void *h[4] = {ik, iv, ok, ov};
-    const size_t n[4] = {inner, inner, outer, outer};
-    hipEvent_t r_ready = nullptr, s_ready = nullptr;
-    hipStream_t copy = nullptr, run = nullptr;
-    int rc = HJGPU_OK;
-    auto hip_ok = [&](hipError_t e, const char *what) { if (rc == HJGPU_OK && e != hipSuccess) rc = fail(ctx, HJGPU_EHIP, what, e); };
-    for (int i = 0; i < 4 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d[i], n[i] * sizeof(uint32_t));
-    if (rows && inner && outer) {
-        const size_t workers = algorithm == 0 ? (size_t)hj_npj_probe_grid(ctx->cus, outer) * 4
-                                              : (size_t)std::max(hj_join_workers(ctx->tune, ctx->cus, false, true), hj_join_workers(ctx->tune, ctx->cus, true, true));
-        dev_out.block_size = rows->capacity >= (64u << 20) ? 65536 : 1024;
-        dev_out.capacity = (rows->capacity / dev_out.block_size + 1 + workers) * dev_out.block_size;
-        for (int i = 0; i < 3 && rc == HJGPU_OK; ++i) rc = hjgpu_malloc(ctx, &d_rows[i], dev_out.capacity * sizeof(uint32_t));
-        dev_out.d_keys = (uint32_t *)d_rows[0]; dev_out.d_outer_vals = (uint32_t *)d_rows[1];
-        dev_out.d_inner_vals = (uint32_t *)d_rows[2];
-        out = &dev_out;
-    }
-    // the upload stream in the high-priority queue pool: its copies never share a hardware queue with the join's kernels
-    int least = 0, greatest = 0;
-    hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    // The context's OWN streams, made once and kept (as in the batched path): the page-locked staging buffers' events
-    // (host_stage_ev) outlive a call, and an event that was last recorded on a stream which has since been destroyed made
-    // the runtime's next hipEventSynchronize on it fail at random ("operation not permitted when stream is capturing" /
-    // "... on an event last recorded in a capturing stream": it looks at the dead stream) - round 4, seen once the
-    // multi-GPU host call ran this path on the ranks' contexts again and again.
-    if (!ctx->host_streams[0]) hip_ok(hipStreamCreateWithPriority(&ctx->host_streams[0], hipStreamNonBlocking, greatest), "hipStreamCreate(copy)");
-    if (!ctx->host_streams[1]) hip_ok(hipStreamCreateWithFlags(&ctx->host_streams[1], hipStreamNonBlocking), "hipStreamCreate(run)");
-    copy = ctx->host_streams[0]; run = ctx->host_streams[1];
-    hip_ok(hipEventCreateWithFlags(&r_ready, hipEventDisableTiming), "hipEventCreate");
-    hip_ok(hipEventCreateWithFlags(&s_ready, hipEventDisableTiming), "hipEventCreate");
-    PhjPlan pl;
-    size_t buckets = 0; uint32_t factor = 0;
-    if (rc == HJGPU_OK) {
-        // allocate the workspace before the clocks start, like the reference's mamalloc()s before
-        // its timed region (npj.cpp:982-1000 vs 861-863); with the placement search: what the host programs print is the
-        // device time of the join, and the twin's placement is 0.4 ms of it
-        if (algorithm == 0) rc = npj_prepare(ctx, inner, np, &buckets, &factor);
-        else rc = phj_prepare(ctx, inner, outer, pp, algorithm == 2 ? ((pp && pp->chunks) ? pp->chunks : 8) : 1, &pl);
-    }
-    float ms_upload = 0;
-    if (rc == HJGPU_OK) {
-        const auto t0 = std::chrono::steady_clock::now();
-        int next = 0;
-        // probe side first, build side behind it: PHJ / CPRA partition S while R is still arriving
-        const int order[4] = {2, 3, 0, 1};
-        for (int k = 0; k < 4 && rc == HJGPU_OK; ++k) {
-            const int i = order[k];
-            rc = upload_column(ctx, d[i], h[i], n[i] * sizeof(uint32_t), copy, &next);
-            if (rc == HJGPU_OK && i == 3) hip_ok(hipEventRecord(s_ready, copy), "hipEventRecord");
-        }
-        hip_ok(hipEventRecord(r_ready, copy), "hipEventRecord");
-        const uint32_t *rk = (const uint32_t *)d[0], *rv = (const uint32_t *)d[1];
-        const uint32_t *sk = (const uint32_t *)d[2], *sv = (const uint32_t *)d[3];
-        if (rc == HJGPU_OK) {
-            if (algorithm == 0) {
-                // NPJ builds first: it needs R, which arrives last
-                hip_ok(hipStreamWaitEvent(run, r_ready, 0), "hipStreamWaitEvent");
-                if (rc == HJGPU_OK) rc = npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, run, npj_unique(ctx, np));
-            } else {
-                hip_ok(hipStreamWaitEvent(run, s_ready, 0), "hipStreamWaitEvent");
-                if (rc == HJGPU_OK) rc = phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, out, run, r_ready);
-            }
-        }
-        if (rc == HJGPU_OK) {
-            hip_ok(hj_stream_synchronize(copy), "hipStreamSynchronize(copy)");
-            ms_upload = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            rc = finish_blocking(ctx, result, out, run);
-        }
-    }
-    // the dense prefix [0, J) of the three result columns -> the caller's host columns
-    float ms_download = 0;
-    if (rc == HJGPU_OK && rows) {
-        // shared columns (hjgpu_join_host_rows_shared): this call's rows go where the cursor puts them
-        const u64 at = cursor ? __atomic_fetch_add(cursor, (uint64_t)result->count, __ATOMIC_RELAXED) : 0;
-        if (at + result->count > rows->capacity) {
-            rc = fail(ctx, HJGPU_EOVERFLOW, "hjgpu_join_host_rows: the result has more rows than rows->capacity (see result->count)");
-        } else if (result->count) {
-            const auto t0 = std::chrono::steady_clock::now();
-            uint32_t *hcol[3] = {rows->keys + at, rows->outer_vals + at, rows->inner_vals + at};
-            for (int i = 0; i < 3 && rc == HJGPU_OK; ++i)
-                rc = download_column(ctx, hcol[i], d_rows[i], result->count * sizeof(uint32_t), copy);
-            if (rc == HJGPU_OK) hip_ok(hj_stream_synchronize(copy), "hipStreamSynchronize(copy)");
-            ms_download = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        }
-    }
-    if (stats && (rc == HJGPU_OK || rc == HJGPU_EOVERFLOW)) {
-        const int rs = hjgpu_get_stats(ctx, stats);
-        if (rc == HJGPU_OK) rc = rs;
-        stats->ms_upload = ms_upload; stats->ms_download = ms_download;
-    }
-    (void)hipDeviceSynchronize();
-    for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
-    for (int i = 0; i < 3; ++i) if (d_rows[i]) (void)hipFree(d_rows[i]);
-    if (r_ready) (void)hipEventDestroy(r_ready);
-    if (s_ready) (void)hipEventDestroy(s_ready);
-    return rc;
-}
-
-// ---- generator ------------------------------------------------------------------
-int hjgpu_generate_range(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
-                         size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
-                         uint32_t inner_factor, uint32_t outer_factor,
-                         uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
-{
-    return hjgpu_generate_zipf(ctx, seed, inner_total, outer_total, inner_begin, inner_count, outer_begin,
-                               outer_count, inner_factor, outer_factor, 0.0, ik, iv, ok, ov, stream_);
-}
-
-int hjgpu_generate_zipf(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
-                        size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
-                        uint32_t inner_factor, uint32_t outer_factor, double zipf,
-                        uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
-{
-    if (!ctx) return HJGPU_EINVAL;
-    if (!(zipf >= 0.0) || zipf > 8.0) return fail(ctx, HJGPU_EINVAL, "zipf exponent must be in [0, 8]");
-    if ((ik && !iv) || (ok && !ov)) return fail(ctx, HJGPU_EINVAL, "key column without payload column");
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = hj_launch_generate(seed, inner_total, inner_begin, inner_count, outer_total, outer_begin,
-                                outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream, zipf);
-    if (rc != HJGPU_OK) return fail(ctx, rc, "generate: bad sizes or launch failure");
-    HIPCHK(ctx, hipStreamSynchronize(stream));
-    return HJGPU_OK;
-}
-
-int hjgpu_generate_select(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, size_t outer_total,
-                          size_t inner_begin, size_t inner_count, size_t outer_begin, size_t outer_count,
-                          uint32_t inner_factor, uint32_t outer_factor, double zipf, double selectivity,
-                          uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, hjgpu_result *expected, void *stream_)
-{
-    if (!ctx) return HJGPU_EINVAL;
-    if (!(zipf >= 0.0) || zipf > 8.0) return fail(ctx, HJGPU_EINVAL, "zipf exponent must be in [0, 8]");
-    if (!(selectivity >= 0.0) || selectivity > 1.0) return fail(ctx, HJGPU_EINVAL, "selectivity must be in [0, 1]");
-    if ((ik && !iv) || (ok && !ov)) return fail(ctx, HJGPU_EINVAL, "key column without payload column");
-    if (expected && outer_total < inner_total)
-        return fail(ctx, HJGPU_EINVAL, "analytic aggregates need unique build keys (outer_total >= inner_total)");
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    u64 *d_expect = nullptr;
-    if (expected) {
-        memset(expected, 0, sizeof(*expected));
-        CHK(ensure(ctx, ctx->moves, 64));
-        d_expect = (u64 *)ctx->moves.p;
-        HIPCHK(ctx, hipMemsetAsync(d_expect, 0, 4 * sizeof(u64), stream));
-    }
-    int rc = hj_launch_generate(seed, inner_total, inner_begin, inner_count, outer_total, outer_begin,
-                                outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream, zipf, selectivity,
-                                ok ? d_expect : nullptr);
-    if (rc != HJGPU_OK) return fail(ctx, rc, "generate: bad sizes or launch failure");
-    if (expected) HIPCHK(ctx, hipMemcpyAsync(expected, d_expect, sizeof(*expected), hipMemcpyDeviceToHost, stream));
-    HIPCHK(ctx, hipStreamSynchronize(stream));
-    return HJGPU_OK;
-}
-
-int hjgpu_generate(hjgpu_ctx *ctx, uint64_t seed, size_t inner, size_t outer_total,
-                   size_t outer_begin, size_t outer_count, uint32_t inner_factor, uint32_t outer_factor,
-                   uint32_t *ik, uint32_t *iv, uint32_t *ok, uint32_t *ov, void *stream_)
-{
-    return hjgpu_generate_range(ctx, seed, inner, outer_total, 0, inner, outer_begin, outer_count,
-                                inner_factor, outer_factor, ik, iv, ok, ov, stream_);
-}
-
-int hjgpu_column_sums(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t fa, uint32_t fb,
-                      uint64_t sums[3], void *stream_)
-{
-    if (!ctx || !sums || (n && !d_keys)) return HJGPU_EINVAL;
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(ensure(ctx, ctx->moves, 64));
-    u64 *d = (u64 *)ctx->moves.p;
-    // hjgpu_get_stats().ms_total afterwards = duration of this one streaming read
-    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
-    ctx->last_algo = 2;
-    record(ctx, EV_BEGIN, stream);
-    CHK(hj_launch_column_sums(d_keys, n, fa, fb, d, stream));
-    record(ctx, EV_GAPS, stream);
-    HIPCHK(ctx, hipMemcpyAsync(sums, d, 3 * sizeof(u64), hipMemcpyDeviceToHost, stream));
-    HIPCHK(ctx, hipStreamSynchronize(stream));
-    return HJGPU_OK;
-}
-
-int hjgpu_stream_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, float *ms, void *stream_)
-{
-    if (!ctx || !d_ptr || !ms) return HJGPU_EINVAL;
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(ensure(ctx, ctx->moves, 64));
-    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
-    record(ctx, EV_BEGIN, stream);
-    CHK(hj_launch_stream_read(d_ptr, bytes, ctx->moves.p, ctx->cus, stream));
-    record(ctx, EV_GAPS, stream);
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
-    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[EV_BEGIN], ctx->ev[EV_GAPS]));
-    ctx->last_algo = 2;
-    return HJGPU_OK;
-}
-
-int hjgpu_random_line_read_ms(hjgpu_ctx *ctx, const void *d_ptr, size_t bytes, size_t reads, float *ms, void *stream_)
-{
-    if (!ctx || !d_ptr || !ms) return HJGPU_EINVAL;
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(ensure(ctx, ctx->moves, 64));
-    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
-    record(ctx, EV_BEGIN, stream);
-    CHK(hj_launch_random_line_read(d_ptr, bytes, reads, ctx->moves.p, ctx->cus, stream));
-    record(ctx, EV_GAPS, stream);
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
-    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[EV_BEGIN], ctx->ev[EV_GAPS]));
-    ctx->last_algo = 2;
-    return HJGPU_OK;
-}
-
-int hjgpu_random_cas_ms(hjgpu_ctx *ctx, void *d_ptr, size_t bytes, size_t ops, int in_flight, int load_first, float *ms, void *stream_)
-{
-    if (!ctx || !d_ptr || !ms) return HJGPU_EINVAL;
-    hipStream_t stream = (hipStream_t)stream_;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(ensure(ctx, ctx->moves, 64));
-    HIPCHK(ctx, hipMemsetAsync(d_ptr, 0, bytes, stream));              // every bucket empty: outside the timed span
-    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
-    record(ctx, EV_BEGIN, stream);
-    CHK(hj_launch_random_cas(d_ptr, bytes, ops, in_flight, load_first != 0, ctx->moves.p, ctx->cus, stream));
-    record(ctx, EV_GAPS, stream);
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
-    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev[EV_BEGIN], ctx->ev[EV_GAPS]));
-    ctx->last_algo = 2;
-    return HJGPU_OK;
 }
 
 }  // extern "C"

@@ -31,7 +31,7 @@ def resources(source):
 
 
 @pytest.mark.parametrize("source", ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip", "gen_kernels.hip",
-                                    "hjgpu_api.hip", "hjgpu_multi.hip"])
+                                    "audit_kernels.hip", "hjgpu_api.hip", "hjgpu_multi.hip"])
 def test_no_kernel_instance_uses_scratch(source):
     rows = resources(source)
     assert rows, "no kernels found in %s" % source

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round 4, review item 1: is a wave's scratch unsafe next to other queues' kernels, or does the slice pipeline race?
+# (Round 5 removed the -DHJ_SCRATCH_EXPERIMENT variants from the kernel sources: build them from round 4's tree, which
+# tools/build_variant.py does when it is given a revision - e.g. `python tools/build_variant.py scratch_exp1 49bf42e -DHJ_SCRATCH_EXPERIMENT=1`.)
 # Run on the GPU box after building the variants HERE (CPU cross-compile):
-#   for e in 1 2 3 4; do python tools/build_variant.py scratch_exp$e -DHJ_SCRATCH_EXPERIMENT=$e; done
+#   for e in 1 2 3 4; do python tools/build_variant.py scratch_exp$e 49bf42e -DHJ_SCRATCH_EXPERIMENT=$e; done
 #   hipcc --offload-arch=gfx950 -O3 tools/ubench_scratch_race.hip -o hash_join_codes_knl_amd/lib/ubench_scratch_race
 # Everything (failing logs included) goes to gpurun_out/r04_scratch_repro.txt; nothing is filtered except RCCL's banner.
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
