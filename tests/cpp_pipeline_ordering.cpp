@@ -16,7 +16,7 @@
 //     that does not own its partition, a sender's count that differs from what arrived: an ERROR), joins really joined -
 //     so the result of every scenario is compared with a map-based join of the inputs;
 //   * fault injection: --drop-wait k ignores the k-th hipStreamWaitEvent of the run (the checker must then report).
-// usage: cpp_pipeline_ordering <algo cpra|cpra-host|phj|npj> <world> <slices> [--rows] [--no-fused] [--no-in-place] [--two-level]
+// usage: cpp_pipeline_ordering <algo cpra|cpra-host|phj-host|npj-host|phj|npj> <world> <slices> [--rows] [--no-fused] [--no-in-place] [--two-level]
 //                              [--drop-wait k] [--list-waits] [--inner n] [--outer n] [--seed s] [--steps n]
 // prints one line: "ok|FAIL waits=<hipStreamWaitEvent calls> ops=<n> violations=<n> ..."; exit status 0 = result right and no violation.
 #include <algorithm>
@@ -588,7 +588,9 @@ int main(int argc, char **argv)
         std::sort(c.begin(), c.end());
         return c;
     };
-    if (algo == "cpra-host") {
+    if (algo == "cpra-host" || algo == "phj-host" || algo == "npj-host") {
+        const int algorithm = algo == "cpra-host" ? 2 : algo == "phj-host" ? 1 : 0;
+        if (rows && algorithm != 2) { fprintf(stderr, "rows from host columns with a replicated build side run the one-GPU host pipeline per rank: not in this test\n"); return 2; }
         // hjgpu_join_host_multi / hjgpu_join_host_rows_multi, CPRA: host columns cut into the ranks' shares, the build side uploaded
         // first, the probe shard slice by slice (an upload event per slice), the slice pipeline behind it
         bool right = true;
@@ -597,8 +599,8 @@ int main(int argc, char **argv)
             memset(&got, 0, sizeof(got));
             std::vector<uint32_t> hk(outer + 1024), ho(outer + 1024), hi(outer + 1024);
             hjgpu_host_rows hr = {hk.data(), ho.data(), hi.data(), hk.size()};
-            const int rc = rows ? hjgpu_join_host_rows_multi(comm, 2, ik.data(), iv.data(), inner, ok.data(), ov.data(), outer, nullptr, nullptr, &hr, &got, nullptr)
-                                : hjgpu_join_host_multi(comm, 2, ik.data(), iv.data(), inner, ok.data(), ov.data(), outer, nullptr, nullptr, &got, nullptr);
+            const int rc = rows ? hjgpu_join_host_rows_multi(comm, algorithm, ik.data(), iv.data(), inner, ok.data(), ov.data(), outer, nullptr, nullptr, &hr, &got, nullptr)
+                                : hjgpu_join_host_multi(comm, algorithm, ik.data(), iv.data(), inner, ok.data(), ov.data(), outer, nullptr, nullptr, &got, nullptr);
             if (rc != HJGPU_OK) { fprintf(stderr, "step %d: status %d: %s\n", step, rc, hjgpu_comm_last_error(comm)); right = false; break; }
             if (got.count != want[0] || got.sum_keys != want[1] || got.sum_outer_vals != want[2] || got.sum_inner_vals != want[3]) right = false;
             if (rows) {

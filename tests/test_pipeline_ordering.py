@@ -69,7 +69,16 @@ def test_cpra_from_host_columns_is_ordered(recorder, world, options):
     assert rc == 0 and "violations=0 errors=0 result=right" in out, out
 
 
-@pytest.mark.parametrize("scenario", [("cpra-host", 2, 0), ("cpra", 1, 4), ("cpra", 2, 3), ("cpra", 3, 2, "--no-in-place"), ("cpra", 2, 2, "--rows"), ("phj", 3, 1), ("npj", 2, 1)])
+@pytest.mark.parametrize("algo", ["phj-host", "npj-host"])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_replicated_joins_from_host_columns_are_ordered(recorder, algo, world):
+    """hjgpu_join_host_multi, PHJ / NPJ: every rank's shard on its own upload stream, probe side first; the probe shard is
+    partitioned while the build columns are still arriving (the root's build columns gate only the replication)"""
+    rc, out = run(recorder, algo, world, 0)
+    assert rc == 0 and "violations=0 errors=0 result=right" in out, out
+
+
+@pytest.mark.parametrize("scenario", [("cpra-host", 2, 0), ("phj-host", 3, 0), ("cpra", 1, 4), ("cpra", 2, 3), ("cpra", 3, 2, "--no-in-place"), ("cpra", 2, 2, "--rows"), ("phj", 3, 1), ("npj", 2, 1)])
 def test_removing_any_wait_that_orders_something_is_reported(recorder, scenario):
     """Every hipStreamWaitEvent of the run that adds an edge (the waiting stream and the enqueuing host thread do not know the
     event's clock yet) is needed: without it the recorder reports an unordered access or the join comes out wrong.  The
