@@ -1519,6 +1519,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
                     const hjgpu_output *out, void *stream_, bool blocking, void *inner_ready = nullptr)
 {
     if (!ctx) return HJGPU_EINVAL;
+    settle(ctx);                                         // before anything of the context changes: an asynchronous grouped join's worker reads it
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
     PlainRows plain(ctx, blocking);
     CHK(check_columns(ctx, rk, rv, inner));
@@ -1599,7 +1600,7 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
     settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx) return HJGPU_EINVAL;
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
-    PlainRows plain(ctx, blocking);
+    PlainRows plain(ctx, blocking);                      // (settle() is this function's first statement)
     if (!ctx->prepared)
         return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe: no prepared build side (hjgpu_phj_build), or another "
                                        "entry point has used the workspace since");

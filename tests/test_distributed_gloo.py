@@ -1,7 +1,9 @@
-"""CPU tests of the multi-GPU host logic (tests/torch_orchestration.py, a test-side second implementation)
-with world_size 2 and 3 over the gloo backend: ownership, split sizes, exchange
-and reductions.  The data-path operators are replaced by the oracle here; on a
-GPU box the same code drives the C-ABI through GpuOps."""
+"""Multi-PROCESS CPU tests over the gloo backend, world_size 2 and 3: (a) bench.py's own control plane (id broadcast, max over
+ranks, uint64 sums, the gather of every rank's statistics: what `bench.py --gpus N` does under torchrun beside the C++ joins),
+and (b) the ALGORITHM of the two exchanges - ownership, split sizes, all-to-all-v, reductions - stated a third time
+(tests/torch_orchestration.py, round 1's orchestration over torch.distributed with the oracle as the data path).
+(b) is NOT the product's code: the product's C++ orchestration (csrc/hjgpu_multi.hip) is tested directly, on the CPU, by
+tests/test_pipeline_ordering.py (round 5) and on the GPU by tests/test_gpu_multi.py."""
 import os
 import socket
 import sys
