@@ -60,6 +60,7 @@ def parse(argv=None):
                     help="0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota)")
     ap.add_argument("--enqueue-only", action="store_true",
                     help="N = 1: time the enqueue-only entry points (hjgpu_*_async: all K6 stores non-temporal) instead of the blocking ones")
+    ap.add_argument("--no-solo", action="store_true", help="N = 1: do not set option solo (every store non-temporal, as in a process that runs other work beside the joins)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra N = 1 measurements (NPJ, one-GPU CPRA, materialising PHJ, configs[0] on the CPU)")
     ap.add_argument("--materialize", action="store_true", help="kept for compatibility: the materialising PHJ is on by default")
@@ -441,6 +442,11 @@ def main():
         hj = comm.ctx[0]
     else:
         hj = H.HjGpu(local_rank)
+    # N = 1: this process has ONE stream and one context, and its step is a blocking join: option "solo" (the joins' partial-line stores
+    # stay plain; the line says so in config.solo_stores).  The multi-GPU joins and every enqueue-only form never use it.
+    solo = not multi and not args.enqueue_only and not args.no_solo
+    if solo:
+        hj.set_option("solo", "1")
     for o in args.option:
         name, _, value = o.partition("=")
         hj.set_option(name, value)
@@ -498,9 +504,9 @@ def main():
         s = torch.cuda.current_stream().cuda_stream
         a = (rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer)
         # One step = one complete join through the BLOCKING entry point - the counterpart of the reference's run() / run_hj(), which
-        # return when the join is done (npj.cpp:861-918) - on this process's only stream: a solo join, whose partial-line and row
-        # stores stay plain (DESIGN section 3 "Round 5").  The enqueue-only forms, which may run beside other streams' work and
-        # therefore write everything non-temporal, are timed as secondary.phj_enqueue_only.
+        # return when the join is done (npj.cpp:861-918) - on this process's only stream, with option "solo" (see above): its
+        # partial-line and row stores stay plain (DESIGN section 3 "Round 5").  The enqueue-only forms, which may run beside other
+        # streams' work and therefore write everything non-temporal, are timed as secondary.phj_enqueue_only.
         if args.enqueue_only:
             if args.algo == "phj":
                 hj.phj_async(*a, prm, d_result.data_ptr(), s)
@@ -637,6 +643,8 @@ def main():
                    "algorithm": args.algo, "inner_tuples": inner, "outer_tuples_per_gpu": outer,
                    "outer_tuples_total": outer_total,
                    "fanout": [st["fanout1"], st["fanout2"]], "groups": int(st.get("groups", 0)),
+                   # option "solo" (blocking joins of a process that runs nothing else on the device): partial-line stores plain
+                   "solo_stores": bool(solo),
                    "parallelism": parallelism},
         "roofline": roofline,
         "roofline_kernels": kernels,
@@ -801,6 +809,8 @@ def main():
         hj1 = H.HjGpu(local_rank)
         try:
             hj1.set_option("placement", "1")
+            if solo:
+                hj1.set_option("solo", "1")
             hj1.reserve(inner, outer)
             ms, ph = time_steps(lambda: hj1.phj_async(*a, prm, d_result.data_ptr(), stream), warm=2, steps=min(args.steps, 10), ctx=hj1)
             ok_ = [int(x) & MASK64 for x in d_result.tolist()] == expect_local

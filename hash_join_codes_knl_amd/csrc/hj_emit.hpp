@@ -71,7 +71,7 @@ struct Emitter {
         // Row stores of a join that runs beside other streams' kernels and copies (enqueue-only joins, the batched host
         // pipelines, the multi-GPU *_rows calls) are NON-TEMPORAL: plain stores that sit dirty in an XCD's L2 while another
         // queue's kernel boundary writes back and invalidates it can be lost (round 5, DESIGN section 3: K6 lost stores that
-        // way in 1.3 of 10^4 pipeline steps).  A blocking join on its own stream keeps plain stores (4 % faster rows).
+        // way in 1.5 of 10^4 pipeline steps).  A blocking join of a context with option "solo" keeps plain stores (4 % faster rows).
         if (nt) {
             __builtin_nontemporal_store(key, &ok[pos]);
             __builtin_nontemporal_store(outer_val, &oov[pos]);

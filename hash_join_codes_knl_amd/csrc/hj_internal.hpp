@@ -65,6 +65,10 @@ struct HjTuning {
     int placement_ms = 500;         // "placement_ms": wall-clock budget of one placement search (0 = none): when it is spent the best block so far is
                                     // taken (round 4's driver run spent 3.07 s in a search that found no fast block among twelve)
     bool placement_log = false;     // "placement_log": the search prints every candidate's fill time and its choice to stderr (diagnostics)
+    bool solo = false;              // "solo": the caller promises that NOTHING else runs on the device beside this context's blocking joins (one
+                                    // process, one stream - the reference's programs): their partial-line stores (K6) and result rows stay plain,
+                                    // 0.34 ms per 64 M x 1 G step faster.  Default 0: every store that may sit dirty in an L2 is non-temporal (round 5:
+                                    // plain stores are lost beside other queues' kernel boundaries, 1.5 in 10^4 pipeline steps)
     bool audit = false;             // "audit" (diagnostics): every stage leaves a checksum of its output (audit_kernels.hip, hjgpu_audit_read)
     int hist_min_lds = 0;           // "hist_min_lds" (diagnostics): K4 asks for at least this many bytes of LDS per workgroup (nothing else then shares its CU)
     int reserve_cus = 0;            // "reserve_cus": CUs that K6's persistent grid leaves free (multi-GPU: room for RCCL's kernels)

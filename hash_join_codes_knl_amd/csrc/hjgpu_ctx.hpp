@@ -112,11 +112,12 @@ const uint32_t DEFAULT_F0 = 0x7FEB352Du;      // grouped plans: pass 0 (phj_grou
 int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
 void settle(hjgpu_ctx *ctx);
 
-// Result rows of a BLOCKING join (the caller waits for it: nothing of this context runs beside it) leave through plain stores;
-// every enqueue-only join and every pipeline (host batches, multi-GPU slices) writes its rows with non-temporal stores.
+// Result rows and partial-line stores of a SOLO join - a blocking call of a context with option "solo": the caller waits for it and
+// promises that nothing else runs on the device beside it - are plain; every other join (enqueue-only, host batches, multi-GPU
+// slices, and every blocking call without the option) writes them non-temporal (DESIGN section 3 "Round 5").
 struct PlainRows {
     hjgpu_ctx *ctx;
-    PlainRows(hjgpu_ctx *c, bool blocking) : ctx(c) { if (ctx) ctx->rows_plain = blocking; }
+    PlainRows(hjgpu_ctx *c, bool blocking) : ctx(c) { if (ctx) ctx->rows_plain = blocking && ctx->tune.solo; }
     ~PlainRows() { if (ctx) ctx->rows_plain = false; }
 };
 

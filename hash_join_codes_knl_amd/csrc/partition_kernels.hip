@@ -62,8 +62,9 @@ __device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
 // waits for the rest of the line), while the 16-byte whole-line stores are FASTER non-temporal than plain
 // (profiles/r05_ab_stores.txt, ms pass 1 / pass 2 at 64 M x 1 G in the same allocations: all plain 2.99 / 3.07, 16-byte nt
 // 2.93 / 2.96, all nt 3.07 / 3.13, only 8-byte nt 3.37 / 3.20).  So: whole lines always non-temporal; partial lines non-temporal
-// unless the launch is SOLO (ScatterArgs::nt_partial = 0: a blocking join, nothing of its context runs beside it - the
-// condition under which no store was ever lost: 0 wrong steps in 15 000 on one stream with every store plain).
+// unless the launch is SOLO (ScatterArgs::nt_partial = 0: a blocking join of a context whose option "solo" says that nothing else
+// runs on the device beside it - the condition under which no store was ever lost: 0 wrong steps in 15 000 on one stream with
+// every store plain).
 __device__ __forceinline__ void k6_store8(u64 *p, u64 v, bool nt)
 {
 #if HJ_K6_STORE == 1
@@ -1492,6 +1493,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("group_async")) return parse_flag(value, &t->group_async);
     if (is("placement_log")) return parse_flag(value, &t->placement_log);
     if (is("audit")) return parse_flag(value, &t->audit);
+    if (is("solo")) return parse_flag(value, &t->solo);
     if (is("hist_min_lds")) {
         char *end = nullptr;
         const long x = strtol(value, &end, 10);
@@ -1569,7 +1571,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "group_async", "host_batch", "placement", "placement_ms", "placement_log", "audit", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "group_async", "host_batch", "placement", "placement_ms", "placement_log", "audit", "solo", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

@@ -161,7 +161,10 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * "scatter_prof", "merged_plan", "piece_interleave" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
  * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
  * twin, 1..16; "placement_ms": the search's wall-clock budget, default 500, 0 = none; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples), "group_always" and "group_async" (0 / 1): the
- * grouped plans of hjgpu_phj / hjgpu_cpra (below); diagnostics: "audit" (0 / 1: every stage of a join leaves a checksum of its output,
+ * grouped plans of hjgpu_phj / hjgpu_cpra (below); "solo" (0 / 1, default 0: the caller promises that nothing else runs on the device beside this context's BLOCKING joins - one process,
+ * one stream, as the reference's programs: the joins' partial-line and row stores then stay plain, 4 % faster; without the
+ * promise every store that could sit dirty in an L2 is non-temporal, because plain stores ARE lost beside other queues' kernel
+ * boundaries: 1.5 in 10^4 steps of the multi-GPU pipeline, DESIGN section 3 "Round 5"); diagnostics: "audit" (0 / 1: every stage of a join leaves a checksum of its output,
  * hjgpu_audit_read below), "hist_min_lds" (bytes of LDS a histogram workgroup asks for at least: nothing else then shares its CU).
  * Unknown names and malformed values: HJGPU_EINVAL. */
 int  hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value);

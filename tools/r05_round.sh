@@ -49,9 +49,9 @@ validation2)
   stress --steps 8000 --slices 8 --option exchange_in_place=0
   stress --steps 8000 --slices 1
   HJGPU_DEBUG_FLAT_PRIORITIES=1 stress --steps 15000 --slices 8
-  # the solo form (blocking hjgpu_phj on one stream: partial-line stores plain, DESIGN section 3 "Round 5"): every step checked
-  echo "## tools/stress_single.py --algo phj --steps 15000" >> $out/$sweep
-  timeout -k 10 400 python3 tools/stress_single.py --algo phj --steps 15000 2>&1 | quiet | tee -a $out/$sweep | grep --line-buffered "^\.\.\."
+  # the solo form (blocking hjgpu_phj on one stream with option solo: partial-line stores plain, DESIGN section 3 "Round 5"): every step checked
+  echo "## tools/stress_single.py --algo phj --steps 15000 --solo" >> $out/$sweep
+  timeout -k 10 400 python3 tools/stress_single.py --algo phj --steps 15000 --solo 2>&1 | quiet | tee -a $out/$sweep | grep --line-buffered "^\.\.\."
   [ ${PIPESTATUS[0]} = 0 ] || { note "WRONG or failed: stress_single.py"; bad=1; }
   note "validation2 bad=$bad"; [ $bad = 0 ] || exit 1
   ;;

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--inner", type=int, default=64_000_000)
     ap.add_argument("--outer", type=int, default=1_000_000_000)
+    ap.add_argument("--solo", action="store_true", help="option solo: partial-line stores plain (a process that runs nothing else on the device)")
     a = ap.parse_args()
     import hash_join_codes_knl_amd as H
     from hash_join_codes_knl_amd import api
@@ -25,6 +26,8 @@ def main():
         lib.hjgpu_debug_scratch.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
         lib.hjgpu_debug_scratch(None, 1)
     hj = H.HjGpu(0)
+    if a.solo:
+        hj.set_option("solo", "1")           # the form bench.py's headline runs in: partial-line stores plain
     ik, iv, ok, ov = hj.column(a.inner), hj.column(a.inner), hj.column(a.outer), hj.column(a.outer)
     hj.generate(1, a.inner, a.outer, 0, a.outer, 0x2545F491, 0x9E3779B1, ik, iv, ok, ov)
     sums = hj.column_sums(ok, a.outer, 0x9E3779B1, 0x2545F491)

@@ -22,6 +22,7 @@ def main():
     a = ap.parse_args()
     import hash_join_codes_knl_amd as H
     hj = H.HjGpu(0)
+    hj.set_option("solo", "1")               # blocking joins of a process that runs nothing else: partial-line stores plain (DESIGN section 3 "Round 5")
     ik, iv, ok, ov = hj.column(a.inner), hj.column(a.inner), hj.column(a.outer), hj.column(a.outer)
     hj.generate(1, a.inner, a.outer, 0, a.outer, 0x2545F491, 0x9E3779B1, ik, iv, ok, ov)
     sums = hj.column_sums(ok, a.outer, 0x9E3779B1, 0x2545F491)
