@@ -501,3 +501,32 @@ def test_full_size_cpra_in_64_chunks(hj):
         assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=chunks)) == want
     for c in (ik, iv, ok, ov):
         c.free()
+
+
+def test_option_solo_changes_stores_not_results(oracle):
+    """Option solo (the caller's promise that nothing else runs on the device beside the context's blocking joins): K6's
+    partial-line stores and the result rows stay plain instead of non-temporal - same aggregates, same rows, all three
+    algorithms; the enqueue-only forms ignore it (they always write non-temporal)."""
+    ik, iv, ok, ov = oracle.generate(600_000, 150_000, seed=77)
+    want = numpy_join(ik, iv, ok, ov)
+    with H.HjGpu() as ctx:
+        rk, rv, sk, sv = (ctx.column(c) for c in (ik, iv, ok, ov))
+        d = ctx.column(4, np.uint64)
+        for solo in ("0", "1"):
+            ctx.set_option("solo", solo)
+            for algo, prm in (("phj", None), ("cpra", H.PhjParams(chunks=5)), ("npj", None)):
+                assert getattr(ctx, algo)(rk, rv, len(ik), sk, sv, len(ok), prm) == want
+                getattr(ctx, algo + "_async")(rk, rv, len(ik), sk, sv, len(ok), prm, d)
+                ctx.synchronize()
+                assert tuple(int(x) for x in d.download()) == want
+            block = 1024
+            cap = (want[0] // block + ctx.device_info()["compute_units"] * 16 + 8) * block
+            jk, jo, ji = ctx.column(cap), ctx.column(cap), ctx.column(cap)
+            assert ctx.phj(rk, rv, len(ik), sk, sv, len(ok), out=(jk, jo, ji, cap, block)) == want
+            rows = sort_rows(jk.download()[:want[0]], jo.download()[:want[0]], ji.download()[:want[0]])
+            for a, b in zip(rows, materialised_rows(ik, iv, ok, ov)):
+                assert np.array_equal(a, b)
+            for c in (jk, jo, ji):
+                c.free()
+        for c in (rk, rv, sk, sv, d):
+            c.free()
