@@ -15,6 +15,9 @@
 #include "hj_device.hpp"
 
 #define HJ_NO_CURSOR (~0ull)
+#ifndef HJ_ROW_STORE
+#define HJ_ROW_STORE 1
+#endif
 
 // The cursor is addressed as LDS (address space 3), not through a generic pointer: with a generic `volatile u64 *`
 // the compiler emitted flat_load / flat_store with `s_waitcnt vmcnt(0)` around every emit - FLAT operations count on
@@ -29,13 +32,12 @@ struct Emitter {
     u64 *block_counter;
     uint32_t *overflow;
     volatile hj_lds_u64 *cursor;   // this wave's cursor, in LDS (ds_read_b64 / ds_write_b64)
-    bool nt;                       // non-temporal row stores (uniform)
 
     __device__ __forceinline__ void init(uint32_t *k, uint32_t *ov, uint32_t *iv, u64 bs, u64 bl,
-                                         u64 *bc, uint32_t *ovf, u64 *lds_cursor, bool nt_rows = false)
+                                         u64 *bc, uint32_t *ovf, u64 *lds_cursor)
     {
         ok = k; oov = ov; oiv = iv; block_size = bs; block_limit = bl;
-        block_counter = bc; overflow = ovf; cursor = (volatile hj_lds_u64 *)lds_cursor; nt = nt_rows;
+        block_counter = bc; overflow = ovf; cursor = (volatile hj_lds_u64 *)lds_cursor;
     }
 
     // Called by the lanes that have a match (any subset of the wave).
@@ -68,18 +70,19 @@ struct Emitter {
             next = base + (n - room);
         }
         if (rank == 0) *cursor = next;
-        // Row stores of a join that runs beside other streams' kernels and copies (enqueue-only joins, the batched host
-        // pipelines, the multi-GPU *_rows calls) are NON-TEMPORAL: plain stores that sit dirty in an XCD's L2 while another
-        // queue's kernel boundary writes back and invalidates it can be lost (round 5, DESIGN section 3: K6 lost stores that
-        // way in 1.5 of 10^4 pipeline steps).  A blocking join of a context with option "solo" keeps plain stores (4 % faster rows).
-        if (nt) {
-            __builtin_nontemporal_store(key, &ok[pos]);
-            __builtin_nontemporal_store(outer_val, &oov[pos]);
-            __builtin_nontemporal_store(inner_val, &oiv[pos]);
-        } else {
-            ok[pos] = key;
-            oov[pos] = outer_val;
-            oiv[pos] = inner_val;
-        }
+        // Result rows leave through NON-TEMPORAL stores (HJ_ROW_STORE = 1, the product; 0 = plain, for A/B builds): plain stores
+        // that sit dirty in an XCD's L2 while another queue's kernel boundary writes back and invalidates it can be lost (round 5,
+        // K6 lost stores that way in 1.5 of 10^4 pipeline steps), and a materialising join runs beside other
+        // streams' work in every pipeline (host batches, multi-GPU slices).  A compile-time choice: a run-time flag around the
+        // three stores was merged by the compiler into ONE plain store per column (the nt hint does not survive the merge).
+#if HJ_ROW_STORE
+        __builtin_nontemporal_store(key, &ok[pos]);
+        __builtin_nontemporal_store(outer_val, &oov[pos]);
+        __builtin_nontemporal_store(inner_val, &oiv[pos]);
+#else
+        ok[pos] = key;
+        oov[pos] = outer_val;
+        oiv[pos] = inner_val;
+#endif
     }
 };

@@ -66,7 +66,7 @@ struct HjTuning {
                                     // taken (round 4's driver run spent 3.07 s in a search that found no fast block among twelve)
     bool placement_log = false;     // "placement_log": the search prints every candidate's fill time and its choice to stderr (diagnostics)
     bool solo = false;              // "solo": the caller promises that NOTHING else runs on the device beside this context's blocking joins (one
-                                    // process, one stream - the reference's programs): their partial-line stores (K6) and result rows stay plain,
+                                    // process, one stream - the reference's programs): their partial-line stores (K6) stay plain,
                                     // 0.34 ms per 64 M x 1 G step faster.  Default 0: every store that may sit dirty in an L2 is non-temporal (round 5:
                                     // plain stores are lost beside other queues' kernel boundaries, 1.5 in 10^4 pipeline steps)
     bool audit = false;             // "audit" (diagnostics): every stage leaves a checksum of its output (audit_kernels.hip, hjgpu_audit_read)
@@ -159,7 +159,8 @@ struct ScatterArgs {
     uint32_t range_begin, range_count;   // pass 1: this launch covers ranges [range_begin, +range_count) (0, 0 = all)
     const u64 *range_base;          // [ranges][F] absolute output position of each (range, partition)
     u64 *prof;                      // diagnostics (HJGPU_SCATTER_PROF=1): s_memtime ticks per phase, else NULL
-    uint32_t nt_partial;            // 1: the 8-byte (partial-line) stores are non-temporal too (every launch that is not solo, see k6_store8)
+    uint32_t nt_partial;            // 1: the 8-byte (partial-line) stores are non-temporal too (every launch that is not solo: selects the
+                                    // NTP instance of the kernel, see k6_store8)
 };
 
 struct JoinArgs {
@@ -185,7 +186,6 @@ struct JoinArgs {
     u64 *block_counter;                  // device
     u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
     uint32_t *overflow;                  // device flag
-    uint32_t nt_rows;                    // 1: the rows leave through non-temporal stores (joins that run beside other streams' work, hj_emit.hpp)
     uint32_t big_tables;                 // hj_join_config_big() instead of hj_join_config()
     // broadcast join (tiny build side, nothing partitioned): P = 1, the relations are the caller's columns, the
     // empty sentinel is *sentinel (a value no build key equals, found by hj_launch_broadcast_meta)
@@ -306,7 +306,6 @@ struct NpjProbeArgs {
     u64 *block_counter;
     u64 *final_offsets;
     uint32_t *overflow;
-    uint32_t nt_rows;                    // as JoinArgs::nt_rows
 };
 int hj_launch_npj_probe(const NpjProbeArgs &a, int cus, hipStream_t stream, int *grid_out);
 

@@ -783,7 +783,6 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             ja.block_counter = &st->block_counter;
             ja.final_offsets = (u64 *)ctx->final_offsets.p;
             ja.overflow = &st->overflow;
-            ja.nt_rows = ctx->rows_plain ? 0u : 1u;
         }
         CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
         if (audit) CHK(hj_audit_copy(reinterpret_cast<const u64 *>(&st->result), audit + 4 * 6, 4, stream));
@@ -858,7 +857,6 @@ int npj_probe_enqueue(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t *sv, si
             pa.ok = out->d_keys; pa.oov = out->d_outer_vals; pa.oiv = out->d_inner_vals;
             pa.block_size = bs; pa.block_limit = bl; pa.block_counter = &st->block_counter;
             pa.final_offsets = (u64 *)ctx->final_offsets.p; pa.overflow = &st->overflow;
-            pa.nt_rows = ctx->rows_plain ? 0u : 1u;
         }
         CHK(hj_launch_npj_probe(pa, ctx->cus, stream, nullptr));
     }
@@ -1352,7 +1350,6 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
         ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
-        ja.nt_rows = ctx->rows_plain ? 0u : 1u;
     }
     CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     record(ctx, EV_JOIN, stream);

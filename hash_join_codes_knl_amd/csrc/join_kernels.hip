@@ -99,7 +99,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
 
     Emitter em;
     em.init(a.ok, a.oov, a.oiv, a.block_size, a.block_limit, a.block_counter, a.overflow,
-            &wave_cursor[wave], a.nt_rows != 0);
+            &wave_cursor[wave]);
     // (the multi-fill half of a _UNIQUE join runs behind the single-fill half on the same stream, with the same grid: wave w of
     // workgroup b goes on in the block that wave w of workgroup b left open, and leaves its cursor in the same slot - one
     // launch's worth of worker slots for close_gaps, not two)

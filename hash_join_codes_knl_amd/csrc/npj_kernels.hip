@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs
     const int wave = threadIdx.x >> 6;
     Emitter em;
     em.init(a.ok, a.oov, a.oiv, a.block_size, a.block_limit, a.block_counter, a.overflow,
-            &wave_cursor[wave], a.nt_rows != 0);
+            &wave_cursor[wave]);
     if (hj_lane() == 0) wave_cursor[wave] = HJ_NO_CURSOR;
 
     const uint32_t a0 = (uint32_t)(((uintptr_t)a.keys >> 2) & 3);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_line_kernel(NpjProb
     const int wave = threadIdx.x >> 6;
     Emitter em;
     em.init(a.ok, a.oov, a.oiv, a.block_size, a.block_limit, a.block_counter, a.overflow,
-            &wave_cursor[wave], a.nt_rows != 0);
+            &wave_cursor[wave]);
     if (hj_lane() == 0) wave_cursor[wave] = HJ_NO_CURSOR;
 
     const uint32_t a0 = (uint32_t)(((uintptr_t)a.keys >> 2) & 3);

@@ -62,21 +62,19 @@ __device__ __forceinline__ void k6_store16(u64 *p, uint4 v)
 // waits for the rest of the line), while the 16-byte whole-line stores are FASTER non-temporal than plain
 // (profiles/r05_ab_stores.txt, ms pass 1 / pass 2 at 64 M x 1 G in the same allocations: all plain 2.99 / 3.07, 16-byte nt
 // 2.93 / 2.96, all nt 3.07 / 3.13, only 8-byte nt 3.37 / 3.20).  So: whole lines always non-temporal; partial lines non-temporal
-// unless the launch is SOLO (ScatterArgs::nt_partial = 0: a blocking join of a context whose option "solo" says that nothing else
+// unless the launch is SOLO (ScatterArgs::nt_partial = 0 selects the NTP = false instance: a blocking join of a context whose option "solo" says that nothing else
 // runs on the device beside it - the condition under which no store was ever lost: 0 wrong steps in 15 000 on one stream with
 // every store plain).
-__device__ __forceinline__ void k6_store8(u64 *p, u64 v, bool nt)
+template <bool NT>
+__device__ __forceinline__ void k6_store8(u64 *p, u64 v)
 {
 #if HJ_K6_STORE == 1
-    if (nt) __builtin_nontemporal_store(v, p); else *p = v;
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 #elif HJ_K6_STORE == 4
-    (void)nt;
     __builtin_nontemporal_store(v, p);
 #elif HJ_K6_STORE == 2
-    (void)nt;
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
-    (void)nt;
     *p = v;
 #endif
 }
@@ -855,7 +853,10 @@ int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStre
 //   a line written by two waves in the same sweep  3.3 (no cost)
 // i.e. a partial line is not kept in the XCD's L2 until somebody completes it: it becomes a
 // read-modify-write at the memory side unless the rest arrives at about the same time.
-template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY>
+// NTP: the 8-byte (partial-line) stores are non-temporal too - every launch that is not solo (k6_store8).  A template parameter:
+// as a run-time flag around each store the two branches were merged by the compiler into ONE plain store (the nt hint does not
+// survive the merge; found in the ISA after a run in which "non-temporal" partial stores cost nothing).
+template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY, bool NTP = true>
 __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
 {
     static_assert(!CARRY || (RANGED && OUT_PACKED), "carry needs private cursors and packed output");
@@ -1281,7 +1282,6 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
             constexpr uint32_t NG = BLOCK / 16;
             const uint32_t gid = tid >> 4, sub = tid & 15;
             u64 *__restrict__ out64 = reinterpret_cast<u64 *>(a.kout);
-            const bool nt8 = a.nt_partial != 0;                     // (uniform)
             auto move_unit = [&](uint32_t p, uint32_t c) {
                 const uint32_t m = meta[p], e = m & 0xFFFFu, fc = m >> 16;
                 if (e == 0) return;
@@ -1300,8 +1300,8 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                         if (v0 && v1) {
                             const u64 t0 = fetch(s - off), t1 = fetch(s + 1 - off);
                             k6_store16(out64 + base + s, make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32)));
-                        } else if (v0) k6_store8(out64 + base + s, fetch(s - off), nt8);
-                        else if (v1) k6_store8(out64 + base + s + 1, fetch(s + 1 - off), nt8);
+                        } else if (v0) k6_store8<NTP>(out64 + base + s, fetch(s - off));
+                        else if (v1) k6_store8<NTP>(out64 + base + s + 1, fetch(s + 1 - off));
                     }
                     s += 32;
                 }
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                     const u64 t0 = src[s], t1 = src[s + 1];
                     k6_store16(out64 + base + s, make_uint4((uint32_t)t0, (uint32_t)(t0 >> 32), (uint32_t)t1, (uint32_t)(t1 >> 32)));
                 }
-                if (s < s_end) k6_store8(out64 + base + s, src[s], nt8);            // the run ends on an even slot
+                if (s < s_end) k6_store8<NTP>(out64 + base + s, src[s]);            // the run ends on an even slot
             };
             const uint32_t nunits = F + wsum[NW + 1];
             for (uint32_t u = gid; u < nunits; u += NG) {
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
                 for (uint32_t idx = tid; idx < F * LINE; idx += BLOCK) {
                     const uint32_t p = idx / LINE, j = idx % LINE;
                     const u64 ti = tinfo[p];
-                    if (j < ((uint32_t)ti & (LINE - 1))) k6_store8(out64 + (ti >> 4) + j, stage[hist[p] + (meta[p] & 0xFFFFu) + j], nt8);
+                    if (j < ((uint32_t)ti & (LINE - 1))) k6_store8<NTP>(out64 + (ti >> 4) + j, stage[hist[p] + (meta[p] & 0xFFFFu) + j]);
                 }
             }
         } else {
@@ -1387,13 +1387,13 @@ int hj_scatter_tile(const HjTuning &t, int pass, uint32_t F, bool out_packed)
     return c.block * c.vpt * 4;
 }
 
-template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY>
+template <int BLOCK, int VPT, bool RANGED, bool IN_PACKED, bool OUT_PACKED, bool CARRY, bool NTP = true>
 static int launch_scatter_t(const ScatterArgs &a, bool want_prof, int cus, hipStream_t stream)
 {
     const size_t lds = scatter_lds(BLOCK, VPT, a.F, CARRY, !RANGED);
     if (lds > HJ_LDS_LIMIT) return HJGPU_EINVAL;
     static HjPerDeviceOnce once;
-    if (hj_allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY>),
+    if (hj_allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY, NTP>),
                              (int)HJ_LDS_LIMIT, &once) != HJGPU_OK)
         return HJGPU_EHIP;
     // persistent grid: as many workgroups per CU as LDS (160 KiB) and threads (2048) allow
@@ -1413,7 +1413,7 @@ static int launch_scatter_t(const ScatterArgs &a, bool want_prof, int cus, hipSt
         (void)hipMemsetAsync(prof, 0, 8 * sizeof(u64), stream);
         b.prof = prof;
     }
-    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY>), dim3(grid), dim3(BLOCK), lds, stream, b);
+    hipLaunchKernelGGL((scatter_kernel<BLOCK, VPT, RANGED, IN_PACKED, OUT_PACKED, CARRY, NTP>), dim3(grid), dim3(BLOCK), lds, stream, b);
     if (b.prof) {
         u64 h[8];
         (void)hipMemcpyAsync(h, prof, sizeof(h), hipMemcpyDeviceToHost, stream);
@@ -1432,10 +1432,16 @@ static int launch_scatter_t(const ScatterArgs &a, bool want_prof, int cus, hipSt
 // pass 2: packed in, packed out, atomic cursors
 #define SCATTER_CASE(B, V)                                                                   \
     if (c.block == B && c.vpt == V) {                                                        \
-        if (a.ranged && !a.in_packed && a.out_packed && c.carry) return launch_scatter_t<B, V, true, false, true, true>(a, t.scatter_prof, cus, stream);   \
-        if (a.ranged && !a.in_packed && a.out_packed) return launch_scatter_t<B, V, true, false, true, false>(a, t.scatter_prof, cus, stream);  \
+        if (a.ranged && !a.in_packed && a.out_packed && c.carry)                                                                                            \
+            return a.nt_partial ? launch_scatter_t<B, V, true, false, true, true, true>(a, t.scatter_prof, cus, stream)                                     \
+                                : launch_scatter_t<B, V, true, false, true, true, false>(a, t.scatter_prof, cus, stream);                                    \
+        if (a.ranged && !a.in_packed && a.out_packed)                                                                                                        \
+            return a.nt_partial ? launch_scatter_t<B, V, true, false, true, false, true>(a, t.scatter_prof, cus, stream)                                    \
+                                : launch_scatter_t<B, V, true, false, true, false, false>(a, t.scatter_prof, cus, stream);                                   \
         if (a.ranged && !a.in_packed && !a.out_packed) return launch_scatter_t<B, V, true, false, false, false>(a, t.scatter_prof, cus, stream); \
-        if (!a.ranged && a.in_packed && a.out_packed) return launch_scatter_t<B, V, false, true, true, false>(a, t.scatter_prof, cus, stream);   \
+        if (!a.ranged && a.in_packed && a.out_packed)                                                                                                        \
+            return a.nt_partial ? launch_scatter_t<B, V, false, true, true, false, true>(a, t.scatter_prof, cus, stream)                                    \
+                                : launch_scatter_t<B, V, false, true, true, false, false>(a, t.scatter_prof, cus, stream);                                   \
         return HJGPU_EINVAL;                                                                 \
     }
 
