@@ -26,7 +26,11 @@
 // profiles/r03_ab_emit.txt - but an emit no longer serialises the wave's memory pipeline).
 typedef __attribute__((address_space(3))) u64 hj_lds_u64;
 
-struct Emitter {
+// NT: the rows leave through non-temporal stores (EmitterT<true>, every join that may run beside other work) or plain ones
+// (EmitterT<false>: solo joins, option "solo").  A template parameter: a run-time flag around the three stores was merged by the
+// compiler into ONE plain store per column (tests/test_store_policy_isa.py reads the machine code).
+template <bool NT>
+struct EmitterT {
     uint32_t *ok, *oov, *oiv;
     u64 block_size, block_limit;
     u64 *block_counter;
@@ -70,19 +74,20 @@ struct Emitter {
             next = base + (n - room);
         }
         if (rank == 0) *cursor = next;
-        // Result rows leave through NON-TEMPORAL stores (HJ_ROW_STORE = 1, the product; 0 = plain, for A/B builds): plain stores
-        // that sit dirty in an XCD's L2 while another queue's kernel boundary writes back and invalidates it can be lost (round 5,
-        // K6 lost stores that way in 1.5 of 10^4 pipeline steps), and a materialising join runs beside other
-        // streams' work in every pipeline (host batches, multi-GPU slices).  A compile-time choice: a run-time flag around the
-        // three stores was merged by the compiler into ONE plain store per column (the nt hint does not survive the merge).
-#if HJ_ROW_STORE
-        __builtin_nontemporal_store(key, &ok[pos]);
-        __builtin_nontemporal_store(outer_val, &oov[pos]);
-        __builtin_nontemporal_store(inner_val, &oiv[pos]);
-#else
-        ok[pos] = key;
-        oov[pos] = outer_val;
-        oiv[pos] = inner_val;
-#endif
+        // Plain row stores that sit dirty in an XCD's L2 while another queue's kernel boundary writes back and invalidates it can
+        // be lost (round 5, DESIGN section 3: K6 lost stores that way in 1.5 of 10^4 pipeline steps), and a materialising join runs
+        // beside other streams' work in every pipeline (host batches, multi-GPU slices): non-temporal there.  They cost the rows
+        // 14 % (4.83 against 4.24 ms per 10^9 rows: 4-byte stores do not fill lines the way K6's 16-byte ones do), which a solo join
+        // need not pay.  HJ_ROW_STORE = 0 builds every instance with plain row stores (A/B).
+        if constexpr (NT && HJ_ROW_STORE) {
+            __builtin_nontemporal_store(key, &ok[pos]);
+            __builtin_nontemporal_store(outer_val, &oov[pos]);
+            __builtin_nontemporal_store(inner_val, &oiv[pos]);
+        } else {
+            ok[pos] = key;
+            oov[pos] = outer_val;
+            oiv[pos] = inner_val;
+        }
     }
 };
+typedef EmitterT<true> Emitter;     // NPJ: always non-temporal rows

@@ -186,6 +186,7 @@ struct JoinArgs {
     u64 *block_counter;                  // device
     u64 *final_offsets;                  // device [gridDim.x] end cursor per workgroup
     uint32_t *overflow;                  // device flag
+    uint32_t nt_rows;                    // 1: result rows through non-temporal stores (every join but a solo one: selects the NTROWS instance)
     uint32_t big_tables;                 // hj_join_config_big() instead of hj_join_config()
     // broadcast join (tiny build side, nothing partitioned): P = 1, the relations are the caller's columns, the
     // empty sentinel is *sentinel (a value no build key equals, found by hj_launch_broadcast_meta)

@@ -783,6 +783,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             ja.block_counter = &st->block_counter;
             ja.final_offsets = (u64 *)ctx->final_offsets.p;
             ja.overflow = &st->overflow;
+            ja.nt_rows = ctx->rows_plain ? 0u : 1u;
         }
         CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
         if (audit) CHK(hj_audit_copy(reinterpret_cast<const u64 *>(&st->result), audit + 4 * 6, 4, stream));
@@ -1350,6 +1351,7 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
         ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
+        ja.nt_rows = ctx->rows_plain ? 0u : 1u;
     }
     CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     record(ctx, EV_JOIN, stream);

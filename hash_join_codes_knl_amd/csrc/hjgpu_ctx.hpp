@@ -74,7 +74,7 @@ struct hjgpu_ctx {
     bool has_pending_out = false;
     bool last_had_output = false;   // hjgpu_get_async_status: the last enqueued join wrote result columns
     bool rows_plain = false;        // the join being enqueued is SOLO - a blocking call of a context with option "solo": plain partial-line stores
-                                    // in K6 (k6_store8); every other launch writes them non-temporal
+                                    // in K6 (k6_store8) and plain result rows (join_kernel<..., NTROWS = false>); every other launch writes them non-temporal
     // grouped plans (phj_grouped): pass-0 twins of the four columns, the groups' offsets, and the call's accumulated phase
     // times (hjgpu_get_stats returns those while stats_override is set; any later operation's first event clears it)
     DevBuf grp[4], grp_off;
@@ -114,7 +114,8 @@ void settle(hjgpu_ctx *ctx);
 
 // The partial-line stores (K6) of a SOLO join - a blocking call of a context with option "solo": the caller waits for it and promises
 // that nothing else runs on the device beside it - are plain; every other join (enqueue-only, host batches, multi-GPU slices, and
-// every blocking call without the option) writes them non-temporal (DESIGN section 3 "Round 5").  Result rows are always non-temporal.
+// every blocking call without the option) writes them non-temporal (DESIGN section 3 "Round 5").  The same for the result rows of PHJ / CPRA
+// (join_kernel's NTROWS instances); NPJ's rows are always non-temporal.
 struct PlainRows {
     hjgpu_ctx *ctx;
     PlainRows(hjgpu_ctx *c, bool blocking) : ctx(c) { if (ctx) ctx->rows_plain = blocking && ctx->tune.solo; }

@@ -187,6 +187,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
         ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
         ja.block_size = bs; ja.block_limit = bl; ja.block_counter = &st->block_counter;
         ja.final_offsets = (u64 *)ctx->final_offsets.p; ja.overflow = &st->overflow;
+        ja.nt_rows = ctx->rows_plain ? 0u : 1u;
     }
     CHK(hj_launch_join(ja, ctx->tune, ctx->cus, stream));
     record(ctx, EV_JOIN, stream);

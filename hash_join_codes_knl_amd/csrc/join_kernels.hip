@@ -65,7 +65,8 @@ constexpr int hj_join_waves_per_simd(int block, int log2slots)
     return w < 1 ? 1 : w;
 }
 
-template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE, bool DEDUP = false>
+// NTROWS: result rows through non-temporal stores (EmitterT<true>; JoinArgs::nt_rows) - false only for solo joins
+template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE, bool DEDUP = false, bool NTROWS = true>
 __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) void join_kernel(JoinArgs a)
 {
     static_assert(UNIQUE || !DEDUP, "DEDUP is the multi-fill half of a _UNIQUE join");
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     const u64 *__restrict__ r64 = reinterpret_cast<const u64 *>(a.rk);
     const uint32_t tf0 = a.tf0, tf1 = a.tf1;
 
-    Emitter em;
+    EmitterT<NTROWS> em;
     em.init(a.ok, a.oov, a.oiv, a.block_size, a.block_limit, a.block_counter, a.overflow,
             &wave_cursor[wave]);
     // (the multi-fill half of a _UNIQUE join runs behind the single-fill half on the same stream, with the same grid: wave w of
@@ -530,10 +531,16 @@ int hj_join_workers(const HjTuning &t, int cus, bool big_tables, bool unique)
     return join_grid(cus, c) * (c.block / 64);
 }
 
+// (the plain-row instances serve solo materialising joins only; aggregate-only joins never emit: the NTROWS = true instance)
+#define JOIN_LAUNCH(B, L, U, P, UNQ, DD, ARGS)                                                                          \
+    do {                                                                                                                \
+        if ((ARGS).ok && !(ARGS).nt_rows) hipLaunchKernelGGL((join_kernel<B, L, U, P, UNQ, DD, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, ARGS); \
+        else hipLaunchKernelGGL((join_kernel<B, L, U, P, UNQ, DD, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, ARGS);                              \
+    } while (0)
 #define JOIN_CASE(B, L, U, UNQ)                                                                   \
     if (c.block == B && c.log2slots == L && c.batch == U && (b.unique != 0) == UNQ) {             \
-        if (b.packed) hipLaunchKernelGGL((join_kernel<B, L, U, true, UNQ>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
-        else hipLaunchKernelGGL((join_kernel<B, L, U, false, UNQ>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);          \
+        if (b.packed) JOIN_LAUNCH(B, L, U, true, UNQ, false, b);                                  \
+        else JOIN_LAUNCH(B, L, U, false, UNQ, false, b);                                          \
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
     }
 
@@ -561,13 +568,8 @@ bool hj_join_config_built(const JoinConfig &c, bool unique)
     if (c.block == B && c.log2slots == L && b.unique) {                                           \
         JoinArgs d = b;                                                                           \
         d.work_counter = b.work_counter2;                                                         \
-        if (b.packed) {                                                                           \
-            hipLaunchKernelGGL((join_kernel<B, L, 2, true, true, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b);  \
-            hipLaunchKernelGGL((join_kernel<B, L, 1, true, true, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, d);   \
-        } else {                                                                                  \
-            hipLaunchKernelGGL((join_kernel<B, L, 2, false, true, false>), dim3(join_grid(cus, c)), dim3(B), 0, stream, b); \
-            hipLaunchKernelGGL((join_kernel<B, L, 1, false, true, true>), dim3(join_grid(cus, c)), dim3(B), 0, stream, d);  \
-        }                                                                                         \
+        if (b.packed) { JOIN_LAUNCH(B, L, 2, true, true, false, b); JOIN_LAUNCH(B, L, 1, true, true, true, d); }      \
+        else { JOIN_LAUNCH(B, L, 2, false, true, false, b); JOIN_LAUNCH(B, L, 1, false, true, true, d); }             \
         return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;                           \
     }
 

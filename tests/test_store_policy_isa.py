@@ -6,7 +6,7 @@ run-time flag around those stores looked right in the source and was WRONG in th
 into one plain store - so the policy is a template parameter / a build-time macro, and this test reads the ISA:
   scatter_kernel<..., NTP = true>   no plain 8- or 16-byte global store at all
   scatter_kernel<..., NTP = false>  16-byte stores non-temporal, 8-byte stores plain (option solo)
-  join_kernel / npj_probe*          every 4-byte row store non-temporal"""
+  join_kernel<..., NTROWS = true>   every 4-byte row store non-temporal (NTROWS = false: plain, solo joins); npj_probe_line_kernel: non-temporal"""
 import collections
 import os
 import re
@@ -54,12 +54,21 @@ def test_k6_store_policy_in_the_machine_code(tmp_path):
     assert seen[True] >= 16 and seen[False] >= 16
 
 
-@pytest.mark.parametrize("source,prefix", [("join_kernels.hip", "_Z11join_kernel"), ("npj_kernels.hip", "_Z21npj_probe_line_kernel")])
-def test_result_rows_are_non_temporal_in_the_machine_code(tmp_path, source, prefix):
-    kernels = {k: v for k, v in isa(source, tmp_path).items() if k.startswith(prefix)}
+def test_result_rows_follow_the_policy_in_the_machine_code(tmp_path):
+    """join_kernel<..., NTROWS>: every 4-byte row store non-temporal in the instances every pipeline uses, plain in the solo ones"""
+    kernels = {k: v for k, v in isa("join_kernels.hip", tmp_path).items() if k.startswith("_Z11join_kernel")}
+    seen = {True: 0, False: 0}
+    for name, stores in kernels.items():
+        nt_rows = re.findall(r"Lb([01])E", name)[3] == "1"         # PACKED, UNIQUE, DEDUP, NTROWS
+        seen[nt_rows] += 1
+        assert stores[("global_store_dword", not nt_rows)] == 0 and stores[("global_store_dword", nt_rows)] >= 3, (name, stores)
+    assert seen[True] >= 10 and seen[False] >= 10
+
+
+def test_npj_rows_are_non_temporal_in_the_machine_code(tmp_path):
+    kernels = {k: v for k, v in isa("npj_kernels.hip", tmp_path).items() if k.startswith("_Z21npj_probe_line_kernel")}
     assert kernels
     for name, stores in kernels.items():
-        if source == "npj_kernels.hip" and "ILb0E" in name:     # the instances that do not materialise have no row stores
+        if "ILb0E" in name:                                       # the instances that do not materialise have no row stores
             continue
-        assert stores[("global_store_dword", False)] == 0, (name, stores)
-        assert stores[("global_store_dword", True)] >= 3, (name, stores)
+        assert stores[("global_store_dword", False)] == 0 and stores[("global_store_dword", True)] >= 3, (name, stores)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 evidence run (GPU box), in the parts a 20-minute GPU call holds: tools/r05_round.sh tests | validation | validation2 | profiles | report
+# Round-5 evidence run (GPU box), in the parts a 20-minute GPU call holds: tools/r05_round.sh tests | validation | validation2 | profiles | dist | report
 # Every artefact carries the kernel hash of the library that produced it; a part stops before it measures anything when the built
 # library is not the tree's, and tools/r05_collect.sh refuses artefacts of another hash AND any sweep that contains a wrong step.
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -63,7 +63,7 @@ profiles)
   python3 bench.py --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err; note "bench rc=$?"
   bash tools/pmc_sq.sh r05 > $out/r05_pmc_sq.log 2>&1; note "pmc rc=$?"
   ;;
-report)
+dist)
   # the multi-GPU entry points through RCCL at world 1 (bench.py --force-dist; the PHJ line carries secondary.cpra_multi =
   # BASELINE configs[4]'s per-rank shape), two processes on this one GPU (--rehearse-solo), all quoted workload shapes
   timeout -k 10 400 python3 bench.py --force-dist --steps 8 --warmup 2 --cpu-outer 0 > $out/r05_bench_force_dist_configs4.json 2> $out/r05_fd_phj.err; note "fd phj+configs4 rc=$?"
@@ -72,6 +72,8 @@ report)
   done
   timeout -k 10 300 python3 bench.py --force-dist --algo cpra --steps 8 --warmup 2 --cpu-outer 0 --exchange-slices 8 > $out/r05_bench_force_dist_cpra_8slices.json 2>/dev/null
   timeout -k 10 500 python3 bench.py --gpus 2 --rehearse-solo --steps 4 --warmup 1 --cpu-outer 0 --configs4-steps 2 > $out/r05_bench_rehearse_solo.json 2> $out/r05_rehearse.err; note "rehearse-solo rc=$?"
+  ;;
+report)
   python3 tools/report.py > $out/r05_report.md 2> $out/r05_report.err; note "report rc=$?"
   ;;
 *) echo "unknown part $part"; exit 2;;
