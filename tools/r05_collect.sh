@@ -18,7 +18,8 @@ for f in r05_bench.json r05_bench_force_dist_configs4.json r05_bench_force_dist_
   if [ "$h" != "$tree" ]; then echo "REFUSED: $f carries kernel hash $h, the tree is $tree"; ok=0; continue; fi
   cp gpurun_out/$f profiles/$f
 done
-grep -q "kernel hash $tree part profiles" gpurun_out/r05_rc.txt || { echo "REFUSED: the profiles part did not run on kernel hash $tree"; ok=0; }
+# (the parts' own rc files, or - for parts run before the round script wrote one per part - the call's log)
+cat gpurun_out/r05_rc_profiles.txt gpurun_out/r05_profiles_call.log 2>/dev/null | grep -q "kernel hash $tree part profiles" || { echo "REFUSED: the profiles part did not run on kernel hash $tree"; ok=0; }
 for f in r05_cpra_64M_1G_kernel_stats.csv r05_materialized_64M_1G_kernel_stats.csv r05_npj_64M_1G_kernel_stats.csv r05_phj_64M_1G_kernel_stats.csv r05_report.md; do
   [ -s gpurun_out/$f ] || { echo "missing: $f"; ok=0; continue; }
   cp gpurun_out/$f profiles/$f
@@ -26,5 +27,7 @@ done
 [ -s gpurun_out/pmc_sq_r05.csv ] && cp gpurun_out/pmc_sq_r05.csv profiles/r05_pmc_sq.csv && python3 tools/pmc_sq_summary.py profiles/r05_pmc_sq.csv > profiles/r05_pmc_sq_summary.txt
 { echo "# tools/kernel_resources.py (hipcc -Rpass-analysis=kernel-resource-usage, gfx950) on the round-5 sources (kernel hash $tree): VGPRs, spills, scratch bytes per lane, waves per SIMD"
   for f in partition_kernels.hip join_kernels.hip npj_kernels.hip audit_kernels.hip; do python3 tools/kernel_resources.py hash_join_codes_knl_amd/csrc/$f; done; } > profiles/r05_kernel_resources.txt
-grep "kernel hash\|rc=\|bad=" gpurun_out/r05_rc.txt | tail -20
+for f in $(grep -l "^kernel hash $tree" gpurun_out/r05_rc*.txt gpurun_out/r05_*_call.log 2>/dev/null); do
+  awk -v t="$tree" '/^kernel hash/ { on = ($3 == t) } on' $f | grep "^kernel hash\|^[a-z0-9+ -]*rc=\|bad="
+done | sort -u
 [ $ok = 1 ] && echo "collected for kernel hash $tree" || { echo "collected WITH GAPS OR WRONG STEPS for kernel hash $tree"; exit 1; }

@@ -18,8 +18,10 @@ print(tree)
 PY
 ) || { echo "r05_round: refusing to collect evidence with a stale library"; exit 1; }
 part=${1:-tests}
-echo "kernel hash $hash part $part $(date -u +%FT%RZ)" | tee -a $out/r05_rc.txt
-note() { echo "$*" | tee -a $out/r05_rc.txt; }
+# one rc file per part: every gpurun call starts with an empty gpurun_out/ and the merge replaces files of the same name
+rc=$out/r05_rc_$part.txt
+echo "kernel hash $hash part $part $(date -u +%FT%RZ)" | tee $rc
+note() { echo "$*" | tee -a $rc; }
 quiet() { grep --line-buffered -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl"; }
 stress() {   # every step of the slice pipeline checked; the tool exits 1 on a wrong step
   echo "## tools/stress_cpra.py $*" >> $out/$sweep

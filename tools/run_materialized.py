@@ -18,6 +18,7 @@ def main():
     inner, outer = 64_000_000, 1_000_000_000
     fi, fo = 0x2545F491, 0x9E3779B1
     with H.HjGpu(0) as hj:
+        hj.set_option("solo", "1")       # as bench.py's `materialized` leg: a blocking join in a process that runs nothing else (plain rows)
         ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
         hj.generate(1, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
         sums = hj.column_sums(ok, outer, fo, fi)
