@@ -289,6 +289,7 @@ def workspace_report(hj):
     return {"ms_reserve": round(st["ms_reserve"], 1), "candidates_tried": int(st["placement_tried"]),
             "chosen_fill_ms": round(fill, 3), "chosen_fill_TBs": round(st["placement_bytes"] / (fill * 1e-3) / 1e12, 2) if fill > 0 else None,
             "chosen_is_fast_kind": bool(fill > 0 and st["placement_bytes"] / (fill * 1e-3) >= 5.5e12),
+            "search_ms": round(st["placement_search_ms"], 1),
             "search_timeboxed": bool(st["placement_timeboxed"]), "search_budget_ms": 500}
 
 

@@ -77,7 +77,7 @@ class Stats(C.Structure):
                 ("ms_inner_wait", C.c_float), ("ms_upload", C.c_float), ("ms_download", C.c_float),
                 ("ms_reserve", C.c_float), ("fanout1", C.c_uint32), ("fanout2", C.c_uint32), ("batches", C.c_uint32), ("buckets", C.c_uint64),
                 ("ms_scatter0", C.c_float), ("groups", C.c_uint32),
-                ("placement_tried", C.c_uint32), ("placement_timeboxed", C.c_uint32), ("placement_fill_ms", C.c_float),
+                ("placement_tried", C.c_uint32), ("placement_timeboxed", C.c_uint32), ("placement_fill_ms", C.c_float), ("placement_search_ms", C.c_float),
                 ("placement_bytes", C.c_uint64)]
 
     def as_dict(self):

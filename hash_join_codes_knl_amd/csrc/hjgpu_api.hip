@@ -27,7 +27,25 @@ int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e)
 // worker itself, which calls the same planning functions)
 void settle(hjgpu_ctx *ctx)
 {
-    if (ctx && ctx->grp_worker.joinable() && ctx->grp_worker.get_id() != std::this_thread::get_id()) ctx->grp_worker.join();
+    if (!ctx || ctx->grp_worker.get_id() == std::this_thread::get_id()) return;        // (the worker's own calls)
+    if (ctx->grp_worker.joinable()) ctx->grp_worker.join();
+    // everything of the asynchronous grouped join is enqueued now: what its growth of the workspace left behind can go (hipFree waits
+    // for the device, the join included)
+    ctx->defer_free = false;
+    if (!ctx->graveyard.empty()) {
+        (void)hipSetDevice(ctx->device);
+        for (void *p : ctx->graveyard) (void)hipFree(p);
+        ctx->graveyard.clear();
+    }
+}
+
+// hipFree of a workspace buffer - later, where the context's worker must not wait for the device (hjgpu_ctx::defer_free)
+static int release(hjgpu_ctx *ctx, void *p)
+{
+    if (!p) return HJGPU_OK;
+    if (ctx->defer_free) { ctx->graveyard.push_back(p); return HJGPU_OK; }
+    HIPCHK(ctx, hipFree(p));
+    return HJGPU_OK;
 }
 
 
@@ -63,7 +81,7 @@ hipError_t hj_stream_synchronize(hipStream_t st)
 int ensure(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return HJGPU_OK;
-    if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    if (b.p) { CHK(release(ctx, b.p)); b.p = nullptr; b.cap = 0; }
     // round up so that repeated small growth does not reallocate, and keep a
     // 16-byte tail so aligned vector reads of the last elements stay inside
     size_t want = (bytes + 255) / 256 * 256 + 256;
@@ -89,11 +107,12 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     const int tries = ctx->tune.placement;
     // (twins below 1 GiB - the headline's 512 MB build-side twin, a grouped plan's per-group twins - gain nothing from the
     // search: profiles/r04_ab_placed_min.txt)
-    if (tries <= 1 || bytes < ((size_t)1 << 30)) return ensure(ctx, b, bytes);
+    // (no search in the worker thread of an asynchronous grouped join: its candidates could not be freed, see hjgpu_ctx::defer_free)
+    if (tries <= 1 || bytes < ((size_t)1 << 30) || ctx->defer_free) return ensure(ctx, b, bytes);
     if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     const size_t want = (bytes + 255) / 256 * 256 + 256;
     void *cand[16];
-    float ms[16];
+    float ms[16], alloc_ms[16];
     int n = 0, best = -1;
     // the probes run on the context's own non-blocking stream: nothing is issued on the legacy NULL stream (which
     // would synchronise every blocking stream of the process, and is not legal while another stream captures)
@@ -118,7 +137,9 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
             timeboxed = true;
             break;
         }
+        const auto alloc_began = std::chrono::steady_clock::now();
         if (hipMalloc(&cand[n], want) != hipSuccess) { (void)hipGetLastError(); break; }
+        alloc_ms[n] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - alloc_began).count();
         ms[n] = 1e30f;
         for (int rep = 0; rep < 2; ++rep) {                                  // the first touch of fresh memory is slower
             float t = 1e30f;
@@ -134,10 +155,14 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     if (best < 0) return fail(ctx, HJGPU_ENOMEM, "hipMalloc(workspace)");
     if (ctx->tune.placement_log) {
         fprintf(stderr, "hjgpu placement: %zu bytes,", want);
-        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f ms%s", ms[i], i == best ? "*" : "");
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f ms%s (hipMalloc %.1f ms)", ms[i], i == best ? "*" : "", alloc_ms[i]);
         fprintf(stderr, " (%.2f TB/s taken)\n", (double)want / (ms[best] * 1e-3) / 1e12);
     }
     for (int i = 0; i < n; ++i) if (i != best) (void)hipFree(cand[i]);
+    // what the search cost beyond one plain allocation: everything from its first hipMalloc to the last candidate freed, minus the kept
+    // block's own hipMalloc (hjgpu_stats.placement_search_ms; ms_reserve also holds every other allocation of the workspace and, in a
+    // fresh process, the first kernel launch's code-object load)
+    ctx->placement_search_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - search_began).count() - alloc_ms[best];
     b.p = cand[best]; b.cap = want;
     ctx->placement_tried = (uint32_t)n; ctx->placement_timeboxed = timeboxed ? 1u : 0u;
     ctx->placement_fill_ms = ms[best]; ctx->placement_bytes = want;
@@ -982,7 +1007,7 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->grp_in) (void)hipEventDestroy(ctx->grp_in);
-    if (ctx->grp_stream) (void)hipStreamDestroy(ctx->grp_stream);
+    for (hipStream_t s : ctx->grp_streams) if (s) (void)hipStreamDestroy(s);
     if (ctx->grp_flag) (void)hipFree(ctx->grp_flag);
     for (int b = 0; b < 4; ++b) {
         if (ctx->host_stage[b]) (void)hipHostFree(ctx->host_stage[b]);
@@ -1048,7 +1073,7 @@ static void fill_reserve(const hjgpu_ctx *ctx, hjgpu_stats *s)
 {
     s->ms_reserve = ctx->ms_reserve;
     s->placement_tried = ctx->placement_tried; s->placement_timeboxed = ctx->placement_timeboxed;
-    s->placement_fill_ms = ctx->placement_fill_ms; s->placement_bytes = (uint64_t)ctx->placement_bytes;
+    s->placement_fill_ms = ctx->placement_fill_ms; s->placement_search_ms = ctx->placement_search_ms; s->placement_bytes = (uint64_t)ctx->placement_bytes;
 }
 
 int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
@@ -1478,7 +1503,24 @@ static int grouped_async(hjgpu_ctx *ctx, uint32_t groups, uint32_t chunks,
                          const uint32_t *sk, const uint32_t *sv, size_t outer,
                          const hjgpu_phj_params *prm, const hjgpu_output *out, hjgpu_result *d_result, hipStream_t stream)
 {
-    if (!ctx->grp_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->grp_stream, hipStreamNonBlocking));
+    {
+        // the workspace a grouped plan of this size usually needs, grown HERE (hjgpu_reserve's estimate: one group 10 % above the mean):
+        // what the worker still has to grow - a larger largest group - it grows without freeing anything (hjgpu_ctx::defer_free)
+        ReserveClock clock(ctx);
+        PhjPlan pl;
+        CHK(grouped_twins(ctx, group_layout(groups), inner, outer));
+        CHK(phj_prepare(ctx, inner / groups + inner / groups / 10, outer / groups + outer / groups / 10, prm, chunks, &pl));
+    }
+    {
+        // the worker's stream: a priority class the caller's stream is not in (their hardware queues are pooled per class)
+        int least = 0, greatest = 0, mine = 0;
+        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (hipStreamGetPriority(stream, &mine) != hipSuccess) { (void)hipGetLastError(); mine = 0; }
+        const int which = (mine == 0 && greatest < 0) ? 0 : 1;             // default-priority callers: the class above; others: the default class
+        if (!ctx->grp_streams[which])
+            HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->grp_streams[which], hipStreamNonBlocking, which == 0 ? greatest : 0));
+        ctx->grp_stream = ctx->grp_streams[which];
+    }
     if (!ctx->grp_in) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->grp_in, hipEventDisableTiming));
     if (!ctx->grp_flag) {
         HIPCHK(ctx, hipExtMallocWithFlags(reinterpret_cast<void **>(&ctx->grp_flag), sizeof(uint64_t), hipMallocSignalMemory));
@@ -1497,6 +1539,7 @@ static int grouped_async(hjgpu_ctx *ctx, uint32_t groups, uint32_t chunks,
     if (prm) prm_copy = *prm;
     if (out) out_copy = *out;
     ctx->grp_status = HJGPU_OK;
+    ctx->defer_free = true;                                  // until settle() has joined the worker
     ctx->grp_worker = std::thread([=]() {
         hipStream_t ws = ctx->grp_stream;
         int rc = hipSetDevice(ctx->device) == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
@@ -1528,8 +1571,19 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
     ctx->last_had_output = out && out->d_keys;
-    const uint32_t groups = inner_ready ? 0 : grouped_groups(ctx, inner, outer, prm);
-    if (groups > 1 && outer && !blocking && ctx->tune.group_async) {
+    const uint32_t groups = grouped_groups(ctx, inner, outer, prm);
+    bool wait_here = blocking || !ctx->tune.group_async;
+    if (groups > 1 && outer && inner_ready) {
+        // hjgpu_phj_overlapped_async (hjgpu_phj_multi's local join): a grouped plan reads the build side in its first command (pass 0
+        // of R), so the overlap of the build side's arrival with the probe side's first pass is given up - pass 0 is 20 ms of a 69 ms
+        // plan at 1 G x 4 G, a broadcast of 1 G tuples takes longer than that on any link.  And the CALLING thread waits for the
+        // groups' sizes: the caller is a rank's host thread inside a blocking multi-GPU join, whose streams must not be held in
+        // hardware while the other ranks of the process work beside them.
+        HIPCHK(ctx, hipStreamWaitEvent(stream, (hipEvent_t)inner_ready, 0));
+        inner_ready = nullptr;
+        wait_here = true;
+    }
+    if (groups > 1 && outer && !wait_here) {
         // enqueue-only: the context's worker thread waits for the groups' sizes, not the caller (grouped_async)
         settle(ctx);
         return grouped_async(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, d_result, stream);

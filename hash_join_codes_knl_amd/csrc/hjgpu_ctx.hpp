@@ -85,7 +85,14 @@ struct hjgpu_ctx {
     // it need not be the caller) and the CALLER's stream waits for a counter in signal memory that the worker's last command
     // raises.  Any later use of the context joins the worker first (settle).
     std::thread grp_worker;
-    hipStream_t grp_stream = nullptr;
+    hipStream_t grp_stream = nullptr;      // the worker's stream of the current / last such join: one of grp_streams
+    hipStream_t grp_streams[2] = {nullptr, nullptr};   // [0] priority above the default, [1] the default priority: never the CALLER's
+                                    // stream's own priority - streams of one priority share hardware queues once a process has more of
+                                    // them than queues, and the worker's commands must not sit behind the caller's waiting stream
+    // While the worker runs, the caller's stream waits in hardware for it: hipFree - which waits for every stream of the device -
+    // would wait for ever.  Buffers that grow in the worker are kept here and freed when the worker has been joined (settle).
+    bool defer_free = false;
+    std::vector<void *> graveyard;
     hipEvent_t grp_in = nullptr;
     uint64_t *grp_flag = nullptr;   // hipExtMallocWithFlags(hipMallocSignalMemory): joins of this context finished so far
     uint64_t grp_seq = 0;
@@ -98,7 +105,7 @@ struct hjgpu_ctx {
     // the last placement search (ensure_placed): candidate blocks it allocated and filled, the kept block's fill time and size,
     // whether the budget (option "placement_ms") ended it
     uint32_t placement_tried = 0, placement_timeboxed = 0;
-    float placement_fill_ms = 0;
+    float placement_fill_ms = 0, placement_search_ms = 0;
     size_t placement_bytes = 0;
 };
 

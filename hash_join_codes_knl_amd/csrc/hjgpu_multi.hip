@@ -769,7 +769,11 @@ void add_stats(hjgpu_stats *acc, const hjgpu_stats &s)
     acc->ms_total += s.ms_total; acc->ms_histogram += s.ms_histogram; acc->ms_plan += s.ms_plan;
     acc->ms_scatter1 += s.ms_scatter1; acc->ms_scatter2 += s.ms_scatter2; acc->ms_join += s.ms_join;
     acc->ms_build += s.ms_build; acc->ms_close_gaps += s.ms_close_gaps; acc->ms_inner_wait += s.ms_inner_wait;
+    acc->ms_scatter0 += s.ms_scatter0;
     acc->fanout1 = s.fanout1; acc->fanout2 = s.fanout2; acc->buckets = s.buckets; acc->ms_reserve = s.ms_reserve;
+    acc->groups = s.groups;                                          // (a rank's local join by a grouped plan)
+    acc->placement_tried = s.placement_tried; acc->placement_timeboxed = s.placement_timeboxed;
+    acc->placement_fill_ms = s.placement_fill_ms; acc->placement_search_ms = s.placement_search_ms; acc->placement_bytes = s.placement_bytes;
 }
 
 float elapsed(hipEvent_t a, hipEvent_t b)

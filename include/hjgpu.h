@@ -129,9 +129,12 @@ typedef struct {
     /* the context's last placement search (option "placement": candidate blocks for a buffer of 1 GiB and more that K6's
      * pass 1 scatters into; outside every timed join): blocks allocated and filled, 1 when the search's wall-clock budget
      * (option "placement_ms", default 500) ended it before a fast block was found, the kept block's fill time and size
-     * (bytes / ms = its fill rate: >= 5.5 TB/s is the fast kind) */
+     * (bytes / ms = its fill rate: >= 5.5 TB/s is the fast kind), and what the search cost: its wall clock
+     * beyond the kept block's own hipMalloc (ms_reserve above is ALL growth of the workspace: every allocation, and in a fresh
+     * process the first kernel's code-object load) */
     uint32_t placement_tried, placement_timeboxed;
     float    placement_fill_ms;
+    float    placement_search_ms;
     uint64_t placement_bytes;
 } hjgpu_stats;
 
@@ -258,7 +261,14 @@ int  hjgpu_npj(hjgpu_ctx *ctx,
  * device only): in the blocking forms the caller; in the *_async forms (round 5) a worker thread of the context, on a stream
  * of its own - the call returns at once, the CALLER's stream goes on when the worker's last command has raised a counter in
  * signal memory (hipStreamWaitValue64), and any later use of the context joins the worker first; a failure there is what
- * hjgpu_get_async_status returns (option "group_async" = 0: the call waits itself, as in round 4).  Explicit fan-outs in
+ * hjgpu_get_async_status returns (option "group_async" = 0: the call waits itself, as in round 4).  While the caller's stream
+ * waits in hardware, two things must not happen, and the library sees to both: the worker never frees device memory (hipFree
+ * waits for every stream of the device; the call reserves the usual workspace itself, what the worker still grows is freed when
+ * the worker has been joined), and the worker's stream is of another priority class than the caller's (hardware queues are
+ * pooled per class and shared inside one: the worker's commands must not queue behind the waiting stream).  The CALLER must not
+ * make the worker wait either: nothing that the join's inputs depend on may be enqueued behind the call on the same stream.
+ * hjgpu_phj_overlapped_async with a grouped plan waits for the build side first and lets the calling thread wait for the groups
+ * (it is hjgpu_phj_multi's local join: a rank's share of any size is grouped there).  Explicit fan-outs in
  * params are never grouped; option "group_from" = 0 turns the plan off. */
 int  hjgpu_phj(hjgpu_ctx *ctx,
                const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
@@ -290,7 +300,8 @@ int  hjgpu_phj_async(hjgpu_ctx *ctx,
  * `inner_ready_event` (a hipEvent_t passed as void*, recorded by the caller on the
  * stream that produces them, e.g. an RCCL broadcast) has fired: the probe side is
  * histogrammed and partitioned first, the wait sits right before the first kernel
- * that reads R.  This is how the multi-GPU PHJ hides the build-side broadcast. */
+ * that reads R.  This is how the multi-GPU PHJ hides the build-side broadcast.
+ * (A grouped plan - see hjgpu_phj - reads R first: the stream waits for the event, and the CALLING thread waits for the groups.) */
 int  hjgpu_phj_overlapped_async(hjgpu_ctx *ctx,
                      const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,
                      const uint32_t *d_outer_keys, const uint32_t *d_outer_vals, size_t outer,

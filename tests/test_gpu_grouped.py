@@ -172,6 +172,10 @@ def test_grouped_plan_through_the_enqueue_only_form_returns_at_once(grouped, alg
     getattr(grouped, algo)(ik, iv, inner, ok, ov, outer)
     t_blocking = time.perf_counter() - t0
     d = [grouped.column(4, np.uint64) for _ in range(2)]
+    # (the context's first such call makes the worker's stream - a hardware queue of its own priority class - and the signal memory)
+    getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[0])
+    grouped.synchronize()
+    grouped.get_async_status()
     t0 = time.perf_counter()
     getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[0])
     t_call = time.perf_counter() - t0
@@ -187,6 +191,37 @@ def test_grouped_plan_through_the_enqueue_only_form_returns_at_once(grouped, alg
     grouped.synchronize()
     assert tuple(int(x) for x in d[0].download()) == want
     _free(ik, iv, ok, ov, *d)
+
+
+def test_first_grouped_join_of_a_context_through_the_enqueue_only_form(oracle):
+    """The worker thread of an asynchronous grouped plan grows the workspace while the caller's stream waits for it in hardware:
+    it must not free anything then (hipFree waits for every stream of the device - for ever).  A fresh context, no blocking call
+    before; few distinct build keys, so that the largest group is far above the mean and the worker has to grow what the call
+    reserved; then a larger join on the same context (grows in the caller's thread, after the worker was joined)."""
+    rng = np.random.default_rng(5)
+    for scale in (1, 6):
+        ctx = H.HjGpu()
+        try:
+            ctx.set_option("group_from", "1000")
+            ctx.set_option("group_always", "1")
+            for rep in (1, scale):
+                distinct = rng.choice(np.arange(1, 1 << 31, dtype=np.uint32), size=64, replace=False)
+                ik = np.repeat(distinct, 500 * rep)
+                iv = rng.integers(0, 1 << 32, size=len(ik), dtype=np.uint32)
+                ok = rng.choice(distinct, size=50_000 * rep)
+                ov = rng.integers(0, 1 << 32, size=len(ok), dtype=np.uint32)
+                want = numpy_join(ik, iv, ok, ov)
+                ctx.set_option("group_inner", str(len(ik) // 8))
+                rk, rv, sk, sv = _cols(ctx, ik, iv, ok, ov)
+                d = ctx.column(4, np.uint64)
+                ctx.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, d)
+                ctx.synchronize()
+                ctx.get_async_status()
+                assert tuple(int(x) for x in d.download()) == want
+                assert ctx.stats()["groups"] >= 8
+                _free(rk, rv, sk, sv, d)
+        finally:
+            ctx.close()
 
 
 def test_pass_zero_is_independent_of_the_callers_pass_factors(grouped, oracle):

@@ -612,6 +612,43 @@ def test_materialised_rows_through_the_multi_gpu_entry_points(worlds, oracle, wo
             c.free()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind", ["unique", "dups", "half"])
+def test_replicated_build_is_joined_by_a_grouped_plan_where_a_rank_needs_one(worlds, oracle, world, kind):
+    """hjgpu_phj_multi / hjgpu_phj_multi_rows with a build side beyond two passes' reach (here: options group_from / group_always
+    on the ranks' contexts): every rank's local join (hjgpu_phj_overlapped_async) takes the grouped plan - the reference's third
+    pass, phj.cpp:1791-1808 - through the context's worker thread, after the build side has arrived; aggregates and rows equal
+    the definition, the statistics name the groups."""
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, kind, seed=40 + world)
+    want = numpy_join(ik, iv, ok, ov)
+    wk, wo, wi = materialised_rows(ik, iv, ok, ov)
+    per = -(-len(ik) // 5)
+    for ctx in comm.ctx:
+        ctx.set_option("group_from", "1000")
+        ctx.set_option("group_always", "1")
+        ctx.set_option("group_inner", str(per))
+    try:
+        for root in (0, world - 1):
+            shards, cols = replicated_shards(comm, ik, iv, ok, ov, root)
+            got, st = comm.phj_multi(shards, root)
+            assert got == want, (world, kind, root)
+            assert st["join"]["groups"] == -(-len(ik) // per) and st["join"]["ms_scatter0"] > 0
+            assert comm.phj_multi(shards, root, H.PhjParams(fanout1=16, fanout2=3))[1]["join"]["groups"] == 0     # explicit fan-outs: never grouped
+            outs, ocols = _rank_outputs(comm, [want[0]] * world, 1024, 1, max(s[5] for s in shards))
+            got_rows, _, counts = comm.phj_multi_rows(shards, outs, root)
+            assert got_rows == want and sum(counts) == want[0]
+            gk, go, gi = _gather_rows(outs, counts)
+            assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi)
+            for c in cols + ocols:
+                c.free()
+    finally:
+        for ctx in comm.ctx:
+            ctx.set_option("group_from", "300000000")
+            ctx.set_option("group_always", "0")
+            ctx.set_option("group_inner", "64000000")
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_unique_rows_and_host_rows_through_the_multi_gpu_entry_points(worlds, oracle, world):
     comm = worlds(world)
