@@ -31,7 +31,7 @@ EXPORTS = [
     "hjgpu_npj_async", "hjgpu_phj_async", "hjgpu_cpra_async", "hjgpu_phj_overlapped_async",
     "hjgpu_phj_build", "hjgpu_phj_probe", "hjgpu_phj_probe_async",
     "hjgpu_partition_packed_async", "hjgpu_partition_packed_own_last_async", "hjgpu_phj_build_prepartitioned", "hjgpu_phj_probe_prepartitioned_async",
-    "hjgpu_partition_packed_counted_async", "hjgpu_phj_probe_prepartitioned_counted_async", "hjgpu_prepartitioned_plan",
+    "hjgpu_partition_packed_counted_async", "hjgpu_phj_probe_prepartitioned_counted_async", "hjgpu_prepartitioned_plan", "hjgpu_grouped_plan",
     "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
     "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
     "hjgpu_comm_get_info", "hjgpu_comm_preflight", "hjgpu_comm_get_forensics",
@@ -257,6 +257,7 @@ def load_library(build_if_missing=True):
     L.hjgpu_partition_packed_counted_async.argtypes = [vp, vp, vp, sz, u32, u32, u32, u32, u32, u32, vp, vp, vp, vp]
     L.hjgpu_phj_probe_prepartitioned_counted_async.argtypes = [vp, vp, C.POINTER(PrePartitioned), vp, vp, vp]
     L.hjgpu_prepartitioned_plan.argtypes = [vp, sz, u32, C.POINTER(PhjParams), C.POINTER(u32), C.POINTER(u32)]
+    L.hjgpu_grouped_plan.argtypes = [vp, sz, sz, C.POINTER(PhjParams), C.POINTER(u32)]
     L.hjgpu_phj_build_prepartitioned.argtypes = [vp, vp, C.POINTER(PrePartitioned), sz, C.POINTER(PhjParams), vp]
     L.hjgpu_phj_probe_prepartitioned_async.argtypes = [vp, vp, C.POINTER(PrePartitioned), vp, vp]
     L.hjgpu_join_host.argtypes = [vp, C.c_int, vp, vp, sz, vp, vp, sz, C.POINTER(PhjParams),

@@ -189,6 +189,16 @@ uint32_t grouped_groups(const hjgpu_ctx *ctx, size_t inner, size_t outer, const 
     return (uint32_t)std::min<size_t>((inner + per - 1) / per, 192);
 }
 
+}  // namespace hjapi (closed for the entry point below)
+int hjgpu_grouped_plan(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *params, uint32_t *groups)
+{
+    if (!ctx || !groups) return HJGPU_EINVAL;
+    const uint32_t g = hjapi::grouped_groups(ctx, inner, outer, params);
+    *groups = g > 1 ? g : 0;
+    return HJGPU_OK;
+}
+namespace hjapi {
+
 GroupLayout group_layout(uint32_t G)
 {
     GroupLayout l;

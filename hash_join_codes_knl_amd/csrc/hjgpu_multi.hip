@@ -170,6 +170,8 @@ struct hjgpu_comm {
     bool cpra_fused_counts = true;           // option "cpra_fused_counts": the senders' histogram pass counts the receivers' final partitions
                                              // too when G * k * F2 <= 32768 (build sides up to ~114 M rows): the receivers skip K4p
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
+    bool cpra_grouped = true;                // option "cpra_grouped": a rank's share beyond two passes' reach is joined by a grouped plan (the ranks
+                                             // agree on it from the relations' total sizes: one 16-byte all-reduce before the build side's exchange)
     char err[512];
     char why_broken[512];
     std::mutex err_mu;                       // the local ranks' enqueue work runs on one host thread per rank (each_rank)
@@ -591,6 +593,10 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     r.device = device; r.global = global;
     int rc = hjgpu_create(device, &r.join);
     if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_create(join context)");
+    // a grouped plan of a rank's local join is waited for by the rank's own host thread (the multi-GPU joins are blocking calls): no
+    // stream of the rank is ever held in hardware for commands that are not enqueued yet
+    rc = hjgpu_set_option(r.join, "group_async", "0");
+    if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_set_option(join context, group_async)");
     rc = hjgpu_create(device, &r.part);
     if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_create(partition context)");
     HIPM(c, hipSetDevice(device));
@@ -1187,9 +1193,40 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
             (void)hjgpu_audit_read(c->ranks[l].part, &seq_part[(size_t)l], 0, 0, nullptr, nullptr);
             (void)hjgpu_audit_read(c->ranks[l].join, &seq_join[(size_t)l], 0, 0, nullptr, nullptr);
         }
+    // A rank's share beyond two passes' reach (a build side of ~228 M rows per rank and more, with a probe side large enough for a
+    // third pass to pay: hjgpu_grouped_plan, the rule of hjgpu_phj) is joined by a GROUPED plan.  Every rank has to take the same
+    // road - it decides the shape of the exchange - so the rule is fed what every rank can know: the relations' TOTAL sizes (one
+    // all-reduce of two words), a rank's share taken as 1 / G of them.  The grouped road: exchange with fan-out G in separate
+    // columns (round 2's two-level plan), the probe side in ONE slice, then the rank's complete local join - whose plan groups.
+    bool grouped = false;
+    const int asked_slices = slices;
+    if (c->cpra_grouped) {
+        std::vector<u64 *> words;
+        for (int l = 0; l < L; ++l) {
+            Rank &r = c->ranks[l];
+            HIPM(c, hipSetDevice(r.device));
+            u64 *h = hp_result(r, G);
+            h[0] = shards[l].inner; h[1] = shards[l].outer;
+            HIPM(c, hipMemcpyAsync(r.d_cnt.p, h, 2 * sizeof(u64), hipMemcpyHostToDevice, r.comm));
+            words.push_back(static_cast<u64 *>(r.d_cnt.p));
+        }
+        const std::vector<hipStream_t> comms = streams_of(c, &Rank::comm);
+        CHKM(c->transport->all_reduce_u64(words.data(), 2, comms.data()));
+        for (int l = 0; l < L; ++l) {
+            Rank &r = c->ranks[l];
+            HIPM(c, hipSetDevice(r.device));
+            HIPM(c, hipMemcpyAsync(hp_result(r, G), r.d_cnt.p, 2 * sizeof(u64), hipMemcpyDeviceToHost, r.comm));
+        }
+        for (int l = 0; l < L; ++l) CHKM(wait_stream(c, l, c->ranks[l].comm, "sizes"));
+        const u64 *tot = hp_result(c->ranks[0], G);
+        uint32_t groups = 0;
+        JOINM(c, c->ranks[0].join, hjgpu_grouped_plan(c->ranks[0].join, (size_t)(tot[0] / G), (size_t)(tot[1] / G), prm, &groups));
+        grouped = groups > 1;
+        if (grouped) slices = 1;
+    }
     // one-level plan while the receiver can take one piece per source rank (<= 8 pieces): fan-out G * k with G * k <= 192,
     // the widest pass 1 whose whole-line carry still fits beside a 16 K-tuple tile
-    if (c->nranks <= 8 && !c->cpra_two_level) step.k = (uint32_t)(c->cpra_k > 0 && c->cpra_k * c->nranks <= 192 ? c->cpra_k : 192 / c->nranks);
+    if (c->nranks <= 8 && !c->cpra_two_level && !grouped) step.k = (uint32_t)(c->cpra_k > 0 && c->cpra_k * c->nranks <= 192 ? c->cpra_k : 192 / c->nranks);
     const uint32_t K = step.k;
     // the layout of what local rank l received (pieces = one per source rank), rows [lo, hi) of it
     auto layout_of = [&](int l, const std::vector<u64> &pieces, u64 lo, u64 hi) {
@@ -1246,9 +1283,13 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         // the workspace is sized for 1.5 of that, larger batches are probed in pieces
         const size_t per = shards[l].outer / (size_t)slices + 16;
         max_outer[l] = (per * 3 / 2 > ((size_t)1 << 20) ? per * 3 / 2 : ((size_t)1 << 20)) & ~size_t(15);
+        if (grouped) max_outer[l] = ~size_t(0) >> 1;         // the local join takes what arrived in one call
         HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipStreamWaitEvent(r.main, r.ev_rx, 0));
+        // (the grouped road enqueues nothing here: its one local join waits for the probe side's exchange, which the exchange stream
+        // runs after the build side's)
+        if (!grouped) HIPM(c, hipStreamWaitEvent(r.main, r.ev_rx, 0));
         if (from_host && l == 0) HIPM(c, hipEventRecord(r.ev_t0, r.main));
+        if (grouped) continue;                               // no prepared build side: the local join is one whole hjgpu_phj
         if (inner_recv[l] && K) {
             const hjgpu_prepartitioned lay = layout_of(l, inner_pieces[l], inner_pieces[l][0], inner_pieces[l][0] + inner_recv[l]);
             JOINM(c, r.join, hjgpu_phj_build_prepartitioned(r.join, static_cast<const uint64_t *>(inner_base[l]), &lay, max_outer[l], prm, r.main));
@@ -1261,7 +1302,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     // slice's times means waiting for that slice - which would hold the single driving host thread until join(i-1)
     // has finished before partition(i+1) can be enqueued, i.e. the pipeline would be measured out of shape.
     // The build's times are read when the host blocks anyway (the first probe slice's partition counts).
-    bool build_stats_pending = stats && inner_recv[0];
+    bool build_stats_pending = stats && inner_recv[0] && !grouped;
     // ---- probe side in slices: partition(i+1) | exchange(i) | join(i-1) ----------------------------------
     // R join S = union_i (R join S_i): the slice results add up (add_result_kernel).
     // Materialised rows: a slice's rows follow the rows of the slices before it in the rank's result columns; where
@@ -1324,7 +1365,13 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                         else
                         JOINM(c, r.join, hjgpu_phj_probe_prepartitioned_async(r.join, static_cast<const uint64_t *>(got_base[l]), &lay,
                                                                               reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
-                    } else
+                    } else if (grouped)
+                        // the rank's whole local join; its plan groups where the share needs it (the build side has arrived: the exchange
+                        // stream received it before the probe side, whose arrival this stream has just waited for)
+                        JOINM(c, r.join, hjgpu_phj_overlapped_async(r.join, static_cast<const uint32_t *>(r.rrecv_k.p), static_cast<const uint32_t *>(r.rrecv_v.p),
+                                                                    (size_t)inner_recv[l], sk + b, sv + b, m, prm,
+                                                                    reinterpret_cast<hjgpu_result *>(acc + 8), r.main, nullptr));
+                    else
                     JOINM(c, r.join, hjgpu_phj_probe_async(r.join, sk + b, sv + b, m, reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
                     hipLaunchKernelGGL(add_result_kernel, dim3(1), dim3(64), 0, r.main, acc, acc + 8);
                     HIPM(c, hipGetLastError());
@@ -1356,7 +1403,9 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         // and only then does the host wait for partition(i)'s counts: the device works on join(i-1) and partition(i)
         // while the host and the ranks settle the sizes of exchange(i) (with the join enqueued after that wait, every
         // slice cost a world of one ~0.15-0.2 ms of idle device: 4 slices 13.0 -> 12.2-12.6 ms, 8 slices 16.7 -> 14.9-15.0 ms)
-        CHKM(step.begin_exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr, from_host && slice_events ? i : -1));
+        // (host path with an event per uploaded slice: the one slice of a grouped join is the whole shard - its last upload)
+        CHKM(step.begin_exchange(in, 1 + slot, slot, from_host ? &Rank::ev_up_s : nullptr,
+                                 from_host && slice_events ? (grouped ? asked_slices - 1 : i) : -1));
         if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
         CHKM(step.finish_exchange(in, 1 + slot, slot));
         if (build_stats_pending && i == 0) {
@@ -1616,6 +1665,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
     if (strcmp(name, "exchange_in_place") == 0) { c->exchange_in_place = x != 0; return HJGPU_OK; }
     if (strcmp(name, "cpra_k") == 0) { if (x < 0 || x > 192) return cfail(c, HJGPU_EINVAL, "cpra_k: 0 ... 192"); c->cpra_k = (int)x; return HJGPU_OK; }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
+    if (strcmp(name, "cpra_grouped") == 0) { c->cpra_grouped = x != 0; return HJGPU_OK; }
     if (strcmp(name, "cpra_fused_counts") == 0) { c->cpra_fused_counts = x != 0; return HJGPU_OK; }
     if (strcmp(name, "host_rows_batched") == 0) { c->host_rows_batched = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }

@@ -417,6 +417,10 @@ int  hjgpu_phj_probe_prepartitioned_counted_async(hjgpu_ctx *ctx, const uint64_t
                                                   const uint64_t *d_counts, hjgpu_result *d_result, void *stream);
 int  hjgpu_prepartitioned_plan(hjgpu_ctx *ctx, size_t inner, uint32_t fanout1, const hjgpu_phj_params *params,
                                uint32_t *fanout2, uint32_t *factor2);
+/* The planning rule of hjgpu_phj / hjgpu_cpra for relations of these sizes (the reference plans its passes from the partition
+ * count, phj.cpp:1791-1808): *groups = the groups of the grouped plan, 0 = one or two passes.  hjgpu_cpra_multi asks it, with a
+ * rank's share of the relations' total sizes, which road its ranks take. */
+int  hjgpu_grouped_plan(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *params, uint32_t *groups);
 
 /* ---- whole joins on HOST columns (what the npj/phj/cpra mains call after
  * their fread()s, npj.cpp:1013-1039): upload, join, return aggregates.
@@ -526,7 +530,11 @@ hjgpu_ctx *hjgpu_comm_ctx(hjgpu_comm *comm, int local_rank);
  * the process can exit.  "stall_rank" (k) / "stall_ms" (n): fault injection for tests, loopback transport only - rank
  * k arrives n ms late at every collective.  "exchange_in_place" (0 / 1, default 1): a CPRA rank keeps its own partitions
  * where its partitioning wrote them and receives the others' pieces behind them (no copy of the message to itself);
- * "cpra_two_level" (0 / 1): round 2's CPRA plan (used automatically beyond 8 ranks); "self_via_rccl" (tests);
+ * "cpra_two_level" (0 / 1): round 2's CPRA plan (used automatically beyond 8 ranks); "cpra_grouped" (0 / 1, default 1): the ranks
+ * agree, from the relations' total sizes (one all-reduce of two words before the build side's exchange), whether a rank's share needs a
+ * grouped plan (hjgpu_grouped_plan on local rank 0's join context: set "group_from" / "group_inner" / "group_always" alike on every
+ * rank); if so the exchange has fan-out ranks, the probe side travels in one slice and every rank runs a whole local join whose plan
+ * groups; "self_via_rccl" (tests);
  * "debug_forensics" (0 / 1, hjgpu_comm_get_forensics below). */
 int  hjgpu_comm_set_option(hjgpu_comm *comm, const char *name, const char *value);
 /* What the communicator really is: the transport's own view of the world (ncclCommCount / ncclCommUserRank /

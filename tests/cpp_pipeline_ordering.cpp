@@ -16,7 +16,7 @@
 //     that does not own its partition, a sender's count that differs from what arrived: an ERROR), joins really joined -
 //     so the result of every scenario is compared with a map-based join of the inputs;
 //   * fault injection: --drop-wait k ignores the k-th hipStreamWaitEvent of the run (the checker must then report).
-// usage: cpp_pipeline_ordering <algo cpra|cpra-host|phj-host|npj-host|phj|npj> <world> <slices> [--rows] [--no-fused] [--no-in-place] [--two-level]
+// usage: cpp_pipeline_ordering <algo cpra|cpra-host|phj-host|npj-host|phj|npj> <world> <slices> [--rows] [--no-fused] [--no-in-place] [--two-level] [--grouped]
 //                              [--drop-wait k] [--list-waits] [--inner n] [--outer n] [--seed s] [--steps n]
 // prints one line: "ok|FAIL waits=<hipStreamWaitEvent calls> ops=<n> violations=<n> ..."; exit status 0 = result right and no violation.
 #include <algorithm>
@@ -388,6 +388,8 @@ int hjgpu_partition_async(hjgpu_ctx *c, const uint32_t *k, const uint32_t *v, si
     memcpy(off, prefix.data(), ((size_t)F + 1) * 8);
     return HJGPU_OK;
 }
+bool mock_grouped = false;                   // --grouped: the planning rule says "grouped" (the ranks then take CPRA's grouped road)
+int hjgpu_grouped_plan(hjgpu_ctx *, size_t, size_t, const hjgpu_phj_params *, uint32_t *groups) { *groups = mock_grouped ? 4 : 0; return HJGPU_OK; }
 int hjgpu_prepartitioned_plan(hjgpu_ctx *, size_t, uint32_t, const hjgpu_phj_params *prm, uint32_t *F2, uint32_t *f2)
 {
     *F2 = (prm && prm->fanout2) ? prm->fanout2 : 5;
@@ -549,6 +551,7 @@ int main(int argc, char **argv)
         else if (a == "--no-fused") fused = false;
         else if (a == "--no-in-place") in_place = false;
         else if (a == "--two-level") two_level = true;
+        else if (a == "--grouped") mock_grouped = true;
         else if (a == "--drop-wait" && i + 1 < argc) rec::drop_wait = atol(argv[++i]);
         else if (a == "--list-waits") rec::list_waits = true;
         else if (a == "--inner" && i + 1 < argc) inner = (size_t)atol(argv[++i]);

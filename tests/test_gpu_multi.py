@@ -649,6 +649,47 @@ def test_replicated_build_is_joined_by_a_grouped_plan_where_a_rank_needs_one(wor
             ctx.set_option("group_inner", "64000000")
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind", ["unique", "dups", "half"])
+def test_cpra_takes_the_grouped_road_where_a_ranks_share_needs_it(worlds, oracle, world, kind):
+    """hjgpu_cpra_multi / hjgpu_cpra_multi_rows with options group_from / group_always on the ranks' contexts: the ranks agree from
+    the relations' total sizes (hjgpu_grouped_plan) to exchange with fan-out ranks, the probe side in one slice, and to run a whole
+    local join per rank whose plan groups (phj.cpp:1791-1808's third pass on a rank's share).  Aggregates and rows equal the
+    definition; comm option cpra_grouped = 0 keeps the one-level plan (multi-fill partitions), same answer."""
+    comm = worlds(world)
+    ik, iv, ok, ov = relations(oracle, kind, seed=50 + world)
+    want = numpy_join(ik, iv, ok, ov)
+    wk, wo, wi = materialised_rows(ik, iv, ok, ov)
+    per = max(len(ik) // world // 5, 1)
+    for ctx in comm.ctx:
+        ctx.set_option("group_from", "1000")
+        ctx.set_option("group_always", "1")
+        ctx.set_option("group_inner", str(per))
+    try:
+        shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+        for slices in (0, 3):
+            got, st = comm.cpra_multi(shards, None, slices)
+            assert got == want, (world, kind, slices)
+            assert st["join"]["groups"] >= 4 and st["join"]["ms_scatter0"] > 0, st["join"]
+        comm.set_option("cpra_grouped", 0)
+        got, st = comm.cpra_multi(shards, None, 3)
+        assert got == want and st["join"]["groups"] == 0
+        comm.set_option("cpra_grouped", 1)
+        outs, ocols = _rank_outputs(comm, [want[0]] * world, 1024, 2, max(s[5] for s in shards) * world)
+        got_rows, _, counts = comm.cpra_multi_rows(shards, outs, None, 3)
+        assert got_rows == want and sum(counts) == want[0]
+        gk, go, gi = _gather_rows(outs, counts)
+        assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi)
+        for c in cols + ocols:
+            c.free()
+    finally:
+        comm.set_option("cpra_grouped", 1)
+        for ctx in comm.ctx:
+            ctx.set_option("group_from", "300000000")
+            ctx.set_option("group_always", "0")
+            ctx.set_option("group_inner", "64000000")
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_unique_rows_and_host_rows_through_the_multi_gpu_entry_points(worlds, oracle, world):
     comm = worlds(world)

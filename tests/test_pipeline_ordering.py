@@ -40,6 +40,8 @@ def run(exe, *args):
 CPRA = [(w, s, o) for w in (1, 2, 3, 8) for s in (1, 3, 4, 8) for o in ((), ("--rows",))]
 CPRA += [(w, s, o) for w in (1, 2, 3) for s in (1, 4)
          for o in (("--no-fused",), ("--no-in-place",), ("--no-fused", "--no-in-place"), ("--two-level",), ("--rows", "--no-fused"))]
+# the grouped road (a rank's share beyond two passes' reach: sizes all-reduce, exchange in separate columns, one slice, whole local join)
+CPRA += [(w, 4, o) for w in (1, 2, 3, 8) for o in (("--grouped",), ("--grouped", "--rows"))]
 
 
 @pytest.mark.parametrize("world,slices,options", CPRA)
@@ -60,7 +62,7 @@ def test_replicated_build_side_joins_are_ordered(recorder, algo, world, options)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-@pytest.mark.parametrize("options", [(), ("--rows",), ("--no-fused",)])
+@pytest.mark.parametrize("options", [(), ("--rows",), ("--no-fused",), ("--grouped",)])
 def test_cpra_from_host_columns_is_ordered(recorder, world, options):
     """hjgpu_join_host_multi / hjgpu_join_host_rows_multi, CPRA: the build side is uploaded first, the probe shard in the eight
     slices the join takes it in - slice i's partitioning waits for slice i's upload event only (cpra2.cpp:2110-2136 reads all
@@ -78,7 +80,7 @@ def test_replicated_joins_from_host_columns_are_ordered(recorder, algo, world):
     assert rc == 0 and "violations=0 errors=0 result=right" in out, out
 
 
-@pytest.mark.parametrize("scenario", [("cpra-host", 2, 0), ("phj-host", 3, 0), ("cpra", 1, 4), ("cpra", 2, 3), ("cpra", 3, 2, "--no-in-place"), ("cpra", 2, 2, "--rows"), ("phj", 3, 1), ("npj", 2, 1)])
+@pytest.mark.parametrize("scenario", [("cpra-host", 2, 0), ("phj-host", 3, 0), ("cpra", 1, 4), ("cpra", 2, 3), ("cpra", 3, 2, "--no-in-place"), ("cpra", 2, 2, "--rows"), ("cpra", 2, 4, "--grouped"), ("cpra-host", 2, 0, "--grouped"), ("phj", 3, 1), ("npj", 2, 1)])
 def test_removing_any_wait_that_orders_something_is_reported(recorder, scenario):
     """Every hipStreamWaitEvent of the run that adds an edge (the waiting stream and the enqueuing host thread do not know the
     event's clock yet) is needed: without it the recorder reports an unordered access or the join comes out wrong.  The

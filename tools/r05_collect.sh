@@ -12,6 +12,7 @@ for f in r05_validation.txt r05_validation2.txt; do
   grep -v "^\.\.\." gpurun_out/$f > profiles/$f
 done
 for f in r05_bench.json r05_bench_force_dist_configs4.json r05_bench_force_dist_cpra.json r05_bench_force_dist_npj.json r05_bench_force_dist_cpra_8slices.json r05_bench_rehearse_solo.json \
+         r05_bench_force_dist_phj_1G_4G.json r05_bench_force_dist_cpra_700M_4G.json r05_bench_force_dist_cpra_700M_4G_ungrouped.json \
          r05_traffic.json r05_npj_traffic.json r05_cpra_traffic.json r05_materialized_traffic.json r05_unique_traffic.json; do
   [ -s gpurun_out/$f ] || { echo "missing: $f"; ok=0; continue; }
   h=$(python3 -c "import json,sys; print(json.load(open('gpurun_out/$f')).get('kernel_hash'))")

@@ -39,21 +39,21 @@ validation)
   HJ_FUZZ_SEED=9501 HJ_FUZZ_CASES=600 timeout -k 10 600 python3 -m pytest tests/test_gpu_fuzz.py -m gpu -q 2>&1 | tail -1 | tee -a $out/$sweep | grep -q " passed" || { note "fuzz failed"; bad=1; }
   echo "## HJ_FUZZ_SEED=9502 HJ_FUZZ_CASES=400 tests/test_gpu_multi.py -k random_multi" >> $out/$sweep
   HJ_FUZZ_SEED=9502 HJ_FUZZ_CASES=400 timeout -k 10 400 python3 -m pytest tests/test_gpu_multi.py -m gpu -q -k random_multi 2>&1 | tail -1 | tee -a $out/$sweep | grep -q " passed" || { note "random_multi failed"; bad=1; }
-  stress --steps 20000 --slices 8
-  stress --steps 20000 --slices 8 --unique
+  stress --steps 15000 --slices 8
+  stress --steps 15000 --slices 8 --unique
   note "validation bad=$bad"; [ $bad = 0 ] || exit 1
   ;;
 validation2)
   sweep=r05_validation2.txt; bad=0
   echo "# validation sweep, second part, kernel hash $hash, $(date -u +%FT%RZ)" > $out/$sweep
-  stress --steps 6000 --slices 8 --world 2 --transport loopback --unique
-  stress --steps 3000 --slices 4 --world 8 --transport loopback
-  stress --steps 8000 --slices 8 --option exchange_in_place=0
-  stress --steps 8000 --slices 1
-  HJGPU_DEBUG_FLAT_PRIORITIES=1 stress --steps 15000 --slices 8
+  stress --steps 4000 --slices 8 --world 2 --transport loopback --unique
+  stress --steps 2000 --slices 4 --world 8 --transport loopback
+  stress --steps 5000 --slices 8 --option exchange_in_place=0
+  stress --steps 5000 --slices 1
+  HJGPU_DEBUG_FLAT_PRIORITIES=1 stress --steps 8000 --slices 8
   # the solo form (blocking hjgpu_phj on one stream with option solo: partial-line stores plain, DESIGN section 3 "Round 5"): every step checked
-  echo "## tools/stress_single.py --algo phj --steps 15000 --solo" >> $out/$sweep
-  timeout -k 10 400 python3 tools/stress_single.py --algo phj --steps 15000 --solo 2>&1 | quiet | tee -a $out/$sweep | grep --line-buffered "^\.\.\."
+  echo "## tools/stress_single.py --algo phj --steps 10000 --solo" >> $out/$sweep
+  timeout -k 10 400 python3 tools/stress_single.py --algo phj --steps 10000 --solo 2>&1 | quiet | tee -a $out/$sweep | grep --line-buffered "^\.\.\."
   [ ${PIPESTATUS[0]} = 0 ] || { note "WRONG or failed: stress_single.py"; bad=1; }
   note "validation2 bad=$bad"; [ $bad = 0 ] || exit 1
   ;;
@@ -73,6 +73,11 @@ dist)
     timeout -k 10 300 python3 bench.py --force-dist --algo $algo --steps 8 --warmup 2 --cpu-outer 0 > $out/r05_bench_force_dist_$algo.json 2> $out/r05_fd_$algo.err; note "fd $algo rc=$?"
   done
   timeout -k 10 300 python3 bench.py --force-dist --algo cpra --steps 8 --warmup 2 --cpu-outer 0 --exchange-slices 8 > $out/r05_bench_force_dist_cpra_8slices.json 2>/dev/null
+  # a rank's share beyond two passes' reach, through the multi-GPU entry points at RCCL world 1: PHJ 1 G x 4 G (the rank's local join groups),
+  # CPRA 700 M x 4 G on the grouped road and, for comparison, with comm option cpra_grouped=0 (one-level plan, multi-fill partitions)
+  timeout -k 10 300 python3 bench.py --force-dist --inner 1000000000 --outer 4000000000 --steps 3 --warmup 1 --cpu-outer 0 --no-secondary > $out/r05_bench_force_dist_phj_1G_4G.json 2> $out/r05_fd_phj_big.err; note "fd phj 1Gx4G rc=$?"
+  timeout -k 10 300 python3 bench.py --force-dist --algo cpra --inner 700000000 --outer 4000000000 --steps 3 --warmup 1 --cpu-outer 0 --no-secondary > $out/r05_bench_force_dist_cpra_700M_4G.json 2> $out/r05_fd_cpra_big.err; note "fd cpra 700Mx4G grouped rc=$?"
+  timeout -k 10 300 python3 bench.py --force-dist --algo cpra --inner 700000000 --outer 4000000000 --steps 3 --warmup 1 --cpu-outer 0 --no-secondary --comm-option cpra_grouped=0 > $out/r05_bench_force_dist_cpra_700M_4G_ungrouped.json 2> $out/r05_fd_cpra_big0.err; note "fd cpra 700Mx4G ungrouped rc=$?"
   timeout -k 10 500 python3 bench.py --gpus 2 --rehearse-solo --steps 4 --warmup 1 --cpu-outer 0 --configs4-steps 2 > $out/r05_bench_rehearse_solo.json 2> $out/r05_rehearse.err; note "rehearse-solo rc=$?"
   ;;
 report)
