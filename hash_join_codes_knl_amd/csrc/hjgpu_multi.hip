@@ -170,8 +170,9 @@ struct hjgpu_comm {
     bool cpra_fused_counts = true;           // option "cpra_fused_counts": the senders' histogram pass counts the receivers' final partitions
                                              // too when G * k * F2 <= 32768 (build sides up to ~114 M rows): the receivers skip K4p
     bool cpra_two_level = false;             // option "cpra_two_level": round 2's CPRA (exchange with fan-out G, then a complete local PHJ)
-    bool cpra_grouped = true;                // option "cpra_grouped": a rank's share beyond two passes' reach is joined by a grouped plan (the ranks
-                                             // agree on it from the relations' total sizes: one 16-byte all-reduce before the build side's exchange)
+    int cpra_grouped = 1;                    // option "cpra_grouped": a rank's share beyond two passes' reach is joined by a grouped plan (the ranks
+                                             // agree on it from the relations' total sizes: one 16-byte all-reduce before the build side's exchange);
+                                             // 1: where the grouped ROAD pays (cpra_join), 2: wherever hjgpu_grouped_plan groups (tests), 0: never
     char err[512];
     char why_broken[512];
     std::mutex err_mu;                       // the local ranks' enqueue work runs on one host thread per rank (each_rank)
@@ -1222,6 +1223,17 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         uint32_t groups = 0;
         JOINM(c, c->ranks[0].join, hjgpu_grouped_plan(c->ranks[0].join, (size_t)(tot[0] / G), (size_t)(tot[1] / G), prm, &groups));
         grouped = groups > 1;
+        if (grouped && c->cpra_grouped == 1) {
+            // The ROAD costs more than hjgpu_phj's grouped plan: its exchange is a pass over both relations that is no pass of the join
+            // (the one-level plan's exchange IS the join's pass 1), and exchange and join do not overlap.  hjgpu_phj's rule (hjgpu_api.hip
+            // grouped_groups) with two passes' worth of overhead instead of one: every table fill beyond the first probes a partition's
+            // probe tuples again, ~3.2 ms per 10^9 probe tuples and fill; a pass is ~5 ms per 10^9 tuples of both relations.  Measured
+            // at RCCL world 1 (profiles/r05_bench_force_dist_cpra_700M_4G*.json): 700 M x 4 G 70.0 ms on the one-level plan (3 fills per
+            // partition), 111.5 ms on the grouped road - the rule says one-level; it says grouped from ~9 fills on (2 G x 8 G per rank).
+            const double in = (double)(tot[0] / G), out = (double)(tot[1] / G);
+            const double reach = (double)(HJGPU_MAX_PARTS / 2) * 16384.0 * 0.85;       // two passes, 16 K-slot tables: ~228 M build rows
+            if ((in / reach - 1.0) * 3.2 * out < 1.1 * 2.0 * 5.0 * (in + out)) grouped = false;
+        }
         if (grouped) slices = 1;
     }
     // one-level plan while the receiver can take one piece per source rank (<= 8 pieces): fan-out G * k with G * k <= 192,
@@ -1665,7 +1677,7 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
     if (strcmp(name, "exchange_in_place") == 0) { c->exchange_in_place = x != 0; return HJGPU_OK; }
     if (strcmp(name, "cpra_k") == 0) { if (x < 0 || x > 192) return cfail(c, HJGPU_EINVAL, "cpra_k: 0 ... 192"); c->cpra_k = (int)x; return HJGPU_OK; }
     if (strcmp(name, "cpra_two_level") == 0) { c->cpra_two_level = x != 0; return HJGPU_OK; }
-    if (strcmp(name, "cpra_grouped") == 0) { c->cpra_grouped = x != 0; return HJGPU_OK; }
+    if (strcmp(name, "cpra_grouped") == 0) { if (x < 0 || x > 2) return cfail(c, HJGPU_EINVAL, "cpra_grouped: 0, 1 or 2"); c->cpra_grouped = (int)x; return HJGPU_OK; }
     if (strcmp(name, "cpra_fused_counts") == 0) { c->cpra_fused_counts = x != 0; return HJGPU_OK; }
     if (strcmp(name, "host_rows_batched") == 0) { c->host_rows_batched = x != 0; return HJGPU_OK; }
     if (strcmp(name, "debug_serialize") == 0) { c->debug_serialize = (int)x; return HJGPU_OK; }

@@ -566,6 +566,7 @@ int main(int argc, char **argv)
     hjgpu_comm_set_option(comm, "cpra_fused_counts", fused ? "1" : "0");
     hjgpu_comm_set_option(comm, "exchange_in_place", in_place ? "1" : "0");
     hjgpu_comm_set_option(comm, "cpra_two_level", two_level ? "1" : "0");
+    hjgpu_comm_set_option(comm, "cpra_grouped", mock_grouped ? "2" : "1");      // 2: the road whenever the planning rule groups
     // relations: unique non-zero build keys, probe keys drawn from them and from outside, ragged shares (one rank may get nothing)
     std::vector<uint32_t> ik(inner), iv(inner), ok(outer), ov(outer);
     for (size_t i = 0; i < inner; ++i) { ik[i] = (uint32_t)(i + 1) * 2654435761u | 1u; iv[i] = rnd(); }

@@ -667,14 +667,16 @@ def test_cpra_takes_the_grouped_road_where_a_ranks_share_needs_it(worlds, oracle
         ctx.set_option("group_inner", str(per))
     try:
         shards, cols = chunked_shards(comm, ik, iv, ok, ov)
+        comm.set_option("cpra_grouped", 2)               # wherever the planning rule groups (1: only where the road's extra pass pays)
         for slices in (0, 3):
             got, st = comm.cpra_multi(shards, None, slices)
             assert got == want, (world, kind, slices)
             assert st["join"]["groups"] >= 4 and st["join"]["ms_scatter0"] > 0, st["join"]
-        comm.set_option("cpra_grouped", 0)
-        got, st = comm.cpra_multi(shards, None, 3)
-        assert got == want and st["join"]["groups"] == 0
-        comm.set_option("cpra_grouped", 1)
+        for never in (0, 1):                             # the one-level plan (multi-fill partitions where needed), same answer
+            comm.set_option("cpra_grouped", never)
+            got, st = comm.cpra_multi(shards, None, 3)
+            assert got == want and st["join"]["groups"] == 0
+        comm.set_option("cpra_grouped", 2)
         outs, ocols = _rank_outputs(comm, [want[0]] * world, 1024, 2, max(s[5] for s in shards) * world)
         got_rows, _, counts = comm.cpra_multi_rows(shards, outs, None, 3)
         assert got_rows == want and sum(counts) == want[0]

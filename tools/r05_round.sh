@@ -74,9 +74,10 @@ dist)
   done
   timeout -k 10 300 python3 bench.py --force-dist --algo cpra --steps 8 --warmup 2 --cpu-outer 0 --exchange-slices 8 > $out/r05_bench_force_dist_cpra_8slices.json 2>/dev/null
   # a rank's share beyond two passes' reach, through the multi-GPU entry points at RCCL world 1: PHJ 1 G x 4 G (the rank's local join groups),
-  # CPRA 700 M x 4 G on the grouped road and, for comparison, with comm option cpra_grouped=0 (one-level plan, multi-fill partitions)
+  # CPRA 700 M x 4 G on the grouped road (comm option cpra_grouped=2: wherever the planning rule groups) and on the one-level plan
+  # (cpra_grouped=0; the default, 1, chooses it here: the road's extra pass does not pay at 3 fills per partition)
   timeout -k 10 300 python3 bench.py --force-dist --inner 1000000000 --outer 4000000000 --steps 3 --warmup 1 --cpu-outer 0 --no-secondary > $out/r05_bench_force_dist_phj_1G_4G.json 2> $out/r05_fd_phj_big.err; note "fd phj 1Gx4G rc=$?"
-  timeout -k 10 300 python3 bench.py --force-dist --algo cpra --inner 700000000 --outer 4000000000 --steps 3 --warmup 1 --cpu-outer 0 --no-secondary > $out/r05_bench_force_dist_cpra_700M_4G.json 2> $out/r05_fd_cpra_big.err; note "fd cpra 700Mx4G grouped rc=$?"
+  timeout -k 10 300 python3 bench.py --force-dist --algo cpra --inner 700000000 --outer 4000000000 --steps 3 --warmup 1 --cpu-outer 0 --no-secondary --comm-option cpra_grouped=2 > $out/r05_bench_force_dist_cpra_700M_4G.json 2> $out/r05_fd_cpra_big.err; note "fd cpra 700Mx4G grouped rc=$?"
   timeout -k 10 300 python3 bench.py --force-dist --algo cpra --inner 700000000 --outer 4000000000 --steps 3 --warmup 1 --cpu-outer 0 --no-secondary --comm-option cpra_grouped=0 > $out/r05_bench_force_dist_cpra_700M_4G_ungrouped.json 2> $out/r05_fd_cpra_big0.err; note "fd cpra 700Mx4G ungrouped rc=$?"
   timeout -k 10 500 python3 bench.py --gpus 2 --rehearse-solo --steps 4 --warmup 1 --cpu-outer 0 --configs4-steps 2 > $out/r05_bench_rehearse_solo.json 2> $out/r05_rehearse.err; note "rehearse-solo rc=$?"
   ;;
@@ -85,4 +86,4 @@ report)
   ;;
 *) echo "unknown part $part"; exit 2;;
 esac
-tail -5 $out/r05_rc.txt
+tail -5 $rc
