@@ -193,7 +193,7 @@ def test_grouped_plan_through_the_enqueue_only_form_returns_at_once(grouped, alg
     _free(ik, iv, ok, ov, *d)
 
 
-def test_first_grouped_join_of_a_context_through_the_enqueue_only_form(oracle):
+def test_first_grouped_join_of_a_context_through_the_enqueue_only_form(hj, oracle):
     """The worker thread of an asynchronous grouped plan grows the workspace while the caller's stream waits for it in hardware:
     it must not free anything then (hipFree waits for every stream of the device - for ever).  A fresh context, no blocking call
     before; few distinct build keys, so that the largest group is far above the mean and the worker has to grow what the call
@@ -222,6 +222,45 @@ def test_first_grouped_join_of_a_context_through_the_enqueue_only_form(oracle):
                 _free(rk, rv, sk, sv, d)
         finally:
             ctx.close()
+
+
+def test_asynchronous_grouped_joins_in_a_process_with_more_streams_than_hardware_queues(hj, oracle):
+    """Streams of one priority class share hardware queues once there are more of them than queues (4 per class): a caller's
+    stream that waits in hardware for the context's worker must not have the worker's commands queued behind it.  The worker's
+    stream is of another class than the caller's; here 24 busy streams of the default class exist before the joins, and the
+    joins are enqueued on several of them in turn (and on the legacy stream)."""
+    import torch
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(device=dev) for _ in range(24)]
+    junk = torch.zeros(1 << 20, dtype=torch.int32, device=dev)
+    for st in streams:                                   # every stream has run something: its hardware queue is assigned
+        with torch.cuda.stream(st):
+            junk.add_(1)
+    torch.cuda.synchronize()
+    ik, iv, ok, ov = oracle.generate(400_000, 120_000, seed=21)
+    want = numpy_join(ik, iv, ok, ov)
+    ctx = H.HjGpu()
+    try:
+        ctx.set_option("group_from", "1000")
+        ctx.set_option("group_always", "1")
+        ctx.set_option("group_inner", str(len(ik) // 6))
+        rk, rv, sk, sv = _cols(ctx, ik, iv, ok, ov)
+        d = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(6)]
+        torch.cuda.synchronize()
+        callers = [streams[0].cuda_stream, streams[5].cuda_stream, streams[11].cuda_stream, None, streams[23].cuda_stream, streams[2].cuda_stream]
+        for res, st in zip(d, callers):
+            ctx.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, res.data_ptr(), st)
+            for other in streams[::3]:                   # the other streams keep working beside the waiting one
+                with torch.cuda.stream(other):
+                    junk.add_(1)
+        ctx.get_async_status()
+        torch.cuda.synchronize()
+        for res in d:
+            assert tuple(int(x) & ((1 << 64) - 1) for x in res.tolist()) == want
+        assert ctx.stats()["groups"] >= 6
+        _free(rk, rv, sk, sv)
+    finally:
+        ctx.close()
 
 
 def test_pass_zero_is_independent_of_the_callers_pass_factors(grouped, oracle):
