@@ -11,6 +11,14 @@ for f in r05_validation.txt r05_validation2.txt; do
   if grep -q "WRONG" gpurun_out/$f; then echo "WRONG STEPS in $f (copied, and this script fails):"; grep "WRONG\|steps wrong" gpurun_out/$f; ok=0; fi
   grep -v "^\.\.\." gpurun_out/$f > profiles/$f
 done
+if [ -s gpurun_out/r05_validation3.txt ]; then      # optional third part
+  f=r05_validation3.txt
+  if ! grep -q "kernel hash $tree" gpurun_out/$f; then echo "REFUSED: $f does not name kernel hash $tree"; ok=0
+  else
+    if grep -q "WRONG" gpurun_out/$f; then echo "WRONG STEPS in $f (copied, and this script fails):"; grep "WRONG\|steps wrong" gpurun_out/$f; ok=0; fi
+    grep -v "^\.\.\." gpurun_out/$f > profiles/$f
+  fi
+fi
 for f in r05_bench.json r05_bench_force_dist_configs4.json r05_bench_force_dist_cpra.json r05_bench_force_dist_npj.json r05_bench_force_dist_cpra_8slices.json r05_bench_rehearse_solo.json \
          r05_bench_force_dist_phj_1G_4G.json r05_bench_force_dist_cpra_700M_4G.json r05_bench_force_dist_cpra_700M_4G_ungrouped.json \
          r05_traffic.json r05_npj_traffic.json r05_cpra_traffic.json r05_materialized_traffic.json r05_unique_traffic.json; do

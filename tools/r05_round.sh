@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 evidence run (GPU box), in the parts a 20-minute GPU call holds: tools/r05_round.sh tests | validation | validation2 | profiles | dist | report
+# Round-5 evidence run (GPU box), in the parts a 20-minute GPU call holds: tools/r05_round.sh tests | validation | validation2 | validation3 | profiles | dist | report
 # Every artefact carries the kernel hash of the library that produced it; a part stops before it measures anything when the built
 # library is not the tree's, and tools/r05_collect.sh refuses artefacts of another hash AND any sweep that contains a wrong step.
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -56,6 +56,14 @@ validation2)
   timeout -k 10 400 python3 tools/stress_single.py --algo phj --steps 10000 --solo 2>&1 | quiet | tee -a $out/$sweep | grep --line-buffered "^\.\.\."
   [ ${PIPESTATUS[0]} = 0 ] || { note "WRONG or failed: stress_single.py"; bad=1; }
   note "validation2 bad=$bad"; [ $bad = 0 ] || exit 1
+  ;;
+validation3)
+  # more of the same on the final library (the first two parts were cut to fit the round's GPU budget)
+  sweep=r05_validation3.txt; bad=0
+  echo "# validation sweep, third part, kernel hash $hash, $(date -u +%FT%RZ)" > $out/$sweep
+  stress --steps 13000 --slices 8
+  stress --steps 13000 --slices 8 --unique
+  note "validation3 bad=$bad"; [ $bad = 0 ] || exit 1
   ;;
 profiles)
   # kernel stats, PMC traffic of every leg of the N = 1 line, the default bench line with the traffic attached, SQ counters
