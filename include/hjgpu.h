@@ -267,6 +267,10 @@ int  hjgpu_npj(hjgpu_ctx *ctx,
  * the worker has been joined), and the worker's stream is of another priority class than the caller's (hardware queues are
  * pooled per class and shared inside one: the worker's commands must not queue behind the waiting stream).  The CALLER must not
  * make the worker wait either: nothing that the join's inputs depend on may be enqueued behind the call on the same stream.
+ * Beside such a join, default-priority streams that share the waiting stream's hardware queue (a process with more than 4 of them)
+ * are held until it ends, hipFree from any thread returns only then, and hipStreamQuery of other streams reports "not ready"
+ * until then although their work has run (tools/ubench_wait_value.hip, profiles/r05_wait_value.txt): callers with many streams
+ * or pollers set "group_async" = 0.
  * hjgpu_phj_overlapped_async with a grouped plan waits for the build side first and lets the calling thread wait for the groups
  * (it is hjgpu_phj_multi's local join: a rank's share of any size is grouped there).  Explicit fan-outs in
  * params are never grouped; option "group_from" = 0 turns the plan off. */
