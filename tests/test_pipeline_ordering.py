@@ -107,3 +107,18 @@ def test_removing_any_wait_that_orders_something_is_reported(recorder, scenario)
         if rc == 0:
             undetected.append(k)
     assert undetected == [], "dropped waits that went unnoticed: %r of %r" % (undetected, fresh)
+
+
+def test_the_ranks_host_threads_are_race_free_under_tsan(tmp_path_factory):
+    """The orchestration drives every local rank from a host thread of its own (each_rank): the same replay built with
+    -fsanitize=thread - shared vectors of the step, the communicator's error text, the pinned scratch - must be silent."""
+    exe = str(tmp_path_factory.mktemp("pipeline_ordering_tsan") / "pipeline_ordering_tsan")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-g", "-x", "c++", "-I", os.path.join(ROOT, "tests", "mock_hip"),
+                           "-fsanitize=thread", os.path.join(ROOT, "tests", "cpp_pipeline_ordering.cpp"), "-o", exe, "-lpthread", "-ldl"])
+    env = dict(ENV, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    for scenario in (("cpra", 2, 4), ("cpra", 3, 3, "--rows"), ("cpra", 8, 4), ("cpra", 2, 4, "--grouped"), ("cpra", 3, 4, "--no-fused", "--no-in-place"),
+                     ("cpra", 2, 1, "--two-level"), ("phj", 3, 1), ("npj", 2, 1, "--rows"), ("cpra-host", 2, 0), ("cpra-host", 2, 0, "--grouped"),
+                     ("phj-host", 3, 0), ("npj-host", 2, 0)):
+        p = subprocess.run([exe] + [str(a) for a in scenario], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0 and "ThreadSanitizer" not in p.stdout, (scenario, p.stdout[-3000:])
+        assert "violations=0 errors=0 result=right" in p.stdout, (scenario, p.stdout[-500:])
