@@ -18,16 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def resources(source):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"),
-                          os.path.join(ROOT, "hash_join_codes_knl_amd", "csrc", source)],
-                         capture_output=True, text=True, check=True).stdout
-    rows = {}
-    for line in out.splitlines():
-        m = re.match(r"(.*?)\s+vgpr\s+(\d+)\s+spill v(\d+) s(\d+)\s+scratch (\d+)\s+occ (\d+)", line)
-        if m:
-            rows[m.group(1).strip()] = dict(vgpr=int(m.group(2)), vspill=int(m.group(3)), sspill=int(m.group(4)),
-                                            scratch=int(m.group(5)), occ=int(m.group(6)))
-    return rows
+    """the compiler's kernel-resource remarks of one source (tests/device_compile.py: the same compile the ISA tests read;
+    tools/kernel_resources.py prints the same table)"""
+    from device_compile import compile_device
+    return compile_device(source)[1]
 
 
 @pytest.mark.parametrize("source", ["partition_kernels.hip", "join_kernels.hip", "npj_kernels.hip", "gen_kernels.hip",

@@ -19,10 +19,8 @@ CSRC = os.path.join(ROOT, "hash_join_codes_knl_amd", "csrc")
 
 
 def isa(source, tmp_path):
-    out = str(tmp_path / (source + ".s"))
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-DHJGPU_KERNEL_HASH=\"isa\"", "--cuda-device-only", "-S",
-                           os.path.join(CSRC, source), "-o", out], stderr=subprocess.DEVNULL)
-    text = open(out).read()
+    from device_compile import compile_device
+    text = compile_device(source)[0]
     kernels = {}
     for m in re.finditer(r"^(_Z\w+):\s*; @", text, re.M):
         body = text[m.end():text.find("s_endpgm", m.end())]
