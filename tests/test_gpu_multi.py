@@ -684,6 +684,11 @@ def test_cpra_takes_the_grouped_road_where_a_ranks_share_needs_it(worlds, oracle
         assert np.array_equal(gk, wk) and np.array_equal(go, wo) and np.array_equal(gi, wi)
         for c in cols + ocols:
             c.free()
+        # from host columns (./cpra with several GPUs): the probe shard arrives in uploaded slices, the grouped road takes it whole
+        got, st = comm.join_host_multi(2, ik, iv, ok, ov)
+        assert got == want and st["join"]["groups"] >= 4
+        got, st = comm.join_host_multi(1, ik, iv, ok, ov)            # ./phj: every rank's local join groups the replicated build side
+        assert got == want and st["join"]["groups"] >= 4
     finally:
         comm.set_option("cpra_grouped", 1)
         for ctx in comm.ctx:
