@@ -17,6 +17,22 @@
 namespace hj_exchange {
 typedef unsigned long long u64;
 
+// Does CPRA's GROUPED ROAD pay for a rank's share of `in` build and `out` probe rows (hjgpu_multi.hip cpra_join, comm option
+// "cpra_grouped" = 1)?  The road - exchange with fan-out ranks, one probe slice, a whole local join whose plan groups - costs one
+// pass more than hjgpu_phj's grouped plan: its exchange is a pass over both relations that is no pass of the join (the one-level
+// plan's exchange IS the join's pass 1), and exchange and join do not overlap.  So: hjgpu_phj's rule (hjgpu_api.hip
+// grouped_groups) with two passes' worth of overhead instead of one - every table fill beyond the first probes a partition's probe
+// rows again, ~3.2 ms per 10^9 probe rows and fill; a pass is ~5 ms per 10^9 rows of both relations.  `reach` = the build rows two
+// passes bring down to single-fill tables (max_parts / 2 partitions of 16 K-slot tables at 0.85).  Measured at RCCL world 1
+// (profiles/r05_bench_force_dist_cpra_700M_4G*.json): 700 M x 4 G 70.0 ms on the one-level plan (3 fills per partition), 105.8 ms on
+// the grouped road - the rule says one-level there; it says grouped from ~9 fills on (2 G x 8 G per rank).
+inline bool grouped_road_pays(u64 in, u64 out, u64 max_parts)
+{
+    const double reach = (double)(max_parts / 2) * 16384.0 * 0.85;
+    const double fills = (double)in / reach;
+    return (fills - 1.0) * 3.2 * (double)out >= 1.1 * 2.0 * 5.0 * ((double)in + (double)out);
+}
+
 // where this rank's message to every destination starts in its send buffer, and how long it is
 inline void send_layout(const u64 *prefix, size_t per, int G, int me, u64 n, bool own_last, u64 *soff, u64 *scnt)
 {

@@ -1223,17 +1223,8 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         uint32_t groups = 0;
         JOINM(c, c->ranks[0].join, hjgpu_grouped_plan(c->ranks[0].join, (size_t)(tot[0] / G), (size_t)(tot[1] / G), prm, &groups));
         grouped = groups > 1;
-        if (grouped && c->cpra_grouped == 1) {
-            // The ROAD costs more than hjgpu_phj's grouped plan: its exchange is a pass over both relations that is no pass of the join
-            // (the one-level plan's exchange IS the join's pass 1), and exchange and join do not overlap.  hjgpu_phj's rule (hjgpu_api.hip
-            // grouped_groups) with two passes' worth of overhead instead of one: every table fill beyond the first probes a partition's
-            // probe tuples again, ~3.2 ms per 10^9 probe tuples and fill; a pass is ~5 ms per 10^9 tuples of both relations.  Measured
-            // at RCCL world 1 (profiles/r05_bench_force_dist_cpra_700M_4G*.json): 700 M x 4 G 70.0 ms on the one-level plan (3 fills per
-            // partition), 111.5 ms on the grouped road - the rule says one-level; it says grouped from ~9 fills on (2 G x 8 G per rank).
-            const double in = (double)(tot[0] / G), out = (double)(tot[1] / G);
-            const double reach = (double)(HJGPU_MAX_PARTS / 2) * 16384.0 * 0.85;       // two passes, 16 K-slot tables: ~228 M build rows
-            if ((in / reach - 1.0) * 3.2 * out < 1.1 * 2.0 * 5.0 * (in + out)) grouped = false;
-        }
+        // (1: only where the road's extra pass pays - exchange_layout.hpp grouped_road_pays says why and where)
+        if (grouped && c->cpra_grouped == 1 && !hj_exchange::grouped_road_pays(tot[0] / G, tot[1] / G, HJGPU_MAX_PARTS)) grouped = false;
         if (grouped) slices = 1;
     }
     // one-level plan while the receiver can take one piece per source rank (<= 8 pieces): fan-out G * k with G * k <= 192,

@@ -119,8 +119,27 @@ static int play(int G, int k, bool own_last, int shape, double headroom)
     return in_place << 8;       // how many ranks exchanged in place (reported, not an error)
 }
 
+// the rule of CPRA's grouped road at the sizes it was measured and derived for (exchange_layout.hpp grouped_road_pays)
+static int road_rule()
+{
+    const u64 M = 1000000ull, parts = 32768;
+    struct { u64 in, out; bool pays; } c[] = {
+        {64 * M, 1000 * M, false},        // BASELINE configs[2] / [3]: single-fill tables, nothing to group
+        {128 * M, 2000 * M, false},       // configs[4]'s per-rank share
+        {700 * M, 4000 * M, false},       // measured: 70.0 ms one-level against 105.8 ms on the road
+        {1000 * M, 4000 * M, false},      // hjgpu_phj groups this (69 against 96 ms); the road's extra pass eats the gain
+        {2000 * M, 8000 * M, true},       // ~9 fills per partition
+        {4000 * M, 8000 * M, true},
+        {2000 * M, 100 * M, false},       // a small probe side never pays for passes over the build side
+    };
+    for (auto &x : c)
+        if (hj_exchange::grouped_road_pays(x.in, x.out, parts) != x.pays) { printf("road rule: %llu x %llu\n", x.in, x.out); return 1; }
+    return 0;
+}
+
 int main()
 {
+    if (road_rule()) return 1;
     int cases = 0, in_place_ranks = 0, copying_ranks = 0;
     for (int G = 1; G <= 8; ++G)
         for (int k : {0, 1, 3, 192 / G})
