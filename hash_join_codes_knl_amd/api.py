@@ -23,7 +23,7 @@ EXPORTS = [
     "hjgpu_kernel_hash", "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
     "hjgpu_get_device_info", "hjgpu_set_option", "hjgpu_reserve", "hjgpu_get_stats",
     "hjgpu_get_async_status", "hjgpu_accumulate_async_status", "hjgpu_set_async_output", "hjgpu_output_capacity",
-    "hjgpu_malloc", "hjgpu_malloc_placed", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize", "hjgpu_audit_read",
+    "hjgpu_malloc", "hjgpu_malloc_placed", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize", "hjgpu_audit_read", "hjgpu_audit_recheck",
     "hjgpu_host_alloc", "hjgpu_host_free",
     "hjgpu_histogram", "hjgpu_partition", "hjgpu_partition_async", "hjgpu_join_partitions",
     "hjgpu_npj_build", "hjgpu_npj_probe",
@@ -34,7 +34,7 @@ EXPORTS = [
     "hjgpu_partition_packed_counted_async", "hjgpu_phj_probe_prepartitioned_counted_async", "hjgpu_prepartitioned_plan", "hjgpu_grouped_plan",
     "hjgpu_comm_create_local", "hjgpu_comm_get_id", "hjgpu_comm_create_rank", "hjgpu_comm_destroy",
     "hjgpu_comm_last_error", "hjgpu_comm_size", "hjgpu_comm_ctx", "hjgpu_comm_set_option", "hjgpu_comm_barrier",
-    "hjgpu_comm_get_info", "hjgpu_comm_preflight", "hjgpu_comm_get_forensics",
+    "hjgpu_comm_get_info", "hjgpu_comm_preflight", "hjgpu_comm_get_forensics", "hjgpu_comm_recheck", "hjgpu_comm_get_frozen",
     "hjgpu_phj_multi", "hjgpu_npj_multi", "hjgpu_cpra_multi", "hjgpu_join_host_multi",
     "hjgpu_phj_multi_rows", "hjgpu_npj_multi_rows", "hjgpu_cpra_multi_rows", "hjgpu_join_host_rows_multi",
     "hjgpu_join_host", "hjgpu_join_host_rows", "hjgpu_join_host_rows_shared", "hjgpu_generate", "hjgpu_generate_range", "hjgpu_generate_zipf", "hjgpu_generate_select", "hjgpu_column_sums", "hjgpu_stream_read_ms", "hjgpu_random_line_read_ms", "hjgpu_random_cas_ms",
@@ -226,6 +226,9 @@ def load_library(build_if_missing=True):
     L.hjgpu_comm_preflight.argtypes = [vp, sz, C.POINTER(Preflight)]
     L.hjgpu_comm_get_forensics.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(sz)]
     L.hjgpu_audit_read.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64, u32, C.POINTER(C.c_uint64), vp]
+    L.hjgpu_audit_recheck.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(sz)]
+    L.hjgpu_comm_recheck.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(sz)]
+    L.hjgpu_comm_get_frozen.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(sz)]
     L.hjgpu_phj_multi_rows.argtypes = [vp, C.POINTER(Shard), C.POINTER(ShardRows), C.c_int, C.POINTER(PhjParams), C.POINTER(Result), C.POINTER(MultiStats)]
     L.hjgpu_npj_multi_rows.argtypes = [vp, C.POINTER(Shard), C.POINTER(ShardRows), C.c_int, C.POINTER(NpjParams), C.POINTER(Result), C.POINTER(MultiStats)]
     L.hjgpu_cpra_multi_rows.argtypes = [vp, C.POINTER(Shard), C.POINTER(ShardRows), C.POINTER(PhjParams), C.c_int, C.POINTER(Result), C.POINTER(MultiStats)]
@@ -730,6 +733,43 @@ class HjComm:
                 recs.append([[int(buf[at + 4 * s + w]) for w in range(4)] for s in range(8)])
                 at += 32
             out.append((rank, recs[:npart], recs[npart:]))
+        return out
+
+    def recheck(self):
+        """hjgpu_comm_recheck: the last audited calls' partition checks again with the device quiet; per local rank and context
+        (global rank, context 0 partitioning / 1 join, [(stage, [4 words as a fresh kernel counts], [4 words as the host counts from a hipMemcpy])])."""
+        n = C.c_size_t(0)
+        self._check(self.lib.hjgpu_comm_recheck(self.handle, None, 0, C.byref(n)))
+        buf = (C.c_uint64 * max(1, n.value))()
+        self._check(self.lib.hjgpu_comm_recheck(self.handle, buf, n.value, C.byref(n)))
+        out, at = [], 0
+        while at < n.value:
+            rank, which, k = int(buf[at]), int(buf[at + 1]), int(buf[at + 2])
+            at += 3
+            checks = []
+            for _ in range(k):
+                checks.append((int(buf[at]), [int(buf[at + 1 + w]) for w in range(4)], [int(buf[at + 5 + w]) for w in range(4)]))
+                at += 9
+            out.append((rank, which, checks))
+        return out
+
+    def frozen(self):
+        """hjgpu_comm_get_frozen (option debug_forensics = 2): the stages of the last step found wrong while their buffers were intact:
+        [(global rank, context, slice, record[8][4], [(stage, fresh kernel's 4 words, host copy's 4 words)])]"""
+        n = C.c_size_t(0)
+        self._check(self.lib.hjgpu_comm_get_frozen(self.handle, None, 0, C.byref(n)))
+        buf = (C.c_uint64 * max(1, n.value))()
+        self._check(self.lib.hjgpu_comm_get_frozen(self.handle, buf, n.value, C.byref(n)))
+        out, at = [], 0
+        while at < n.value:
+            rank, which, sl, k = int(buf[at]), int(buf[at + 1]), int(C.c_int64(buf[at + 2]).value), int(buf[at + 3])
+            rec = [[int(buf[at + 4 + 4 * s + w]) for w in range(4)] for s in range(8)]
+            at += 36
+            checks = []
+            for _ in range(k):
+                checks.append((int(buf[at]), [int(buf[at + 1 + w]) for w in range(4)], [int(buf[at + 5 + w]) for w in range(4)]))
+                at += 9
+            out.append((rank, which, sl, rec, checks))
         return out
 
     def preflight(self, link_bytes=256 << 20):

@@ -326,8 +326,16 @@ int audit_begin(hjgpu_ctx *ctx, int kind, size_t inner, size_t outer, hipStream_
     HIPCHK(ctx, hipMemsetAsync(r, 0, words * sizeof(u64), stream));
     CHK(hj_audit_meta(r + 4 * (HJ_AUDIT_STAGES - 1), ctx->audit_seq, (u64)kind, (u64)inner, (u64)outer, stream));
     ctx->audit_seq += 1;
+    ctx->audit_checks.clear();
     *rec = r;
     return HJGPU_OK;
+}
+
+int audit_partitions(hjgpu_ctx *ctx, int stage, const u64 *tuples, const u64 *beg, const u64 *end, uint32_t parts, const HjAuditHash &h, u64 *rec,
+                     hipStream_t stream)
+{
+    ctx->audit_checks.push_back(hjgpu_ctx::AuditCheck{stage, tuples, beg, end, parts, h});
+    return hj_audit_partitions(tuples, beg, end, parts, h, rec + 4 * stage, ctx->cus, stream);
 }
 
 // The enqueue paths are not valid inside a HIP stream capture: a replayed graph of one PHJ step faulted on
@@ -612,14 +620,14 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     auto audit_pass1 = [&](int r) -> int {
         if (!audit || !nn[r] || pre || pl.C != 1 || pl.F2 <= 1) return HJGPU_OK;
         const HjAuditHash h = {pl.f1, pl.F1, 0u, 1u, 1u, pl.F1};
-        return hj_audit_partitions(reinterpret_cast<const u64 *>(ctx->tmp[2 * r].p), m.off1[r], nullptr, pl.F1, h, audit + 4 * (r ? 1 : 4), ctx->cus, stream);
+        return audit_partitions(ctx, r ? 1 : 4, reinterpret_cast<const u64 *>(ctx->tmp[2 * r].p), m.off1[r], nullptr, pl.F1, h, audit, stream);
     };
     auto audit_final = [&](int r) -> int {
         if (!audit || !nn[r]) return HJGPU_OK;
         const bool two = pl.F2 > 1;
         const u64 *fin_r = reinterpret_cast<const u64 *>(two ? ctx->tmp[4 + 2 * r].p : ctx->tmp[2 * r].p);
         const HjAuditHash h = {pre ? pl.pre_f1 : pl.f1, pre ? pl.pre_F1tot : pl.F1, pre ? pl.pre_base : 0u, pl.f2, pl.F2, pl.P};
-        return hj_audit_partitions(fin_r, m.off2[r], m.end2[r], (pad2 ? 1u : pl.C) * pl.P, h, audit + 4 * (r ? 2 : 5), ctx->cus, stream);
+        return audit_partitions(ctx, r ? 2 : 5, fin_r, m.off2[r], m.end2[r], (pad2 ? 1u : pl.C) * pl.P, h, audit, stream);
     };
     // the stages of one relation's partitioning
     auto k4 = [&](int r) -> int {          // one read of the key column gives the histograms of both passes
@@ -1259,6 +1267,59 @@ int hjgpu_audit_read(hjgpu_ctx *ctx, uint64_t *next_seq, uint64_t first_seq, uin
                                    reinterpret_cast<const u64 *>(ctx->audit.p) + (size_t)((first_seq + i) % HJ_AUDIT_RING) * words,
                                    words * sizeof(u64), hipMemcpyDeviceToHost, stream));
     HIPCHK(ctx, hj_stream_synchronize(stream));
+    return HJGPU_OK;
+}
+
+// Option "audit", second look: the partition checks of the context's LAST audited call once more, with the device quiet -
+// (a) by a fresh kernel (through the XCDs' L2s, after a device-wide synchronisation: every L2 written back and invalidated), and
+// (b) on the host, from a copy of the buffer made with hipMemcpy (the copy engine reads memory, not an L2).  A stage whose
+// first check was wrong and whose memory is wrong here LOST stores; one whose memory is right here was READ STALE.
+int hjgpu_audit_recheck(hjgpu_ctx *ctx, uint64_t *words, size_t capacity, size_t *checks)
+{
+    settle(ctx);
+    if (!ctx || !checks) return HJGPU_EINVAL;
+    *checks = ctx->audit_checks.size();
+    if (!words || capacity < ctx->audit_checks.size()) return HJGPU_OK;      // the caller asks again with room for 9 words per check
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    u64 *d_rec = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_rec, 4 * sizeof(u64)));
+    if (!ctx->aux) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    size_t i = 0;
+    for (const hjgpu_ctx::AuditCheck &c : ctx->audit_checks) {
+        uint64_t *w = words + 9 * i++;
+        w[0] = (uint64_t)c.stage;
+        u64 fresh[4] = {0, 0, 0, 0};
+        HIPCHK(ctx, hipMemsetAsync(d_rec, 0, sizeof(fresh), ctx->aux));
+        CHK(hj_audit_partitions(c.tuples, c.beg, c.end, c.parts, c.h, d_rec, ctx->cus, ctx->aux));
+        HIPCHK(ctx, hipMemcpyAsync(fresh, d_rec, sizeof(fresh), hipMemcpyDeviceToHost, ctx->aux));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->aux));
+        for (int k = 0; k < 4; ++k) w[1 + k] = fresh[k];
+        // the host's view: bounds first, then the rows they span
+        std::vector<u64> beg(c.parts + 1), end(c.parts);
+        HIPCHK(ctx, hipMemcpy(beg.data(), c.beg, (c.end ? c.parts : c.parts + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+        if (c.end) HIPCHK(ctx, hipMemcpy(end.data(), c.end, c.parts * sizeof(u64), hipMemcpyDeviceToHost));
+        else for (uint32_t q = 0; q < c.parts; ++q) end[q] = beg[q + 1];
+        u64 lo = ~0ull, hi = 0;
+        for (uint32_t q = 0; q < c.parts; ++q) if (end[q] > beg[q]) { lo = std::min(lo, beg[q]); hi = std::max(hi, end[q]); }
+        u64 host[4] = {0, 0, 0, 0};
+        if (hi > lo) {
+            std::vector<u64> rows(hi - lo);
+            HIPCHK(ctx, hipMemcpy(rows.data(), c.tuples + lo, (hi - lo) * sizeof(u64), hipMemcpyDeviceToHost));
+            auto H = [](uint32_t key, uint32_t f, uint32_t N) { return (uint32_t)(((u64)(uint32_t)(key * f) * N) >> 32); };
+            for (uint32_t q = 0; q < c.parts; ++q) {
+                const uint32_t want = q % c.h.modulo;
+                for (u64 j = beg[q]; j < end[q]; ++j) {
+                    const u64 t = rows[j - lo];
+                    const uint32_t key = (uint32_t)t;
+                    if ((H(key, c.h.f1, c.h.F1) - c.h.p1_base) * c.h.F2 + H(key, c.h.f2, c.h.F2) != want) ++host[0];
+                    host[1] += key; host[2] += t >> 32; ++host[3];
+                }
+            }
+        }
+        for (int k = 0; k < 4; ++k) w[5 + k] = host[k];
+    }
+    HIPCHK(ctx, hipFree(d_rec));
     return HJGPU_OK;
 }
 

@@ -101,6 +101,9 @@ struct hjgpu_ctx {
     // explicit partition bounds of an own-last layout
     DevBuf audit, audit_lay;
     uint64_t audit_seq = 0;
+    // the partition checks of the LAST audited call, as they were launched: hjgpu_audit_recheck does them again with the device quiet
+    struct AuditCheck { int stage; const u64 *tuples, *beg, *end; uint32_t parts; HjAuditHash h; };
+    std::vector<AuditCheck> audit_checks;
     float ms_reserve = 0;           // wall clock of the workspace growth so far (allocations + placement probes)
     // the last placement search (ensure_placed): candidate blocks it allocated and filled, the kept block's fill time and size,
     // whether the budget (option "placement_ms") ended it
@@ -209,6 +212,9 @@ MetaLayout carve(void *base, uint32_t C, uint32_t F1, uint32_t P, size_t ranges,
 void choose_fanout(const HjTuning &tune, size_t inner, const hjgpu_phj_params *prm, uint32_t *F1, uint32_t *F2, bool *big_tables);
 void record(hjgpu_ctx *ctx, int which, hipStream_t s);
 int audit_begin(hjgpu_ctx *ctx, int kind, size_t inner, size_t outer, hipStream_t stream, u64 **rec);
+// hj_audit_partitions into stage `stage` of the call's record, remembered for hjgpu_audit_recheck
+int audit_partitions(hjgpu_ctx *ctx, int stage, const u64 *tuples, const u64 *beg, const u64 *end, uint32_t parts, const HjAuditHash &h, u64 *rec,
+                     hipStream_t stream);
 int refuse_capture(hjgpu_ctx *ctx, hipStream_t stream);
 int check_columns(hjgpu_ctx *ctx, const uint32_t *k, const uint32_t *v, size_t n);
 int setup_output(hjgpu_ctx *ctx, const hjgpu_output *out, uint32_t workers, u64 *block_size, u64 *block_limit);

@@ -159,6 +159,10 @@ struct hjgpu_comm {
     int debug_forensics = 0;                 // option "debug_forensics": option "audit" on every rank's two contexts; a CPRA step keeps the
                                              // records of its partitioning calls and joins (hjgpu_comm_get_forensics)
     std::vector<u64> forensics;              // per local rank: {global rank, partitioning records, join records}, then the records (32 words each)
+    // "debug_forensics" = 2: every slice's records are read as soon as the slice's partitioning / join has finished - before the next use of
+    // its buffers is enqueued - and a stage whose sums differ from its input's is looked at again ON THE SPOT (hjgpu_audit_recheck):
+    // per event {global rank, context (0 partitioning, 1 join), slice, checks n, the call's record (32 words)} + n x 9 words
+    std::vector<u64> frozen;
     int debug_serialize = 0;                 // option "debug_serialize" (diagnostics): bit 0 host waits after every slice's join, bit 1 the
                                              // partitioning waits for the joins enqueued so far, bit 2 the exchange waits for them,
                                              // bit 3 a join waits for the partitioning enqueued so far (with bit 1: the two never overlap)
@@ -1391,6 +1395,43 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         if (c->debug_serialize & 1) for (int l = 0; l < L; ++l) CHKM(wait_stream(c, l, c->ranks[l].main, "join"));
         return HJGPU_OK;
     };
+    // option "debug_forensics" = 2 (see hjgpu_comm::frozen): the last record of a context, read behind `stream`; when a partition check of it
+    // differs from what the call read - or a probe's result from the batch it read - the checks are done again at once, device quiet
+    auto freeze_check = [&](int l, int which, int slice) -> int {
+        Rank &r = c->ranks[l];
+        hjgpu_ctx *ctx = which ? r.join : r.part;
+        HIPM(c, hipSetDevice(r.device));
+        uint64_t next = 0;
+        JOINM(c, ctx, hjgpu_audit_read(ctx, &next, 0, 0, nullptr, nullptr));
+        if (next <= (which ? seq_join : seq_part)[(size_t)l]) return HJGPU_OK;          // no call of this step yet
+        uint64_t rec[32];
+        JOINM(c, ctx, hjgpu_audit_read(ctx, nullptr, next - 1, 1, rec, which ? r.main : r.prep));
+        auto differs = [&](int stage, int input) { return rec[4 * stage] != 0 || rec[4 * stage + 1] != rec[4 * input + 1] || rec[4 * stage + 2] != rec[4 * input + 2] || rec[4 * stage + 3] != rec[4 * input + 3]; };
+        const uint64_t kind = rec[4 * 7 + 1];
+        bool bad = false;
+        if (kind == 3) bad = differs(1, 0);                                              // a partitioning call: output vs input
+        if (kind == 1) bad = differs(5, 3);                                              // the build: final partitions vs what it read
+        // a probe: final partitions vs the batch, and the result vs the batch (the stress workload: unique build keys, selectivity 1)
+        if (kind == 2) {
+            bad = differs(2, 0) || rec[4 * 6] != rec[3] || rec[4 * 6 + 1] != rec[1] || rec[4 * 6 + 2] != rec[2];
+            // ... and the prepared build side as this probe found it vs what its build read (the step's first join call; nobody waited
+            // for the build when it was enqueued: its arrival overlaps the first slice's partitioning)
+            uint64_t b[32];
+            JOINM(c, ctx, hjgpu_audit_read(ctx, nullptr, seq_join[(size_t)l], 1, b, r.main));
+            if (b[4 * 7 + 1] == 1)
+                for (int w = 0; w < 4; ++w) if (rec[4 * 5 + w] != (w ? b[4 * 3 + w] : 0)) bad = true;
+        }
+        if (!bad) return HJGPU_OK;
+        size_t n = 0;
+        JOINM(c, ctx, hjgpu_audit_recheck(ctx, nullptr, 0, &n));
+        const size_t at = c->frozen.size();
+        c->frozen.resize(at + 4 + 32 + 9 * n, 0);
+        c->frozen[at] = (u64)r.global; c->frozen[at + 1] = (u64)which; c->frozen[at + 2] = (u64)slice; c->frozen[at + 3] = (u64)n;
+        memcpy(c->frozen.data() + at + 4, rec, sizeof(rec));
+        if (n) JOINM(c, ctx, hjgpu_audit_recheck(ctx, reinterpret_cast<uint64_t *>(c->frozen.data() + at + 36), n, &n));
+        return HJGPU_OK;
+    };
+    if (c->debug_forensics >= 2) c->frozen.clear();
     std::vector<u64> pending;
     std::vector<std::vector<u64>> pending_pieces;
     std::vector<const void *> pending_base;
@@ -1411,6 +1452,11 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                                  from_host && slice_events ? (grouped ? asked_slices - 1 : i) : -1));
         if (pending_slice >= 0) CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
         CHKM(step.finish_exchange(in, 1 + slot, slot));
+        if (c->debug_forensics >= 2)
+            for (int l = 0; l < L; ++l) {
+                CHKM(freeze_check(l, 0, i));                            // partition(i): the host has just waited for its counts
+                if (pending_slice >= 0) CHKM(freeze_check(l, 1, pending_slice));           // join(i - 1): waited for here; join(i) is not enqueued yet
+            }
         if (build_stats_pending && i == 0) {
             // the host has just waited for this slice's partition counts and the counts gather; the build was enqueued
             // before both and is (nearly always) done: reading its events costs the pipeline nothing
@@ -1424,6 +1470,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
         pending_slice = i;
     }
     CHKM(join_slice(pending_slice, pending_slice & 1, pending, pending_pieces, pending_base));
+    if (c->debug_forensics >= 2) for (int l = 0; l < L; ++l) CHKM(freeze_check(l, 1, pending_slice));
     const int status = reduce_results(c, result);
     if (status != HJGPU_OK && status != HJGPU_EOVERFLOW) return status;
     if (c->debug_forensics) {
@@ -1696,6 +1743,42 @@ int hjgpu_comm_set_option(hjgpu_comm *c, const char *name, const char *value)
         return HJGPU_OK;
     }
     return cfail(c, HJGPU_EINVAL, "hjgpu_comm_set_option: unknown option");
+}
+
+// hjgpu_audit_recheck on both contexts of every local rank (option "debug_forensics"): words = for every local rank and context
+// {global rank, context (0 partitioning, 1 join), n} followed by n x 9 words
+int hjgpu_comm_recheck(hjgpu_comm *c, uint64_t *words, size_t capacity, size_t *count)
+{
+    if (!c || !count) return HJGPU_EINVAL;
+    std::vector<u64> all;
+    for (auto &r : c->ranks) {
+        hjgpu_ctx *both[2] = {r.part, r.join};
+        for (int which = 0; which < 2; ++which) {
+            size_t n = 0;
+            if (!both[which]) continue;
+            JOINM(c, both[which], hjgpu_audit_recheck(both[which], nullptr, 0, &n));
+            const size_t at = all.size();
+            all.resize(at + 3 + 9 * n, 0);
+            all[at] = (u64)r.global; all[at + 1] = (u64)which; all[at + 2] = (u64)n;
+            if (n) JOINM(c, both[which], hjgpu_audit_recheck(both[which], reinterpret_cast<uint64_t *>(all.data() + at + 3), n, &n));
+        }
+    }
+    *count = all.size();
+    if (!words || capacity < all.size()) return HJGPU_OK;
+    if (!all.empty()) memcpy(words, all.data(), all.size() * sizeof(u64));
+    return HJGPU_OK;
+}
+
+// option "debug_forensics" = 2: the stages of the last hjgpu_cpra_multi step that were found wrong while their buffers were still intact, each
+// looked at again on the spot: per event {global rank, context (0 partitioning, 1 join), slice, n, the call's record (32 words)} + n x 9 words
+// (hjgpu_audit_recheck)
+int hjgpu_comm_get_frozen(hjgpu_comm *c, uint64_t *words, size_t capacity, size_t *count)
+{
+    if (!c || !count) return HJGPU_EINVAL;
+    *count = c->frozen.size();
+    if (!words || capacity < c->frozen.size()) return HJGPU_OK;
+    if (!c->frozen.empty()) memcpy(words, c->frozen.data(), c->frozen.size() * sizeof(u64));
+    return HJGPU_OK;
 }
 
 int hjgpu_comm_get_forensics(hjgpu_comm *c, uint64_t *words, size_t capacity, size_t *count)

@@ -310,7 +310,7 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
         u64 *beg = reinterpret_cast<u64 *>(ctx->audit_lay.p), *end = beg + HJGPU_MAX_FANOUT + 1;
         CHK(hj_audit_own_last(m.off2[0], fanout, own_first, own_count, n, beg, end, stream));
         const HjAuditHash h = {factor, fanout, 0u, 1u, 1u, fanout};
-        CHK(hj_audit_partitions(reinterpret_cast<const u64 *>(d_tuples_out), beg, end, fanout, h, audit + 4, ctx->cus, stream));
+        CHK(audit_partitions(ctx, 1, reinterpret_cast<const u64 *>(d_tuples_out), beg, end, fanout, h, audit, stream));
     }
     record(ctx, EV_GAPS, stream);
     return HJGPU_OK;

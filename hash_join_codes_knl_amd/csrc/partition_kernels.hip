@@ -890,6 +890,13 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     uint32_t mycc[BPT];                                             // CARRY: tuples of my bins waiting in `carry`
 #pragma unroll
     for (int i = 0; i < BPT; ++i) { mycur[i] = 0; mycc[i] = 0; }
+#ifdef HJ_FORENSIC_PRIVATE_WORD
+    // forensic builds only (tools/build_variant.py <name> -DHJ_FORENSIC_PRIVATE_WORD=1, never the product): pass 1 carries one private
+    // word, written once and never read - round 4's "variant 9", with which K6 loses stores in a third of the steps beside another
+    // stream's kernels: the high-rate form of the loss, used to tell a lost store from a stale read (tools/scratch_two_streams.py --recheck)
+    volatile uint32_t forensic_private[2];
+    if (RANGED) { forensic_private[0] = 0; forensic_private[1] = (uint32_t)threadIdx.x; }
+#endif
 
     // ---- the sequence of tiles this workgroup processes ------------------------------
     // Work is CLAIMED, not owned: pass 1 takes whole ranges, pass 2 single tiles, in order, from a

@@ -182,6 +182,13 @@ int  hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value);
  * the sequence number the next call will get; records[count][32] = the calls first_seq .. first_seq + count - 1 (waits for
  * `stream`). */
 int  hjgpu_audit_read(hjgpu_ctx *ctx, uint64_t *next_seq, uint64_t first_seq, uint32_t count, uint64_t *records, void *stream);
+/* Option "audit", second look (diagnostics): the partition checks of the context's LAST audited call done again with the device quiet
+ * (hipDeviceSynchronize first) - by a fresh kernel, and on the host from a copy of the partitions made with hipMemcpy (the copy
+ * engine reads memory, not an XCD's L2).  words[checks][9] = {stage, the four words as the fresh kernel counts them, the four words
+ * as the host counts them}; *checks = the checks there are, nothing is done when capacity (in checks) is smaller.  A stage whose
+ * record was wrong and whose memory is wrong here lost stores; one whose memory is right here was read stale
+ * (tools/stress_cpra.py --forensics prints the verdict for every wrong step). */
+int  hjgpu_audit_recheck(hjgpu_ctx *ctx, uint64_t *words, size_t capacity, size_t *checks);
 /* Pre-size the internal workspace (partition scratch twins = hj.h's [1]
  * columns, NPJ table) so that no allocation happens inside a timed join. */
 int  hjgpu_reserve(hjgpu_ctx *ctx, size_t inner_tuples, size_t outer_tuples);
@@ -577,6 +584,14 @@ int  hjgpu_comm_preflight(hjgpu_comm *comm, size_t link_bytes, hjgpu_preflight *
  * are; nothing is copied when capacity is smaller.  tools/stress_cpra.py --forensics prints them for every wrong step:
  * the stage whose sums differ from its input's is the kernel that lost the tuples. */
 int  hjgpu_comm_get_forensics(hjgpu_comm *comm, uint64_t *words, size_t capacity, size_t *count);
+/* hjgpu_audit_recheck on both contexts of every local rank: words[] = for every local rank and context {global rank, context
+ * (0 exchange-level partitioning, 1 join), n} followed by n x 9 words; *count = the words there are. */
+int  hjgpu_comm_recheck(hjgpu_comm *comm, uint64_t *words, size_t capacity, size_t *count);
+/* "debug_forensics" = 2: hjgpu_cpra_multi reads every slice's records on the host as soon as the slice's partitioning / join has finished -
+ * before the next use of its buffers is enqueued (the overlap of a slice's join with the next slice's partitioning stays) - and a stage
+ * whose sums differ from its input's is looked at again on the spot (hjgpu_audit_recheck).  words[] = per event {global rank, context,
+ * slice, n, the call's record (32 words)} followed by n x 9 words.  Empty after a step whose records all agreed. */
+int  hjgpu_comm_get_frozen(hjgpu_comm *comm, uint64_t *words, size_t capacity, size_t *count);
 /* every local rank's streams drained, then a collective over all ranks */
 int  hjgpu_comm_barrier(hjgpu_comm *comm);
 

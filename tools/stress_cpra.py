@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--unique", action="store_true", help="HJGPU_FLAG_UNIQUE (same result here: the build keys are unique)")
     ap.add_argument("--forensics", action="store_true", help="communicator option debug_forensics: every stage of every step leaves "
                     "checksums (option audit); a wrong step prints the stage whose output lacked the tuples")
+    ap.add_argument("--freeze", action="store_true", help="debug_forensics = 2: every slice's records are read as soon as the slice is done and a wrong stage is looked "
+                    "at again at once - by a fresh kernel and from a hipMemcpy on the host - while its buffers are intact (any number of slices)")
+    ap.add_argument("--recheck-first", action="store_true", help="with --forensics: step 0's report includes the second look (hjgpu_comm_recheck) although the step is right")
     ap.add_argument("--option", action="append", default=[])
     ap.add_argument("--ctx-option", action="append", default=[], help="hjgpu_set_option on every rank's join context")
     a = ap.parse_args()
@@ -56,11 +59,11 @@ def main():
         expect = [expect[0] + ro] + [(x + y) & ((1 << 64) - 1) for x, y in zip(expect[1:], sums)]
         cols += c
         shards.append((c[0], c[1], ri, c[2], c[3], ro))
-    if a.forensics:
-        comm.set_option("debug_forensics", 1)
+    if a.forensics or a.freeze:
+        comm.set_option("debug_forensics", 2 if a.freeze else 1)
     M = (1 << 64) - 1
 
-    def report(step):
+    def report(step, second_look=True):
         """names every stage of the step whose checksum differs from what the stage read (workload: selectivity 1, unique build keys)"""
         found = []
         for rank, parts, joins in comm.forensics():
@@ -87,6 +90,56 @@ def main():
                     if p_[1][1:] != j_[side][1:]:
                         found.append("rank %d call %d: the join read %+d tuples, key sum %+d vs what the partitioning left" % (rank, i, j_[side][3] - p_[1][3], (j_[side][1] - p_[1][1] + (1 << 63)) % (1 << 64) - (1 << 63)))
         print("step %d forensics: %s" % (step, "; ".join(found) if found else "every stage's checksums agree"), flush=True)
+        # second look with the device quiet (hjgpu_comm_recheck): the LAST partitioning call and the LAST join of every rank - with
+        # --slices 1 that is the whole probe side - by a fresh kernel and on the host from a hipMemcpy of the partitions
+        if a.freeze:
+            ev = comm.frozen()
+            if not ev:
+                print("    freeze: no stage was found wrong while its buffers were intact", flush=True)
+            for rank, which, sl, rec, checks in ev:
+                kind = rec[7][1]
+                res = rec[6]
+                print("    freeze: rank %d %s context, slice %d, call kind %d: record %s" % (rank, "join" if which else "partitioning", sl, kind, rec[:7]), flush=True)
+                for stage, fresh, host in checks:
+                    want = rec[3 if stage in (4, 5) else 0]
+                    if stage == 5 and kind == 2:
+                        want = None                            # (the build call's input is not in this record: compare the three views only)
+                    ok = (lambda x: x[0] == 0 and x[1:] == want[1:]) if want else (lambda x: x == host)
+                    if ok(rec[stage]):
+                        verdict = "right on the call's stream" + ("" if ok(fresh) and ok(host) else ", WRONG now")
+                    elif not ok(host):
+                        verdict = "MEMORY IS WRONG (hipMemcpy to the host%s): stores LOST" % (", the fresh kernel alike" if fresh == host else "; the fresh kernel sees %s" % fresh)
+                    elif ok(fresh):
+                        verdict = "memory is RIGHT now (host copy and fresh kernel): the call's own check read STALE data"
+                    else:
+                        verdict = "host copy right, fresh kernel wrong"
+                    print("        stage %d: on the call's stream %s | fresh kernel, device quiet %s | host copy %s -> %s" % (stage, rec[stage], fresh, host, verdict), flush=True)
+                if kind == 2 and (res[0] != rec[0][3] or res[1] != rec[0][1]):
+                    print("        the join's result: count %+d vs the batch it read" % (res[0] - rec[0][3]), flush=True)
+            return
+        if not second_look:
+            return
+        ranks = {r: (p_, j_) for r, p_, j_ in comm.forensics()}
+        for rank, which, checks in comm.recheck():
+            recs = ranks[rank][which]
+            if not recs:
+                continue
+            first = recs[-1]                                   # the record of the context's last call: what the checks saw on the call's stream
+            for stage, fresh, host in checks:
+                want = first[3 if stage in (4, 5) else 0]      # what the call read: stage 0 (probe side / a partitioning call's input), 3 (build side)
+                if stage in (4, 5) and not any(want):          # a probe of a prepared build side: what the BUILD call read
+                    want = recs[0][3]
+                ok = lambda x: x[0] == 0 and x[1:] == want[1:]
+                if ok(first[stage]):
+                    verdict = "right all along" if ok(fresh) and ok(host) else "RIGHT on the call's stream, wrong now"
+                elif not ok(host):
+                    verdict = "MEMORY IS WRONG (hipMemcpy to the host%s): the stores are LOST" % (", fresh kernel alike" if fresh == host else "; the fresh kernel sees something else again")
+                elif ok(fresh):
+                    verdict = "memory is RIGHT now (host copy and fresh kernel): the check on the call's stream read STALE data"
+                else:
+                    verdict = "host copy right, fresh kernel wrong"
+                print("    rank %d %s context, stage %d: on the call's stream %s | fresh kernel, device quiet %s | host copy %s | input %s -> %s"
+                      % (rank, "join" if which else "partitioning", stage, first[stage], fresh, host, want, verdict), flush=True)
 
     bad = 0
     for s in range(a.steps):
@@ -96,10 +149,10 @@ def main():
         if list(got) != expect:
             bad += 1
             print("step %d WRONG: count %+d, sums %s" % (s, got[0] - expect[0], ["%+d" % ((x - y + (1 << 63)) % (1 << 64) - (1 << 63)) for x, y in zip(got[1:], expect[1:])]), flush=True)
-            if a.forensics:
+            if a.forensics or a.freeze:
                 report(s)
-        elif a.forensics and s == 0:
-            report(s)
+        elif (a.forensics or a.freeze) and s == 0:
+            report(s, a.recheck_first)
     print("%s world %d slices %d options %s: %d of %d steps wrong, last %.2f ms" % (a.transport, G, a.slices, a.option + a.ctx_option + (["unique"] if a.unique else []), bad, a.steps, st["ms_wall"]), flush=True)
     if has_dbg:
         # HJ_SCRATCH_EXPERIMENT variants 2-4: values that came back from the private segment, compared in the kernel
