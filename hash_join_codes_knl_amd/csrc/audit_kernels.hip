@@ -74,17 +74,17 @@ __global__ void audit_own_last_kernel(const u64 *__restrict__ prefix, uint32_t F
     u64 b = prefix[p];
     if (p >= own_first + own_count) b -= own_rows;
     else if (p >= own_first) b = n - own_rows + (prefix[p] - prefix[own_first]);
-    beg[p] = b; end[p] = b + (prefix[p + 1] - prefix[p]);
+    hj_store(&beg[p], b); hj_store(&end[p], b + (prefix[p + 1] - prefix[p]));
 }
 
 __global__ void audit_copy_kernel(const u64 *__restrict__ src, u64 *__restrict__ dst, uint32_t words)
 {
-    if (threadIdx.x < words) dst[threadIdx.x] = src[threadIdx.x];
+    if (threadIdx.x < words) hj_store(&dst[threadIdx.x], src[threadIdx.x]);
 }
 
 __global__ void audit_meta_kernel(u64 *__restrict__ dst, u64 a, u64 b, u64 c, u64 d)
 {
-    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+    hj_store(&dst[0], a); hj_store(&dst[1], b); hj_store(&dst[2], c); hj_store(&dst[3], d);
 }
 
 inline int launched() { return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP; }

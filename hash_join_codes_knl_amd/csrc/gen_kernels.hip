@@ -12,6 +12,7 @@
 // goal (the host-side oracle generator covers that, oracle/hj_oracle.c).
 #include "hj_device.hpp"
 #include "hj_internal.hpp"
+#include <algorithm>
 #include <math.h>
 
 // lowbias32: a bijection on 32-bit integers with mix32(0) == 0, hence
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
             if (ip < a.distinct) r = ip;                               // every distinct key once
             else r = __umul64hi(splitmix64(ip ^ ~a.seed), a.distinct); // then repeats (outer < inner)
             const uint32_t k = mix32(a.key_base + (uint32_t)r);
-            a.ik[j] = k;
-            a.iv[j] = k * a.inner_factor;
+            hj_store(&a.ik[j], k);
+            hj_store(&a.iv[j], k * a.inner_factor);
         }
     }
     if (a.ok) {
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256) void generate_kernel(GenArgs a)
                 if (r >= a.distinct) r = a.distinct - 1;
             } else r = __umul64hi(splitmix64(jp ^ a.seed), a.distinct);  // then uniform picks
             const uint32_t k = mix32(a.key_base + (uint32_t)(a.outer_shift + r));
-            a.ok[j] = k;
-            a.ov[j] = k * a.outer_factor;
+            hj_store(&a.ok[j], k);
+            hj_store(&a.ov[j], k * a.outer_factor);
             if (r < a.join_d) { e_n += 1; e_k += k; e_o += (uint32_t)(k * a.outer_factor); e_i += (uint32_t)(k * a.inner_factor); }
         }
         if (a.expect) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void column_sums_kernel(const uint32_t *__rest
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
                           hipStream_t stream)
 {
-    if (hipMemsetAsync(sums3, 0, 3 * sizeof(u64), stream) != hipSuccess) return HJGPU_EHIP;
+    if (hj_zero_async(sums3, 3 * sizeof(u64), stream) != hipSuccess) return HJGPU_EHIP;
     hipLaunchKernelGGL(column_sums_kernel, dim3(2048), dim3(256), 0, stream, keys, (u64)n, fa, fb, sums3);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(1024) void stream_read_kernel(const uint4 *__restri
         const uint4 a = p[0], b = p[1024], c = p[2048], d = p[3072];
         acc.x ^= a.x ^ b.y; acc.y ^= c.z ^ d.w; acc.z ^= a.z ^ c.x; acc.w ^= b.w ^ d.y;
     }
-    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = acc;      // keeps the loads alive
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) hj_store(sink, acc);      // keeps the loads alive
 }
 
 int hj_launch_stream_read(const void *p, size_t bytes, void *sink16, int cus, hipStream_t stream)
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void random_line_read_kernel(const uint4 *__re
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc.x ^= v[i].x; acc.y ^= v[i].y; acc.z ^= v[i].z; acc.w ^= v[i].w; }
     }
-    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) *sink = acc;      // keeps the loads alive
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) hj_store(sink, acc);      // keeps the loads alive
 }
 
 int hj_launch_random_line_read(const void *p, size_t bytes, size_t reads, void *sink16, int cus, hipStream_t stream)
@@ -311,9 +312,9 @@ __global__ __launch_bounds__(256) void copy_to_host_kernel(uint32_t *__restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[i + j * stride];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[i + j * stride] = v[j];
+        for (int j = 0; j < 8; ++j) hj_store(&dst[i + j * stride], v[j]);
     }
-    for (; i < n; i += stride) dst[i] = src[i];
+    for (; i < n; i += stride) hj_store(&dst[i], src[i]);
 }
 
 int hj_launch_copy_to_host(void *host_mapped, const void *d, size_t bytes, hipStream_t stream)
@@ -322,6 +323,61 @@ int hj_launch_copy_to_host(void *host_mapped, const void *d, size_t bytes, hipSt
     if (((uintptr_t)host_mapped & 3) || ((uintptr_t)d & 3) || (bytes & 3)) return HJGPU_EALIGN;
     hipLaunchKernelGGL(copy_to_host_kernel, dim3(64), dim3(256), 0, stream, (uint32_t *)host_mapped, (const uint32_t *)d, (u64)(bytes / 4));
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+// Clears and device-to-device copies of the library's own state and of the caller's columns: own kernels, because the runtime's
+// (hipMemsetAsync, hipMemcpyAsync) store plainly and the library's store policy (hj_device.hpp) has no plain store beside other
+// queues' work - NPJ's 2 GB table clear writes as many bytes as a K6 pass over the build side.  Any 4-byte aligned range; the
+// body in 16-byte non-temporal stores.
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t *__restrict__ p, u64 words)
+{
+    // words [0, head) up to the first 16-byte boundary, 16-byte vectors, then the tail
+    const u64 head = min(words, (u64)((16 - ((uintptr_t)p & 15)) & 15) / 4);
+    const u64 vecs = (words - head) / 4, tail0 = head + vecs * 4;
+    uint4 *v = reinterpret_cast<uint4 *>(p + head);
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, stride = (u64)gridDim.x * 256;
+    for (u64 i = tid; i < vecs; i += stride) hj_store(&v[i], make_uint4(0, 0, 0, 0));
+    if (tid < head) hj_store(&p[tid], 0u);
+    if (tid < words - tail0) hj_store(&p[tail0 + tid], 0u);
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, u64 words, uint32_t vec)
+{
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, stride = (u64)gridDim.x * 256;
+    if (vec) {              // both 16-byte aligned: 4 vectors in flight per lane
+        const u64 vecs = words / 4;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        u64 i = tid;
+        for (; i + 3 * stride < vecs; i += 4 * stride) {
+            const uint4 a = hj_load_nt(s4 + i), b = hj_load_nt(s4 + i + stride), c = hj_load_nt(s4 + i + 2 * stride), d = hj_load_nt(s4 + i + 3 * stride);
+            hj_store(&d4[i], a); hj_store(&d4[i + stride], b); hj_store(&d4[i + 2 * stride], c); hj_store(&d4[i + 3 * stride], d);
+        }
+        for (; i < vecs; i += stride) hj_store(&d4[i], hj_load_nt(s4 + i));
+        if (tid < words - vecs * 4) hj_store(&dst[vecs * 4 + tid], src[vecs * 4 + tid]);
+    } else
+        for (u64 i = tid; i < words; i += stride) hj_store(&dst[i], src[i]);
+}
+
+hipError_t hj_zero_async(void *p, size_t bytes, hipStream_t stream)
+{
+    if (!bytes) return hipSuccess;
+    if (((uintptr_t)p & 3) || (bytes & 3)) return hipMemsetAsync(p, 0, bytes, stream);      // (no such caller: every clear is of 4-byte words)
+    const u64 words = bytes / 4;
+    const unsigned grid = (unsigned)std::min<u64>((words / 4 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, stream, (uint32_t *)p, words);
+    return hipGetLastError();
+}
+
+hipError_t hj_copy_async(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+    if (!bytes) return hipSuccess;
+    if (((uintptr_t)dst & 3) || ((uintptr_t)src & 3) || (bytes & 3)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    const u64 words = bytes / 4;
+    const uint32_t vec = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0 ? 1u : 0u;
+    const unsigned grid = (unsigned)std::min<u64>((words / (vec ? 16 : 1) + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, stream, (uint32_t *)dst, (const uint32_t *)src, words, vec);
+    return hipGetLastError();
 }
 
 int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream)

@@ -29,6 +29,22 @@ __device__ __forceinline__ uint4 hj_load_nt(const uint4 *p)
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+// THE STORE POLICY (round 6).  K6's plain stores were LOST IN MEMORY beside other queues' kernels - 1.3-1.5 in 10^4 steps of the
+// multi-stream pipelines, the damaged partitions read back wrong through hipMemcpy and through a fresh kernel with the device quiet
+// (profiles/r06_lost_or_stale.txt) - and never with non-temporal stores.  The mechanism is below the ISA and a stand-alone kernel pair
+// does not show it (tools/ubench_partial_line_race.hip), so nothing says that other kernels' plain stores are exempt: EVERY global
+// store of every kernel of the library is non-temporal (hj_store), the two solo forms excepted (option "solo": K6's partial-line stores
+// and the result rows of a blocking join that runs alone on the device).  tests/test_store_policy_isa.py reads the machine code of
+// every kernel source and fails on a plain global store outside that list.  Atomics are performed at the memory side.
+__device__ __forceinline__ void hj_store(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void hj_store(u64 *p, u64 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void hj_store(uint4 *p, uint4 v)
+{
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    const v4u_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4u_t *>(p));
+}
+
 // Workgroup barrier that orders LDS traffic only.  HIP's __syncthreads() also drains
 // the vector-memory counter (s_waitcnt vmcnt(0)), which turns every global load issued
 // before it into an exposed round trip; kernels that keep loads (or stores) in flight

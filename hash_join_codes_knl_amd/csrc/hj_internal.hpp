@@ -356,5 +356,9 @@ int hj_launch_row_sums(const u64 *counts, uint32_t F1, uint32_t F2, u64 *out, hi
 int hj_launch_random_line_read(const void *p, size_t bytes, size_t reads, void *sink16, int cus, hipStream_t stream);
 int hj_launch_random_cas(void *p, size_t bytes, size_t ops, int in_flight, bool load_first, void *sink8, int cus, hipStream_t stream);
 int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream);
+// the library's clears and device-to-device copies (gen_kernels.hip): own kernels with non-temporal stores instead of the runtime's
+// hipMemsetAsync / hipMemcpyAsync, whose fill and copy kernels store plainly (the store policy: hj_device.hpp)
+hipError_t hj_zero_async(void *p, size_t bytes, hipStream_t stream);
+hipError_t hj_copy_async(void *dst, const void *src, size_t bytes, hipStream_t stream);
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
                           hipStream_t stream);

@@ -4,6 +4,7 @@
 // cpra2.cpp:1697-1986): phase order, pass planning, factor choice.  Barriers
 // between phases become stream order; there is no host round trip inside a join.
 #include "hjgpu_ctx.hpp"
+#include "hj_device.hpp"
 
 using namespace hjapi;
 
@@ -323,7 +324,7 @@ int audit_begin(hjgpu_ctx *ctx, int kind, size_t inner, size_t outer, hipStream_
     const size_t words = (size_t)HJ_AUDIT_STAGES * 4;
     CHK(ensure(ctx, ctx->audit, (size_t)HJ_AUDIT_RING * words * sizeof(u64)));
     u64 *r = reinterpret_cast<u64 *>(ctx->audit.p) + (size_t)(ctx->audit_seq % HJ_AUDIT_RING) * words;
-    HIPCHK(ctx, hipMemsetAsync(r, 0, words * sizeof(u64), stream));
+    HIPCHK(ctx, hj_zero_async(r, words * sizeof(u64), stream));
     CHK(hj_audit_meta(r + 4 * (HJ_AUDIT_STAGES - 1), ctx->audit_seq, (u64)kind, (u64)inner, (u64)outer, stream));
     ctx->audit_seq += 1;
     ctx->audit_checks.clear();
@@ -553,14 +554,14 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         unsigned char *z1 = reinterpret_cast<unsigned char *>(m.counts[1]);
         unsigned char *zt = reinterpret_cast<unsigned char *>(m.tickets);
         unsigned char *ze = z0 + m.counts_bytes;
-        if (mode == PHJ_WHOLE) HIPCHK(ctx, hipMemsetAsync(z0, 0, m.counts_bytes, stream));
+        if (mode == PHJ_WHOLE) HIPCHK(ctx, hj_zero_async(z0, m.counts_bytes, stream));
         if (mode == PHJ_BUILD_ONLY) {
-            HIPCHK(ctx, hipMemsetAsync(z0, 0, (size_t)(z1 - z0), stream));
-            HIPCHK(ctx, hipMemsetAsync(zt, 0, (size_t)(ze - zt), stream));
+            HIPCHK(ctx, hj_zero_async(z0, (size_t)(z1 - z0), stream));
+            HIPCHK(ctx, hj_zero_async(zt, (size_t)(ze - zt), stream));
         }
-        if (mode == PHJ_PROBE_ONLY) HIPCHK(ctx, hipMemsetAsync(z1, 0, (size_t)(ze - z1), stream));
+        if (mode == PHJ_PROBE_ONLY) HIPCHK(ctx, hj_zero_async(z1, (size_t)(ze - z1), stream));
     }
-    if (mode != PHJ_BUILD_ONLY) HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+    if (mode != PHJ_BUILD_ONLY) HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
 
     Pass1Geom geom[2] = {make_geom(ctx->tune, rk, inner, pl.C, pl.F1, true), make_geom(ctx->tune, sk, outer, pl.C, pl.F1, true)};
     if (pre)
@@ -672,7 +673,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             // chunks was pass 1, cpra2.cpp:1757-1827): K4p counts per (piece, final partition), K5 lays pass 2 out,
             // K6 pass 2 reads the pieces where they are.  16 + 8 bytes per tuple less than partitioning from scratch.
             if (nn[r] && pre->counts[r])
-                HIPCHK(ctx, hipMemcpyAsync(m.counts[r], pre->counts[r], (size_t)pl.C * pl.P * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+                HIPCHK(ctx, hj_copy_async(m.counts[r], pre->counts[r], (size_t)pl.C * pl.P * sizeof(u64), stream));
             else if (nn[r]) CHK(hj_launch_hist_packed(pre->tuples[r], pre->ch[r], pl.pre_f1, pl.pre_F1tot, pl.pre_base, pl.F1,
                                                       pl.f2, pl.F2, m.counts[r], ctx->cus, stream));
             record(ctx, ev[0], stream);
@@ -716,7 +717,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
             ba.ranges_per_batch = pl.batch_ranges; ba.F1 = pl.F1; ba.F2 = pl.F2;
             ba.tile2 = (uint32_t)hj_scatter_tile(ctx->tune, 2, pl.F2, true);
             CHK(hj_launch_batch_plan(ba, batches, stream));
-            HIPCHK(ctx, hipMemsetAsync(m.btickets, 0, m.btickets_bytes, stream));
+            HIPCHK(ctx, hj_zero_async(m.btickets, m.btickets_bytes, stream));
             record(ctx, ev[1], stream);
             for (uint32_t b = 0; b < batches; ++b) {
                 uint32_t *tbuf = (uint32_t *)ctx->tmp[1 + 2 * (b & 1)].p;
@@ -923,9 +924,9 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
     u64 *table = reinterpret_cast<u64 *>(ctx->table.p);
     record(ctx, EV_BEGIN, stream);
-    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+    HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
     // K1 set() npj.cpp:865-868 ; K2 build() 871-877
-    HIPCHK(ctx, hipMemsetAsync(table, 0, buckets * sizeof(u64), stream));
+    HIPCHK(ctx, hj_zero_async(table, buckets * sizeof(u64), stream));
     // whole joins own their table: line-hashed layout (operator-level hjgpu_npj_build / _probe keep
     // the reference's hash so that their tables stay interchangeable with the reference's)
     const bool line = !ctx->tune.npj_refhash;
@@ -940,7 +941,7 @@ int npj_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size_t i
 // hjgpu_accumulate_async_status: the two flags of the last join -> two running uint64 counters
 __global__ void accumulate_flags_kernel(const DevState *__restrict__ st, u64 *__restrict__ flags)
 {
-    if (threadIdx.x == 0) { if (st->zero_key) flags[0] += 1; if (st->overflow) flags[1] += 1; }
+    if (threadIdx.x == 0) { if (st->zero_key) hj_store(&flags[0], flags[0] + 1); if (st->overflow) hj_store(&flags[1], flags[1] + 1); }
 }
 
 // the one-shot output of hjgpu_set_async_output
@@ -1290,7 +1291,7 @@ int hjgpu_audit_recheck(hjgpu_ctx *ctx, uint64_t *words, size_t capacity, size_t
         uint64_t *w = words + 9 * i++;
         w[0] = (uint64_t)c.stage;
         u64 fresh[4] = {0, 0, 0, 0};
-        HIPCHK(ctx, hipMemsetAsync(d_rec, 0, sizeof(fresh), ctx->aux));
+        HIPCHK(ctx, hj_zero_async(d_rec, sizeof(fresh), ctx->aux));
         CHK(hj_audit_partitions(c.tuples, c.beg, c.end, c.parts, c.h, d_rec, ctx->cus, ctx->aux));
         HIPCHK(ctx, hipMemcpyAsync(fresh, d_rec, sizeof(fresh), hipMemcpyDeviceToHost, ctx->aux));
         HIPCHK(ctx, hipStreamSynchronize(ctx->aux));
@@ -1349,7 +1350,7 @@ int hjgpu_npj_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t *rv, size
     ctx->last_had_output = out && out->d_keys;
     CHK(npj_enqueue(ctx, rk, rv, inner, sk, sv, outer, buckets, factor, out, stream, npj_unique(ctx, prm)));
     if (d_result)
-        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(ctx, hj_copy_async(d_result, ctx->state.p, sizeof(hjgpu_result), stream));
     return HJGPU_OK;
 }
 
@@ -1424,8 +1425,8 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, big, unique), &bs, &bl));
 
     record(ctx, EV_BEGIN, stream);
-    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
-    HIPCHK(ctx, hipMemsetAsync(item_part, 0, (items + 2) * sizeof(uint32_t), stream));
+    HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
+    HIPCHK(ctx, hj_zero_async(item_part, (items + 2) * sizeof(uint32_t), stream));
     for (int e : {EV_S_HIST, EV_S_PLAN, EV_S_SC1, EV_S_SC2}) record(ctx, e, stream);
     if (inner_ready) HIPCHK(ctx, hipStreamWaitEvent(stream, inner_ready, 0));
     record(ctx, EV_WAITED, stream);
@@ -1616,7 +1617,7 @@ static int grouped_async(hjgpu_ctx *ctx, uint32_t groups, uint32_t chunks,
         int rc = hipSetDevice(ctx->device) == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
         if (rc == HJGPU_OK)
             rc = phj_grouped(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, has_prm ? &prm_copy : nullptr, has_out ? &out_copy : nullptr, ws);
-        if (rc == HJGPU_OK && d_result && hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, ws) != hipSuccess)
+        if (rc == HJGPU_OK && d_result && hj_copy_async(d_result, ctx->state.p, sizeof(hjgpu_result), ws) != hipSuccess)
             rc = HJGPU_EHIP;
         ctx->grp_status = rc;
         // whatever happened, the caller's stream must not wait for ever
@@ -1671,7 +1672,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
         CHK(phj_enqueue(ctx, pl, rk, rv, inner, sk, sv, outer, out, stream, (hipEvent_t)inner_ready));
     }
     if (d_result)
-        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(ctx, hj_copy_async(d_result, ctx->state.p, sizeof(hjgpu_result), stream));
     if (blocking) return finish_blocking(ctx, result, out, stream);
     return HJGPU_OK;
 }
@@ -1739,7 +1740,7 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
     // the build columns themselves are not read again: their partitions live in the workspace
     CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, sk, sv, outer, out, stream, nullptr, PHJ_PROBE_ONLY));
     if (d_result)
-        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(ctx, hj_copy_async(d_result, ctx->state.p, sizeof(hjgpu_result), stream));
     if (blocking) return finish_blocking(ctx, result, out, stream);
     return HJGPU_OK;
 }

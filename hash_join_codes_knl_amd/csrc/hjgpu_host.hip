@@ -277,16 +277,16 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
         memset(&again, 0, sizeof(again));
         if (ok && npj) {
             // the accumulated result already holds this batch (counts are exact when rows overflow): what the second run adds is dropped
-            ok = hipMemcpyAsync(saved, &st->result, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess &&
-                 hipMemsetAsync(&st->block_counter, 0, 3 * sizeof(u64), run) == hipSuccess &&
-                 hipMemsetAsync(&st->overflow, 0, sizeof(uint32_t), run) == hipSuccess &&
-                 hipMemsetAsync(&st->nmoves, 0, sizeof(uint32_t), run) == hipSuccess &&
+            ok = hj_copy_async(saved, &st->result, sizeof(hjgpu_result), run) == hipSuccess &&
+                 hj_zero_async(&st->block_counter, 3 * sizeof(u64), run) == hipSuccess &&
+                 hj_zero_async(&st->overflow, sizeof(uint32_t), run) == hipSuccess &&
+                 hj_zero_async(&st->nmoves, sizeof(uint32_t), run) == hipSuccess &&
                  npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor, &o, run, line, unique) == HJGPU_OK &&
                  hipMemcpyAsync(&again, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run) == hipSuccess &&
-                 hipMemcpyAsync(&st->result, saved, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess;
+                 hj_copy_async(&st->result, saved, sizeof(hjgpu_result), run) == hipSuccess;
         } else if (ok) {
             ok = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, &o, run, nullptr, PHJ_PROBE_ONLY) == HJGPU_OK &&
-                 hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + j, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run) == hipSuccess &&
+                 hj_copy_async(static_cast<hjgpu_result *>(d_res) + j, ctx->state.p, sizeof(hjgpu_result), run) == hipSuccess &&
                  hipMemcpyAsync(&again, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run) == hipSuccess;
         }
         // the slot's probe rows are needed until here: the next upload into the slot waits for THIS record
@@ -296,7 +296,7 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
         // broke before its restore was enqueued.
         const bool drained = hj_stream_synchronize(run) == hipSuccess;
         if (!ok && npj && saved && drained)
-            (void)hipMemcpy(&st->result, saved, sizeof(hjgpu_result), hipMemcpyDeviceToDevice);
+            (void)(hj_copy_async(&st->result, saved, sizeof(hjgpu_result), run) == hipSuccess && hj_stream_synchronize(run) == hipSuccess);
         if (!drained) ok = false;
         if (ok) ok = !again.overflow && again.dense == need;
         if (ok) {
@@ -323,8 +323,8 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             // K1 set() npj.cpp:865-868 ; K2 build() 871-877; the probes of all batches add to ONE result (atomics on the state)
             rc = refuse_capture(ctx, run);
             hip_ok(hipEventRecord(b0, run), "hipEventRecord");
-            hip_ok(hipMemsetAsync(st, 0, sizeof(DevState), run), "hipMemsetAsync(state)");
-            hip_ok(hipMemsetAsync(table, 0, buckets * sizeof(u64), run), "hipMemsetAsync(table)");
+            hip_ok(hj_zero_async(st, sizeof(DevState), run), "clearing the state");
+            hip_ok(hj_zero_async(table, buckets * sizeof(u64), run), "clearing the table");
             if (rc == HJGPU_OK) rc = hj_launch_npj_build((const uint32_t *)d_r[0], (const uint32_t *)d_r[1], inner, table, buckets, factor,
                                                         &st->zero_key, ctx->cus, run, line);
             hip_ok(hipEventRecord(b1, run), "hipEventRecord");
@@ -350,9 +350,9 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
                 record(ctx, EV_R_HIST, run);
                 if (rows) {
                     // the output protocol's counters start over with every batch; the result and the zero-key flag add up
-                    hip_ok(hipMemsetAsync(&st->block_counter, 0, 3 * sizeof(u64), run), "hipMemsetAsync(counters)");
-                    hip_ok(hipMemsetAsync(&st->overflow, 0, sizeof(uint32_t), run), "hipMemsetAsync(overflow)");
-                    hip_ok(hipMemsetAsync(&st->nmoves, 0, sizeof(uint32_t), run), "hipMemsetAsync(nmoves)");
+                    hip_ok(hj_zero_async(&st->block_counter, 3 * sizeof(u64), run), "clearing the counters");
+                    hip_ok(hj_zero_async(&st->overflow, sizeof(uint32_t), run), "clearing the overflow flag");
+                    hip_ok(hj_zero_async(&st->nmoves, sizeof(uint32_t), run), "clearing the move count");
                 }
                 rc = npj_probe_enqueue(ctx, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m, table, buckets, factor,
                                        rows ? &dev_out[slot] : nullptr, run, line, unique);
@@ -364,7 +364,7 @@ static int join_host_batched(hjgpu_ctx *ctx, int algorithm, const uint32_t *ik, 
             } else if (rc == HJGPU_OK) {
                 rc = phj_enqueue(ctx, pl, nullptr, nullptr, inner, (const uint32_t *)d_s[slot][0], (const uint32_t *)d_s[slot][1], m,
                                  rows ? &dev_out[slot] : nullptr, run, nullptr, PHJ_PROBE_ONLY);
-                hip_ok(hipMemcpyAsync(static_cast<hjgpu_result *>(d_res) + i, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, run),
+                hip_ok(hj_copy_async(static_cast<hjgpu_result *>(d_res) + i, ctx->state.p, sizeof(hjgpu_result), run),
                        "hipMemcpyAsync(result)");
                 if (rows) {
                     hip_ok(hipMemcpyAsync(&h_state[i], ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, run), "hipMemcpyAsync(state)");

@@ -34,6 +34,12 @@
 #include "../../include/hjgpu.h"
 #include "exchange_layout.hpp"
 
+// The library's store policy (csrc/hj_device.hpp): no plain global store beside other queues' work - K6's were lost in memory, 1.3-1.5 in
+// 10^4 pipeline steps.  This file's clears and device-to-device copies are the library's own kernels (csrc/gen_kernels.hip), not the
+// runtime's hipMemsetAsync / hipMemcpyAsync, and its few small kernels store non-temporally.
+hipError_t hj_zero_async(void *p, size_t bytes, hipStream_t stream);
+hipError_t hj_copy_async(void *dst, const void *src, size_t bytes, hipStream_t stream);
+
 typedef unsigned long long u64;
 
 
@@ -445,9 +451,8 @@ struct RcclTransport : Transport {
             if (scnt[l][me] != rcnt[l][me]) return cfail(c, HJGPU_EINVAL, "all_to_all_v: a rank's counts for itself disagree");
             if (!scnt[l][me]) continue;
             HIPM(c, hipSetDevice(c->ranks[l].device));
-            HIPM(c, hipMemcpyAsync(static_cast<char *>(recv[l]) + roff[l][me] * elem_bytes,
-                                   static_cast<const char *>(send[l]) + soff[l][me] * elem_bytes, scnt[l][me] * elem_bytes,
-                                   hipMemcpyDeviceToDevice, streams[l]));
+            HIPM(c, hj_copy_async(static_cast<char *>(recv[l]) + roff[l][me] * elem_bytes,
+                                   static_cast<const char *>(send[l]) + soff[l][me] * elem_bytes, scnt[l][me] * elem_bytes, streams[l]));
         }
         if (G == 1 && self_copy) return HJGPU_OK;
         Group g(c, R);
@@ -489,7 +494,7 @@ __global__ void sum_rows_kernel(const u64 *__restrict__ rows, u64 *__restrict__ 
     if (i >= count) return;
     u64 s = 0;
     for (uint32_t r = 0; r < nrows; ++r) s += rows[(u64)r * count + i];
-    out[i] = s;
+    __builtin_nontemporal_store(s, &out[i]);
 }
 
 // fault injection: a rank that does not arrive at a collective for `ms` (a host function on its stream: the GPU is
@@ -586,11 +591,11 @@ struct LoopbackTransport : Transport {
 // dst[0..3] += src[0..3]: the aggregates of one probe batch join the rank's running result
 __global__ void add_result_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src)
 {
-    if (threadIdx.x < 4) dst[threadIdx.x] += src[threadIdx.x];
+    if (threadIdx.x < 4) __builtin_nontemporal_store(dst[threadIdx.x] + src[threadIdx.x], &dst[threadIdx.x]);
 }
 
 // a status flag raised from the host side of the pipeline (stream-ordered with the joins that read / reduce it)
-__global__ void bump_kernel(u64 *flag) { *flag += 1; }
+__global__ void bump_kernel(u64 *flag) { __builtin_nontemporal_store(*flag + 1, flag); }
 
 // ---- construction ---------------------------------------------------------------------------------
 int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
@@ -862,7 +867,7 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, hjg
         CHKM(ensure(c, r, r.rbuf, c->transport->replicate_capacity(bytes)));
         bufs.push_back(r.rbuf.p);
         HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipMemsetAsync(r.d_res.p, 0, 12 * sizeof(u64), r.main));
+        HIPM(c, hj_zero_async(r.d_res.p, 12 * sizeof(u64), r.main));
         HIPM(c, hipEventRecord(r.ev_x0, r.comm));
         if (from_host) {
             HIPM(c, hipStreamWaitEvent(r.main, r.ev_up_s, 0));       // the probe shard is in HBM
@@ -870,8 +875,8 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, hjg
         }
         if (r.global == root && inner) {
             uint32_t *b = static_cast<uint32_t *>(r.rbuf.p);
-            HIPM(c, hipMemcpyAsync(b, shards[l].d_inner_keys, inner * sizeof(uint32_t), hipMemcpyDeviceToDevice, r.comm));
-            HIPM(c, hipMemcpyAsync(b + stride, shards[l].d_inner_vals, inner * sizeof(uint32_t), hipMemcpyDeviceToDevice, r.comm));
+            HIPM(c, hj_copy_async(b, shards[l].d_inner_keys, inner * sizeof(uint32_t), r.comm));
+            HIPM(c, hj_copy_async(b + stride, shards[l].d_inner_vals, inner * sizeof(uint32_t), r.comm));
         }
     }
     const std::vector<hipStream_t> comms = streams_of(c, &Rank::comm);
@@ -1045,8 +1050,8 @@ struct CpraStep {
                                                        static_cast<uint32_t *>(b.sk->p), static_cast<uint32_t *>(b.sv->p),
                                                        reinterpret_cast<uint64_t *>(d_off), r.prep));
             else {
-                HIPM(c, hipMemsetAsync(d_off, 0, (F + 1) * sizeof(u64), r.prep));
-                if (counted) HIPM(c, hipMemsetAsync(r.cnt2[slot].p, 0, F * F2 * sizeof(u64), r.prep));
+                HIPM(c, hj_zero_async(d_off, (F + 1) * sizeof(u64), r.prep));
+                if (counted) HIPM(c, hj_zero_async(r.cnt2[slot].p, F * F2 * sizeof(u64), r.prep));
             }
             HIPM(c, hipMemcpyAsync(h_off, d_off, (F + 1) * sizeof(u64), hipMemcpyDeviceToHost, r.prep));
             HIPM(c, hipEventRecord(r.ev_part[slot], r.prep));
@@ -1141,9 +1146,9 @@ struct CpraStep {
                 const size_t mine = (size_t)k * F2, all = (size_t)fanout() * F2;
                 int piece = 0;
                 auto take = [&](int sender) -> int {
-                    HIPM(c, hipMemcpyAsync(static_cast<u64 *>(r.cnt_recv[slot].p) + (size_t)piece * mine,
+                    HIPM(c, hj_copy_async(static_cast<u64 *>(r.cnt_recv[slot].p) + (size_t)piece * mine,
                                            static_cast<const u64 *>(r.cnt2_all[slot].p) + (size_t)sender * all + (size_t)r.global * mine,
-                                           mine * sizeof(u64), hipMemcpyDeviceToDevice, r.comm));
+                                           mine * sizeof(u64), r.comm));
                     ++piece;
                     return HJGPU_OK;
                 };
@@ -1247,7 +1252,7 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
     };
     for (Rank &r : c->ranks) {
         HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipMemsetAsync(r.d_res.p, 0, 12 * sizeof(u64), r.main));
+        HIPM(c, hj_zero_async(r.d_res.p, 12 * sizeof(u64), r.main));
         // timing events of the slices' waits, one pair per slice, read after the step (nobody waits in between)
         while (r.ev_w.size() < 2 * (size_t)slices) {
             hipEvent_t e = nullptr;
@@ -1539,7 +1544,7 @@ int fail_create(hjgpu_comm *c, int rc, const char *what = nullptr)
 __global__ void pattern_kernel(u64 *__restrict__ p, u64 n, u64 seed)
 {
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        p[i] = (seed + i) * 0x9E3779B97F4A7C15ull + (seed << 17);
+        __builtin_nontemporal_store((u64)((seed + i) * 0x9E3779B97F4A7C15ull + (seed << 17)), &p[i]);
 }
 inline u64 pattern_at(u64 seed, u64 i) { return (seed + i) * 0x9E3779B97F4A7C15ull + (seed << 17); }
 
@@ -1829,7 +1834,7 @@ int hjgpu_comm_preflight(hjgpu_comm *c, size_t link_bytes, hjgpu_preflight *rep)
         CHKM(ensure(c, r, r.pre, words * sizeof(u64) + (Gs + 1) * link_bytes + 256));
         base[l] = static_cast<u64 *>(r.pre.p);
         HIPM(c, hipSetDevice(r.device));
-        HIPM(c, hipMemsetAsync(base[l], 0, words * sizeof(u64), r.comm));
+        HIPM(c, hj_zero_async(base[l], words * sizeof(u64), r.comm));
         hipLaunchKernelGGL(pattern_kernel, dim3(64), dim3(256), 0, r.comm, base[l], (u64)W, (u64)(1000 + r.global));                       // all-gather
         hipLaunchKernelGGL(pattern_kernel, dim3(256), dim3(256), 0, r.comm, base[l] + W + Gs * W, (u64)(Gs * W), (u64)(5000 + r.global));   // all-to-all
         hipLaunchKernelGGL(pattern_kernel, dim3(64), dim3(256), 0, r.comm, base[l] + W + 3 * Gs * W, (u64)W, (u64)(9000 + r.global));       // all-reduce

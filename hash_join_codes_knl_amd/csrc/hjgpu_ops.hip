@@ -32,7 +32,7 @@ int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_
     for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
     ctx->last_algo = 2;
     record(ctx, EV_BEGIN, stream);
-    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
+    HIPCHK(ctx, hj_zero_async(m.counts[0], m.counts_bytes, stream));
     if (n) CHK(hj_launch_hist2(d_keys, geom, factor, fanout, 1u, 1u, m.counts[0], m.range_counts[0], m.tickets,
                                ctx->cus, stream));
     PlanArgs pa;
@@ -62,8 +62,7 @@ int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_
         sa.nt_partial = ctx->rows_plain ? 0u : 1u;
                 CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }
-    HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64),
-                               hipMemcpyDeviceToDevice, stream));
+    HIPCHK(ctx, hj_copy_async(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), stream));
     record(ctx, EV_GAPS, stream);
     return HJGPU_OK;
 }
@@ -82,13 +81,13 @@ int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t f
         return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 32768] and factor odd");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, (size_t)fanout * sizeof(u64), stream));
+    HIPCHK(ctx, hj_zero_async(d_counts, (size_t)fanout * sizeof(u64), stream));
     if (n) {
         // the per-range counts are a by-product here; they go to scratch
         const Pass1Geom g = make_geom(ctx->tune, d_keys, n, 1, 1, false);
         CHK(ensure(ctx, ctx->moves, ((size_t)g.ranges_per_chunk + 16) * sizeof(uint32_t)));
         uint32_t *ticket = (uint32_t *)ctx->moves.p + g.ranges_per_chunk;
-        HIPCHK(ctx, hipMemsetAsync(ticket, 0, 8 * sizeof(uint32_t), stream));
+        HIPCHK(ctx, hj_zero_async(ticket, 8 * sizeof(uint32_t), stream));
         CHK(hj_launch_hist2(d_keys, g, 1u, 1u, factor, fanout, (u64 *)d_counts,
                             (uint32_t *)ctx->moves.p, ticket, ctx->cus, stream));
     }
@@ -152,7 +151,7 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
     const bool unique = ctx->tune.unique || (passes->flags & HJGPU_FLAG_UNIQUE);
     CHK(setup_output(ctx, out, (uint32_t)hj_join_workers(ctx->tune, ctx->cus, false, unique), &bs, &bl));
     record(ctx, EV_BEGIN, stream);
-    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
+    HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
     // counts = adjacent differences of the caller's offsets, then the usual plan
     // (re-derives identical offsets and the work-item prefix)
     CHK(hj_launch_offsets_to_counts((const u64 *)roff, m.counts[0], pl.P, stream));
@@ -212,8 +211,8 @@ int hjgpu_npj_build(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
-    HIPCHK(ctx, hipMemsetAsync(st, 0, sizeof(DevState), stream));
-    HIPCHK(ctx, hipMemsetAsync(d_table, 0, buckets * sizeof(u64), stream));
+    HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
+    HIPCHK(ctx, hj_zero_async(d_table, buckets * sizeof(u64), stream));
     if (n) CHK(hj_launch_npj_build(d_keys, d_vals, n, (u64 *)d_table, buckets, factor, &st->zero_key, ctx->cus, stream));
     return finish_blocking(ctx, nullptr, nullptr, stream);
 }
@@ -228,7 +227,7 @@ int hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->state, sizeof(DevState)));
-    HIPCHK(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(DevState), stream));
+    HIPCHK(ctx, hj_zero_async(ctx->state.p, sizeof(DevState), stream));
     record(ctx, EV_BEGIN, stream); record(ctx, EV_R_HIST, stream);
     CHK(npj_probe_enqueue(ctx, d_keys, d_vals, n, (const u64 *)d_table, buckets, factor, out, stream, false, ctx->tune.unique));
     ctx->last_algo = 0;
@@ -264,12 +263,12 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
     record(ctx, EV_BEGIN, stream);
     u64 *audit = nullptr;                  // option "audit": stage 0 the columns as read, stage 1 the packed output where it lies
     CHK(audit_begin(ctx, 3, n, 0, stream, &audit));
-    HIPCHK(ctx, hipMemsetAsync(m.counts[0], 0, m.counts_bytes, stream));
+    HIPCHK(ctx, hj_zero_async(m.counts[0], m.counts_bytes, stream));
     if (d_counts2) {
         // the same read of the keys also counts the RECEIVERS' second level (bin = p1 * fanout2 + p2, the join's fused
         // histogram): they then need no histogram pass of their own over what arrives (K4p).  The pass-1 counts of this
         // call are the row sums.
-        HIPCHK(ctx, hipMemsetAsync(d_counts2, 0, (size_t)fanout * fanout2 * sizeof(u64), stream));
+        HIPCHK(ctx, hj_zero_async(d_counts2, (size_t)fanout * fanout2 * sizeof(u64), stream));
         if (n) {
             u64 *fused = reinterpret_cast<u64 *>(d_counts2);
             CHK(hj_launch_hist2(d_keys, geom, factor, fanout, factor2, fanout2, fused, m.range_counts[0], m.tickets, ctx->cus, stream, (size_t)ctx->tune.hist_min_lds));
@@ -303,7 +302,7 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
         sa.nt_partial = ctx->rows_plain ? 0u : 1u;
                 CHK(hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream));
     }
-    HIPCHK(ctx, hipMemcpyAsync(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(ctx, hj_copy_async(d_offsets, m.off2[0], ((size_t)fanout + 1) * sizeof(u64), stream));
     if (audit && n) {
         CHK(hj_audit_sums_columns(d_keys, d_vals, n, audit, ctx->cus, stream));
         CHK(ensure(ctx, ctx->audit_lay, (size_t)2 * (HJGPU_MAX_FANOUT + 1) * sizeof(u64)));
@@ -452,7 +451,7 @@ static int probe_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const 
     ctx->last_had_output = out && out->d_keys;
     CHK(phj_enqueue(ctx, pl, nullptr, nullptr, ctx->prepared_inner, nullptr, nullptr, outer, out, stream, nullptr, PHJ_PROBE_ONLY, &pre));
     if (d_result)
-        HIPCHK(ctx, hipMemcpyAsync(d_result, ctx->state.p, sizeof(hjgpu_result), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(ctx, hj_copy_async(d_result, ctx->state.p, sizeof(hjgpu_result), stream));
     return HJGPU_OK;
 }
 
@@ -501,7 +500,7 @@ int hjgpu_generate_select(hjgpu_ctx *ctx, uint64_t seed, size_t inner_total, siz
         memset(expected, 0, sizeof(*expected));
         CHK(ensure(ctx, ctx->moves, 64));
         d_expect = (u64 *)ctx->moves.p;
-        HIPCHK(ctx, hipMemsetAsync(d_expect, 0, 4 * sizeof(u64), stream));
+        HIPCHK(ctx, hj_zero_async(d_expect, 4 * sizeof(u64), stream));
     }
     int rc = hj_launch_generate(seed, inner_total, inner_begin, inner_count, outer_total, outer_begin,
                                 outer_count, inner_factor, outer_factor, ik, iv, ok, ov, stream, zipf, selectivity,
@@ -577,7 +576,7 @@ int hjgpu_random_cas_ms(hjgpu_ctx *ctx, void *d_ptr, size_t bytes, size_t ops, i
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure(ctx, ctx->moves, 64));
-    HIPCHK(ctx, hipMemsetAsync(d_ptr, 0, bytes, stream));              // every bucket empty: outside the timed span
+    HIPCHK(ctx, hj_zero_async(d_ptr, bytes, stream));              // every bucket empty: outside the timed span
     for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
     record(ctx, EV_BEGIN, stream);
     CHK(hj_launch_random_cas(d_ptr, bytes, ops, in_flight, load_first != 0, ctx->moves.p, ctx->cus, stream));

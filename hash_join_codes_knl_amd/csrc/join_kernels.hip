@@ -453,7 +453,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
 
     // ---- per-wave cursors -> final offsets (close_gaps input) ---------------------
     if (a.ok && hj_lane() == 0)
-        a.final_offsets[(u64)blockIdx.x * NW + wave] = wave_cursor[wave];
+        hj_store(&a.final_offsets[(u64)blockIdx.x * NW + wave], wave_cursor[wave]);
 
     // ---- workgroup reduction of the aggregates, 4 atomics per workgroup ---------
     acc_n = wave_reduce_sum(acc_n); acc_k = wave_reduce_sum(acc_k);
@@ -492,10 +492,10 @@ __global__ __launch_bounds__(1024) void broadcast_meta_kernel(const uint32_t *__
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        *m.sentinel = first_free;
-        m.roff[0] = 0; m.rend[0] = inner; m.soff[0] = 0; m.send[0] = outer;
-        m.slice_prefix[0] = 0; m.slice_prefix[1] = (u64)nslices * groups;
-        m.slices[0] = (u64)nslices | ((u64)groups << 32);
+        hj_store(m.sentinel, first_free);
+        hj_store(&m.roff[0], (u64)0); hj_store(&m.rend[0], inner); hj_store(&m.soff[0], (u64)0); hj_store(&m.send[0], outer);
+        hj_store(&m.slice_prefix[0], (u64)0); hj_store(&m.slice_prefix[1], (u64)nslices * groups);
+        hj_store(&m.slices[0], (u64)nslices | ((u64)groups << 32));
     }
 }
 

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_kernel(NpjProbeArgs
         }
     }
     if (a.ok && hj_lane() == 0)
-        a.final_offsets[(u64)blockIdx.x * NW + wave] = wave_cursor[wave];
+        hj_store(&a.final_offsets[(u64)blockIdx.x * NW + wave], wave_cursor[wave]);
     acc_n = wave_reduce_sum(acc_n); acc_k = wave_reduce_sum(acc_k);
     acc_o = wave_reduce_sum(acc_o); acc_i = wave_reduce_sum(acc_i);
     if (hj_lane() == 0) { red[0][wave] = acc_n; red[1][wave] = acc_k; red[2][wave] = acc_o; red[3][wave] = acc_i; }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NPJ_PROBE_BLOCK) void npj_probe_line_kernel(NpjProb
         }
     }
     if (MATERIALIZE && hj_lane() == 0)
-        a.final_offsets[(u64)blockIdx.x * NW + wave] = wave_cursor[wave];
+        hj_store(&a.final_offsets[(u64)blockIdx.x * NW + wave], wave_cursor[wave]);
     acc_n = wave_reduce_sum(acc_n); acc_k = wave_reduce_sum(acc_k);
     acc_o = wave_reduce_sum(acc_o); acc_i = wave_reduce_sum(acc_i);
     if (hj_lane() == 0) { red[0][wave] = acc_n; red[1][wave] = acc_k; red[2][wave] = acc_o; red[3][wave] = acc_i; }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(CG_BLOCK) void close_gaps_plan_kernel(
 {
     // an overflowed join left cursors that do not describe disjoint holes: plan nothing
     if (*overflow) {
-        if (threadIdx.x == 0) { *nmoves = 0; *dense_count = 0; }
+        if (threadIdx.x == 0) { hj_store(nmoves, 0u); hj_store(dense_count, (u64)0); }
         return;
     }
     __shared__ u64 hole_beg[CG_MAX];            // sorted hole starts, then prefix of the destination sizes
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(CG_BLOCK) void close_gaps_plan_kernel(
     const uint32_t count = (uint32_t)sh_count;
     const u64 top = sh_top, J = top - sh_holes;
     if (count == 0) {
-        if (tid == 0) { *nmoves = 0; *dense_count = 0; }
+        if (tid == 0) { hj_store(nmoves, 0u); hj_store(dense_count, (u64)0); }
         return;
     }
     // destination part of hole i: [b_i, min(e_i, J)); source stretch i: [max(e_{i-1}, J), b_i), i >= 1
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(CG_BLOCK) void close_gaps_plan_kernel(
     // the stretches' start positions are needed by other threads and LDS is full: global scratch
     // behind the move list (same workgroup, read after a barrier)
     u64 *stretch_beg = reinterpret_cast<u64 *>(moves + 2 * HJ_MAX_WORKERS);
-    for (uint32_t i = lo, j = 0; i < hi; ++i, ++j) if (i < count) stretch_beg[i] = sb[j];
+    for (uint32_t i = lo, j = 0; i < hi; ++i, ++j) if (i < count) hj_store(&stretch_beg[i], sb[j]);
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t i = lo, j = 0; i < hi; ++i, ++j) {
@@ -473,16 +473,16 @@ __global__ __launch_bounds__(CG_BLOCK) void close_gaps_plan_kernel(
             if (s0 >= t1) break;
             if (s1 > t0 && s1 > s0) {
                 const u64 a0 = max(t0, s0), a1 = min(t1, s1);       // overlapping slots
-                moves[at].dst = db[j] + (a0 - t0);
-                moves[at].src = stretch_beg[s] + (a0 - s0);
-                moves[at].cnt = a1 - a0;
+                hj_store(&moves[at].dst, db[j] + (a0 - t0));
+                hj_store(&moves[at].src, stretch_beg[s] + (a0 - s0));
+                hj_store(&moves[at].cnt, a1 - a0);
                 ++at;
             }
             ++s;
         }
     }
-    if (tid == CG_BLOCK - 1) *nmoves = (uint32_t)(mbase + mine);
-    if (tid == 0) *dense_count = J;
+    if (tid == CG_BLOCK - 1) hj_store(nmoves, (uint32_t)(mbase + mine));
+    if (tid == 0) hj_store(dense_count, J);
 }
 
 // The whole chip copies the planned moves: one move per workgroup at a time
@@ -496,9 +496,10 @@ __global__ __launch_bounds__(256) void close_gaps_copy_kernel(
     for (uint32_t m = blockIdx.x; m < nm; m += gridDim.x) {
         const u64 dst = moves[m].dst, src = moves[m].src, cnt = moves[m].cnt;
         for (u64 i = threadIdx.x; i < cnt; i += 256) {
-            k[dst + i] = k[src + i];
-            ov[dst + i] = ov[src + i];
-            iv[dst + i] = iv[src + i];
+            // (non-temporal like the rows themselves: a move that is lost leaves a hole's stale row inside the dense result)
+            hj_store(&k[dst + i], k[src + i]);
+            hj_store(&ov[dst + i], ov[src + i]);
+            hj_store(&iv[dst + i], iv[src + i]);
         }
     }
 }

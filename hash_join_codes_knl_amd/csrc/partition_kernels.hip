@@ -82,7 +82,7 @@ __device__ __forceinline__ void k6_store8(u64 *p, u64 v)
 // --------------------------------------------------------------------------
 // K4: fused two-level histogram + per-range pass-1 counts.
 // A workgroup walks whole ranges (Pass1Geom); for every range it leaves the
-// F1 pass-1 counts of that range in range_counts[range][F1] (plain stores), and
+// F1 pass-1 counts of that range in range_counts[range][F1] (non-temporal stores like every store of the library, hj_device.hpp), and
 // it accumulates the fused (p1,p2) histogram of everything it saw in LDS, flushed
 // once at the end with one global atomic per non-empty bin.
 // --------------------------------------------------------------------------
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
                     best = max(best, ((u64)v << 32) | (p1 * F2 + p2));
                 }
                 sum = (uint32_t)wave_reduce_sum((u64)sum);
-                if (hj_lane() == 0) { rc[p1] = sum - range_hist[p1]; range_hist[p1] = sum; }
+                if (hj_lane() == 0) { hj_store(&rc[p1], sum - range_hist[p1]); range_hist[p1] = sum; }
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) best = max(best, (u64)__shfl_down((unsigned long long)best, d, 64));
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
         } else {
             for (uint32_t i = threadIdx.x; i < F1; i += BLOCK) {
                 const uint32_t v = range_hist[i];
-                rc[i] = v;
+                hj_store(&rc[i], v);
                 if (v) atomicAdd(&lds_hist[i], v);              // single pass: fused == pass-1 histogram
             }
         }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64) void row_sums_kernel(const u64 *__restrict__ co
     u64 s = 0;
     for (uint32_t j = threadIdx.x; j < F2; j += 64) s += counts[(u64)blockIdx.x * F2 + j];
     s = wave_reduce_sum(s);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;
+    if (threadIdx.x == 0) hj_store(&out[blockIdx.x], s);
 }
 
 int hj_launch_row_sums(const u64 *counts, uint32_t F1, uint32_t F2, u64 *out, hipStream_t stream)
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void range_base_kernel(
     if (group_bins) first += hj_group_shift(off1[p / group_bins * group_bins], p / group_bins);
     u64 run = first + block_exclusive_scan<256, u64>(sum, scratch);
     for (uint32_t j = lo; j < hi; ++j) {
-        range_base[(row0 + j) * F1 + p] = run;
+        hj_store(&range_base[(row0 + j) * F1 + p], run);
         run += range_counts[(row0 + j) * F1 + p];
     }
 }
@@ -455,13 +455,13 @@ __device__ void plan_scan(uint32_t n, F f, u64 *__restrict__ out, u64 base, u64 
         u64 run = base + block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
 #pragma unroll
         for (int j = 0; j < MAXPER; ++j)
-            if (lo + j < hi) { out[lo + j] = run; then(lo + j, v[j], run); run += v[j]; }
-        if (write_total && threadIdx.x == PLAN_BLOCK - 1) out[n] = run;   // last thread's run == base + total
+            if (lo + j < hi) { hj_store(&out[lo + j], run); then(lo + j, v[j], run); run += v[j]; }
+        if (write_total && threadIdx.x == PLAN_BLOCK - 1) hj_store(&out[n], run);   // last thread's run == base + total
     } else {
         for (uint32_t i = lo; i < hi; ++i) sum += f(i);
         u64 run = base + block_exclusive_scan<PLAN_BLOCK, u64>(sum, scratch);
-        for (uint32_t i = lo; i < hi; ++i) { const u64 x = f(i); out[i] = run; then(i, x, run); run += x; }
-        if (write_total && threadIdx.x == PLAN_BLOCK - 1) out[n] = run;
+        for (uint32_t i = lo; i < hi; ++i) { const u64 x = f(i); hj_store(&out[i], run); then(i, x, run); run += x; }
+        if (write_total && threadIdx.x == PLAN_BLOCK - 1) hj_store(&out[n], run);
     }
     __syncthreads();
 }
@@ -518,13 +518,13 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
     if (!PAD) {
         // dense final layout: partition q occupies [off2[q], off2[q + 1])
         plan_scan(P, [&](uint32_t i) { return cnt[i]; }, off2, base, scratch,
-                  [&](uint32_t i, u64 n, u64 first) { end2[i] = first + n; });
+                  [&](uint32_t i, u64 n, u64 first) { hj_store(&end2[i], first + n); });
         // off2[P] of this chunk is the next chunk's first row (same value: chunks are contiguous)
-        for (uint32_t i = threadIdx.x; i < P; i += PLAN_BLOCK) a.cur2[r][(u64)c * P + i] = off2[i];
+        for (uint32_t i = threadIdx.x; i < P; i += PLAN_BLOCK) hj_store(&a.cur2[r][(u64)c * P + i], off2[i]);
         for (uint32_t p1 = threadIdx.x; p1 < a.F1; p1 += PLAN_BLOCK) {
             const u64 o = off2[(u64)p1 * a.F2];
-            a.off1[r][(u64)c * a.F1 + p1] = o;
-            a.cur1[r][(u64)c * a.F1 + p1] = o;
+            hj_store(&a.off1[r][(u64)c * a.F1 + p1], o);
+            hj_store(&a.cur1[r][(u64)c * a.F1 + p1], o);
         }
     } else {
         // Two passes: the pass-1 output (= pass-2 input) stays dense, the FINAL layout starts every
@@ -580,27 +580,27 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
             if (q0 < P) {
                 if (q0 % F2 == 0) {
                     const u64 mine = d + (p_major ? before[q0 / F2] : 0);
-                    a.off1[r][(u64)c * a.F1 + q0 / F2] = mine; a.cur1[r][(u64)c * a.F1 + q0 / F2] = mine;
-                    if (p_major && c == 0) a.seg2[r][q0 / F2] = d;
+                    hj_store(&a.off1[r][(u64)c * a.F1 + q0 / F2], mine); hj_store(&a.cur1[r][(u64)c * a.F1 + q0 / F2], mine);
+                    if (p_major && c == 0) hj_store(&a.seg2[r][q0 / F2], d);
                 }
-                if (c == 0) { fo[q0] = pd; fe[q0] = pd + t0; fc[q0] = 0; }      // cursor: lines claimed | tail tuples << 32
+                if (c == 0) { hj_store(&fo[q0], pd); hj_store(&fe[q0], pd + t0); hj_store(&fc[q0], (u64)0); }      // cursor: lines claimed | tail tuples << 32
             }
             if (q1 < P) {
                 const u64 d1 = d + n0, p1 = pd + padded(t0);
                 if (q1 % F2 == 0) {
                     const u64 mine = d1 + (p_major ? before[q1 / F2] : 0);
-                    a.off1[r][(u64)c * a.F1 + q1 / F2] = mine; a.cur1[r][(u64)c * a.F1 + q1 / F2] = mine;
-                    if (p_major && c == 0) a.seg2[r][q1 / F2] = d1;
+                    hj_store(&a.off1[r][(u64)c * a.F1 + q1 / F2], mine); hj_store(&a.cur1[r][(u64)c * a.F1 + q1 / F2], mine);
+                    if (p_major && c == 0) hj_store(&a.seg2[r][q1 / F2], d1);
                 }
-                if (c == 0) { fo[q1] = p1; fe[q1] = p1 + t1; fc[q1] = 0; }
+                if (c == 0) { hj_store(&fo[q1], p1); hj_store(&fe[q1], p1 + t1); hj_store(&fc[q1], (u64)0); }
             }
             drun += dt; prun += pt;
         }
     }
     if (threadIdx.x == 0) {
-        a.seg1[r][c] = base;
-        if (c == C - 1) { a.seg1[r][C] = a.n[r]; a.off1[r][(u64)C * a.F1] = a.n[r]; }
-        if (PAD && a.p_major && c == 0) a.seg2[r][a.F1] = a.n[r];
+        hj_store(&a.seg1[r][c], base);
+        if (c == C - 1) { hj_store(&a.seg1[r][C], a.n[r]); hj_store(&a.off1[r][(u64)C * a.F1], a.n[r]); }
+        if (PAD && a.p_major && c == 0) hj_store(&a.seg2[r][a.F1], a.n[r]);
     }
 }
 
@@ -648,10 +648,10 @@ __global__ __launch_bounds__(PLAN_BLOCK) void tile_desc_kernel(PlanArgs a)
         const u64 t0 = tp2[i], t1 = min(tp2[i + 1], (u64)a.tdesc_cap);
         for (u64 t = t0 + (threadIdx.x & 63); t < t1; t += 64) {
             const u64 g0 = (gb & ~3ull) + (t - t0) * tile2;
-            td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
+            hj_store(&td[2 * t], make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32)));
             // third word: first entry of the segment's final partitions in the cursor / offset tables - shared by
             // all chunks in the line-aligned layout, per (chunk, pass-1 partition) in the dense one
-            td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), (a.pad2 ? sgm % a.F1 : sgm) * a.F2, sgm);
+            hj_store(&td[2 * t + 1], make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), (a.pad2 ? sgm % a.F1 : sgm) * a.F2, sgm));
         }
     }
 }
@@ -701,19 +701,19 @@ __device__ __forceinline__ void plan_items_body(const PlanArgs &a)
         plan_scan2(first, unused, total, t2, scratch2, parity);
         first += run;
         if (q0 < P) {
-            a.slice_prefix[q0] = first;
-            a.slices[q0] = s0;
+            hj_store(&a.slice_prefix[q0], first);
+            hj_store(&a.slices[q0], s0);
             // item -> partition directory: the join reads one word instead of a binary search
-            for (u64 i = 0; i < n0; ++i) a.item_part[first + i] = q0;
+            for (u64 i = 0; i < n0; ++i) hj_store(&a.item_part[first + i], q0);
         }
         if (q1 < P) {
-            a.slice_prefix[q1] = first + n0;
-            a.slices[q1] = s1;
-            for (u64 i = 0; i < n1; ++i) a.item_part[first + n0 + i] = q1;
+            hj_store(&a.slice_prefix[q1], first + n0);
+            hj_store(&a.slices[q1], s1);
+            for (u64 i = 0; i < n1; ++i) hj_store(&a.item_part[first + n0 + i], q1);
         }
         run += total;
     }
-    if (threadIdx.x == 0) a.slice_prefix[P] = run;
+    if (threadIdx.x == 0) hj_store(&a.slice_prefix[P], run);
     // the multi-fill half of a _UNIQUE join (join_kernel<.., UNIQUE, DEDUP>) returns at once when this stays 0
     if (a.multi_fill && multi) atomicAdd(a.multi_fill, multi);
 }
@@ -732,24 +732,24 @@ __global__ __launch_bounds__(PLAN_BLOCK) void batch_plan_kernel(BatchPlanArgs a)
     const u64 off = block_exclusive_scan<PLAN_BLOCK, u64>(total, scratch);
     u64 *boff = a.boff + (u64)b * (F1 + 1);
     if (mine) {
-        boff[p] = off;
-        if (p == F1 - 1) boff[F1] = off + total;
+        hj_store(&boff[p], off);
+        if (p == F1 - 1) hj_store(&boff[F1], off + total);
         u64 run = off;
-        for (uint32_t r = rb; r < re; ++r) { a.range_base[(u64)r * F1 + p] = run; run += a.range_counts[(u64)r * F1 + p]; }
+        for (uint32_t r = rb; r < re; ++r) { hj_store(&a.range_base[(u64)r * F1 + p], run); run += a.range_counts[(u64)r * F1 + p]; }
     }
     __syncthreads();
     const u64 tiles = mine ? hj_tiles_of(off, off + total, 0, a.tile2) : 0;
     const u64 t0 = block_exclusive_scan<PLAN_BLOCK, u64>(tiles, scratch);
     u64 *tp = a.tp2b + (u64)b * (F1 + 1);
     if (mine) {
-        tp[p] = t0;
-        if (p == F1 - 1) tp[F1] = t0 + tiles;
+        hj_store(&tp[p], t0);
+        if (p == F1 - 1) hj_store(&tp[F1], t0 + tiles);
         uint4 *td = a.tdesc + (u64)b * a.tdesc_cap * 2;
         const u64 gb = off, ge = off + total;
         for (u64 t = t0; t < t0 + tiles && t < a.tdesc_cap; ++t) {
             const u64 g0 = (gb & ~3ull) + (t - t0) * a.tile2;
-            td[2 * t] = make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32));
-            td[2 * t + 1] = make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), p * a.F2, p);
+            hj_store(&td[2 * t], make_uint4((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)ge, (uint32_t)(ge >> 32)));
+            hj_store(&td[2 * t + 1], make_uint4((uint32_t)g0, (uint32_t)(g0 >> 32), p * a.F2, p));
         }
     }
 }
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void chunk_tail_sums_kernel(const u64 *__restr
     if (q >= P) return;
     u64 t = 0;
     for (uint32_t c = 8; c < C; ++c) t += counts[(u64)c * P + q];
-    more[q] = t;
+    hj_store(&more[q], t);
 }
 
 int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
@@ -814,7 +814,7 @@ int hj_launch_exscan(const u64 *in, u64 *out, uint32_t n, hipStream_t stream)
 __global__ void offsets_to_counts_kernel(const u64 *__restrict__ off, u64 *__restrict__ counts, uint32_t P)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) counts[i] = off[i + 1] - off[i];
+    if (i < P) hj_store(&counts[i], off[i + 1] - off[i]);
 }
 
 int hj_launch_offsets_to_counts(const u64 *off, u64 *counts, uint32_t P, hipStream_t stream)

@@ -275,6 +275,9 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t bytes, hipStream_t s_)
     memset(dst, v, bytes);
     return hipSuccess;
 }
+// the library's own clears and device-to-device copies (csrc/gen_kernels.hip: kernels with non-temporal stores): recorded like the runtime's
+hipError_t hj_zero_async(void *p, size_t bytes, hipStream_t s) { return hipMemsetAsync(p, 0, bytes, s); }
+hipError_t hj_copy_async(void *dst, const void *src, size_t bytes, hipStream_t s) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s); }
 hipError_t hipMemset(void *dst, int v, size_t bytes) { LOCK; hipMemsetAsync(dst, v, bytes, nullptr); rec::host_waited(rec::of(nullptr)); return hipSuccess; }
 hipError_t hipLaunchHostFunc(hipStream_t s_, hipHostFn_t, void *) { LOCK; rec::Scope op(rec::of(s_), "host function"); return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }

@@ -86,3 +86,8 @@ inline void mock_launch(const char *name, void (*kernel)(K...), dim3 grid, dim3 
         }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) mock_launch(#kernel, kernel, grid, block, stream, __VA_ARGS__)
+
+// clang's non-temporal store (the library's store policy, csrc/hj_device.hpp): a plain store on the CPU
+#ifndef __clang__
+#define __builtin_nontemporal_store(value, ptr) (*(ptr) = (value))
+#endif
