@@ -6,7 +6,7 @@ package holds its sources (csrc/), the C++ hosts that keep the reference's
 ctypes binding used by tests and bench.py.  No CPU fallback exists anywhere.
 """
 from .api import (HjGpu, HjGpuError, DeviceColumn, NpjParams, PhjParams, Output, Result, Stats,
-                  load_library, kernel_hash, EXPORTS, FLAG_UNIQUE, HjComm, Shard, MultiStats, TRANSPORT_RCCL, TRANSPORT_LOOPBACK)
+                  load_library, kernel_hash, library_hash, EXPORTS, FLAG_UNIQUE, HjComm, Shard, MultiStats, TRANSPORT_RCCL, TRANSPORT_LOOPBACK)
 from . import build
 
 __all__ = ["HjGpu", "HjGpuError", "DeviceColumn", "NpjParams", "PhjParams", "Output", "Result",

@@ -20,7 +20,7 @@ MAX_PARTS = 32768
 FLAG_UNIQUE = 1
 
 EXPORTS = [
-    "hjgpu_kernel_hash", "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
+    "hjgpu_kernel_hash", "hjgpu_library_hash", "hjgpu_device_count", "hjgpu_create", "hjgpu_destroy", "hjgpu_last_error", "hjgpu_status_string",
     "hjgpu_get_device_info", "hjgpu_set_option", "hjgpu_reserve", "hjgpu_get_stats",
     "hjgpu_get_async_status", "hjgpu_accumulate_async_status", "hjgpu_set_async_output", "hjgpu_output_capacity",
     "hjgpu_malloc", "hjgpu_malloc_placed", "hjgpu_free", "hjgpu_memcpy_h2d", "hjgpu_memcpy_d2h", "hjgpu_synchronize", "hjgpu_audit_read", "hjgpu_audit_recheck",
@@ -182,6 +182,8 @@ def load_library(build_if_missing=True):
     vp, sz, u32, u64p = C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64)
     L.hjgpu_kernel_hash.restype = C.c_char_p
     L.hjgpu_kernel_hash.argtypes = []
+    L.hjgpu_library_hash.restype = C.c_char_p
+    L.hjgpu_library_hash.argtypes = []
     L.hjgpu_device_count.argtypes = [C.POINTER(C.c_int)]
     L.hjgpu_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.hjgpu_destroy.argtypes = [vp]
@@ -276,10 +278,15 @@ def load_library(build_if_missing=True):
                                         vp, vp, vp, vp, C.POINTER(Result), vp]
     L.hjgpu_column_sums.argtypes = [vp, vp, sz, u32, u32, u64p, vp]
     for name in EXPORTS:
-        if name not in ("hjgpu_last_error", "hjgpu_status_string", "hjgpu_comm_last_error", "hjgpu_comm_ctx", "hjgpu_kernel_hash"):
+        if name not in ("hjgpu_last_error", "hjgpu_status_string", "hjgpu_comm_last_error", "hjgpu_comm_ctx", "hjgpu_kernel_hash", "hjgpu_library_hash"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def library_hash():
+    """hjgpu_library_hash(): every source the loaded library was built from (evidence headers)."""
+    return load_library().hjgpu_library_hash().decode()
 
 
 def kernel_hash():

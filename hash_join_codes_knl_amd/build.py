@@ -44,6 +44,22 @@ def kernel_hash():
     return h.hexdigest()[:16]
 
 
+def library_hash():
+    """Identifies the LIBRARY a piece of evidence was taken with: every source that goes into libhjgpu.so - csrc/*.hip, csrc/*.hpp and
+    include/hjgpu.h (hjgpu_library_hash()).  The kernel hash above gates PMC traffic (what the kernels move); stress / validation
+    logs and the bench line carry this one, so a change of the orchestration (hjgpu_multi.hip, hjgpu_host.hip) changes their header."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    with open(os.path.join(ROOT, "include", "hjgpu.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -69,7 +85,7 @@ def build_library(force=False, verbose=True):
         obj = os.path.join(LIB, os.path.basename(src) + ".o")
         if force or _newer(obj, deps):
             cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++20", "-fPIC",
-                   "-Wall", "-Wno-unused-function", "-DHJGPU_KERNEL_HASH=\"%s\"" % kernel_hash(), "-c", src, "-o", obj]
+                   "-Wall", "-Wno-unused-function", "-DHJGPU_KERNEL_HASH=\"%s\"" % kernel_hash(), "-DHJGPU_LIBRARY_HASH=\"%s\"" % library_hash(), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

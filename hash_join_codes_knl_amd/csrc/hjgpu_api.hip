@@ -980,6 +980,10 @@ const char *hjgpu_status_string(int s)
 #define HJGPU_KERNEL_HASH "unknown"
 #endif
 const char *hjgpu_kernel_hash(void) { return HJGPU_KERNEL_HASH; }
+#ifndef HJGPU_LIBRARY_HASH
+#define HJGPU_LIBRARY_HASH "unknown"
+#endif
+const char *hjgpu_library_hash(void) { return HJGPU_LIBRARY_HASH; }
 
 int hjgpu_device_count(int *count)
 {

@@ -150,6 +150,9 @@ typedef struct {
 /* hash of the kernel sources this library was built from: measurements (profiles/ traffic files) name the
  * kernels they were taken with, bench.py refuses counters of other kernels */
 const char *hjgpu_kernel_hash(void);
+/* hash of EVERY source of this library (every .hip and .hpp file under csrc, this header): stress / validation logs and the bench line name the
+ * library they were taken with - a change of the orchestration changes it, the kernel hash above need not */
+const char *hjgpu_library_hash(void);
 int  hjgpu_device_count(int *count);                      /* visible GPUs (hosts that do not link HIP) */
 int  hjgpu_create(int device, hjgpu_ctx **ctx);           /* device < 0: current device      */
 int  hjgpu_destroy(hjgpu_ctx *ctx);

@@ -48,3 +48,27 @@ def test_bench_without_a_gpu_fails_loudly():
                         "--inner", "1000", "--outer", "10000"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{") and '"value"' in l]
+
+
+def test_library_hash_covers_every_source_of_the_library(tmp_path, monkeypatch):
+    """evidence headers name the LIBRARY: two trees that differ only in the orchestration (hjgpu_multi.hip) hash differently,
+    while the kernel hash - which gates PMC traffic - stays"""
+    import shutil
+    from hash_join_codes_knl_amd import build as B
+    k0, l0 = B.kernel_hash(), B.library_hash()
+    root = tmp_path / "tree"
+    shutil.copytree(B.CSRC, root / "hash_join_codes_knl_amd" / "csrc")
+    (root / "include").mkdir()
+    shutil.copy(os.path.join(B.ROOT, "include", "hjgpu.h"), root / "include" / "hjgpu.h")
+    monkeypatch.setattr(B, "CSRC", str(root / "hash_join_codes_knl_amd" / "csrc"))
+    monkeypatch.setattr(B, "ROOT", str(root))
+    assert (B.kernel_hash(), B.library_hash()) == (k0, l0)
+    with open(root / "hash_join_codes_knl_amd" / "csrc" / "hjgpu_multi.hip", "a") as f:
+        f.write("\n// one more line in the orchestration\n")
+    assert B.kernel_hash() == k0 and B.library_hash() != l0
+    with open(root / "include" / "hjgpu.h", "a") as f:
+        f.write("\n")
+    l1 = B.library_hash()
+    with open(root / "hash_join_codes_knl_amd" / "csrc" / "exchange_layout.hpp", "a") as f:
+        f.write("\n")
+    assert B.library_hash() != l1

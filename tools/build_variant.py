@@ -42,7 +42,7 @@ def main():
                 continue
             o = os.path.join(tmp, f + ".o")
             subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-O3", "-std=c++20", "-fPIC", "-w",
-                                   "-DHJGPU_KERNEL_HASH=\"%s\"" % name] + defines + ["-c", s, "-o", o])
+                                   "-DHJGPU_KERNEL_HASH=\"%s\"" % name, "-DHJGPU_LIBRARY_HASH=\"%s\"" % name] + defines + ["-c", s, "-o", o])
             objs.append(o)
         so = os.path.join(out_dir, name + ".so")
         subprocess.check_call([B._hipcc(), "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", so] + objs + ["-ldl"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Repeats hjgpu_cpra_multi on one communicator and reports every step whose result differs from the analytic
-aggregates (a race in the slice pipeline shows up as an occasional wrong step, not as a wrong final step).
-usage: python tools/stress_cpra.py [--world 1 --transport rccl|loopback --slices 8 --steps 40 --inner N --outer N --option name=value ...]"""
+"""Repeats hjgpu_cpra_multi (or, --algo phj / npj, hjgpu_phj_multi / hjgpu_npj_multi) on one communicator and reports every step
+whose result differs from the analytic aggregates (a race in a pipeline shows up as an occasional wrong step, not as a wrong final step).
+usage: python tools/stress_cpra.py [--algo cpra|phj|npj --world 1 --transport rccl|loopback --slices 8 --steps 40 --inner N --outer N --option name=value ...]"""
 import argparse
 import os
 import sys
@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--algo", default="cpra", choices=["cpra", "phj", "npj"], help="phj / npj: the build side replicated from rank 0, the probe side sharded")
     ap.add_argument("--world", type=int, default=1)
     ap.add_argument("--transport", default="rccl")
     ap.add_argument("--slices", type=int, default=8)
@@ -34,7 +35,7 @@ def main():
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     lib = api.load_library()
     knobs = {k: v for k, v in os.environ.items() if k.startswith(("HSA_", "GPU_MAX_HW", "HJGPU_LIBRARY", "AMD_SERIALIZE", "HIP_LAUNCH_BLOCKING"))}
-    print("library %s, kernel hash %s, env %s" % (os.path.basename(os.environ.get("HJGPU_LIBRARY", "libhjgpu.so")), H.kernel_hash(), knobs), flush=True)
+    print("library %s, library hash %s, kernel hash %s, env %s" % (os.path.basename(os.environ.get("HJGPU_LIBRARY", "libhjgpu.so")), H.library_hash(), H.kernel_hash(), knobs), flush=True)
     has_dbg = hasattr(lib, "hjgpu_debug_scratch")
     if has_dbg:
         lib.hjgpu_debug_scratch.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
@@ -53,6 +54,21 @@ def main():
     for g in range(G):
         ctx = comm.ctx[g]
         ri, ro = a.inner // G, a.outer // G
+        if a.algo != "cpra":
+            # replicated build side: all of it on rank 0 (the root), nothing elsewhere; the probe side in G shards
+            sk, sv = ctx.column(ro), ctx.column(ro)
+            rk = rv = None
+            if g == 0:
+                rk, rv = ctx.column(ri * G), ctx.column(ri * G)
+                ctx.generate_range(1, ri * G, ro * G, 0, ri * G, 0, ro, fi, fo, rk, rv, sk, sv)
+            else:
+                scratch = [ctx.column(16), ctx.column(16)]
+                ctx.generate_range(1, ri * G, ro * G, 0, 16, g * ro, ro, fi, fo, scratch[0], scratch[1], sk, sv)
+            sums = ctx.column_sums(sk, ro, fo, fi)
+            expect = [expect[0] + ro] + [(x + y) & ((1 << 64) - 1) for x, y in zip(expect[1:], sums)]
+            cols += [sk, sv]
+            shards.append((rk, rv, ri * G, sk, sv, ro))
+            continue
         c = [ctx.column(ri), ctx.column(ri), ctx.column(ro), ctx.column(ro)]
         ctx.generate_range(1, ri * G, ro * G, g * ri, ri, g * ro, ro, fi, fo, *c)
         sums = ctx.column_sums(c[2], ro, fo, fi)
@@ -145,7 +161,12 @@ def main():
     for s in range(a.steps):
         if s and s % 1000 == 0:
             print("... %d steps, %d wrong so far" % (s, bad), flush=True)
-        got, st = comm.cpra_multi(shards, H.PhjParams(flags=H.FLAG_UNIQUE) if a.unique else None, a.slices)
+        if a.algo == "cpra":
+            got, st = comm.cpra_multi(shards, H.PhjParams(flags=H.FLAG_UNIQUE) if a.unique else None, a.slices)
+        elif a.algo == "phj":
+            got, st = comm.phj_multi(shards, 0, H.PhjParams(flags=H.FLAG_UNIQUE) if a.unique else None)
+        else:
+            got, st = comm.npj_multi(shards, 0, H.NpjParams(flags=H.FLAG_UNIQUE) if a.unique else None)
         if list(got) != expect:
             bad += 1
             print("step %d WRONG: count %+d, sums %s" % (s, got[0] - expect[0], ["%+d" % ((x - y + (1 << 63)) % (1 << 64) - (1 << 63)) for x, y in zip(got[1:], expect[1:])]), flush=True)
@@ -153,7 +174,7 @@ def main():
                 report(s)
         elif (a.forensics or a.freeze) and s == 0:
             report(s, a.recheck_first)
-    print("%s world %d slices %d options %s: %d of %d steps wrong, last %.2f ms" % (a.transport, G, a.slices, a.option + a.ctx_option + (["unique"] if a.unique else []), bad, a.steps, st["ms_wall"]), flush=True)
+    print("%s %s world %d slices %d options %s: %d of %d steps wrong, last %.2f ms" % (a.algo, a.transport, G, a.slices, a.option + a.ctx_option + (["unique"] if a.unique else []), bad, a.steps, st["ms_wall"]), flush=True)
     if has_dbg:
         # HJ_SCRATCH_EXPERIMENT variants 2-4: values that came back from the private segment, compared in the kernel
         d = (ctypes.c_uint64 * 40)()

@@ -56,7 +56,7 @@ def main():
                 print("step %d WRONG: count %+d" % (s, got[0] - want[0]), flush=True)
     st = hj.stats()
     print("%s%s one stream%s, library %s (%s): %d of %d steps wrong; last step %.2f ms (pass 1 %.2f, pass 2 %.2f, join %.2f)"
-          % (a.algo, "_async" if a.enqueue_only else "", (", options " + " ".join(a.ctx_option) + ", %d groups" % st["groups"]) if a.ctx_option else "", os.path.basename(os.environ.get("HJGPU_LIBRARY", "libhjgpu.so")), H.kernel_hash(), bad, a.steps,
+          % (a.algo, "_async" if a.enqueue_only else "", (", options " + " ".join(a.ctx_option) + ", %d groups" % st["groups"]) if a.ctx_option else "", os.path.basename(os.environ.get("HJGPU_LIBRARY", "libhjgpu.so")), "library hash " + H.library_hash(), bad, a.steps,
              st["ms_total"], st["ms_scatter1"], st["ms_scatter2"], st["ms_join"]), flush=True)
     if has_dbg:
         d = (ctypes.c_uint64 * 40)()
