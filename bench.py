@@ -60,7 +60,9 @@ def parse(argv=None):
                     help="0 = the CPUs this process may use (affinity mask capped by the cgroup CPU quota)")
     ap.add_argument("--enqueue-only", action="store_true",
                     help="N = 1: time the enqueue-only entry points (hjgpu_*_async: all K6 stores non-temporal) instead of the blocking ones")
-    ap.add_argument("--no-solo", action="store_true", help="N = 1: do not set option solo (every store non-temporal, as in a process that runs other work beside the joins)")
+    ap.add_argument("--solo", action="store_true", help="N = 1: the headline with option solo (the caller's promise that nothing else runs on the device: K6's partial-line "
+                    "stores and the result rows plain); the default line measures the library's DEFAULT policy and reports the solo form in secondary.phj_solo")
+    ap.add_argument("--no-solo", action="store_true", help="kept for compatibility: the default since round 6")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra N = 1 measurements (NPJ, one-GPU CPRA, materialising PHJ, configs[0] on the CPU)")
     ap.add_argument("--materialize", action="store_true", help="kept for compatibility: the materialising PHJ is on by default")
@@ -169,9 +171,10 @@ def sum_over_ranks(dist, torch, values):
     return [int(v) & MASK64 for v in t.tolist()]
 
 
-def cpu_baseline(hj, args, algo):
+def cpu_baseline(hj, args, algo, more=()):
     """The oracle's restatement of the reference's CPU algorithm ("port"), timed on
-    this host's cores on a bounded sample of the same workload shape."""
+    this host's cores on a bounded sample of the same workload shape.  `more`: further algorithms joined on the SAME host columns
+    (one generation, one download): the entries come back under "others" (the NPJ and CPRA legs' baselines)."""
     from oracle import oracle as O
     outer = min(args.cpu_outer, args.outer)
     inner = max(1, int(args.inner * (outer / args.outer)))
@@ -201,24 +204,37 @@ def cpu_baseline(hj, args, algo):
             "conflict-serialised vector scatter (phj.cpp:1099-1160)" if simd == 2 else
             "scalar stores into the write-combining lines", rates[simd], rates[3 - simd] if 3 - simd in rates else 0.0)
     O.set_simd(simd)
-    tm = O.Timing()
-    if algo == "npj":
-        res = O.npj(hik, hiv, hok, hov, threads=threads, load=0.90, timing=tm)     # npj.cpp:944
-    elif algo == "cpra":
-        res = O.cpra(hik, hiv, hok, hov, threads=threads, timing=tm)
-    else:
-        res = O.phj(hik, hiv, hok, hov, threads=threads, timing=tm)
+
+    def one(which):
+        tm = O.Timing()
+        if which == "npj":
+            res = O.npj(hik, hiv, hok, hov, threads=threads, load=0.90, timing=tm)     # npj.cpp:944
+        elif which == "cpra":
+            res = O.cpra(hik, hiv, hok, hov, threads=threads, timing=tm)
+        else:
+            res = O.phj(hik, hiv, hok, hov, threads=threads, timing=tm)
+        ok_ = res == (outer, sums[0], sums[1], sums[2])
+        return {"value": outer / tm.seconds / 1e9, "unit": "Gtuples/s", "cores": threads,
+                "kind": "port",
+                "sample": "%s |R|=%d join |S|=%d (same generator, 1/%g of the per-GPU workload), "
+                          "oracle/hj_oracle.c pthreads restatement of %s with %s operators%s, %d threads "
+                          "(%d CPUs online, cgroup quota applied), %.3f s, checksum %s"
+                          % (which, inner, outer, args.outer / outer, "run() (npj.cpp:769-927, load 0.90)" if which == "npj" else "run_hj",
+                             "AVX-512 (oracle/hj_oracle_avx512.c)" if simd else "scalar", calib if which != "npj" else "", threads, os.cpu_count() or 0,
+                             tm.seconds, "ok" if ok_ else "MISMATCH"),
+                "seconds": tm.seconds}
+
+    out = one(algo)
+    others = {}
+    for which in more:
+        try:
+            others[which] = one(which)
+        except Exception as ex:          # reported, never required
+            others[which] = {"value": None, "unit": "Gtuples/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     O.set_simd(False)
-    ok_ = res == (outer, sums[0], sums[1], sums[2])
-    return {"value": outer / tm.seconds / 1e9, "unit": "Gtuples/s", "cores": threads,
-            "kind": "port",
-            "sample": "%s |R|=%d join |S|=%d (same generator, 1/%g of the per-GPU workload), "
-                      "oracle/hj_oracle.c pthreads restatement of run_hj with %s operators%s, %d threads "
-                      "(%d CPUs online, cgroup quota applied), %.3f s, checksum %s"
-                      % (algo, inner, outer, args.outer / outer,
-                         "AVX-512 (oracle/hj_oracle_avx512.c)" if simd else "scalar", calib, threads, os.cpu_count() or 0,
-                         tm.seconds, "ok" if ok_ else "MISMATCH"),
-            "seconds": tm.seconds}
+    if others:
+        out["others"] = others
+    return out
 
 
 def cpu_baseline_config0(hj, args):
@@ -443,9 +459,10 @@ def main():
         hj = comm.ctx[0]
     else:
         hj = H.HjGpu(local_rank)
-    # N = 1: this process has ONE stream and one context, and its step is a blocking join: option "solo" (the joins' partial-line stores
-    # stay plain; the line says so in config.solo_stores).  The multi-GPU joins and every enqueue-only form never use it.
-    solo = not multi and not args.enqueue_only and not args.no_solo
+    # N = 1: the headline is the blocking join with the library's DEFAULT store policy (every store non-temporal: what any caller gets).
+    # --solo: option "solo" for the headline (plain partial-line stores; the line says so in config.solo_stores); the default line
+    # reports that form beside it (secondary.phj_solo).  The multi-GPU joins and every enqueue-only form never use it.
+    solo = not multi and not args.enqueue_only and args.solo and not args.no_solo
     if solo:
         hj.set_option("solo", "1")
     for o in args.option:
@@ -805,6 +822,15 @@ def main():
         sec["phj_enqueue_only"] = {"workload": "the headline through hjgpu_phj_async (enqueue-only: partial-line stores non-temporal too)",
                                    "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2), "checksum_ok": ok_,
                                    "phase_ms": {k2: round(ph[k2], 4) for k2 in phases if k2 in ph}}
+        # the headline with option "solo" (the caller's promise that nothing else runs on the device beside its blocking joins: K6's partial-line
+        # stores plain): same context, same workspace, the option set for these steps only
+        if not solo:
+            hj.set_option("solo", "1")
+            ms, ph = time_steps(lambda: hj.phj(*a, prm), warm=2, steps=min(args.steps, 10))
+            sec["phj_solo"] = {"workload": "the headline with option solo (blocking hjgpu_phj, partial-line stores plain: a process that runs nothing else on the device)",
+                               "ms_per_step": round(ms, 4), "gtuples_per_s": round(outer / ms / 1e6, 2), "checksum_ok": list(hj.phj(*a, prm)) == expect_local,
+                               "phase_ms": {k2: round(ph[k2], 4) for k2 in phases if k2 in ph}}
+            hj.set_option("solo", "0")
         # the headline WITHOUT the placement search (option placement=1: the first allocation is taken): what a step costs when
         # the probe side's pass-1 twin is whatever block hipMalloc returns (a context of its own, closed afterwards)
         hj1 = H.HjGpu(local_rank)
@@ -842,9 +868,14 @@ def main():
         # come from the library's placement-aware allocator (hjgpu_malloc_placed), outside the timed calls
         jcols = [hj.column(cap, placed=True) for _ in range(3)]
         jk, jo, ji = (torch.empty(0, dtype=torch.int32, device=dev) for _ in range(3))
-        # MEAN over as many steps as the headline (after one untimed call), min / max beside it - not a best-of
-        mt = {"ms_join": [], "ms_close_gaps": [], "ms_total": []}
-        for it in range(args.steps + 1):
+        # MEAN over as many steps as the headline (after one untimed call), min / max beside it - not a best-of.
+        # Two policies: "materialized_default" = the library's default (result rows through non-temporal stores: what any caller gets),
+        # "materialized" = option solo (plain rows: a process that runs nothing else on the device; the form of rounds 2-5's line)
+        rw = 8 * n_tuples
+        for leg_name, leg_solo in (("materialized_default", False), ("materialized", True)):
+          hj.set_option("solo", "1" if leg_solo else "0")
+          mt = {"ms_join": [], "ms_close_gaps": [], "ms_total": []}
+          for it in range(args.steps + 1):
             res = hj.phj(rk.data_ptr(), rv.data_ptr(), inner, sk.data_ptr(), sv.data_ptr(), outer, prm,
                          out=(jcols[0].ptr, jcols[1].ptr, jcols[2].ptr, cap, block),
                          stream=torch.cuda.current_stream().cuda_stream)
@@ -852,13 +883,15 @@ def main():
             for k2 in mt:
                 if it:
                     mt[k2].append(stx[k2])
-        j = res[0]
-        ok_rows = list(res) == expect_local and hj.column_sums(jcols[0].ptr, j, 1, 1)[0] == expect_local[1]
-        mean = {k2: sum(v) / len(v) for k2, v in mt.items()}
-        tj = mean["ms_join"] + mean["ms_close_gaps"]
-        rw = 8 * n_tuples + 12 * j
-        tj_each = [a_ + b_ for a_, b_ in zip(mt["ms_join"], mt["ms_close_gaps"])]
-        out["materialized"] = {"rows": j, "steps": len(mt["ms_total"]), "statistic": "mean over the steps (min / max beside it)",
+          j = res[0]
+          ok_rows = (list(res) == expect_local and hj.column_sums(jcols[0].ptr, j, 1, 1)[0] == expect_local[1]
+                     and hj.column_sums(jcols[1].ptr, j, 1, 1)[0] == expect_local[2] and hj.column_sums(jcols[2].ptr, j, 1, 1)[0] == expect_local[3])
+          mean = {k2: sum(v) / len(v) for k2, v in mt.items()}
+          tj = mean["ms_join"] + mean["ms_close_gaps"]
+          rw = 8 * n_tuples + 12 * j
+          tj_each = [a_ + b_ for a_, b_ in zip(mt["ms_join"], mt["ms_close_gaps"])]
+          out[leg_name] = {"rows": j, "steps": len(mt["ms_total"]), "statistic": "mean over the steps (min / max beside it)",
+                               "row_stores": "plain (option solo)" if leg_solo else "non-temporal (the default policy)",
                                "ms_join": round(mean["ms_join"], 4), "ms_close_gaps": round(mean["ms_close_gaps"], 4),
                                "ms_total": round(mean["ms_total"], 4),
                                "ms_join_min_max": [round(min(mt["ms_join"]), 4), round(max(mt["ms_join"]), 4)],
@@ -870,13 +903,16 @@ def main():
                                                               round(rw / (min(tj_each) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)],
                                "roofline_join": roof(rw, tj, 1, stream_read_gbs),
                                "block_size": block, "rows_checksum_ok": bool(ok_rows)}
+        hj.set_option("solo", "1" if solo else "0")
         out["materialized"]["traffic_source"] = attach_secondary_traffic(H, "materialized", [(out["materialized"]["roofline_join"], ("join_kernel", "mean"))])
         del jk, jo, ji
         for c in jcols:
             c.free()
     if rank == 0 and args.cpu_outer > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline(hj, args, args.algo)
+            out["cpu_baseline"] = cpu_baseline(hj, args, args.algo, ("npj", "cpra") if extras else ())
+            for which, entry in out["cpu_baseline"].pop("others", {}).items():          # the NPJ and CPRA legs' own CPU baselines
+                out.get("secondary", {}).get(which, {})["cpu_baseline"] = entry
         except Exception as ex:          # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "Gtuples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (ex,)}

@@ -329,16 +329,16 @@ int hj_launch_copy_to_host(void *host_mapped, const void *d, size_t bytes, hipSt
 // (hipMemsetAsync, hipMemcpyAsync) store plainly and the library's store policy (hj_device.hpp) has no plain store beside other
 // queues' work - NPJ's 2 GB table clear writes as many bytes as a K6 pass over the build side.  Any 4-byte aligned range; the
 // body in 16-byte non-temporal stores.
-__global__ __launch_bounds__(256) void zero_kernel(uint32_t *__restrict__ p, u64 words)
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t *__restrict__ p, u64 words, uint32_t word)
 {
     // words [0, head) up to the first 16-byte boundary, 16-byte vectors, then the tail
     const u64 head = min(words, (u64)((16 - ((uintptr_t)p & 15)) & 15) / 4);
     const u64 vecs = (words - head) / 4, tail0 = head + vecs * 4;
     uint4 *v = reinterpret_cast<uint4 *>(p + head);
     const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x, stride = (u64)gridDim.x * 256;
-    for (u64 i = tid; i < vecs; i += stride) hj_store(&v[i], make_uint4(0, 0, 0, 0));
-    if (tid < head) hj_store(&p[tid], 0u);
-    if (tid < words - tail0) hj_store(&p[tail0 + tid], 0u);
+    for (u64 i = tid; i < vecs; i += stride) hj_store(&v[i], make_uint4(word, word, word, word));
+    if (tid < head) hj_store(&p[tid], word);
+    if (tid < words - tail0) hj_store(&p[tail0 + tid], word);
 }
 
 __global__ __launch_bounds__(256) void copy_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, u64 words, uint32_t vec)
@@ -359,15 +359,17 @@ __global__ __launch_bounds__(256) void copy_kernel(uint32_t *__restrict__ dst, c
         for (u64 i = tid; i < words; i += stride) hj_store(&dst[i], src[i]);
 }
 
-hipError_t hj_zero_async(void *p, size_t bytes, hipStream_t stream)
+hipError_t hj_fill_async(void *p, uint32_t word, size_t bytes, hipStream_t stream)
 {
     if (!bytes) return hipSuccess;
-    if (((uintptr_t)p & 3) || (bytes & 3)) return hipMemsetAsync(p, 0, bytes, stream);      // (no such caller: every clear is of 4-byte words)
+    if (((uintptr_t)p & 3) || (bytes & 3)) return word == 0 ? hipMemsetAsync(p, 0, bytes, stream) : hipErrorInvalidValue;      // (no such caller: every clear is of 4-byte words)
     const u64 words = bytes / 4;
     const unsigned grid = (unsigned)std::min<u64>((words / 4 + 255) / 256 + 1, 2048);
-    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, stream, (uint32_t *)p, words);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, stream, (uint32_t *)p, words, word);
     return hipGetLastError();
 }
+
+hipError_t hj_zero_async(void *p, size_t bytes, hipStream_t stream) { return hj_fill_async(p, 0u, bytes, stream); }
 
 hipError_t hj_copy_async(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {

@@ -86,8 +86,15 @@ struct HjTuning {
     // grouped_groups() says the extra pass pays (several table fills per partition AND a probe side large enough).
     long long group_from = 300000000, group_inner = 64000000;
     bool group_always = false;
-    bool group_async = true;        // "group_async": a grouped plan through hjgpu_phj_async / hjgpu_cpra_async returns at once (a worker thread of the
-                                    // context plans the groups, the caller's stream waits for its last command); 0: the call waits itself
+    // "group_device" (default 1): a grouped plan is planned ON THE DEVICE - the groups' sizes and first rows stay in device memory
+    // (group_desc_kernel), every kernel of a group's join reads them from there, and the whole plan is one stream-ordered sequence like
+    // any other join: enqueue-only calls return at once, nobody waits for pass 0 (phj.cpp:1791-1863 plans and runs its passes inside
+    // run_hj).  The workspace is sized for groups of up to (1 + "group_slack" / 100) x the mean group ("group_slack": per cent, default
+    // 50); a group beyond that (heavy duplicates) is skipped and flagged, the result marked invalid, and the join is done again by the
+    // HOST-planned form (option 0: always that form - the calling thread waits for pass 0 and for every group) at the caller's next
+    // blocking touch point (the blocking calls themselves; hjgpu_get_async_status for the enqueue-only ones).
+    bool group_device = true;
+    int group_slack = 50;
     long long batch_tuples = 0;     // "batch_tuples": probe-side tuples per partitioning batch (0 = no batching, the default)
     JoinConfig join = {512, 13, 2}; // "join_cfg"
     int scatter_cfg[2][3] = {{0, 0, -1}, {0, 0, -1}};   // "scatter_cfg" / "scatter2_cfg": block, vpt, carry; block 0 = planned
@@ -115,6 +122,8 @@ constexpr uint32_t HJ_MAX_CHUNKS = 64;
 constexpr uint32_t HJ_TICKET_K4 = 0;                          // K4: [r * HJ_MAX_CHUNKS + chunk]
 constexpr uint32_t HJ_TICKET_K6 = 2 * HJ_MAX_CHUNKS;          // K6: [2 * r + pass - 1]
 constexpr uint32_t HJ_TICKET_MULTI_FILL = 2 * HJ_MAX_CHUNKS + 8;
+constexpr uint32_t HJ_TICKET_JOIN = 2 * HJ_MAX_CHUNKS + 10;          // K7+K8: two uint64 work counters (8-byte aligned: the block starts on one), the
+constexpr uint32_t HJ_TICKET_JOIN2 = 2 * HJ_MAX_CHUNKS + 12;         // second for the multi-fill half of a _UNIQUE join - zeroed with the tickets, per join
 constexpr uint32_t HJ_TICKET_WORDS = 2 * HJ_MAX_CHUNKS + 16;
 struct Pass1Geom {
     u64 n, part;                    // chunk c = rows [part * c, c + 1 == chunks ? n : part * (c + 1)): thread_beg / thread_end with
@@ -161,6 +170,8 @@ struct ScatterArgs {
     u64 *prof;                      // diagnostics (HJGPU_SCATTER_PROF=1): s_memtime ticks per phase, else NULL
     uint32_t nt_partial;            // 1: the 8-byte (partial-line) stores are non-temporal too (every launch that is not solo: selects the
                                     // NTP instance of the kernel, see k6_store8)
+    const u64 *dyn;                 // pass 1 of a device-planned group (else NULL): {first row, rows} of the input inside kin / vin, in device
+                                    // memory - geom.n / geom.part are computed from it in the kernel (geom holds the CAPACITY's ranges and tile)
 };
 
 struct JoinArgs {
@@ -199,6 +210,8 @@ struct JoinArgs {
     // plan counted no multi-fill partition (multi_fill, may be NULL = unknown)
     u64 *work_counter2;
     const uint32_t *multi_fill;
+    uint32_t resume;                     // 1 (device-planned groups): every wave goes on in the output block its slot of final_offsets names (HJ_NO_CURSOR:
+                                         // none yet) - the groups' joins share one block counter, one set of open blocks and ONE close_gaps at the end
 };
 
 struct PlanArgs {
@@ -241,6 +254,8 @@ struct PlanArgs {
     // is written in one go (tile order only: entry i of the tile prefix is segment (i % chunks) * F1 + i / chunks)
     uint32_t seg_interleave = 0;
     u64 *seg2[2] = {nullptr, nullptr};   // [F1 + 1] p_major: the pass-1 partitions' bounds
+    // a device-planned group (else NULL): {first row, rows} of relation r in device memory; n[r] and chunk_part[r] are then computed from it
+    const u64 *dyn[2] = {nullptr, nullptr};
 };
 
 // A relation that arrives pass-1-partitioned in pieces (the multi-GPU CPRA's receiving side): piece c = rows
@@ -254,7 +269,13 @@ int hj_launch_hist_packed(const u64 *tuples, const HjChunks &ch, uint32_t f1, ui
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
                     u64 *counts, uint32_t *range_counts, uint32_t *work_counter /* [chunks], zeroed */,
-                    int cus, hipStream_t stream, size_t min_lds = 0);
+                    int cus, hipStream_t stream, size_t min_lds = 0, const u64 *dyn = nullptr /* device: {first row, rows}, see ScatterArgs::dyn */);
+// Grouped plans on the device: from pass 0's offsets (dense prefixes of the F0 = G * bins counters of both relations) to one descriptor per
+// group, desc[g] = {build first row, build rows, probe first row, probe rows} (first rows as pass 0 laid the groups out: hj_group_shift).
+// A group with an empty side gets no rows at all (nothing can match); one beyond cap_r / cap_s rows gets none either and raises *skew.
+int hj_launch_group_desc(const u64 *roff, const u64 *soff, uint32_t G, uint32_t bins, u64 cap_r, u64 cap_s, u64 *desc, uint32_t *skew, hipStream_t stream);
+// d_result of a device-planned grouped join: the aggregates, or all ones when a group was skipped (*skew != 0): never a plausible partial count
+int hj_launch_group_result(const hjgpu_result *state, const uint32_t *skew, hjgpu_result *d_result, hipStream_t stream);
 // own_count > 0 (chunks == 1): partitions [own_first, own_first + own_count) are laid out behind all others
 // group_bins > 0 (chunks == 1, own_count == 0): groups of group_bins neighbouring partitions, each group on a 128-byte
 // line: group g (whose dense start is row `dense`) starts at row dense + hj_group_shift(dense, g)
@@ -359,6 +380,7 @@ int hj_launch_fill_probe(void *p, size_t bytes, hipStream_t stream);
 // the library's clears and device-to-device copies (gen_kernels.hip): own kernels with non-temporal stores instead of the runtime's
 // hipMemsetAsync / hipMemcpyAsync, whose fill and copy kernels store plainly (the store policy: hj_device.hpp)
 hipError_t hj_zero_async(void *p, size_t bytes, hipStream_t stream);
+hipError_t hj_fill_async(void *p, uint32_t word, size_t bytes, hipStream_t stream);     // every 4-byte word = `word`
 hipError_t hj_copy_async(void *dst, const void *src, size_t bytes, hipStream_t stream);
 int hj_launch_column_sums(const uint32_t *keys, size_t n, uint32_t fa, uint32_t fb, u64 *sums3,
                           hipStream_t stream);

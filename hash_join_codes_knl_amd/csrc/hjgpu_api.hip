@@ -24,27 +24,9 @@ int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e)
     return status;
 }
 
-// an asynchronous grouped join of this context is still being enqueued by its worker thread: wait for the worker (never from the
-// worker itself, which calls the same planning functions)
-void settle(hjgpu_ctx *ctx)
-{
-    if (!ctx || ctx->grp_worker.get_id() == std::this_thread::get_id()) return;        // (the worker's own calls)
-    if (ctx->grp_worker.joinable()) ctx->grp_worker.join();
-    // everything of the asynchronous grouped join is enqueued now: what its growth of the workspace left behind can go (hipFree waits
-    // for the device, the join included)
-    ctx->defer_free = false;
-    if (!ctx->graveyard.empty()) {
-        (void)hipSetDevice(ctx->device);
-        for (void *p : ctx->graveyard) (void)hipFree(p);
-        ctx->graveyard.clear();
-    }
-}
-
-// hipFree of a workspace buffer - later, where the context's worker must not wait for the device (hjgpu_ctx::defer_free)
 static int release(hjgpu_ctx *ctx, void *p)
 {
     if (!p) return HJGPU_OK;
-    if (ctx->defer_free) { ctx->graveyard.push_back(p); return HJGPU_OK; }
     HIPCHK(ctx, hipFree(p));
     return HJGPU_OK;
 }
@@ -108,8 +90,7 @@ int ensure_placed(hjgpu_ctx *ctx, DevBuf &b, size_t bytes)
     const int tries = ctx->tune.placement;
     // (twins below 1 GiB - the headline's 512 MB build-side twin, a grouped plan's per-group twins - gain nothing from the
     // search: profiles/r04_ab_placed_min.txt)
-    // (no search in the worker thread of an asynchronous grouped join: its candidates could not be freed, see hjgpu_ctx::defer_free)
-    if (tries <= 1 || bytes < ((size_t)1 << 30) || ctx->defer_free) return ensure(ctx, b, bytes);
+    if (tries <= 1 || bytes < ((size_t)1 << 30)) return ensure(ctx, b, bytes);
     if (b.p) { HIPCHK(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     const size_t want = (bytes + 255) / 256 * 256 + 256;
     void *cand[16];
@@ -216,7 +197,8 @@ int grouped_twins(hjgpu_ctx *ctx, const GroupLayout &l, size_t inner, size_t out
     CHK(ensure_placed(ctx, ctx->grp[1], (inner + pad) * sizeof(uint32_t)));
     CHK(ensure_placed(ctx, ctx->grp[2], (outer + pad) * sizeof(uint32_t)));
     CHK(ensure_placed(ctx, ctx->grp[3], (outer + pad) * sizeof(uint32_t)));
-    CHK(ensure(ctx, ctx->grp_off, (size_t)2 * (l.F0 + 1) * sizeof(u64)));
+    // the two relations' pass-0 offsets, then (device-planned groups) one descriptor of four words per group
+    CHK(ensure(ctx, ctx->grp_off, ((size_t)2 * (l.F0 + 1) + (size_t)4 * l.G + 4) * sizeof(u64)));
     return HJGPU_OK;
 }
 
@@ -311,7 +293,14 @@ void choose_fanout(const HjTuning &tune, size_t inner, const hjgpu_phj_params *p
 
 void record(hjgpu_ctx *ctx, int which, hipStream_t s)
 {
-    if (which == EV_BEGIN) ctx->stats_override = false;
+    if (ctx->ev_cur) {
+        // a group of a device-planned grouped join: its own set, and only the six events its merged plan tells apart (a group costs ~20
+        // launches; twelve event records on top of them were a third of the enqueue time of a small group)
+        if (which == EV_BEGIN || which == EV_S_HIST || which == EV_S_PLAN || which == EV_S_SC1 || which == EV_S_SC2 || which == EV_JOIN)
+            (void)hipEventRecord(ctx->ev_cur[which], s);
+        return;
+    }
+    if (which == EV_BEGIN) { ctx->stats_override = false; ctx->grp_ev_groups = 0; }
     ctx->ev_valid[which] = (hipEventRecord(ctx->ev[which], s) == hipSuccess);
 }
 
@@ -446,15 +435,14 @@ Pass1Geom make_geom(const HjTuning &tune, const void *keys, size_t n, uint32_t C
 // ---------------------------------------------------------------------------
 
 int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm,
-                uint32_t chunks, PhjPlan *pl, bool pre, int big_override)
+                uint32_t chunks, PhjPlan *pl, bool pre, int big_override, size_t plan_inner)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     ctx->prepared = false;               // the workspace is about to be re-planned (hjgpu_phj_build sets it again)
     ReserveClock clock(ctx);
     pl->C = chunks;
     pl->pre = pre ? 1u : 0u; pl->pre_f1 = 1; pl->pre_F1tot = 1; pl->pre_base = 0;
     pl->unique = ctx->tune.unique || (prm && (prm->flags & HJGPU_FLAG_UNIQUE));
-    choose_fanout(ctx->tune, inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
+    choose_fanout(ctx->tune, plan_inner ? plan_inner : inner, prm, &pl->F1, &pl->F2, &pl->big_tables);
     if (big_override >= 0) pl->big_tables = big_override != 0;
     if (chunks > 8 && !pre) {
         // More than 8 chunks (the reference takes any #threads, cpra2.cpp:2023): always two passes with line-aligned final
@@ -535,9 +523,10 @@ int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_para
 int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
                 const uint32_t *rk, const uint32_t *rv, size_t inner,
                 const uint32_t *sk, const uint32_t *sv, size_t outer,
-                const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready, PhjMode mode, const PrePieces *pre)
+                const hjgpu_output *out, hipStream_t stream, hipEvent_t inner_ready, PhjMode mode, const PrePieces *pre, const GroupRun *grp)
 {
     CHK(refuse_capture(ctx, stream));
+    if (grp && (pre || mode != PHJ_WHOLE || inner_ready)) return fail(ctx, HJGPU_EINVAL, "internal: a device-planned group is a whole join on resident columns");
     if ((pre != nullptr) != (pl.pre != 0)) return fail(ctx, HJGPU_EINVAL, "internal: plan and relations disagree about pre-partitioning");
     MetaLayout m = carve(ctx->meta.p, pl.C, pl.F1, pl.P, pl.ranges, pl.items_extra, pl.tiles2, pl.batch_cap, pl.tdesc_b_cap);
     DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
@@ -546,7 +535,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
 
     record(ctx, EV_BEGIN, stream);
     u64 *audit = nullptr;                // option "audit": this call's record (else NULL: nothing below is enqueued)
-    CHK(audit_begin(ctx, (int)mode, inner, outer, stream, &audit));
+    if (!grp) CHK(audit_begin(ctx, (int)mode, inner, outer, stream, &audit));   // (device-planned groups are not audited: option "audit" selects the host-planned form)
     // counts[0] | counts[1] | tickets are contiguous: a whole join zeroes all, a prepared build its own
     // histogram and the tickets, a probe of a prepared build the probe side's histogram and the tickets
     {
@@ -561,7 +550,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         }
         if (mode == PHJ_PROBE_ONLY) HIPCHK(ctx, hj_zero_async(z1, (size_t)(ze - z1), stream));
     }
-    if (mode != PHJ_BUILD_ONLY) HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
+    if (mode != PHJ_BUILD_ONLY && !grp) HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));      // (a group: the grouped join's state goes on)
 
     Pass1Geom geom[2] = {make_geom(ctx->tune, rk, inner, pl.C, pl.F1, true), make_geom(ctx->tune, sk, outer, pl.C, pl.F1, true)};
     if (pre)
@@ -585,6 +574,8 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         pa.more[r] = m.more[r];
     }
     pa.tdesc_cap = (uint32_t)m.tdesc_cap;
+    const u64 *dyn[2] = {grp ? grp->desc : nullptr, grp ? grp->desc + 2 : nullptr};           // {first row, rows} of R / S in device memory
+    pa.dyn[0] = dyn[0]; pa.dyn[1] = dyn[1];
     pa.unique = pl.unique ? 1u : 0u;
     pa.multi_fill = m.tickets + HJ_TICKET_MULTI_FILL;          // zeroed with the tickets; counted by the work-item plan, read by the _UNIQUE join
     // two-pass plans: final partitions start on 128-byte lines (pass 2 claims whole lines); option "dense2": dense
@@ -633,7 +624,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     // the stages of one relation's partitioning
     auto k4 = [&](int r) -> int {          // one read of the key column gives the histograms of both passes
         if (nn[r]) CHK(hj_launch_hist2(in_k[r], geom[r], pl.f1, pl.F1, pl.f2, pl.F2, m.counts[r],
-                                       m.range_counts[r], m.tickets + HJ_TICKET_K4 + HJ_MAX_CHUNKS * r, ctx->cus, stream));
+                                       m.range_counts[r], m.tickets + HJ_TICKET_K4 + HJ_MAX_CHUNKS * r, ctx->cus, stream, 0, dyn[r]));
         return HJGPU_OK;
     };
     auto k5b = [&](int r) -> int {
@@ -651,6 +642,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         sa.ranged = 1; sa.work_counter = m.tickets + HJ_TICKET_K6 + 2 * r; sa.geom = geom[r]; sa.range_base = m.range_base[r];
         sa.in_packed = 0; sa.out_packed = 1;
         sa.nt_partial = ctx->rows_plain ? 0u : 1u;
+        sa.dyn = dyn[r];
         return hj_launch_scatter(sa, ctx->tune, scatter_cus(ctx), stream);
     };
     auto pass2 = [&](int r) -> int {       // K6 pass 2: tmp[0..3] -> tmp[4..7], one segment per (chunk, pass-1 partition)
@@ -767,7 +759,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
     // items (the plan kernels are single-workgroup, latency-bound: two sets cost twice the latency, 0.15 ms per step),
     // then pass 1 of both, then pass 2 of both.  The phase events are recorded at the stage boundaries, so
     // hjgpu_get_stats keeps its meaning (histogram / plan / pass 1 / pass 2 of R and S together).
-    const bool merged = mode == PHJ_WHOLE && !inner_ready && !pre && !pl.batch_ranges && ctx->tune.merged_plan;
+    const bool merged = grp || (mode == PHJ_WHOLE && !inner_ready && !pre && !pl.batch_ranges && ctx->tune.merged_plan);   // (a group: always)
     if (merged) {
         CHK(k4(0)); CHK(k4(1));
         record(ctx, EV_S_HIST, stream);
@@ -818,9 +810,11 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         ja.big_tables = pl.big_tables ? 1u : 0u;
         ja.unique = pl.unique ? 1u : 0u;
         ja.result = &st->result;
-        ja.work_counter = &st->work_counter;
-        ja.work_counter2 = &st->work_counter2;
+        // (the work counters live with the tickets: zeroed with them, per join - also for a group, whose DevState is the grouped join's)
+        ja.work_counter = reinterpret_cast<u64 *>(m.tickets + HJ_TICKET_JOIN);
+        ja.work_counter2 = reinterpret_cast<u64 *>(m.tickets + HJ_TICKET_JOIN2);
         ja.multi_fill = m.tickets + HJ_TICKET_MULTI_FILL;
+        ja.resume = grp ? 1u : 0u;
         if (bs) {
             ja.ok = out->d_keys; ja.oov = out->d_outer_vals; ja.oiv = out->d_inner_vals;
             ja.block_size = bs; ja.block_limit = bl;
@@ -833,7 +827,7 @@ int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl,
         if (audit) CHK(hj_audit_copy(reinterpret_cast<const u64 *>(&st->result), audit + 4 * 6, 4, stream));
     }
     record(ctx, EV_JOIN, stream);
-    if (bs && inner && outer && mode != PHJ_BUILD_ONLY) {
+    if (bs && inner && outer && mode != PHJ_BUILD_ONLY && !grp) {
         CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals,
                                     (const u64 *)ctx->final_offsets.p,
                                     (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables, pl.unique), bs, &st->block_counter,
@@ -869,7 +863,6 @@ bool npj_unique(const hjgpu_ctx *ctx, const hjgpu_npj_params *prm)
 int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_t *buckets,
                 uint32_t *factor)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     ReserveClock clock(ctx);
     double load = (prm && prm->load > 0) ? prm->load : 0.25;
     if (load > 0.99) return fail(ctx, HJGPU_EINVAL, "load factor must be <= 0.99");
@@ -958,6 +951,10 @@ const hjgpu_output *take_async_output(hjgpu_ctx *ctx, const hjgpu_output *given)
 // ===========================================================================
 // extern "C"
 // ===========================================================================
+static int phj_grouped(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks, const uint32_t *rk, const uint32_t *rv, size_t inner,
+                       const uint32_t *sk, const uint32_t *sv, size_t outer, const hjgpu_phj_params *prm, const hjgpu_output *out, hipStream_t stream);
+static void grouped_caps(const hjgpu_ctx *ctx, uint32_t G, size_t inner, size_t outer, size_t *cap_r, size_t *cap_s, size_t *plan_inner);
+
 extern "C" {
 
 const char *hjgpu_status_string(int s)
@@ -1020,7 +1017,6 @@ int hjgpu_create(int device, hjgpu_ctx **out)
 int hjgpu_destroy(hjgpu_ctx *ctx)
 {
     if (!ctx) return HJGPU_OK;
-    settle(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     DevBuf *all[] = {&ctx->tmp[0], &ctx->tmp[1], &ctx->tmp[2], &ctx->tmp[3], &ctx->tmp[4], &ctx->tmp[5],
@@ -1029,9 +1025,8 @@ int hjgpu_destroy(hjgpu_ctx *ctx)
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-    if (ctx->grp_in) (void)hipEventDestroy(ctx->grp_in);
-    for (hipStream_t s : ctx->grp_streams) if (s) (void)hipStreamDestroy(s);
-    if (ctx->grp_flag) (void)hipFree(ctx->grp_flag);
+    for (hipEvent_t e : ctx->grp_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->grp_ev_pass0) if (e) (void)hipEventDestroy(e);
     for (int b = 0; b < 4; ++b) {
         if (ctx->host_stage[b]) (void)hipHostFree(ctx->host_stage[b]);
         if (ctx->host_stage_ev[b]) (void)hipEventDestroy(ctx->host_stage_ev[b]);      // (the events go before the streams they were recorded on)
@@ -1045,7 +1040,6 @@ const char *hjgpu_last_error(const hjgpu_ctx *ctx) { return ctx ? ctx->err : "nu
 
 int hjgpu_set_option(hjgpu_ctx *ctx, const char *name, const char *value)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !name || !value) return HJGPU_EINVAL;
     HjTuning t = ctx->tune;
     if (!hj_tuning_set(&t, name, value)) return fail(ctx, HJGPU_EINVAL, "hjgpu_set_option: unknown option or malformed value");
@@ -1080,10 +1074,12 @@ int hjgpu_reserve(hjgpu_ctx *ctx, size_t inner, size_t outer)
     memset(&prm, 0, sizeof(prm));
     const uint32_t groups = grouped_groups(ctx, inner, outer, nullptr);
     if (groups > 1 && outer) {
-        // a grouped plan: the pass-0 twins, and the two-pass workspace for ONE group (10 % above the mean group)
+        // a grouped plan: the pass-0 twins, and the two-pass workspace for ONE group (the largest the device-planned form allows)
         ReserveClock clock(ctx);
+        size_t cap_r, cap_s, plan_inner;
+        grouped_caps(ctx, groups, inner, outer, &cap_r, &cap_s, &plan_inner);
         CHK(grouped_twins(ctx, group_layout(groups), inner, outer));
-        CHK(phj_prepare(ctx, inner / groups + inner / groups / 10, outer / groups + outer / groups / 10, &prm, 8, &pl));
+        CHK(phj_prepare(ctx, cap_r, cap_s, &prm, 8, &pl, false, -1, plan_inner));
     } else
         CHK(phj_prepare(ctx, inner, outer, &prm, 8, &pl));     // 8 chunks = largest meta
     size_t buckets; uint32_t factor;
@@ -1101,11 +1097,34 @@ static void fill_reserve(const hjgpu_ctx *ctx, hjgpu_stats *s)
 
 int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !s) return HJGPU_EINVAL;
     if (ctx->stats_override) {               // a grouped plan: the sums over pass 0 and the groups' joins, taken as they finished
         *s = ctx->stats;
         fill_reserve(ctx, s);
+        return HJGPU_OK;
+    }
+    if (ctx->grp_ev_groups) {
+        // a device-planned grouped join: pass 0, then the groups' phases added up from their own event sets
+        HIPCHK(ctx, hipEventSynchronize(ctx->grp_ev_pass0[2]));
+        auto between = [&](hipEvent_t a, hipEvent_t b) -> float { float ms = 0; return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f; };
+        hjgpu_stats r = ctx->stats;
+        r.ms_histogram = r.ms_plan = r.ms_scatter1 = r.ms_scatter2 = r.ms_join = r.ms_close_gaps = r.ms_build = r.ms_inner_wait = 0;
+        for (uint32_t g = 0; g < ctx->grp_ev_groups; ++g) {
+            const hipEvent_t *e = ctx->grp_ev.data() + (size_t)g * EV_COUNT;
+            // (both relations' stages run side by side in a group's plan: phj_enqueue's merged form)
+            r.ms_histogram += between(e[EV_BEGIN], e[EV_S_HIST]);
+            r.ms_plan += between(e[EV_S_HIST], e[EV_S_PLAN]);
+            r.ms_scatter1 += between(e[EV_S_PLAN], e[EV_S_SC1]);
+            r.ms_scatter2 += between(e[EV_S_SC1], e[EV_S_SC2]);
+            r.ms_join += between(e[EV_S_SC2], e[EV_JOIN]);
+        }
+        r.ms_scatter0 = between(ctx->grp_ev_pass0[0], ctx->grp_ev_pass0[1]);
+        r.ms_total = between(ctx->grp_ev_pass0[0], ctx->grp_ev_pass0[2]);
+        r.ms_close_gaps = r.ms_total - (r.ms_scatter0 + r.ms_histogram + r.ms_plan + r.ms_scatter1 + r.ms_scatter2 + r.ms_join);   // close_gaps and the gaps between launches
+        if (r.ms_close_gaps < 0) r.ms_close_gaps = 0;
+        r.groups = ctx->grp_ev_groups;
+        fill_reserve(ctx, &r);
+        *s = r;
         return HJGPU_OK;
     }
     if (ctx->ev_valid[EV_GAPS]) HIPCHK(ctx, hipEventSynchronize(ctx->ev[EV_GAPS]));
@@ -1147,15 +1166,31 @@ int hjgpu_get_stats(hjgpu_ctx *ctx, hjgpu_stats *s)
 
 int hjgpu_get_async_status(hjgpu_ctx *ctx, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx) return HJGPU_EINVAL;
-    if (ctx->grp_status != HJGPU_OK) { const int rc = ctx->grp_status; ctx->grp_status = HJGPU_OK; return rc; }     // an asynchronous grouped join failed (text in hjgpu_last_error)
     if (!ctx->state.p) return HJGPU_OK;                  // nothing was ever enqueued
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevState h;
     HIPCHK(ctx, hipMemcpyAsync(&h, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
     HIPCHK(ctx, hipStreamSynchronize(stream));
+    if (ctx->grp_last.valid && h.group_skew) {
+        // the device-planned grouped join skipped a group that was larger than its workspace (its d_result says so: all ones): the same
+        // join again, host-planned - this thread waits for pass 0 and for every group - with the result where the caller expects it
+        const hjgpu_ctx::GroupedCall c = ctx->grp_last;
+        ctx->grp_last.valid = false;
+        const hjgpu_phj_params *prm = c.has_prm ? &c.prm : nullptr;
+        const hjgpu_output *out = c.has_out ? &c.out : nullptr;
+        const uint32_t groups = grouped_groups(ctx, c.inner, c.outer, prm);
+        if (groups > 1) CHK(phj_grouped(ctx, groups, c.chunks, c.rk, c.rv, c.inner, c.sk, c.sv, c.outer, prm, out, stream));
+        else {
+            PhjPlan pl;
+            CHK(phj_prepare(ctx, c.inner, c.outer, prm, c.chunks, &pl));
+            CHK(phj_enqueue(ctx, pl, c.rk, c.rv, c.inner, c.sk, c.sv, c.outer, out, stream));
+        }
+        if (c.d_result) HIPCHK(ctx, hj_copy_async(c.d_result, ctx->state.p, sizeof(hjgpu_result), stream));
+        HIPCHK(ctx, hipMemcpyAsync(&h, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+        HIPCHK(ctx, hipStreamSynchronize(stream));
+    }
     if (h.zero_key) return fail(ctx, HJGPU_EZEROKEY, "NPJ: a build key is 0, the empty-bucket sentinel");
     if (h.overflow) return fail(ctx, HJGPU_EOVERFLOW, "materialised output exceeded its capacity");
     if (ctx->last_had_output && h.dense != h.result.count && (h.result.count != 0 || h.dense != 0))
@@ -1165,7 +1200,6 @@ int hjgpu_get_async_status(hjgpu_ctx *ctx, void *stream_)
 
 int hjgpu_accumulate_async_status(hjgpu_ctx *ctx, uint64_t *d_flags, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_flags) return HJGPU_EINVAL;
     if (!ctx->state.p) return HJGPU_OK;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1257,7 +1291,6 @@ int hjgpu_host_free(hjgpu_ctx *ctx, void *p)
 }
 int hjgpu_audit_read(hjgpu_ctx *ctx, uint64_t *next_seq, uint64_t first_seq, uint32_t count, uint64_t *records, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx) return HJGPU_EINVAL;
     if (next_seq) *next_seq = ctx->audit_seq;
     if (!count) return HJGPU_OK;
@@ -1281,7 +1314,6 @@ int hjgpu_audit_read(hjgpu_ctx *ctx, uint64_t *next_seq, uint64_t first_seq, uin
 // first check was wrong and whose memory is wrong here LOST stores; one whose memory is right here was READ STALE.
 int hjgpu_audit_recheck(hjgpu_ctx *ctx, uint64_t *words, size_t capacity, size_t *checks)
 {
-    settle(ctx);
     if (!ctx || !checks) return HJGPU_EINVAL;
     *checks = ctx->audit_checks.size();
     if (!words || capacity < ctx->audit_checks.size()) return HJGPU_OK;      // the caller asks again with room for 9 words per check
@@ -1402,7 +1434,6 @@ static int broadcast_enqueue(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_t 
                              const hjgpu_phj_params *prm, const hjgpu_output *out, hipStream_t stream,
                              hipEvent_t inner_ready)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     CHK(refuse_capture(ctx, stream));
     ctx->prepared = false;
     const uint32_t tf0 = (prm && prm->table_factor[0]) ? prm->table_factor[0] : DEFAULT_TF0;
@@ -1568,76 +1599,102 @@ static int phj_grouped(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks,
     return HJGPU_OK;
 }
 
-// A grouped plan enqueue-only (hjgpu_phj_async / hjgpu_cpra_async): the groups' sizes are known on the device only, so
-// somebody waits for pass 0 and plans every group from its size - the context's worker thread, on a stream of its own.  The
-// caller's stream is tied in on both ends: the worker's stream starts behind what the caller has enqueued so far (the input
-// columns), and the caller's stream goes on only when the worker's LAST command has raised the context's counter in signal
-// memory (hipStreamWaitValue64 / hipStreamWriteValue64) - the call itself returns at once.  phj.cpp:1791-1863 plans and runs
-// its passes inside run_hj, on the worker threads; nothing there is asynchronous to wait for.
-static int grouped_async(hjgpu_ctx *ctx, uint32_t groups, uint32_t chunks,
-                         const uint32_t *rk, const uint32_t *rv, size_t inner,
-                         const uint32_t *sk, const uint32_t *sv, size_t outer,
-                         const hjgpu_phj_params *prm, const hjgpu_output *out, hjgpu_result *d_result, hipStream_t stream)
+// A grouped plan planned ON THE DEVICE (option "group_device", the default): pass 0 of both relations, one small kernel that turns pass 0's
+// offsets into a descriptor per group (first row and rows of its build and probe columns inside the pass-0 twins), then G two-pass joins
+// enqueued back to back - every kernel of a group's join reads the group's geometry from its descriptor (K4, the plan kernels and K6 pass 1
+// take ScatterArgs::dyn / PlanArgs::dyn; everything behind them works on device-resident offsets anyway).  No host thread waits for
+// anything: the call is enqueue-only like every other join (phj.cpp:1791-1863 plans and runs its passes inside run_hj).  The groups share
+// one join state: aggregates accumulate, the block counter and the waves' open output blocks go on from group to group
+// (JoinArgs::resume), ONE close_gaps ends the join.  The workspace is planned for groups of up to (1 + group_slack / 100) x the mean
+// group (the fan-out for the mean group: a larger one fills its tables more than once); a group beyond that is skipped and
+// DevState::group_skew raised: the caller's next blocking touch point runs the join again in the host-planned form (phj_grouped).
+// rows of the largest group a device-planned grouped join has workspace for, and the build rows its fan-out is planned for
+static void grouped_caps(const hjgpu_ctx *ctx, uint32_t G, size_t inner, size_t outer, size_t *cap_r, size_t *cap_s, size_t *plan_inner)
 {
+    const size_t slack = (size_t)ctx->tune.group_slack;
+    *cap_r = (inner / G + 1) * (100 + slack) / 100 + 65536;
+    *cap_s = (outer / G + 1) * (100 + slack) / 100 + 65536;
+    *plan_inner = inner / G + inner / G / 10 + 1;
+}
+
+static int phj_grouped_device(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks,
+                              const uint32_t *rk, const uint32_t *rv, size_t inner,
+                              const uint32_t *sk, const uint32_t *sv, size_t outer,
+                              const hjgpu_phj_params *prm, const hjgpu_output *out, hjgpu_result *d_result, hipStream_t stream, hipEvent_t inner_ready)
+{
+    const GroupLayout l = group_layout(G);
+    size_t cap_r, cap_s, plan_inner;
+    grouped_caps(ctx, G, inner, outer, &cap_r, &cap_s, &plan_inner);
+    PhjPlan pl;
     {
-        // the workspace a grouped plan of this size usually needs, grown HERE (hjgpu_reserve's estimate: one group 10 % above the mean):
-        // what the worker still has to grow - a larger largest group - it grows without freeing anything (hjgpu_ctx::defer_free)
         ReserveClock clock(ctx);
-        PhjPlan pl;
-        CHK(grouped_twins(ctx, group_layout(groups), inner, outer));
-        CHK(phj_prepare(ctx, inner / groups + inner / groups / 10, outer / groups + outer / groups / 10, prm, chunks, &pl));
+        CHK(grouped_twins(ctx, l, inner, outer));
+        CHK(phj_prepare(ctx, cap_r, cap_s, prm, chunks, &pl, false, -1, plan_inner));
+        // (a group's plan is the merged one: no batched probe-side partitioning, option "batch_tuples")
+        pl.batch_ranges = pl.batch_cap = pl.batch_tile_cap = 0; pl.tdesc_b_cap = 0; pl.batch_bytes = 0;
     }
+    // one set of phase events per group (made once, kept): nobody waits between the groups, hjgpu_get_stats adds their spans up afterwards
+    while (ctx->grp_ev.size() < (size_t)G * EV_COUNT) {
+        hipEvent_t e = nullptr;
+        HIPCHK(ctx, hipEventCreate(&e));
+        ctx->grp_ev.push_back(e);
+    }
+    for (hipEvent_t &e : ctx->grp_ev_pass0) if (!e) HIPCHK(ctx, hipEventCreate(&e));
+    uint32_t *g_rk = (uint32_t *)ctx->grp[0].p, *g_rv = (uint32_t *)ctx->grp[1].p;
+    uint32_t *g_sk = (uint32_t *)ctx->grp[2].p, *g_sv = (uint32_t *)ctx->grp[3].p;
+    u64 *d_off = (u64 *)ctx->grp_off.p, *d_desc = d_off + (size_t)2 * (l.F0 + 1);
+    DevState *st = reinterpret_cast<DevState *>(ctx->state.p);
+    uint32_t f0 = DEFAULT_F0;           // pass 0 splits by a hash independent of the groups' own two passes (see phj_grouped)
     {
-        // the worker's stream: a priority class the caller's stream is not in (their hardware queues are pooled per class)
-        int least = 0, greatest = 0, mine = 0;
-        HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (hipStreamGetPriority(stream, &mine) != hipSuccess) { (void)hipGetLastError(); mine = 0; }
-        const int which = (mine == 0 && greatest < 0) ? 0 : 1;             // default-priority callers: the class above; others: the default class
-        if (!ctx->grp_streams[which])
-            HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->grp_streams[which], hipStreamNonBlocking, which == 0 ? greatest : 0));
-        ctx->grp_stream = ctx->grp_streams[which];
+        const uint32_t f1 = (prm && prm->factor1) ? prm->factor1 : DEFAULT_F1, f2 = (prm && prm->factor2) ? prm->factor2 : DEFAULT_F2;
+        const uint32_t other[3] = {0x7FEB352Du, 0x846CA68Bu, 0xC6A4A793u};
+        for (uint32_t cand : other) if (cand != f1 && cand != f2) { f0 = cand; break; }
     }
-    if (!ctx->grp_in) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->grp_in, hipEventDisableTiming));
-    if (!ctx->grp_flag) {
-        HIPCHK(ctx, hipExtMallocWithFlags(reinterpret_cast<void **>(&ctx->grp_flag), sizeof(uint64_t), hipMallocSignalMemory));
-        HIPCHK(ctx, hipStreamWriteValue64(ctx->grp_stream, ctx->grp_flag, 0, 0));
-        HIPCHK(ctx, hj_stream_synchronize(ctx->grp_stream));
+    const uint32_t workers = (uint32_t)hj_join_workers(ctx->tune, ctx->cus, pl.big_tables, pl.unique);
+    u64 bs = 0, bl = 0;
+    CHK(setup_output(ctx, out, workers, &bs, &bl));
+    HIPCHK(ctx, hipEventRecord(ctx->grp_ev_pass0[0], stream));
+    // pass 0: the probe side first; the build side may still be arriving (hjgpu_phj_overlapped_async)
+    CHK(partition_columns(ctx, sk, sv, outer, f0, l.F0, l.bins, g_sk, g_sv, reinterpret_cast<uint64_t *>(d_off + (l.F0 + 1)), stream));
+    if (inner_ready) HIPCHK(ctx, hipStreamWaitEvent(stream, inner_ready, 0));
+    CHK(partition_columns(ctx, rk, rv, inner, f0, l.F0, l.bins, g_rk, g_rv, reinterpret_cast<uint64_t *>(d_off), stream));
+    // the grouped join's state: cleared ONCE; every wave's output cursor "no block yet"
+    HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
+    if (bs) HIPCHK(ctx, hj_fill_async(ctx->final_offsets.p, 0xFFFFFFFFu, (size_t)workers * sizeof(u64), stream));
+    CHK(hj_launch_group_desc(d_off, d_off + (l.F0 + 1), G, l.bins, (u64)cap_r, (u64)cap_s, d_desc, &st->group_skew, stream));
+    HIPCHK(ctx, hipEventRecord(ctx->grp_ev_pass0[1], stream));
+    for (uint32_t g = 0; g < G; ++g) {
+        const GroupRun run = {d_desc + 4 * (size_t)g};
+        ctx->ev_cur = ctx->grp_ev.data() + (size_t)g * EV_COUNT;
+        const int rc = phj_enqueue(ctx, pl, g_rk, g_rv, cap_r, g_sk, g_sv, cap_s, bs ? out : nullptr, stream, nullptr, PHJ_WHOLE, nullptr, &run);
+        ctx->ev_cur = nullptr;
+        CHK(rc);
     }
-    CHK(ensure(ctx, ctx->state, sizeof(DevState)));
-    const uint64_t seq = ++ctx->grp_seq;
-    HIPCHK(ctx, hipEventRecord(ctx->grp_in, stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->grp_stream, ctx->grp_in, 0));
-    HIPCHK(ctx, hipStreamWaitValue64(stream, ctx->grp_flag, seq, hipStreamWaitValueGte, ~0ull));
-    const bool has_prm = prm != nullptr, has_out = out != nullptr;
-    hjgpu_phj_params prm_copy;
-    hjgpu_output out_copy;
-    memset(&prm_copy, 0, sizeof(prm_copy)); memset(&out_copy, 0, sizeof(out_copy));
-    if (prm) prm_copy = *prm;
-    if (out) out_copy = *out;
-    ctx->grp_status = HJGPU_OK;
-    ctx->defer_free = true;                                  // until settle() has joined the worker
-    ctx->grp_worker = std::thread([=]() {
-        hipStream_t ws = ctx->grp_stream;
-        int rc = hipSetDevice(ctx->device) == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
-        if (rc == HJGPU_OK)
-            rc = phj_grouped(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, has_prm ? &prm_copy : nullptr, has_out ? &out_copy : nullptr, ws);
-        if (rc == HJGPU_OK && d_result && hj_copy_async(d_result, ctx->state.p, sizeof(hjgpu_result), ws) != hipSuccess)
-            rc = HJGPU_EHIP;
-        ctx->grp_status = rc;
-        // whatever happened, the caller's stream must not wait for ever
-        (void)hipStreamWriteValue64(ws, ctx->grp_flag, seq, 0);
-    });
+    if (bs)
+        CHK(hj_launch_close_gaps_ex(out->d_keys, out->d_outer_vals, out->d_inner_vals, (const u64 *)ctx->final_offsets.p, workers, bs,
+                                    &st->block_counter, &st->overflow, ctx->moves.p, &st->nmoves, &st->dense, ctx->cus, stream));
+    if (d_result) CHK(hj_launch_group_result(&st->result, &st->group_skew, d_result, stream));
+    HIPCHK(ctx, hipEventRecord(ctx->grp_ev_pass0[2], stream));
+    // the last event every waiter looks at (hjgpu_get_stats), recorded in the context's own set
+    for (int i = 0; i < EV_COUNT; ++i) ctx->ev_valid[i] = false;
+    record(ctx, EV_BEGIN, stream);
+    record(ctx, EV_GAPS, stream);
+    ctx->grp_ev_groups = G;
+    ctx->stats.fanout1 = pl.F1; ctx->stats.fanout2 = pl.F2; ctx->stats.buckets = 0; ctx->stats.batches = 0;
+    ctx->last_algo = 1;
     return HJGPU_OK;
 }
+
+// does a grouped plan of this context run device-planned?  (option "audit" reads every stage's output with host-known sizes: host-planned)
+static bool grouped_on_device(const hjgpu_ctx *ctx) { return ctx->tune.group_device && !ctx->tune.audit && !ctx->tune.scatter_prof; }
 
 static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
                     const uint32_t *rk, const uint32_t *rv, size_t inner,
                     const uint32_t *sk, const uint32_t *sv, size_t outer,
                     const hjgpu_phj_params *prm, hjgpu_result *result, hjgpu_result *d_result,
-                    const hjgpu_output *out, void *stream_, bool blocking, void *inner_ready = nullptr)
+                    const hjgpu_output *out, void *stream_, bool blocking, void *inner_ready = nullptr, bool local_join = false)
 {
     if (!ctx) return HJGPU_EINVAL;
-    settle(ctx);                                         // before anything of the context changes: an asynchronous grouped join's worker reads it
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
     PlainRows plain(ctx, blocking);
     CHK(check_columns(ctx, rk, rv, inner));
@@ -1647,26 +1704,32 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed
     ctx->last_had_output = out && out->d_keys;
+    ctx->grp_last.valid = false;
     const uint32_t groups = grouped_groups(ctx, inner, outer, prm);
-    bool wait_here = blocking || !ctx->tune.group_async;
-    if (groups > 1 && outer && inner_ready) {
-        // hjgpu_phj_overlapped_async (hjgpu_phj_multi's local join): a grouped plan reads the build side in its first command (pass 0
-        // of R), so the overlap of the build side's arrival with the probe side's first pass is given up - pass 0 is 20 ms of a 69 ms
-        // plan at 1 G x 4 G, a broadcast of 1 G tuples takes longer than that on any link.  And the CALLING thread waits for the
-        // groups' sizes: the caller is a rank's host thread inside a blocking multi-GPU join, whose streams must not be held in
-        // hardware while the other ranks of the process work beside them.
-        HIPCHK(ctx, hipStreamWaitEvent(stream, (hipEvent_t)inner_ready, 0));
-        inner_ready = nullptr;
-        wait_here = true;
-    }
-    if (groups > 1 && outer && !wait_here) {
-        // enqueue-only: the context's worker thread waits for the groups' sizes, not the caller (grouped_async)
-        settle(ctx);
-        return grouped_async(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, d_result, stream);
+    // (the local join of a multi-GPU call - hjgpu_phj_overlapped_async - is always planned on the device: a rank's host thread waits with a
+    // deadline or not at all)
+    if (groups > 1 && outer && (grouped_on_device(ctx) || local_join)) {
+        CHK(phj_grouped_device(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, d_result, stream, (hipEvent_t)inner_ready));
+        if (!blocking) {
+            // what hjgpu_get_async_status needs to do the join again, host-planned, should a group have been larger than its workspace
+            hjgpu_ctx::GroupedCall &c = ctx->grp_last;
+            c.valid = true; c.chunks = chunks; c.rk = rk; c.rv = rv; c.sk = sk; c.sv = sv; c.inner = inner; c.outer = outer;
+            c.has_prm = prm != nullptr; c.has_out = out != nullptr; c.d_result = d_result;
+            if (prm) c.prm = *prm;
+            if (out) c.out = *out;
+            return HJGPU_OK;
+        }
+        DevState h;
+        HIPCHK(ctx, hipMemcpyAsync(&h, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, stream));
+        HIPCHK(ctx, hipStreamSynchronize(stream));
+        if (!h.group_skew) return finish_blocking(ctx, result, out, stream);
+        // a group was larger than the plan's workspace (heavy duplicates): the host-planned form sizes every group's join from its rows
+        CHK(phj_grouped(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, stream));
+        return finish_blocking(ctx, result, out, stream);
     }
     if (groups > 1 && outer) {
-        // (a blocking call, or option group_async = 0: this thread waits for pass 0 and for every group)
-        settle(ctx);
+        // option "group_device" = 0 (or "audit"): this thread waits for pass 0 and for every group - never inside a multi-GPU call, whose
+        // rank threads wait with a deadline (hjgpu_phj_overlapped_async is hjgpu_phj_multi's / hjgpu_cpra_multi's local join)
         CHK(phj_grouped(ctx, groups, chunks, rk, rv, inner, sk, sv, outer, prm, out, stream));
     } else if (broadcast_applies(ctx->tune, inner, outer, chunks, prm)) {
         CHK(broadcast_enqueue(ctx, rk, rv, inner, sk, sv, outer, prm, out, stream, (hipEvent_t)inner_ready));
@@ -1701,7 +1764,7 @@ int hjgpu_phj_overlapped_async(hjgpu_ctx *ctx, const uint32_t *rk, const uint32_
                                void *inner_ready_event)
 {
     return phj_like(ctx, 1, rk, rv, inner, sk, sv, outer, prm, nullptr, d_result, nullptr, stream, false,
-                    inner_ready_event);
+                    inner_ready_event, true);
 }
 
 // ---- build side prepared once, probed by any number of batches ---------------------------------
@@ -1726,7 +1789,6 @@ static int phj_probe_prepared(hjgpu_ctx *ctx, const uint32_t *sk, const uint32_t
                               hjgpu_result *result, hjgpu_result *d_result, const hjgpu_output *out,
                               void *stream_, bool blocking)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx) return HJGPU_EINVAL;
     if (!blocking) out = take_async_output(ctx, out);    // consumed by this call even if it fails below (see hjgpu_npj_async)
     PlainRows plain(ctx, blocking);                      // (settle() is this function's first statement)

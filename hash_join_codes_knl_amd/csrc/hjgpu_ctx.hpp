@@ -32,6 +32,8 @@ struct DevState {
     uint32_t nmoves;
     uint32_t pad;
     u64 work_counter2;      // the multi-fill half of a _UNIQUE join (hj_launch_join)
+    uint32_t group_skew;    // a device-planned grouped join skipped a group that was larger than its workspace (group_desc_kernel)
+    uint32_t pad2;
 };
 
 // probe side (S) is partitioned first, then the build side (R): a caller can overlap the
@@ -75,28 +77,28 @@ struct hjgpu_ctx {
     bool last_had_output = false;   // hjgpu_get_async_status: the last enqueued join wrote result columns
     bool rows_plain = false;        // the join being enqueued is SOLO - a blocking call of a context with option "solo": plain partial-line stores
                                     // in K6 (k6_store8) and plain result rows (join_kernel<..., NTROWS = false>); every other launch writes them non-temporal
-    // grouped plans (phj_grouped): pass-0 twins of the four columns, the groups' offsets, and the call's accumulated phase
-    // times (hjgpu_get_stats returns those while stats_override is set; any later operation's first event clears it)
+    // grouped plans: pass-0 twins of the four columns, the groups' offsets and (device-planned) descriptors, and the call's accumulated
+    // phase times (hjgpu_get_stats returns those while stats_override is set; any later operation's first event clears it)
     DevBuf grp[4], grp_off;
     bool stats_override = false;
     hipStream_t aux = nullptr;      // private non-blocking stream: placement probes of the workspace allocator
-    // Grouped plans through the enqueue-only forms (grouped_async below): the call returns at once; a worker thread of the context
-    // runs pass 0 and the groups on grp_stream (the groups' sizes are known on the device only: somebody has to wait for them,
-    // it need not be the caller) and the CALLER's stream waits for a counter in signal memory that the worker's last command
-    // raises.  Any later use of the context joins the worker first (settle).
-    std::thread grp_worker;
-    hipStream_t grp_stream = nullptr;      // the worker's stream of the current / last such join: one of grp_streams
-    hipStream_t grp_streams[2] = {nullptr, nullptr};   // [0] priority above the default, [1] the default priority: never the CALLER's
-                                    // stream's own priority - streams of one priority share hardware queues once a process has more of
-                                    // them than queues, and the worker's commands must not sit behind the caller's waiting stream
-    // While the worker runs, the caller's stream waits in hardware for it: hipFree - which waits for every stream of the device -
-    // would wait for ever.  Buffers that grow in the worker are kept here and freed when the worker has been joined (settle).
-    bool defer_free = false;
-    std::vector<void *> graveyard;
-    hipEvent_t grp_in = nullptr;
-    uint64_t *grp_flag = nullptr;   // hipExtMallocWithFlags(hipMallocSignalMemory): joins of this context finished so far
-    uint64_t grp_seq = 0;
-    int grp_status = HJGPU_OK;      // of the last asynchronous grouped join (hjgpu_get_async_status)
+    // Device-planned grouped joins (phj_grouped_device): one set of phase events per group - the groups' joins are enqueued back to back
+    // and nobody waits in between, so hjgpu_get_stats adds the groups' spans up afterwards - and what hjgpu_get_async_status needs to
+    // run the join again, host-planned, when a group turned out larger than its workspace (DevState::group_skew)
+    hipEvent_t *ev_cur = nullptr;                        // the set record() writes (NULL: ev)
+    std::vector<hipEvent_t> grp_ev;                      // [groups][EV_COUNT]
+    uint32_t grp_ev_groups = 0;                          // groups of the last device-planned join (0: hjgpu_get_stats reads ev)
+    hipEvent_t grp_ev_pass0[3] = {nullptr, nullptr, nullptr};   // begin, pass 0 done, all done
+    struct GroupedCall {
+        bool valid = false;
+        uint32_t chunks = 1;
+        const uint32_t *rk = nullptr, *rv = nullptr, *sk = nullptr, *sv = nullptr;
+        size_t inner = 0, outer = 0;
+        bool has_prm = false, has_out = false;
+        hjgpu_phj_params prm;
+        hjgpu_output out;
+        hjgpu_result *d_result = nullptr;
+    } grp_last;                                          // the last ENQUEUE-ONLY device-planned grouped join of this context
     // option "audit": the last HJ_AUDIT_RING calls' stage records (audit_kernels.hip), the next call's sequence number, and the
     // explicit partition bounds of an own-last layout
     DevBuf audit, audit_lay;
@@ -120,7 +122,6 @@ const uint32_t DEFAULT_NPJ_FACTOR = 0x9E3779B1u;
 const uint32_t DEFAULT_F0 = 0x7FEB352Du;      // grouped plans: pass 0 (phj_grouped takes another one when a pass factor of the join equals it)
 
 int fail(hjgpu_ctx *ctx, int status, const char *what, hipError_t e = hipSuccess);
-void settle(hjgpu_ctx *ctx);
 
 // The partial-line stores (K6) of a SOLO join - a blocking call of a context with option "solo": the caller waits for it and promises
 // that nothing else runs on the device beside it - are plain; every other join (enqueue-only, host batches, multi-GPU slices, and
@@ -251,11 +252,17 @@ struct PrePieces {
 };
 enum PhjMode { PHJ_WHOLE = 0, PHJ_BUILD_ONLY = 1, PHJ_PROBE_ONLY = 2 };
 
+// plan_inner > 0: the fan-out is planned for a build side of that many rows while the workspace holds `inner` (device-planned groups: the
+// mean group decides the partitions, the largest group the plan allows decides the buffers)
 int phj_prepare(hjgpu_ctx *ctx, size_t inner, size_t outer, const hjgpu_phj_params *prm, uint32_t chunks, PhjPlan *pl, bool pre = false,
-                int big_override = -1);
+                int big_override = -1, size_t plan_inner = 0);
+// One group of a device-planned grouped join: desc = {build first row, build rows, probe first row, probe rows} in device memory; the
+// columns handed to phj_enqueue are the pass-0 twins, `inner` / `outer` the CAPACITY the plan was prepared for.  The join's state
+// (aggregates, block counter, open output blocks) is the whole grouped join's: phj_enqueue neither clears it nor closes the gaps.
+struct GroupRun { const u64 *desc; };
 int phj_enqueue(hjgpu_ctx *ctx, const PhjPlan &pl, const uint32_t *rk, const uint32_t *rv, size_t inner,
                 const uint32_t *sk, const uint32_t *sv, size_t outer, const hjgpu_output *out, hipStream_t stream,
-                hipEvent_t inner_ready = nullptr, PhjMode mode = PHJ_WHOLE, const PrePieces *pre = nullptr);
+                hipEvent_t inner_ready = nullptr, PhjMode mode = PHJ_WHOLE, const PrePieces *pre = nullptr, const GroupRun *grp = nullptr);
 int finish_blocking(hjgpu_ctx *ctx, hjgpu_result *result, const hjgpu_output *out, hipStream_t stream);
 bool npj_unique(const hjgpu_ctx *ctx, const hjgpu_npj_params *prm);
 int npj_prepare(hjgpu_ctx *ctx, size_t inner, const hjgpu_npj_params *prm, size_t *buckets, uint32_t *factor);

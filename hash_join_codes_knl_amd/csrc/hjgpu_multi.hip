@@ -603,10 +603,6 @@ int init_rank(hjgpu_comm *c, Rank &r, int device, int global)
     r.device = device; r.global = global;
     int rc = hjgpu_create(device, &r.join);
     if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_create(join context)");
-    // a grouped plan of a rank's local join is waited for by the rank's own host thread (the multi-GPU joins are blocking calls): no
-    // stream of the rank is ever held in hardware for commands that are not enqueued yet
-    rc = hjgpu_set_option(r.join, "group_async", "0");
-    if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_set_option(join context, group_async)");
     rc = hjgpu_create(device, &r.part);
     if (rc != HJGPU_OK) return cfail(c, rc, "hjgpu_create(partition context)");
     HIPM(c, hipSetDevice(device));
@@ -780,6 +776,22 @@ int sync_all(hjgpu_comm *c)
     return wait_for(c, ws);
 }
 
+// A rank's local join whose plan groups (hjgpu_phj_overlapped_async) is planned on the device and enqueue-only; should one of its groups
+// have been larger than the plan's workspace (heavy duplicates), the join is done again host-planned - here, by the rank's thread, once
+// the stream is known to be idle (a wait with the communicator's deadline: the inputs' arrival is behind it, what follows waits for
+// nothing but this device)
+int settle_grouped_local_join(hjgpu_comm *c, int l, Rank &r, size_t inner, size_t outer, const hjgpu_phj_params *prm)
+{
+    uint32_t groups = 0;
+    if (hjgpu_grouped_plan(r.join, inner, outer, prm, &groups) != HJGPU_OK || !groups) return HJGPU_OK;
+    const int w = wait_stream(c, l, r.main, "join");
+    if (w != HJGPU_OK) return w;
+    const int st = hjgpu_get_async_status(r.join, r.main);
+    // (a zero key / an overflowing result column travel with the flags: hjgpu_accumulate_async_status)
+    if (st != HJGPU_OK && st != HJGPU_EOVERFLOW && st != HJGPU_EZEROKEY) return cfail(c, st, "grouped local join", hjgpu_last_error(r.join));
+    return HJGPU_OK;
+}
+
 void add_stats(hjgpu_stats *acc, const hjgpu_stats &s)
 {
     acc->ms_total += s.ms_total; acc->ms_histogram += s.ms_histogram; acc->ms_plan += s.ms_plan;
@@ -895,6 +907,8 @@ int replicated_join(hjgpu_comm *c, int algorithm, const hjgpu_shard *shards, hjg
             // the probe shard is histogrammed and partitioned while the build side is still arriving
             JOINM(c, r.join, hjgpu_phj_overlapped_async(r.join, rk, rv, inner, shards[l].d_outer_keys, shards[l].d_outer_vals,
                                                         shards[l].outer, pp, d_res, r.main, r.ev_ready));
+            const int sg = settle_grouped_local_join(c, l, r, inner, shards[l].outer, pp);
+            if (sg != HJGPU_OK) return sg;
         } else {
             HIPM(c, hipStreamWaitEvent(r.main, r.ev_ready, 0));     // NPJ builds first: it needs all of R
             JOINM(c, r.join, hjgpu_npj_async(r.join, rk, rv, inner, shards[l].d_outer_keys, shards[l].d_outer_vals,
@@ -1380,9 +1394,13 @@ int cpra_join(hjgpu_comm *c, const hjgpu_shard *shards, hjgpu_shard_rows *rows, 
                     } else if (grouped)
                         // the rank's whole local join; its plan groups where the share needs it (the build side has arrived: the exchange
                         // stream received it before the probe side, whose arrival this stream has just waited for)
+                    {
                         JOINM(c, r.join, hjgpu_phj_overlapped_async(r.join, static_cast<const uint32_t *>(r.rrecv_k.p), static_cast<const uint32_t *>(r.rrecv_v.p),
                                                                     (size_t)inner_recv[l], sk + b, sv + b, m, prm,
                                                                     reinterpret_cast<hjgpu_result *>(acc + 8), r.main, nullptr));
+                        const int sg = settle_grouped_local_join(c, l, r, (size_t)inner_recv[l], m, prm);
+                        if (sg != HJGPU_OK) return sg;
+                    }
                     else
                     JOINM(c, r.join, hjgpu_phj_probe_async(r.join, sk + b, sv + b, m, reinterpret_cast<hjgpu_result *>(acc + 8), r.main));
                     hipLaunchKernelGGL(add_result_kernel, dim3(1), dim3(64), 0, r.main, acc, acc + 8);

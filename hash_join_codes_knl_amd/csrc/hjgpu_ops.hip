@@ -14,7 +14,6 @@ int partition_columns(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_
                              uint32_t factor, uint32_t fanout, uint32_t group_bins, uint32_t *d_keys_out, uint32_t *d_vals_out,
                              uint64_t *d_offsets, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (fanout == 0 || fanout > HJGPU_MAX_FANOUT || !(factor & 1))
         return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 1024] and factor odd");
@@ -75,7 +74,6 @@ extern "C" {
 int hjgpu_histogram(hjgpu_ctx *ctx, const uint32_t *d_keys, size_t n, uint32_t factor,
                     uint32_t fanout, uint64_t *d_counts, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_counts || (n && !d_keys)) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (fanout == 0 || fanout > HJGPU_MAX_PARTS || !(factor & 1))
         return fail(ctx, HJGPU_EINVAL, "fanout must be in [1, 32768] and factor odd");
@@ -117,7 +115,6 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
                           const hjgpu_phj_params *passes, hjgpu_result *result,
                           const hjgpu_output *out, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !passes || !roff || !soff || !rk || !rv || !sk || !sv)
         return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (((uintptr_t)sk & 15) || ((uintptr_t)sv & 15))
@@ -204,7 +201,6 @@ int hjgpu_join_partitions(hjgpu_ctx *ctx,
 int hjgpu_npj_build(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_vals, size_t n,
                     uint64_t *d_table, size_t buckets, uint32_t factor, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_table || (n && (!d_keys || !d_vals))) return fail(ctx, HJGPU_EINVAL, "null pointer");
     if (!(factor & 1) || buckets <= n) return fail(ctx, HJGPU_EINVAL, "factor must be odd and buckets > n");
     hipStream_t stream = (hipStream_t)stream_;
@@ -221,7 +217,6 @@ int hjgpu_npj_probe(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32_t *d_va
                     const uint64_t *d_table, size_t buckets, uint32_t factor,
                     hjgpu_result *result, const hjgpu_output *out, void *stream_)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (!ctx || !d_table || buckets == 0) return fail(ctx, HJGPU_EINVAL, "null pointer");
     CHK(check_columns(ctx, d_keys, d_vals, n));
     hipStream_t stream = (hipStream_t)stream_;
@@ -240,7 +235,6 @@ static int partition_packed(hjgpu_ctx *ctx, const uint32_t *d_keys, const uint32
                             uint64_t *d_tuples_out, uint64_t *d_offsets, void *stream_,
                             uint32_t factor2 = 0, uint32_t fanout2 = 0, uint64_t *d_counts2 = nullptr)
 {
-    settle(ctx);                         // (an asynchronous grouped join of this context may still be enqueuing)
     if (d_counts2 && (fanout2 < 1 || !(factor2 & 1) || factor2 == factor || (u64)fanout * fanout2 > HJGPU_MAX_PARTS))
         return fail(ctx, HJGPU_EINVAL, "fused counts: factor2 odd and different from factor, fanout * fanout2 <= 32768");
     if (!ctx || !d_offsets) return fail(ctx, HJGPU_EINVAL, "null pointer");
@@ -430,7 +424,6 @@ int hjgpu_phj_probe_prepartitioned_counted_async(hjgpu_ctx *ctx, const uint64_t 
 static int probe_prepartitioned(hjgpu_ctx *ctx, const uint64_t *d_tuples, const hjgpu_prepartitioned *lay, const uint64_t *d_counts,
                                 hjgpu_result *d_result, void *stream_)
 {
-    settle(ctx);
     if (!ctx) return HJGPU_EINVAL;
     const hjgpu_output *out = take_async_output(ctx, nullptr);   // consumed by this call even if it fails below (see hjgpu_npj_async)
     if (!ctx->prepared) return fail(ctx, HJGPU_EINVAL, "hjgpu_phj_probe_prepartitioned_async: no prepared build side, or another entry point has used the workspace since");

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
     // (the multi-fill half of a _UNIQUE join runs behind the single-fill half on the same stream, with the same grid: wave w of
     // workgroup b goes on in the block that wave w of workgroup b left open, and leaves its cursor in the same slot - one
     // launch's worth of worker slots for close_gaps, not two)
-    if (hj_lane() == 0) wave_cursor[wave] = (DEDUP && a.ok) ? a.final_offsets[(u64)blockIdx.x * NW + wave] : HJ_NO_CURSOR;
+    // (device-planned groups - JoinArgs::resume - do the same from group to group: one block counter, one set of open blocks, one close_gaps)
+    if (hj_lane() == 0) wave_cursor[wave] = ((DEDUP || a.resume) && a.ok) ? a.final_offsets[(u64)blockIdx.x * NW + wave] : HJ_NO_CURSOR;
 
     u64 acc_n = 0, acc_k = 0, acc_o = 0, acc_i = 0;
     uint32_t empty = 0;

@@ -88,10 +88,14 @@ __device__ __forceinline__ void k6_store8(u64 *p, u64 v)
 // --------------------------------------------------------------------------
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void hist2_kernel(
-    const uint32_t *__restrict__ keys, Pass1Geom geom,
+    const uint32_t *__restrict__ keys, Pass1Geom geom_arg,
     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-    u64 *__restrict__ counts, uint32_t *__restrict__ range_counts, uint32_t *work_counter)
+    u64 *__restrict__ counts, uint32_t *__restrict__ range_counts, uint32_t *work_counter, const u64 *__restrict__ dyn)
 {
+    // a device-planned group (hjgpu_api.hip phj_grouped_device): where the relation starts inside `keys` and how many rows it has are
+    // known on the device only; the ranges per chunk and the tile stay those of the capacity the workspace was planned for
+    Pass1Geom geom = geom_arg;
+    if (dyn) { keys += dyn[0]; geom.n = dyn[1]; geom.part = (geom.n / geom.chunks) & ~(u64)15; }
     extern __shared__ uint32_t lds_hist[];          // [P] fused, then [F1] per-range
     const uint32_t P = F1 * F2;
     uint32_t *range_hist = lds_hist + P;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void hist2_kernel(
 
 int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
                     uint32_t f1, uint32_t F1, uint32_t f2, uint32_t F2,
-                    u64 *counts, uint32_t *range_counts, uint32_t *work_counter, int cus, hipStream_t stream, size_t min_lds)
+                    u64 *counts, uint32_t *range_counts, uint32_t *work_counter, int cus, hipStream_t stream, size_t min_lds, const u64 *dyn)
 {
     constexpr int BLOCK = 1024;
     const uint32_t P = F1 * F2;
@@ -272,7 +276,7 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
     if (gx > geom.ranges_per_chunk) gx = geom.ranges_per_chunk;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(hist2_kernel<BLOCK>, dim3(gx, geom.chunks), dim3(BLOCK), lds, stream, keys, geom,
-                       f1, F1, f2, F2, counts, range_counts, work_counter);
+                       f1, F1, f2, F2, counts, range_counts, work_counter, dyn);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
@@ -514,7 +518,10 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
     const u64 *__restrict__ cnt = a.counts[r] + (u64)c * P;
     u64 *off2 = a.off2[r] + (u64)c * P;
     u64 *end2 = a.end2[r] + (u64)c * P;
-    const u64 base = a.regular[r] ? a.chunk_part[r] * c : a.chunk_beg[r][c];
+    // (a device-planned group: the relation's rows are known on the device only; its chunks are regular)
+    const u64 n_r = a.dyn[r] ? a.dyn[r][1] : a.n[r];
+    const u64 part_r = a.dyn[r] ? ((n_r / C) & ~(u64)15) : a.chunk_part[r];
+    const u64 base = a.regular[r] ? part_r * c : a.chunk_beg[r][c];
     if (!PAD) {
         // dense final layout: partition q occupies [off2[q], off2[q + 1])
         plan_scan(P, [&](uint32_t i) { return cnt[i]; }, off2, base, scratch,
@@ -599,8 +606,8 @@ __global__ __launch_bounds__(PLAN_BLOCK) void plan_offsets_kernel(PlanArgs a)
     }
     if (threadIdx.x == 0) {
         hj_store(&a.seg1[r][c], base);
-        if (c == C - 1) { hj_store(&a.seg1[r][C], a.n[r]); hj_store(&a.off1[r][(u64)C * a.F1], a.n[r]); }
-        if (PAD && a.p_major && c == 0) hj_store(&a.seg2[r][a.F1], a.n[r]);
+        if (c == C - 1) { hj_store(&a.seg1[r][C], n_r); hj_store(&a.off1[r][(u64)C * a.F1], n_r); }
+        if (PAD && a.p_major && c == 0) hj_store(&a.seg2[r][a.F1], n_r);
     }
 }
 
@@ -795,6 +802,39 @@ int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 
+// Grouped plans on the device (hj_internal.hpp: hj_launch_group_desc): one thread per group.
+__global__ __launch_bounds__(256) void group_desc_kernel(const u64 *__restrict__ roff, const u64 *__restrict__ soff, uint32_t G, uint32_t bins,
+                                                         u64 cap_r, u64 cap_s, u64 *__restrict__ desc, uint32_t *skew)
+{
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const u64 rb = roff[(u64)g * bins], re = roff[(u64)(g + 1) * bins];
+    const u64 sb = soff[(u64)g * bins], se = soff[(u64)(g + 1) * bins];
+    u64 rn = re - rb, sn = se - sb;
+    if (rn > cap_r || sn > cap_s) { atomicOr(skew, 1u); rn = 0; sn = 0; }       // beyond what the workspace was planned for: skipped, the join flagged
+    if (rn == 0 || sn == 0) { rn = 0; sn = 0; }                                 // nothing can match
+    hj_store(&desc[4 * (u64)g + 0], rb + hj_group_shift(rb, g)); hj_store(&desc[4 * (u64)g + 1], rn);
+    hj_store(&desc[4 * (u64)g + 2], sb + hj_group_shift(sb, g)); hj_store(&desc[4 * (u64)g + 3], sn);
+}
+
+int hj_launch_group_desc(const u64 *roff, const u64 *soff, uint32_t G, uint32_t bins, u64 cap_r, u64 cap_s, u64 *desc, uint32_t *skew, hipStream_t stream)
+{
+    if (!G || !bins) return HJGPU_EINVAL;
+    hipLaunchKernelGGL(group_desc_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, roff, soff, G, bins, cap_r, cap_s, desc, skew);
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
+__global__ void group_result_kernel(const u64 *__restrict__ state, const uint32_t *__restrict__ skew, u64 *__restrict__ d_result)
+{
+    if (threadIdx.x < 4) hj_store(&d_result[threadIdx.x], *skew ? ~(u64)0 : state[threadIdx.x]);
+}
+
+int hj_launch_group_result(const hjgpu_result *state, const uint32_t *skew, hjgpu_result *d_result, hipStream_t stream)
+{
+    hipLaunchKernelGGL(group_result_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const u64 *>(state), skew, reinterpret_cast<u64 *>(d_result));
+    return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
+}
+
 // Plain exclusive scan of n (<= 2^20) uint64 counters: hjgpu_partition's offsets.
 __global__ __launch_bounds__(PLAN_BLOCK) void exscan_kernel(const u64 *__restrict__ in,
                                                             u64 *__restrict__ out, uint32_t n)
@@ -881,9 +921,13 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
     uint32_t *heavy = wsum + NW + 6;                                // [HJ_MAX_HEAVY] partitions whose run is longer than one unit
 
     const int tid = threadIdx.x;
+    // pass 1 of a device-planned group (ScatterArgs::dyn): first row and rows of the input come from device memory (uniform: scalar loads)
+    Pass1Geom geom = a.geom;
+    u64 in_row0 = 0;
+    if (RANGED && !IN_PACKED && a.dyn) { in_row0 = a.dyn[0]; geom.n = a.dyn[1]; geom.part = (geom.n / geom.chunks) & ~(u64)15; }
     // IN_PACKED inputs are workspace arrays (in_align == 0): tuple g lives in uint4 g/2
-    const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.kin - a.in_align);
-    const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.vin - a.in_align);
+    const uint4 *__restrict__ k4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.kin + in_row0 - a.in_align);
+    const uint4 *__restrict__ v4 = reinterpret_cast<const uint4 *>(IN_PACKED ? a.kin : a.vin + in_row0 - a.in_align);
     const uint32_t factor = a.factor;
     const uint32_t bpt = (F + BLOCK - 1) / BLOCK;                   // bins per thread in the scan
     u64 mycur[BPT];                                                 // RANGED: cursors of my bins
@@ -954,16 +998,16 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(ScatterArgs a)
         t.gb = t.ge = t.g0 = t.cursor_row = 0;
         if (exhausted) return t;
         if (RANGED) {
-            const uint32_t Rc = a.geom.ranges_per_chunk;
-            const uint32_t nranges = a.range_count ? a.range_count : Rc * a.geom.chunks;
+            const uint32_t Rc = geom.ranges_per_chunk;
+            const uint32_t nranges = a.range_count ? a.range_count : Rc * geom.chunks;
             if (!r_open || rt >= rt_end) {
                 r_cur = take_ticket();
                 if (r_cur >= nranges) { exhausted = true; return t; }
                 r_cur += a.range_begin;
                 const uint32_t c = r_cur / Rc, j = r_cur - c * Rc;
-                const u64 cb = a.geom.beg(c), ce = a.geom.beg(c + 1);
-                r_gb = a.geom.align + cb; r_ge = a.geom.align + ce;
-                const u64 tiles = hj_tiles_of(cb, ce, a.geom.align, TILE);
+                const u64 cb = geom.beg(c), ce = geom.beg(c + 1);
+                r_gb = geom.align + cb; r_ge = geom.align + ce;
+                const u64 tiles = hj_tiles_of(cb, ce, geom.align, TILE);
                 rt = tiles * j / Rc; rt_end = tiles * (j + 1) / Rc;
                 r_open = true;
                 t.new_range = true;
@@ -1503,7 +1547,14 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
     if (is("merged_plan")) return parse_flag(value, &t->merged_plan);
     if (is("piece_interleave")) return parse_flag(value, &t->piece_interleave);
     if (is("group_always")) return parse_flag(value, &t->group_always);
-    if (is("group_async")) return parse_flag(value, &t->group_async);
+    if (is("group_device")) return parse_flag(value, &t->group_device);
+    if (is("group_slack")) {
+        char *end = nullptr;
+        const long x = strtol(value, &end, 10);
+        if (end == value || *end || x < 0 || x > 1000) return false;
+        t->group_slack = (int)x;
+        return true;
+    }
     if (is("placement_log")) return parse_flag(value, &t->placement_log);
     if (is("audit")) return parse_flag(value, &t->audit);
     if (is("solo")) return parse_flag(value, &t->solo);
@@ -1584,7 +1635,7 @@ bool hj_tuning_set(HjTuning *t, const char *name, const char *value)
 void hj_tuning_from_env(HjTuning *t)
 {
     static const char *const names[] = {"dense2", "npj_refhash", "no_broadcast", "force_chained", "scatter_prof",
-                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "group_async", "host_batch", "placement", "placement_ms", "placement_log", "audit", "solo", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
+                                        "unique", "merged_plan", "piece_interleave", "range_tiles", "batch_tuples", "group_from", "group_inner", "group_always", "group_device", "group_slack", "host_batch", "placement", "placement_ms", "placement_log", "audit", "solo", "hist_min_lds", "reserve_cus", "join_cfg", "scatter_cfg", "scatter2_cfg"};
     for (const char *n : names) {
         char env[64] = "HJGPU_";
         size_t at = strlen(env);

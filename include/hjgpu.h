@@ -166,7 +166,7 @@ int  hjgpu_get_device_info(hjgpu_ctx *ctx, hjgpu_device_info *info);
  * including the operator-level hjgpu_npj_probe), "force_chained", "no_broadcast", "dense2", "npj_refhash",
  * "scatter_prof", "merged_plan", "piece_interleave" (0 / 1); "range_tiles" (n); "join_cfg" ("block,log2slots,batch"); "scatter_cfg" /
  * "scatter2_cfg" ("block,vectors[,carry]"); "placement" (candidate allocations for the probe side's pass-1
- * twin, 1..16; "placement_ms": the search's wall-clock budget, default 500, 0 = none; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples), "group_always" and "group_async" (0 / 1): the
+ * twin, 1..16; "placement_ms": the search's wall-clock budget, default 500, 0 = none; "placement_log" 1: every candidate's fill time on stderr); "batch_tuples" (n, 0 = off); "group_from" / "group_inner" (tuples), "group_always" and "group_device" (0 / 1), "group_slack" (per cent): the
  * grouped plans of hjgpu_phj / hjgpu_cpra (below); "solo" (0 / 1, default 0: the caller promises that nothing else runs on the device beside this context's BLOCKING joins - one process,
  * one stream, as the reference's programs: the joins' partial-line and row stores then stay plain, 4 % faster; without the
  * promise every store that could sit dirty in an L2 is non-temporal, because plain stores ARE lost beside other queues' kernel
@@ -267,22 +267,19 @@ int  hjgpu_npj(hjgpu_ctx *ctx,
  * or two passes up to HJGPU_MAX_PARTS partitions; a build side beyond their reach (~228 M tuples) whose probe side is
  * large enough for a further pass to pay is joined by a GROUPED plan - pass 0 splits both relations into key-disjoint
  * groups of about "group_inner" (64 M) build tuples, each joined by the two-pass plan, aggregates and rows added up
- * (hjgpu_stats.groups / ms_scatter0).  Somebody has to wait for pass 0 and for every group (their sizes are known on the
- * device only): in the blocking forms the caller; in the *_async forms (round 5) a worker thread of the context, on a stream
- * of its own - the call returns at once, the CALLER's stream goes on when the worker's last command has raised a counter in
- * signal memory (hipStreamWaitValue64), and any later use of the context joins the worker first; a failure there is what
- * hjgpu_get_async_status returns (option "group_async" = 0: the call waits itself, as in round 4).  While the caller's stream
- * waits in hardware, two things must not happen, and the library sees to both: the worker never frees device memory (hipFree
- * waits for every stream of the device; the call reserves the usual workspace itself, what the worker still grows is freed when
- * the worker has been joined), and the worker's stream is of another priority class than the caller's (hardware queues are
- * pooled per class and shared inside one: the worker's commands must not queue behind the waiting stream).  The CALLER must not
- * make the worker wait either: nothing that the join's inputs depend on may be enqueued behind the call on the same stream.
- * Beside such a join, default-priority streams that share the waiting stream's hardware queue (a process with more than 4 of them)
- * are held until it ends, hipFree from any thread returns only then, and hipStreamQuery of other streams reports "not ready"
- * until then although their work has run (tools/ubench_wait_value.hip, profiles/r05_wait_value.txt): callers with many streams
- * or pollers set "group_async" = 0.
- * hjgpu_phj_overlapped_async with a grouped plan waits for the build side first and lets the calling thread wait for the groups
- * (it is hjgpu_phj_multi's local join: a rank's share of any size is grouped there).  Explicit fan-outs in
+ * (hjgpu_stats.groups / ms_scatter0).  The groups are planned ON THE DEVICE (round 6; option "group_device", default 1): pass 0 leaves
+ * the groups' offsets in device memory, one small kernel turns them into a descriptor per group (first row and rows of its build and probe
+ * columns), and every kernel of a group's join reads its geometry from there - the whole plan is ONE stream-ordered sequence on the
+ * caller's stream, exactly like an ungrouped join (phj.cpp:1791-1863 plans and runs its passes inside run_hj).  The *_async forms
+ * therefore return at once for grouped plans too, hold no stream in hardware and use no thread of their own.  The workspace of a
+ * group's join is planned for up to (1 + "group_slack" / 100) x the mean group (default 50); a group beyond that - heavy duplicates -
+ * is SKIPPED and flagged on the device, and the join is then not valid: an *_async call's d_result holds all ones (never a plausible
+ * partial count), and the join is done again in the host-planned form (the calling thread waits for pass 0 and plans every group's
+ * join from its size) at the caller's next blocking touch point - inside the call for the blocking forms, in hjgpu_get_async_status for
+ * the enqueue-only ones (which must therefore be called before d_result or the rows of a grouped plan are trusted; it costs a stream
+ * synchronisation when nothing was skipped).  Option "group_device" = 0: always the host-planned form (the *_async forms then wait
+ * inside the call); option "audit" implies it.  hjgpu_phj_overlapped_async (the local join of hjgpu_phj_multi / hjgpu_cpra_multi) is
+ * always planned on the device; the rank's thread asks for the status after a wait with the communicator's deadline.  Explicit fan-outs in
  * params are never grouped; option "group_from" = 0 turns the plan off. */
 int  hjgpu_phj(hjgpu_ctx *ctx,
                const uint32_t *d_inner_keys, const uint32_t *d_inner_vals, size_t inner,

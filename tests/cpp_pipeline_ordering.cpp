@@ -15,9 +15,9 @@
 //     CPU code with the same contracts - partitions are really made, pieces really checked (a tuple in a piece of a rank
 //     that does not own its partition, a sender's count that differs from what arrived: an ERROR), joins really joined -
 //     so the result of every scenario is compared with a map-based join of the inputs;
-//   * fault injection: --drop-wait k ignores the k-th hipStreamWaitEvent of the run (the checker must then report).
+//   * fault injection: --drop-wait s<stream>#<n> ignores the n-th hipStreamWaitEvent ON THAT STREAM (the checker must then report).
 // usage: cpp_pipeline_ordering <algo cpra|cpra-host|phj-host|npj-host|phj|npj> <world> <slices> [--rows] [--no-fused] [--no-in-place] [--two-level] [--grouped]
-//                              [--drop-wait k] [--list-waits] [--inner n] [--outer n] [--seed s] [--steps n]
+//                              [--drop-wait s<stream>#<n>] [--list-waits] [--inner n] [--outer n] [--seed s] [--steps n]
 // prints one line: "ok|FAIL waits=<hipStreamWaitEvent calls> ops=<n> violations=<n> ..."; exit status 0 = result right and no violation.
 #include <algorithm>
 #include <map>
@@ -49,7 +49,11 @@ struct Op { int stream; uint32_t index; std::string what; };
 std::vector<Op> ops;
 int violations = 0, errors = 0;
 std::vector<std::string> messages;
-long wait_calls = 0, drop_wait = -1;
+long wait_calls = 0;
+// a wait is named by the stream that waits and its ordinal among THAT stream's waits ("s5#3"): every stream is fed by one host thread at a time
+// (each_rank: one thread per rank), so the name means the same wait in every run - a global counter over all ranks' threads did not
+// (round 5: the wait dropped by --drop-wait k was not always wait k of the --list-waits run)
+int drop_stream = -1; long drop_ordinal = -1;
 bool list_waits = false;
 std::vector<std::string> wait_list;          // --list-waits: every hipStreamWaitEvent: which stream, the stream the event was recorded on, did it add an edge
 
@@ -83,6 +87,7 @@ void host_learned() { merge(join_clock, host()); }          // (under mu) a work
 struct MockStream {
     int id;
     uint32_t issued = 0;                 // operations enqueued so far
+    long waits = 0;                      // hipStreamWaitEvent calls on this stream so far
     rec::Clock clock;                    // what the NEXT operation of this stream is ordered after
     struct Pending { void *dst; std::vector<unsigned char> data; };
     std::vector<Pending> to_host;        // copies to host memory, delivered when the host waits for the stream
@@ -204,16 +209,18 @@ hipError_t hipStreamQuery(hipStream_t s) { LOCK; rec::host_waited(rec::of(s)); r
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
     LOCK;
-    const long k = rec::wait_calls++;
+    rec::wait_calls++;
+    MockStream *ws = rec::of(s);
+    const long k = ws->waits++;
     if (rec::list_waits) {
         // an edge is NEW when the waiting stream (with what the enqueuing host thread has waited for) does not know the event's clock yet
         rec::Clock known = rec::of(s)->clock;
         rec::merge(known, rec::host());
         bool fresh = false;
         for (size_t i = 0; e->recorded && i < e->clock.size(); ++i) if (e->clock[i] > (i < known.size() ? known[i] : 0u)) fresh = true;
-        rec::wait_list.push_back(std::to_string(k) + ":s" + std::to_string(rec::of(s)->id) + "<-s" + std::to_string(e->source) + (fresh ? ":new" : ":known"));
+        rec::wait_list.push_back("s" + std::to_string(ws->id) + "#" + std::to_string(k) + ":s" + std::to_string(ws->id) + "<-s" + std::to_string(e->source) + (fresh ? ":new" : ":known"));
     }
-    if (k == rec::drop_wait) return hipSuccess;                   // fault injection: this wait never happened
+    if (ws->id == rec::drop_stream && k == rec::drop_ordinal) return hipSuccess;       // fault injection: this wait never happened
     if (e->recorded) rec::merge(rec::of(s)->clock, e->clock);
     return hipSuccess;
 }
@@ -327,6 +334,7 @@ const char *hjgpu_status_string(int) { return "status"; }
 int hjgpu_set_option(hjgpu_ctx *, const char *, const char *) { return HJGPU_OK; }
 int hjgpu_get_stats(hjgpu_ctx *, hjgpu_stats *s) { memset(s, 0, sizeof(*s)); return HJGPU_OK; }
 int hjgpu_audit_read(hjgpu_ctx *, uint64_t *next, uint64_t, uint32_t, uint64_t *, void *) { if (next) *next = 0; return HJGPU_OK; }
+int hjgpu_audit_recheck(hjgpu_ctx *, uint64_t *, size_t, size_t *checks) { if (checks) *checks = 0; return HJGPU_OK; }
 int hjgpu_malloc_placed(hjgpu_ctx *, void **p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess ? HJGPU_OK : HJGPU_ENOMEM; }
 int hjgpu_host_alloc(hjgpu_ctx *, void **p, size_t bytes) { return hipHostMalloc(p, bytes, 0) == hipSuccess ? HJGPU_OK : HJGPU_ENOMEM; }
 int hjgpu_set_async_output(hjgpu_ctx *c, const hjgpu_output *o) { LOCK; c->out = *o; c->has_out = true; return HJGPU_OK; }
@@ -393,6 +401,8 @@ int hjgpu_partition_async(hjgpu_ctx *c, const uint32_t *k, const uint32_t *v, si
 }
 bool mock_grouped = false;                   // --grouped: the planning rule says "grouped" (the ranks then take CPRA's grouped road)
 int hjgpu_grouped_plan(hjgpu_ctx *, size_t, size_t, const hjgpu_phj_params *, uint32_t *groups) { *groups = mock_grouped ? 4 : 0; return HJGPU_OK; }
+// (a device-planned grouped local join is enqueue-only; the orchestration waits for its stream - with its deadline - and asks for the status)
+int hjgpu_get_async_status(hjgpu_ctx *, void *s) { hipStreamSynchronize((hipStream_t)s); return HJGPU_OK; }
 int hjgpu_prepartitioned_plan(hjgpu_ctx *, size_t, uint32_t, const hjgpu_phj_params *prm, uint32_t *F2, uint32_t *f2)
 {
     *F2 = (prm && prm->fanout2) ? prm->fanout2 : 5;
@@ -555,7 +565,7 @@ int main(int argc, char **argv)
         else if (a == "--no-in-place") in_place = false;
         else if (a == "--two-level") two_level = true;
         else if (a == "--grouped") mock_grouped = true;
-        else if (a == "--drop-wait" && i + 1 < argc) rec::drop_wait = atol(argv[++i]);
+        else if (a == "--drop-wait" && i + 1 < argc) { if (sscanf(argv[++i], "s%d#%ld", &rec::drop_stream, &rec::drop_ordinal) != 2) { fprintf(stderr, "--drop-wait s<stream>#<ordinal>\n"); return 2; } }
         else if (a == "--list-waits") rec::list_waits = true;
         else if (a == "--inner" && i + 1 < argc) inner = (size_t)atol(argv[++i]);
         else if (a == "--outer" && i + 1 < argc) outer = (size_t)atol(argv[++i]);

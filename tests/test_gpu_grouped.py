@@ -155,9 +155,9 @@ def test_grouped_plan_at_a_size_it_is_chosen_for_by_default(hj):
 
 @pytest.mark.parametrize("algo", ["phj", "cpra"])
 def test_grouped_plan_through_the_enqueue_only_form_returns_at_once(grouped, algo):
-    """hjgpu_phj_async / hjgpu_cpra_async with a grouped plan: the call returns before the join has run (the context's worker
-    thread waits for the groups' sizes; the caller's stream waits for the worker's last command), the result is in d_result once
-    the CALLER's stream is idle, calls queue up back to back, and the blocking form gives the same aggregates."""
+    """hjgpu_phj_async / hjgpu_cpra_async with a grouped plan: the groups are planned ON THE DEVICE, so the call is enqueue-only like any
+    other join - it returns before the join has run, the result is in d_result once the caller's stream is idle, calls queue up back to
+    back - and the blocking form and the host-planned form (option group_device = 0) give the same aggregates."""
     import time
     inner, outer = 20_000_000, 100_000_000
     fi, fo = 0x2545F491, 0x9E3779B1
@@ -172,32 +172,91 @@ def test_grouped_plan_through_the_enqueue_only_form_returns_at_once(grouped, alg
     getattr(grouped, algo)(ik, iv, inner, ok, ov, outer)
     t_blocking = time.perf_counter() - t0
     d = [grouped.column(4, np.uint64) for _ in range(2)]
-    # (the context's first such call makes the worker's stream - a hardware queue of its own priority class - and the signal memory)
     getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[0])
     grouped.synchronize()
-    grouped.get_async_status()
+    assert grouped.get_async_status() is None
+    # the stream (the legacy one: torch's default stream too) is given ~40 ms of other work first: a call that waited for the device
+    # would take that long, and the stream is still busy when an enqueue-only call returns
+    import torch
+    junk = torch.zeros(1 << 29, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(60):
+        junk.add_(1)
     t0 = time.perf_counter()
     getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[0])
     t_call = time.perf_counter() - t0
-    getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[1])        # queues behind the first (joins its worker)
+    busy = not torch.cuda.default_stream().query()
+    getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[1])        # queues behind the first
     grouped.synchronize()
     grouped.get_async_status()
     for r in d:
         assert tuple(int(x) for x in r.download()) == want
-    assert grouped.stats()["groups"] == 8
-    assert t_call < 0.5 * t_blocking, (t_call, t_blocking)
-    grouped.set_option("group_async", "0")                # round 4's behaviour: the call itself waits
+    st = grouped.stats()
+    assert st["groups"] == 8 and st["ms_scatter0"] > 0 and st["ms_join"] > 0 and st["ms_total"] >= st["ms_scatter0"] + st["ms_join"]
+    assert busy and t_call < 0.02, (busy, t_call, t_blocking)
+    del junk
+    grouped.set_option("group_device", "0")               # the host-planned form: the call itself waits for pass 0 and for every group
     getattr(grouped, algo + "_async")(ik, iv, inner, ok, ov, outer, None, d[0])
     grouped.synchronize()
     assert tuple(int(x) for x in d[0].download()) == want
+    assert getattr(grouped, algo)(ik, iv, inner, ok, ov, outer) == want and grouped.stats()["groups"] == 8
+    grouped.set_option("group_device", "1")
     _free(ik, iv, ok, ov, *d)
 
 
+def test_a_group_beyond_the_planned_workspace_marks_the_result_and_is_joined_again(hj, oracle):
+    """Device-planned groups have workspace for (1 + group_slack / 100) x the mean group.  With few distinct build keys the largest group is far
+    above that: the enqueue-only join skips it, d_result then holds all ones (never a plausible partial count), and hjgpu_get_async_status
+    does the join again host-planned and leaves the right aggregates (and rows) where the caller expects them; the blocking form does the
+    same inside the call."""
+    rng = np.random.default_rng(11)
+    distinct = rng.choice(np.arange(1, 1 << 31, dtype=np.uint32), size=24, replace=False)
+    ik = np.repeat(distinct, 400_000)                     # 24 keys in 12 groups of 800 000 rows on average: a group with three of them has 1.2 M
+    iv = rng.integers(0, 1 << 32, size=len(ik), dtype=np.uint32)
+    ok = rng.choice(distinct, size=3000)
+    ov = rng.integers(0, 1 << 32, size=len(ok), dtype=np.uint32)
+    # (every probe row matches 400 000 build rows: the aggregates in closed form)
+    per_key_iv = {int(k): int(iv[i * 400_000:(i + 1) * 400_000].sum(dtype=np.uint64)) for i, k in enumerate(distinct)}
+    M = (1 << 64) - 1
+    def closed_form(keys, vals):
+        return (len(keys) * 400_000, int(keys.astype(np.uint64).sum()) * 400_000 & M, int(vals.astype(np.uint64).sum()) * 400_000 & M,
+                sum(per_key_iv[int(k)] for k in keys) & M)
+    want = closed_form(ok, ov)
+    ctx = H.HjGpu()
+    try:
+        for n, v in (("group_from", "1000"), ("group_always", "1"), ("group_inner", str(len(ik) // 12)), ("group_slack", "10")):
+            ctx.set_option(n, v)
+        rk, rv, sk, sv = _cols(ctx, ik, iv, ok, ov)
+        d = ctx.column(4, np.uint64)
+        ctx.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, d)
+        ctx.synchronize()
+        assert tuple(int(x) for x in d.download()) == ((1 << 64) - 1,) * 4          # a group was skipped: the result is MARKED, not partial
+        ctx.get_async_status()                                                       # ... and joined again, host-planned
+        assert tuple(int(x) for x in d.download()) == want
+        assert ctx.phj(rk, rv, len(ik), sk, sv, len(ok)) == want                     # the blocking form falls back inside the call
+        assert ctx.cpra(rk, rv, len(ik), sk, sv, len(ok)) == want
+        # rows: the marked join's rows are not valid; after the status call they are the join's
+        ok2, ov2 = ok[:150].copy(), ov[:150].copy()
+        want2 = closed_form(ok2, ov2)
+        sk2, sv2 = ctx.column(ok2), ctx.column(ov2)
+        cap = ctx.output_capacity(1, len(ok2), want2[0], 4096)
+        cols = [ctx.column(cap) for _ in range(3)]
+        ctx.set_async_output((cols[0], cols[1], cols[2], cap, 4096))
+        ctx.phj_async(rk, rv, len(ik), sk2, sv2, len(ok2), None, d)
+        ctx.get_async_status()
+        assert tuple(int(x) for x in d.download()) == want2
+        rows = [c.download()[:want2[0]] for c in cols]
+        assert tuple(int(r.sum(dtype=np.uint64)) & M for r in rows) == want2[1:]
+        _free(sk2, sv2)
+        _free(rk, rv, sk, sv, d, *cols)
+    finally:
+        ctx.close()
+
+
 def test_first_grouped_join_of_a_context_through_the_enqueue_only_form(hj, oracle):
-    """The worker thread of an asynchronous grouped plan grows the workspace while the caller's stream waits for it in hardware:
-    it must not free anything then (hipFree waits for every stream of the device - for ever).  A fresh context, no blocking call
-    before; few distinct build keys, so that the largest group is far above the mean and the worker has to grow what the call
-    reserved; then a larger join on the same context (grows in the caller's thread, after the worker was joined)."""
+    """A fresh context whose first join is an enqueue-only grouped one (the workspace grows inside the call), with few distinct build keys,
+    so that the largest group is far above the mean - beyond the device plan's workspace, i.e. hjgpu_get_async_status joins again
+    host-planned; then a larger join on the same context (everything grows again)."""
     rng = np.random.default_rng(5)
     for scale in (1, 6):
         ctx = H.HjGpu()
@@ -225,10 +284,9 @@ def test_first_grouped_join_of_a_context_through_the_enqueue_only_form(hj, oracl
 
 
 def test_asynchronous_grouped_joins_in_a_process_with_more_streams_than_hardware_queues(hj, oracle):
-    """Streams of one priority class share hardware queues once there are more of them than queues (4 per class): a caller's
-    stream that waits in hardware for the context's worker must not have the worker's commands queued behind it.  The worker's
-    stream is of another class than the caller's; here 24 busy streams of the default class exist before the joins, and the
-    joins are enqueued on several of them in turn (and on the legacy stream)."""
+    """A grouped join is one stream-ordered sequence on the caller's stream (planned on the device: no worker thread, no stream held in
+    hardware): in a process with far more streams than hardware queues - 24 busy ones here - joins enqueued on several of them in turn
+    (and on the legacy stream) neither stall each other nor the other streams."""
     import torch
     dev = torch.device("cuda:0")
     streams = [torch.cuda.Stream(device=dev) for _ in range(24)]

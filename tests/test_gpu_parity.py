@@ -514,6 +514,31 @@ def test_host_programs_end_to_end(hj, oracle, tmp_path):
         assert ("chunks requested" in p.stderr) == note, p.stderr
 
 
+def test_configs0_npj_64_1000000_16000000_on_written_files(hj, oracle, tmp_path):
+    """BASELINE.json configs[0], the reference's own invocation (npj.cpp:929-947): `./write` generates the relations (1 M probe
+    tuples, 16 M build tuples = 16 copies of every key), `./npj 64 1000000 16000000` joins the files on the GPU; count and the three
+    checksums equal the oracle's restatement of run() (npj.cpp:769-927, load 0.90) on the same files and the join's definition."""
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.abspath(H.__file__)), "lib")
+    subprocess.check_call([os.path.join(lib, "write"), "1", "1000000", "16000000"], cwd=tmp_path, env=dict(os.environ, HJ_SEED="1"),
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ik, iv, ok, ov = [np.fromfile(tmp_path / ("%s_%d.txt" % (p, n)), dtype="<u4")
+                      for p, n in (("ik", 16000000), ("iv", 16000000), ("ok", 1000000), ("ov", 1000000))]
+    want = oracle.npj(ik, iv, ok, ov, threads=4, load=0.90)
+    assert want == oracle.join_definition(ik, iv, ok, ov) and want[0] == 16_000_000
+    p = subprocess.run([os.path.join(lib, "npj"), "64", "1000000", "16000000"], cwd=tmp_path, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert ("join_tuples=%d sum_keys=%d sum_outer_vals=%d sum_inner_vals=%d" % want) in p.stderr, p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1 and float(lines[0]) > 0              # the reference prints the seconds of the join (npj.cpp:1114)
+    # ... and the same relations through the C-ABI on resident columns, rows materialised: 16 rows per probe tuple
+    rk, rv, sk, sv = (hj.column(c) for c in (ik, iv, ok, ov))
+    assert hj.npj(rk, rv, len(ik), sk, sv, len(ok), H.NpjParams(load=0.90)) == want
+    assert hj.phj(rk, rv, len(ik), sk, sv, len(ok)) == want and hj.cpra(rk, rv, len(ik), sk, sv, len(ok)) == want
+    for c in (rk, rv, sk, sv):
+        c.free()
+
+
 def test_host_programs_on_several_ranks(hj, oracle, tmp_path):
     """The multi-GPU path of the C++ hosts (every visible GPU takes a share: hjgpu_comm_create_local +
     hjgpu_join_host_multi), driven here as 3 loopback ranks on the one GPU of the test box and - through RCCL

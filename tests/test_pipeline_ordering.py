@@ -8,7 +8,7 @@ hipStreamWaitEvent or a host-side wait, and this test checks - without a GPU, at
   (stream order, an event edge, or a wait of the enqueuing host thread): 0 violations;
 * the joins come out right (the mock really partitions, exchanges and joins: a tuple that reaches a rank that does not own
   its partition, a sender's histogram that differs from what arrived, a wrong aggregate or row are errors);
-* the check has teeth: with ANY ONE hipStreamWaitEvent that adds an ordering edge removed (--drop-wait k), it reports.
+* the check has teeth: with ANY ONE hipStreamWaitEvent that adds an ordering edge removed (--drop-wait s<stream>#<n>), it reports.
 
 Built with -fsanitize=address,undefined.  This replaces the test-side twin of round 1's orchestration as the CPU evidence
 for SURVEY section 8 row (e) (tests/test_distributed_gloo.py keeps covering bench.py's gloo control plane)."""
@@ -99,7 +99,7 @@ def test_removing_any_wait_that_orders_something_is_reported(recorder, scenario)
         k, edge, kind = w.split(":")
         dst, src = re.match(r"s(-?\d+)<-s(-?\d+)", edge).groups()
         if kind == "new" and rank_of(dst) == rank_of(src):
-            fresh.append(int(k))
+            fresh.append(k)                      # "s<stream>#<ordinal among that stream's waits>": the same wait in every run
     assert len(fresh) >= 4, waits
     undetected = []
     for k in fresh:
