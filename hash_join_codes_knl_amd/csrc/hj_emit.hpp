@@ -89,5 +89,60 @@ struct EmitterT {
             oiv[pos] = inner_val;
         }
     }
+
+    // FOUR rows per lane at once: the lanes that call hold the four matches of one probe vector (one match per probe tuple: the common
+    // case).  Every lane's rows are consecutive, so a column leaves the lane as ONE 16-byte store and the wave as one contiguous piece
+    // of 64 x 16 bytes: whole 128-byte lines wherever the cursor stands on one.  Round 5 measured the 4-byte non-temporal row stores
+    // at +14 % (4.83 against 4.24 ms per 10^9 rows) while K6's whole lines leave FASTER non-temporal than plain.
+    __device__ __forceinline__ void emit4(const uint32_t (&key)[4], const uint32_t (&outer_val)[4], const uint32_t (&inner_val)[4])
+    {
+        if (!ok) return;
+        const u64 m = __ballot(1);
+        const uint32_t n = 4u * (uint32_t)__popcll(m);
+        const uint32_t rank = 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const u64 o = *cursor;
+        const u64 room = (o == HJ_NO_CURSOR) ? 0 : ((o & ~(block_size - 1)) + block_size - o);
+        u64 pos0, pos3, next, base = 0;
+        if (n < room) {
+            pos0 = o + rank; pos3 = pos0 + 3;
+            next = o + n;
+        } else {
+            u64 nb = 0;
+            if (rank == 0) nb = atomicAdd(block_counter, 1ull);
+            nb = ((u64)__builtin_amdgcn_readfirstlane((uint32_t)(nb >> 32)) << 32) | (u64)__builtin_amdgcn_readfirstlane((uint32_t)nb);
+            if (nb >= block_limit) {
+                if (rank == 0) atomicOr(overflow, 1u);
+                nb = block_limit - 1;
+            }
+            base = nb * block_size;
+            pos0 = (rank < room) ? (o + rank) : (base + (rank - room));
+            pos3 = (rank + 3 < room) ? (o + rank + 3) : (base + (rank + 3 - room));
+            next = base + (n - room);
+        }
+        if (rank == 0) *cursor = next;
+        if (pos3 == pos0 + 3) {
+            typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+            const v4u_t k4 = {key[0], key[1], key[2], key[3]}, o4 = {outer_val[0], outer_val[1], outer_val[2], outer_val[3]},
+                        i4 = {inner_val[0], inner_val[1], inner_val[2], inner_val[3]};
+            if constexpr (NT && HJ_ROW_STORE) {
+                __builtin_nontemporal_store(k4, reinterpret_cast<v4u_t *>(&ok[pos0]));
+                __builtin_nontemporal_store(o4, reinterpret_cast<v4u_t *>(&oov[pos0]));
+                __builtin_nontemporal_store(i4, reinterpret_cast<v4u_t *>(&oiv[pos0]));
+            } else {
+                *reinterpret_cast<v4u_t *>(&ok[pos0]) = k4;
+                *reinterpret_cast<v4u_t *>(&oov[pos0]) = o4;
+                *reinterpret_cast<v4u_t *>(&oiv[pos0]) = i4;
+            }
+        } else {
+            // the lane's four rows straddle the end of the block: row by row (rows [0, room - rank) in the old block)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u64 pos = (rank + i < room) ? (o + rank + i) : (base + (rank + i - room));
+                if constexpr (NT && HJ_ROW_STORE) {
+                    __builtin_nontemporal_store(key[i], &ok[pos]); __builtin_nontemporal_store(outer_val[i], &oov[pos]); __builtin_nontemporal_store(inner_val[i], &oiv[pos]);
+                } else { ok[pos] = key[i]; oov[pos] = outer_val[i]; oiv[pos] = inner_val[i]; }
+            }
+        }
+    }
 };
 typedef EmitterT<true> Emitter;     // NPJ: always non-temporal rows

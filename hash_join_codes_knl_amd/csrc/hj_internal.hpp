@@ -273,7 +273,8 @@ int hj_launch_hist2(const uint32_t *keys, const Pass1Geom &geom,
 // Grouped plans on the device: from pass 0's offsets (dense prefixes of the F0 = G * bins counters of both relations) to one descriptor per
 // group, desc[g] = {build first row, build rows, probe first row, probe rows} (first rows as pass 0 laid the groups out: hj_group_shift).
 // A group with an empty side gets no rows at all (nothing can match); one beyond cap_r / cap_s rows gets none either and raises *skew.
-int hj_launch_group_desc(const u64 *roff, const u64 *soff, uint32_t G, uint32_t bins, u64 cap_r, u64 cap_s, u64 *desc, uint32_t *skew, hipStream_t stream);
+int hj_launch_group_desc(const u64 *roff, const u64 *soff, uint32_t G, uint32_t bins, u64 cap_r, u64 cap_s, u64 n_r, u64 n_s, u64 *desc, uint32_t *skew,
+                         hipStream_t stream);
 // d_result of a device-planned grouped join: the aggregates, or all ones when a group was skipped (*skew != 0): never a plausible partial count
 int hj_launch_group_result(const hjgpu_result *state, const uint32_t *skew, hjgpu_result *d_result, hipStream_t stream);
 // own_count > 0 (chunks == 1): partitions [own_first, own_first + own_count) are laid out behind all others

@@ -1661,7 +1661,7 @@ static int phj_grouped_device(hjgpu_ctx *ctx, uint32_t G, uint32_t chunks,
     // the grouped join's state: cleared ONCE; every wave's output cursor "no block yet"
     HIPCHK(ctx, hj_zero_async(st, sizeof(DevState), stream));
     if (bs) HIPCHK(ctx, hj_fill_async(ctx->final_offsets.p, 0xFFFFFFFFu, (size_t)workers * sizeof(u64), stream));
-    CHK(hj_launch_group_desc(d_off, d_off + (l.F0 + 1), G, l.bins, (u64)cap_r, (u64)cap_s, d_desc, &st->group_skew, stream));
+    CHK(hj_launch_group_desc(d_off, d_off + (l.F0 + 1), G, l.bins, (u64)cap_r, (u64)cap_s, (u64)inner, (u64)outer, d_desc, &st->group_skew, stream));
     HIPCHK(ctx, hipEventRecord(ctx->grp_ev_pass0[1], stream));
     for (uint32_t g = 0; g < G; ++g) {
         const GroupRun run = {d_desc + 4 * (size_t)g};

@@ -229,9 +229,18 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t a1 = (key[j] * tf0) >> SHIFT;
+#if defined(HJ_JOIN_LIMIT_STUDY) && HJ_JOIN_LIMIT_STUDY == 1
+            // LIMIT STUDY, never the product (tools/build_variant.py join_one_slot -DHJ_JOIN_LIMIT_STUDY=1; results are WRONG): the second
+            // slot's multiply, address and LDS read do not exist - an upper bound on what ANY scheme that fetches a key's two slots with one
+            // LDS instruction and one address computation could save (round 5's review asked for ds_read2_b64; its two offsets are
+            // immediates of the instruction, the same for every lane, and a fixed distance between a key's slots is no cuckoo table)
+            t1[j] = tab64[a1];
+            t2[j] = t1[j] ^ ((u64)1 << 63);
+#else
             const uint32_t a2 = (a1 + (((key[j] * tf1) >> SHIFT) | 1u)) & MASK;
             t1[j] = tab64[a1];
             t2[j] = tab64[a2];
+#endif
         }
         u64 sk_ = 0, so_ = 0, si_ = 0;
         uint32_t n = 0;
@@ -246,13 +255,42 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
             so_ += (u64)val[j] * m;
             si_ += (h1 ? (uint32_t)(t1[j] >> 32) : 0u);
             si_ += (h2 ? (uint32_t)(t2[j] >> 32) : 0u);
+#if !defined(HJ_EMIT4) || !HJ_EMIT4
             if (a.ok) {
                 // one emit for "this key matched" (with unique build keys that is every lane of the wave:
                 // 64 rows, the cursor moves in whole lines), a second one only for a key found in BOTH slots
                 if (h1 | h2) em.emit(key[j], val[j], (uint32_t)((h1 ? t1[j] : t2[j]) >> 32));
                 if (h1 & h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
             }
+#endif
         }
+#if defined(HJ_EMIT4) && HJ_EMIT4
+        if (a.ok) {
+            // a vector whose four probe tuples matched exactly once each (the common case) leaves as ONE 16-byte store per column and
+            // lane (EmitterT::emit4); any other vector row by row as before
+            bool once[4], twice = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
+                const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]) && !(UNIQUE && h1);
+                once[j] = h1 != h2; twice = twice || (h1 && h2);
+            }
+            if (once[0] && once[1] && once[2] && once[3]) {
+                uint32_t iv4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) iv4[j] = (uint32_t)((((uint32_t)t1[j] == key[j]) ? t1[j] : t2[j]) >> 32);
+                em.emit4(key, val, iv4);
+            } else if (once[0] || once[1] || once[2] || once[3] || twice) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool h1 = valid[j] && ((uint32_t)t1[j] == key[j]);
+                    const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]) && !(UNIQUE && h1);
+                    if (h1 | h2) em.emit(key[j], val[j], (uint32_t)((h1 ? t1[j] : t2[j]) >> 32));
+                    if (h1 & h2) em.emit(key[j], val[j], (uint32_t)(t2[j] >> 32));
+                }
+            }
+        }
+#endif
         acc_n += n; acc_k += sk_; acc_o += so_; acc_i += si_;
         return hits;
     };

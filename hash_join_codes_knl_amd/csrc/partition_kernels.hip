@@ -804,23 +804,26 @@ int hj_launch_plan(const PlanArgs &a, hipStream_t stream)
 
 // Grouped plans on the device (hj_internal.hpp: hj_launch_group_desc): one thread per group.
 __global__ __launch_bounds__(256) void group_desc_kernel(const u64 *__restrict__ roff, const u64 *__restrict__ soff, uint32_t G, uint32_t bins,
-                                                         u64 cap_r, u64 cap_s, u64 *__restrict__ desc, uint32_t *skew)
+                                                         u64 cap_r, u64 cap_s, u64 n_r, u64 n_s, u64 *__restrict__ desc, uint32_t *skew)
 {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= G) return;
     const u64 rb = roff[(u64)g * bins], re = roff[(u64)(g + 1) * bins];
     const u64 sb = soff[(u64)g * bins], se = soff[(u64)(g + 1) * bins];
     u64 rn = re - rb, sn = se - sb;
-    if (rn > cap_r || sn > cap_s) { atomicOr(skew, 1u); rn = 0; sn = 0; }       // beyond what the workspace was planned for: skipped, the join flagged
+    // beyond what the workspace was planned for - or offsets that are no prefix of the relations' rows (a caller who overlaps joins of ONE
+    // context on several streams races on its workspace: never an address outside the columns): skipped, the join flagged
+    if (rn > cap_r || sn > cap_s || re < rb || se < sb || re > n_r || se > n_s) { atomicOr(skew, 1u); rn = 0; sn = 0; }
     if (rn == 0 || sn == 0) { rn = 0; sn = 0; }                                 // nothing can match
     hj_store(&desc[4 * (u64)g + 0], rb + hj_group_shift(rb, g)); hj_store(&desc[4 * (u64)g + 1], rn);
     hj_store(&desc[4 * (u64)g + 2], sb + hj_group_shift(sb, g)); hj_store(&desc[4 * (u64)g + 3], sn);
 }
 
-int hj_launch_group_desc(const u64 *roff, const u64 *soff, uint32_t G, uint32_t bins, u64 cap_r, u64 cap_s, u64 *desc, uint32_t *skew, hipStream_t stream)
+int hj_launch_group_desc(const u64 *roff, const u64 *soff, uint32_t G, uint32_t bins, u64 cap_r, u64 cap_s, u64 n_r, u64 n_s, u64 *desc, uint32_t *skew,
+                         hipStream_t stream)
 {
     if (!G || !bins) return HJGPU_EINVAL;
-    hipLaunchKernelGGL(group_desc_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, roff, soff, G, bins, cap_r, cap_s, desc, skew);
+    hipLaunchKernelGGL(group_desc_kernel, dim3((G + 255) / 256), dim3(256), 0, stream, roff, soff, G, bins, cap_r, cap_s, n_r, n_s, desc, skew);
     return hipGetLastError() == hipSuccess ? HJGPU_OK : HJGPU_EHIP;
 }
 

@@ -297,28 +297,33 @@ def test_asynchronous_grouped_joins_in_a_process_with_more_streams_than_hardware
     torch.cuda.synchronize()
     ik, iv, ok, ov = oracle.generate(400_000, 120_000, seed=21)
     want = numpy_join(ik, iv, ok, ov)
-    ctx = H.HjGpu()
+    # one context per stream (a context owns one workspace: include/hjgpu.h), six joins in flight on six streams at once
+    ctxs = [H.HjGpu() for _ in range(6)]
     try:
-        ctx.set_option("group_from", "1000")
-        ctx.set_option("group_always", "1")
-        ctx.set_option("group_inner", str(len(ik) // 6))
-        rk, rv, sk, sv = _cols(ctx, ik, iv, ok, ov)
+        for ctx in ctxs:
+            ctx.set_option("group_from", "1000")
+            ctx.set_option("group_always", "1")
+            ctx.set_option("group_inner", str(len(ik) // 6))
+        rk, rv, sk, sv = _cols(ctxs[0], ik, iv, ok, ov)
         d = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(6)]
         torch.cuda.synchronize()
         callers = [streams[0].cuda_stream, streams[5].cuda_stream, streams[11].cuda_stream, None, streams[23].cuda_stream, streams[2].cuda_stream]
-        for res, st in zip(d, callers):
-            ctx.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, res.data_ptr(), st)
-            for other in streams[::3]:                   # the other streams keep working beside the waiting one
-                with torch.cuda.stream(other):
-                    junk.add_(1)
-        ctx.get_async_status()
+        for rounds in range(3):
+            for ctx, res, st in zip(ctxs, d, callers):
+                ctx.phj_async(rk, rv, len(ik), sk, sv, len(ok), None, res.data_ptr(), st)
+                for other in streams[::3]:               # the other streams keep working beside the joins
+                    with torch.cuda.stream(other):
+                        junk.add_(1)
+        for ctx, st in zip(ctxs, callers):
+            ctx.get_async_status(st)
         torch.cuda.synchronize()
         for res in d:
             assert tuple(int(x) & ((1 << 64) - 1) for x in res.tolist()) == want
-        assert ctx.stats()["groups"] >= 6
+        assert all(ctx.stats()["groups"] >= 6 for ctx in ctxs)
         _free(rk, rv, sk, sv)
     finally:
-        ctx.close()
+        for ctx in ctxs:
+            ctx.close()
 
 
 def test_pass_zero_is_independent_of_the_callers_pass_factors(grouped, oracle):
