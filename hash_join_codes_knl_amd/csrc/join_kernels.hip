@@ -65,6 +65,13 @@ constexpr int hj_join_waves_per_simd(int block, int log2slots)
     return w < 1 ? 1 : w;
 }
 
+// HJ_EMIT4 (build-time, default 1; 0 for A/B): a probe vector whose four tuples matched exactly once each leaves the lane as ONE 16-byte
+// store per result column (EmitterT::emit4) instead of four 4-byte ones.  Round 6, 64 M x 1 G with 10^9 rows, default policy
+// (non-temporal rows), one process, same allocations: join 4.48 -> 3.83 ms (profiles/r06_ab_emit4.txt) - the 4-byte non-temporal
+// stores cost 14 % over plain ones (round 5), whole 16-byte pieces cost nothing, as in K6.
+#ifndef HJ_EMIT4
+#define HJ_EMIT4 1
+#endif
 // NTROWS: result rows through non-temporal stores (EmitterT<true>; JoinArgs::nt_rows) - false only for solo joins
 template <int BLOCK, int LOG2SLOTS, int BATCH, bool PACKED, bool UNIQUE, bool DEDUP = false, bool NTROWS = true>
 __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) void join_kernel(JoinArgs a)
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
             so_ += (u64)val[j] * m;
             si_ += (h1 ? (uint32_t)(t1[j] >> 32) : 0u);
             si_ += (h2 ? (uint32_t)(t2[j] >> 32) : 0u);
-#if !defined(HJ_EMIT4) || !HJ_EMIT4
+#if !HJ_EMIT4
             if (a.ok) {
                 // one emit for "this key matched" (with unique build keys that is every lane of the wave:
                 // 64 rows, the cursor moves in whole lines), a second one only for a key found in BOTH slots
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
             }
 #endif
         }
-#if defined(HJ_EMIT4) && HJ_EMIT4
+#if HJ_EMIT4
         if (a.ok) {
             // a vector whose four probe tuples matched exactly once each (the common case) leaves as ONE 16-byte store per column and
             // lane (EmitterT::emit4); any other vector row by row as before

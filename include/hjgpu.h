@@ -541,7 +541,8 @@ hjgpu_ctx *hjgpu_comm_ctx(hjgpu_comm *comm, int local_rank);
  * the process can exit.  "stall_rank" (k) / "stall_ms" (n): fault injection for tests, loopback transport only - rank
  * k arrives n ms late at every collective.  "exchange_in_place" (0 / 1, default 1): a CPRA rank keeps its own partitions
  * where its partitioning wrote them and receives the others' pieces behind them (no copy of the message to itself);
- * "cpra_two_level" (0 / 1): round 2's CPRA plan (used automatically beyond 8 ranks); "cpra_grouped" (0 / 1 / 2, default 1): the ranks
+ * "cpra_two_level" (0 / 1): round 2's CPRA plan (used automatically beyond 8 ranks); "cpra_grouped" (0 / 1 / 2, default 1; the SAME value on every
+ * rank: it decides whether a collective is issued, ranks that differ would mismatch their collectives): the ranks
  * agree, from the relations' total sizes (one all-reduce of two words before the build side's exchange), whether a rank's share needs a
  * grouped plan (hjgpu_grouped_plan on local rank 0's join context: set "group_from" / "group_inner" / "group_always" alike on every
  * rank); if so the exchange has fan-out ranks, the probe side travels in one slice and every rank runs a whole local join whose plan

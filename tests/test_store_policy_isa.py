@@ -6,7 +6,7 @@ read the damaged partitions back wrong through hipMemcpy and through a fresh ker
 kernels: EVERY global store of EVERY kernel of the library is non-temporal (csrc/hj_device.hpp: hj_store; the clears and
 device-to-device copies are the library's own kernels, not the runtime's plain-storing hipMemsetAsync / hipMemcpyAsync) except
   scatter_kernel<..., NTP = false>   option "solo": K6's 8-byte partial-line stores plain (its 16-byte whole lines stay non-temporal)
-  join_kernel<..., NTROWS = false>   option "solo": the result rows of a blocking join that runs alone on the device
+  join_kernel<..., NTROWS = false>   option "solo": the result rows (4- and 16-byte stores) of a blocking join that runs alone on the device
   fill_probe_kernel                  the placement search's timing fill of candidate allocations (their content is never read)
   random_cas_kernel                  hjgpu_random_cas_ms, a ceiling measurement (what it leaves behind is never read).
 A run-time flag around a store looked right in the source and was WRONG in the binary once - the compiler merged the two branches
@@ -53,7 +53,7 @@ def allowed_plain(name, plain_name):
         flags = re.findall(r"Lb([01])E", name)                 # RANGED, IN_PACKED, OUT_PACKED, CARRY, NTP
         return {"global_store_dwordx2"} if flags[2] == "1" and flags[4] == "0" else None
     if name.startswith("_Z11join_kernel"):
-        return {"global_store_dword"} if re.findall(r"Lb([01])E", name)[3] == "0" else None      # PACKED, UNIQUE, DEDUP, NTROWS
+        return {"global_store_dword", "global_store_dwordx4"} if re.findall(r"Lb([01])E", name)[3] == "0" else None      # PACKED, UNIQUE, DEDUP, NTROWS
     if "fill_probe_kernel" in plain_name or "random_cas_kernel" in plain_name:
         return {"global_store_dwordx4", "global_store_dwordx2"}
     return None
@@ -100,6 +100,8 @@ def test_result_rows_follow_the_policy_in_the_machine_code():
         nt_rows = re.findall(r"Lb([01])E", name)[3] == "1"         # PACKED, UNIQUE, DEDUP, NTROWS
         seen[nt_rows] += 1
         assert stores[("global_store_dword", not nt_rows)] == 0 and stores[("global_store_dword", nt_rows)] >= 3, (name, stores)
+        # (four rows of a lane at once, EmitterT::emit4: one 16-byte store per column, same policy)
+        assert stores[("global_store_dwordx4", not nt_rows)] == 0 and stores[("global_store_dwordx4", nt_rows)] >= 3, (name, stores)
         assert stores[("global_store_dwordx2", False)] == 0, (name, stores)
     assert seen[True] >= 10 and seen[False] >= 10
 
