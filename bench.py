@@ -14,7 +14,7 @@ library's C++ (hjgpu_phj_multi / hjgpu_cpra_multi, include/hjgpu.h); torch.distr
 (gloo: the ncclUniqueId reaches the ranks, barriers around the timed region, max over ranks of the time).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task).  At N = 1 the line also carries, measured in
-the same process: NPJ (configs[1]) and one-GPU CPRA (`secondary`), the materialising PHJ (`materialized`), the
+the same process: NPJ (configs[1]) and one-GPU CPRA (`secondary`), the materialising PHJ (`materialized_default`, `materialized`), the
 CPU restatement of the same PHJ (`cpu_baseline`) and of configs[0] (`cpu_baseline_config0`).
 """
 import argparse
@@ -31,13 +31,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 INNER_FACTOR, OUTER_FACTOR = 0x2545F491, 0x9E3779B1
 # PMC traffic of the kernels (tools/collect_traffic.py): THIS file, and only while its kernel hash is the
 # running library's (hjgpu_kernel_hash) and it was taken on the workload being run
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")
 # the other legs of the N = 1 line: PMC traffic of the same kernels measured through `tools/collect_traffic.py <args>` (the file
 # records the arguments); attached under the same rule as the headline's - same kernel hash, same workload - or null with the reason
-SECONDARY_TRAFFIC = {"npj": ("r05_npj_traffic.json", ["--algo", "npj"]),
-                     "cpra": ("r05_cpra_traffic.json", ["--algo", "cpra"]),
-                     "phj_unique": ("r05_unique_traffic.json", ["--option", "unique=1"]),
-                     "materialized": ("r05_materialized_traffic.json", ["--materialized"])}
+SECONDARY_TRAFFIC = {"npj": ("r06_npj_traffic.json", ["--algo", "npj"]),
+                     "cpra": ("r06_cpra_traffic.json", ["--algo", "cpra"]),
+                     "phj_unique": ("r06_unique_traffic.json", ["--option", "unique=1"]),
+                     "materialized_default": ("r06_materialized_traffic.json", ["--materialized"])}
 MASK64 = (1 << 64) - 1
 
 
@@ -667,7 +667,7 @@ def main():
         "roofline": roofline,
         "roofline_kernels": kernels,
         "traffic_source": traffic_src,
-        "kernel_hash": H.kernel_hash(),
+        "kernel_hash": H.kernel_hash(), "library_hash": H.library_hash(),
         "join_phase": {"gtuples_per_s_per_gpu": round(outer / (join_ms * 1e-3) / 1e9, 2) if join_ms > 0 else None,
                        "ms": round(join_ms, 4),
                        "hbm_read_frac": round(8 * n_tuples / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if join_ms > 0 else None},
@@ -904,7 +904,7 @@ def main():
                                "roofline_join": roof(rw, tj, 1, stream_read_gbs),
                                "block_size": block, "rows_checksum_ok": bool(ok_rows)}
         hj.set_option("solo", "1" if solo else "0")
-        out["materialized"]["traffic_source"] = attach_secondary_traffic(H, "materialized", [(out["materialized"]["roofline_join"], ("join_kernel", "mean"))])
+        out["materialized_default"]["traffic_source"] = attach_secondary_traffic(H, "materialized_default", [(out["materialized_default"]["roofline_join"], ("join_kernel", "mean"))])
         del jk, jo, ji
         for c in jcols:
             c.free()

@@ -94,6 +94,8 @@ struct EmitterT {
     // case).  Every lane's rows are consecutive, so a column leaves the lane as ONE 16-byte store and the wave as one contiguous piece
     // of 64 x 16 bytes: whole 128-byte lines wherever the cursor stands on one.  Round 5 measured the 4-byte non-temporal row stores
     // at +14 % (4.83 against 4.24 ms per 10^9 rows) while K6's whole lines leave FASTER non-temporal than plain.
+    // Needs block_size >= 512: the up to 256 rows of one call spill into at most ONE newly claimed block and never fill it (a cursor
+    // must not come to rest on the first row of a block nobody claimed).
     __device__ __forceinline__ void emit4(const uint32_t (&key)[4], const uint32_t (&outer_val)[4], const uint32_t (&inner_val)[4])
     {
         if (!ok) return;

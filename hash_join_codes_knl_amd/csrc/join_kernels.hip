@@ -282,7 +282,8 @@ __global__ __launch_bounds__(BLOCK, hj_join_waves_per_simd(BLOCK, LOG2SLOTS)) vo
                 const bool h2 = valid[j] && ((uint32_t)t2[j] == key[j]) && !(UNIQUE && h1);
                 once[j] = h1 != h2; twice = twice || (h1 && h2);
             }
-            if (once[0] && once[1] && once[2] && once[3]) {
+            // (a wave's emit4 writes up to 256 rows and claims at most ONE new block: blocks of 512 rows and more)
+            if (once[0] && once[1] && once[2] && once[3] && a.block_size >= 512) {
                 uint32_t iv4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) iv4[j] = (uint32_t)((((uint32_t)t1[j] == key[j]) ? t1[j] : t2[j]) >> 32);

@@ -447,7 +447,7 @@ def test_full_size_property_two_ranks_64m_by_200m_each(worlds):
 # ---------------------------------------------------------------------------------------------------------------
 # round 3: deadlines, status flags across ranks, materialised rows, preflight
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("algo", ["phj", "cpra"])
+@pytest.mark.parametrize("algo", ["phj", "cpra", "phj-grouped", "cpra-grouped"])
 def test_a_stalled_rank_returns_an_error_within_the_deadline(oracle, algo):
     """Fault injection (loopback option "stall_rank"): rank 1 arrives 2.5 s late at a collective while the communicator's
     deadline is 300 ms.  The call must come back with HJGPU_ERCCL naming the rank instead of hanging (the reference's
@@ -455,7 +455,16 @@ def test_a_stalled_rank_returns_an_error_within_the_deadline(oracle, algo):
     later calls fail fast, destroying it works."""
     ik, iv, ok, ov = relations(oracle, "unique", seed=5)
     comm = H.HjComm.local(3, [0, 0, 0], H.TRANSPORT_LOOPBACK)
+    grouped = algo.endswith("-grouped")
+    algo = algo.split("-")[0]
     try:
+        if grouped:
+            # the ranks' local joins take a GROUPED plan (planned on the device, enqueue-only; the rank's thread then waits for its
+            # stream with the communicator's deadline before it asks for the status - never without one)
+            for ctx in comm.ctx:
+                for n, v in (("group_from", "1000"), ("group_always", "1"), ("group_inner", str(max(1000, len(ik) // 12)))):
+                    ctx.set_option(n, v)
+            comm.set_option("cpra_grouped", 2)
         if algo == "phj":
             shards, cols = replicated_shards(comm, ik, iv, ok, ov, 0)
             run = lambda: comm.phj_multi(shards, 0)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The materialising PHJ alone (3 result columns through the block protocol + close_gaps), for profiling:
-    rocprofv3 --kernel-trace --stats ... -- python3 tools/run_materialized.py [steps]
-Prints one JSON line with its times; bench.py reports the same leg as `materialized`."""
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/run_materialized.py [steps] [solo]
+Prints one JSON line with its times; bench.py reports the same leg as `materialized_default` (the library's default policy: rows through
+non-temporal stores) and, with `solo`, as `materialized` (option solo: plain rows)."""
 import json
 import os
 import sys
@@ -18,7 +19,8 @@ def main():
     inner, outer = 64_000_000, 1_000_000_000
     fi, fo = 0x2545F491, 0x9E3779B1
     with H.HjGpu(0) as hj:
-        hj.set_option("solo", "1")       # as bench.py's `materialized` leg: a blocking join in a process that runs nothing else (plain rows)
+        if "solo" in sys.argv[2:]:
+            hj.set_option("solo", "1")   # bench.py's `materialized` leg: a blocking join in a process that runs nothing else (plain rows)
         ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
         hj.generate(1, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
         sums = hj.column_sums(ok, outer, fo, fi)
