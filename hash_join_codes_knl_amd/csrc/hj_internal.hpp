@@ -114,10 +114,10 @@ int hj_allow_dynamic_lds(const void *kernel, int bytes, HjPerDeviceOnce *once);
 // tiles.  K4 counts per range, K5 turns the counts into per-range write bases,
 // and K6 pass 1 walks the same ranges with private cursors - no global atomics.
 constexpr uint32_t HJ_MAX_RANGE_ENTRIES = 1u << 24;   // ranges * F1 kept below this (64 MiB of counts)
-// Independently partitioned chunks of a relation (CPRA: the reference's #threads, cpra2.cpp:1757-1827, 2023; its runs used up
-// to 129+ threads, the result does not depend on the number).  Beyond 8 chunks the plan is always two passes with
+// Independently partitioned chunks of a relation (CPRA: the reference's #threads, cpra2.cpp:1757-1827, 2023; its runs used 129
+// threads and more - `./cpra 129 ...` is taken as asked -, the result does not depend on the number).  Beyond 8 chunks the plan is always two passes with
 // line-aligned final partitions: the join then sees ONE region per partition whatever the number of chunks.
-constexpr uint32_t HJ_MAX_CHUNKS = 64;
+constexpr uint32_t HJ_MAX_CHUNKS = 256;
 // work-claim counters inside MetaLayout::tickets (uint32 words, zeroed per join)
 constexpr uint32_t HJ_TICKET_K4 = 0;                          // K4: [r * HJ_MAX_CHUNKS + chunk]
 constexpr uint32_t HJ_TICKET_K6 = 2 * HJ_MAX_CHUNKS;          // K6: [2 * r + pass - 1]

@@ -1699,7 +1699,7 @@ static int phj_like(hjgpu_ctx *ctx, uint32_t chunks,
     PlainRows plain(ctx, blocking);
     CHK(check_columns(ctx, rk, rv, inner));
     CHK(check_columns(ctx, sk, sv, outer));
-    if (chunks < 1 || chunks > HJ_MAX_CHUNKS) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 64]");
+    if (chunks < 1 || chunks > HJ_MAX_CHUNKS) return fail(ctx, HJGPU_EINVAL, "chunks must be in [1, 256]");
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(refuse_capture(ctx, stream));                    // before anything is allocated or probed

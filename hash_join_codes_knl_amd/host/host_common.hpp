@@ -250,8 +250,8 @@ inline int run_join(int algorithm, const Args &a, hjgpu_result *res, hjgpu_stats
         hjgpu_phj_params pp;
         memset(&pp, 0, sizeof(pp));
         if (algorithm == 2) {
-            // #threads = independently partitioned chunks (cpra2.cpp:1757-1827, 2023); the library takes up to 64
-            pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 64 ? a.threads : (a.threads > 64 ? 64 : 8));
+            // #threads = independently partitioned chunks (cpra2.cpp:1757-1827, 2023; the reference's runs used 129 and more); the library takes up to 256
+            pp.chunks = (uint32_t)(a.threads >= 1 && a.threads <= 256 ? a.threads : (a.threads > 256 ? 256 : 8));
             if ((int)pp.chunks != a.threads)
                 fprintf(stderr, "cpra: %d chunks requested, %u used (the result does not depend on the chunk count)\n", a.threads, pp.chunks);
         }

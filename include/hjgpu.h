@@ -86,7 +86,7 @@ typedef struct {
     uint32_t table_factor[2];  /* odd table hash / step multipliers; 0 = defaults            */
     uint32_t chunks;           /* CPRA only: number of independently partitioned chunks
                                   (the reference's #threads, cpra2.cpp:1757-1827, 2023); 0 = 8;
-                                  1..64 (HJGPU_EINVAL beyond: the result does not depend on it;
+                                  1..256 (HJGPU_EINVAL beyond: the result does not depend on it;
                                   beyond 8 the plan is always two passes)                    */
     uint32_t flags;            /* HJGPU_FLAG_*                                               */
 } hjgpu_phj_params;

@@ -506,8 +506,8 @@ def test_host_programs_end_to_end(hj, oracle, tmp_path):
             assert len(lines[0].split("\t")) >= 3
         else:
             assert lines[0].startswith("copy:\t") and float(lines[1]) > 0
-    # ./cpra 64: the reference takes any #threads (cpra2.cpp:2023); 64 chunks are used as asked, more are capped with a note
-    for threads, note in ((64, False), (129, True)):
+    # ./cpra 129: the reference takes any #threads (cpra2.cpp:2023; its runs used 129 and more); up to 256 chunks are used as asked, more are capped with a note
+    for threads, note in ((64, False), (129, False), (300, True)):
         p = subprocess.run([os.path.join(lib, "cpra"), str(threads), "400000", "90000"], cwd=tmp_path, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
         assert ("join_tuples=%d sum_keys=%d sum_outer_vals=%d sum_inner_vals=%d" % want) in p.stderr

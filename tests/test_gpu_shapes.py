@@ -460,7 +460,7 @@ def test_options_and_communicator_argument_errors(hj):
         c.free()
 
 
-@pytest.mark.parametrize("chunks", [9, 16, 33, 64])
+@pytest.mark.parametrize("chunks", [9, 16, 33, 64, 129, 256])
 def test_cpra_with_more_chunks_than_eight(hj, chunks):
     """CPRA's chunks are the reference's #threads (cpra2.cpp:1757-1827, 2023: any thread count; its runs used 129 and more).
     Beyond 8 chunks the plan is always two passes with line-aligned final partitions (one region per partition whatever the
@@ -485,19 +485,19 @@ def test_cpra_with_more_chunks_than_eight(hj, chunks):
     with pytest.raises(H.HjGpuError):
         hj.cpra(rk, rk, len(ik), rk, rk, len(ik), H.PhjParams(chunks=chunks, fanout1=64, fanout2=1))
     with pytest.raises(H.HjGpuError):
-        hj.cpra(rk, rk, len(ik), rk, rk, len(ik), H.PhjParams(chunks=65))
+        hj.cpra(rk, rk, len(ik), rk, rk, len(ik), H.PhjParams(chunks=257))
     rk.free()
 
 
 def test_full_size_cpra_in_64_chunks(hj):
-    """64 M x 1 G in 64 chunks (./cpra 64 ...): the same aggregates as in 8 chunks and as PHJ"""
+    """64 M x 1 G in 64 and in 129 chunks (./cpra 129 ...: the reference's own thread count, cpra2.cpp:2023): the same aggregates as in 8 chunks and as PHJ"""
     inner, outer = 64_000_000, 1_000_000_000
     fi, fo = 0x2545F491, 0x9E3779B1
     ik, iv, ok, ov = hj.column(inner), hj.column(inner), hj.column(outer), hj.column(outer)
     hj.generate(5, inner, outer, 0, outer, fi, fo, ik, iv, ok, ov)
     sums = hj.column_sums(ok, outer, fo, fi)
     want = (outer, sums[0], sums[1], sums[2])
-    for chunks in (8, 64, 37):
+    for chunks in (8, 64, 37, 129):
         assert hj.cpra(ik, iv, inner, ok, ov, outer, H.PhjParams(chunks=chunks)) == want
     for c in (ik, iv, ok, ov):
         c.free()
