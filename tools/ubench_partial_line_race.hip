@@ -138,14 +138,19 @@ static void launch_writer(int store, bool priv, int cus, size_t lds, hipStream_t
     if (store == 2 && priv) launch_writer_t<2, true>(cus, lds, st, out, runs, rot, tf, iter, ticket, sink);
 }
 
-struct Mode { const char *name; int store; bool priv; int neighbours; bool flat_priority; };
+struct Mode { const char *name; int store; bool priv; int neighbours; bool flat_priority; bool deps; };
 static const Mode modes[] = {
-    {"plain stores, alone on the device", 0, false, 0, false},
-    {"plain stores, tiny kernels + stream + copies on a second stream (priorities apart)", 0, false, 1, false},
-    {"plain stores, the same on two more streams, ONE priority", 0, false, 2, true},
-    {"plain stores + one private word in the writer, neighbours on two streams", 0, true, 2, true},
-    {"non-temporal partial-line stores only (the product's solo K6), neighbours on two streams", 2, false, 2, true},
-    {"all stores non-temporal (the product's default K6), neighbours on two streams", 1, false, 2, true},
+    {"plain stores, alone on the device", 0, false, 0, false, false},
+    {"plain stores, tiny kernels + stream + copies on a second stream (priorities apart)", 0, false, 1, false, false},
+    {"plain stores, the same on two more streams, ONE priority", 0, false, 2, true, false},
+    {"plain stores + one private word in the writer, neighbours on two streams", 0, true, 2, true, false},
+    {"non-temporal partial-line stores only (the product's solo K6), neighbours on two streams", 2, false, 2, true, false},
+    {"all stores non-temporal (the product's default K6), neighbours on two streams", 1, false, 2, true, false},
+    // what the library's pipelines have beside K6 and the modes above lack: kernels that WAIT FOR EVENTS OF ANOTHER QUEUE (their
+    // dispatch carries a wider acquire), copies from and to page-locked HOST memory in both directions, host-side event waits
+    {"plain stores; neighbours chained across two streams by events, with host <-> device copies", 0, false, 2, true, true},
+    {"plain stores + private word; the same neighbours", 0, true, 2, true, true},
+    {"all stores non-temporal; the same neighbours", 1, false, 2, true, true},
 };
 
 int main(int argc, char **argv)
@@ -179,6 +184,11 @@ int main(int argc, char **argv)
     CHECK(hipMemcpy(d_tf, tile_first.data(), (TILES + 1) * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(d_out, 0, SLOTS * 8)); CHECK(hipMemset(d_nb, 1, nb_vecs * 16)); CHECK(hipMemset(d_ticks, 0, 256));
     std::vector<u64> h_out(SLOTS);
+    void *h_pin = nullptr;
+    CHECK(hipHostMalloc(&h_pin, 4 << 20, hipHostMallocDefault));
+    memset(h_pin, 7, 4 << 20);
+    hipEvent_t ev_dep[2];
+    for (hipEvent_t &e : ev_dep) CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const size_t lds = 150 * 1024;
     const void *writers[3][2] = {{(const void *)writer_kernel<0, false>, (const void *)writer_kernel<0, true>},
                                  {(const void *)writer_kernel<1, false>, (const void *)writer_kernel<1, true>},
@@ -208,7 +218,20 @@ int main(int argc, char **argv)
                     hipLaunchKernelGGL(stream_kernel, dim3(cus), dim3(512), 0, sn[i], d_nb, nb_vecs / 8, (uint4 *)d_sink + 4); ++boundaries;
                     hipLaunchKernelGGL(copy_kernel, dim3(cus / 2), dim3(512), 0, sn[i], d_nb, d_nb2, nb_vecs / 16); ++boundaries;
                     CHECK(hipMemcpyAsync(d_nb2 + (nb_vecs / 2), d_nb, 1 << 20, hipMemcpyDeviceToDevice, sn[i])); ++boundaries;
+                    if (md.deps) {
+                        // host -> device, a kernel behind it, an event; the OTHER neighbour stream waits for that event, runs a kernel, copies
+                        // device -> host: every kernel here starts behind another queue's work or a copy engine's
+                        const int o = 1 - i;
+                        CHECK(hipMemcpyAsync(d_nb2 + (nb_vecs / 4) * (size_t)(i + 1), h_pin, 1 << 20, hipMemcpyHostToDevice, sn[i])); ++boundaries;
+                        hipLaunchKernelGGL(copy_kernel, dim3(cus / 4), dim3(512), 0, sn[i], d_nb2 + (nb_vecs / 4) * (size_t)(i + 1), d_nb2, (u64)(1 << 16)); ++boundaries;
+                        CHECK(hipEventRecord(ev_dep[i], sn[i]));
+                        CHECK(hipStreamWaitEvent(sn[o], ev_dep[i], 0));
+                        hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, sn[o], d_ticks + 16 * o); ++boundaries;
+                        CHECK(hipMemcpyAsync((char *)h_pin + (2 << 20) + (o << 19), d_nb2, 1 << 19, hipMemcpyDeviceToHost, sn[o])); ++boundaries;
+                    }
                 }
+            // (the pipelines' K6 launches start behind events of other streams - the exchange's arrival -: so does this writer)
+            if (md.deps && md.neighbours) CHECK(hipStreamWaitEvent(sw, ev_dep[0], 0));
             hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(1), 0, sw, d_ticket);
             CHECK(hipMemsetAsync(d_rep, 0, sizeof(Report), sw));
             launch_writer(md.store, md.priv, cus, lds, sw, d_out, d_runs, d_rot, d_tf, iter, d_ticket, d_sink);
