@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, review item 1d: >= 20 000 checked steps through each pipeline that runs several streams side by side, on the library of THIS
 # tree (the part stops before it measures anything when the built library is another one).  Every log starts with the library hash.
-#   tools/r06_soak.sh npj | phj | phj2 | host | grouped | cpra      [steps]
+#   tools/r06_soak.sh npj | phj | phj2 | host | grouped | cpra | cprarows | phjrows      [steps]
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export GRAFT_REPO_ROOT=$PWD TMPDIR=/tmp NCCL_SOCKET_IFNAME=lo
 mkdir -p gpurun_out
@@ -27,6 +27,8 @@ npj)     run python3 tools/stress_cpra.py --algo npj --steps $steps ;;
 phj)     run python3 tools/stress_cpra.py --algo phj --steps $steps ;;
 phj2)    run python3 tools/stress_cpra.py --algo phj --steps $steps --world 2 --transport loopback ;;
 cpra)    run python3 tools/stress_cpra.py --algo cpra --steps $steps --slices 8 ;;
+cprarows) run python3 tools/stress_cpra.py --algo cpra --steps $steps --slices 8 --rows ;;
+phjrows) run python3 tools/stress_cpra.py --algo phj --steps $steps --rows ;;
 host)    run python3 tools/stress_host_rows.py --algo phj --steps $steps ;;
 grouped) run python3 tools/stress_async_grouped.py --steps $((steps / 2)) --depth 2 ;;
 *) echo "unknown part $part"; exit 2;;

@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--algo", default="cpra", choices=["cpra", "phj", "npj"], help="phj / npj: the build side replicated from rank 0, the probe side sharded")
+    ap.add_argument("--rows", action="store_true", help="materialise the result (hjgpu_*_multi_rows: per-rank dense rows) and check the ROWS every step: their number and the "
+                    "sums of the three result columns, read back by a kernel of its own (a lost row store or close_gaps move does not change the join's aggregates)")
     ap.add_argument("--world", type=int, default=1)
     ap.add_argument("--transport", default="rccl")
     ap.add_argument("--slices", type=int, default=8)
@@ -157,11 +159,35 @@ def main():
                 print("    rank %d %s context, stage %d: on the call's stream %s | fresh kernel, device quiet %s | host copy %s | input %s -> %s"
                       % (rank, "join" if which else "partitioning", stage, first[stage], fresh, host, want, verdict), flush=True)
 
+    outs = None
+    if a.rows:
+        # every rank's result columns: its share of the rows (selectivity 1: one row per probe tuple) plus the open blocks' slack
+        outs, block = [], 4096
+        for g in range(G):
+            ctx = comm.ctx[g]
+            cap = ctx.output_capacity(0 if a.algo == "npj" else 1, a.outer // G, 2 * (a.outer // G) if a.algo == "cpra" else a.outer // G, block)
+            outs.append((ctx.column(cap, placed=True), ctx.column(cap, placed=True), ctx.column(cap, placed=True), cap, block))
     bad = 0
     for s in range(a.steps):
         if s and s % 1000 == 0:
             print("... %d steps, %d wrong so far" % (s, bad), flush=True)
-        if a.algo == "cpra":
+        if a.rows:
+            pp = H.PhjParams(flags=H.FLAG_UNIQUE) if a.unique else None
+            if a.algo == "cpra":
+                got, st, counts = comm.cpra_multi_rows(shards, outs, pp, a.slices)
+            elif a.algo == "phj":
+                got, st, counts = comm.phj_multi_rows(shards, outs, 0, pp)
+            else:
+                got, st, counts = comm.npj_multi_rows(shards, outs, 0, H.NpjParams(flags=H.FLAG_UNIQUE) if a.unique else None)
+            # the rows themselves: every rank's dense prefix summed by a kernel of its own, column by column
+            rows = [sum(counts), 0, 0, 0]
+            for g in range(G):
+                for c in range(3):
+                    rows[c + 1] = (rows[c + 1] + comm.ctx[g].column_sums(outs[g][c], counts[g], 1, 1)[0]) & ((1 << 64) - 1)
+            if rows != expect:
+                bad += 1
+                print("step %d WRONG ROWS: count %+d, column sums %s" % (s, rows[0] - expect[0], ["%+d" % ((x - y + (1 << 63)) % (1 << 64) - (1 << 63)) for x, y in zip(rows[1:], expect[1:])]), flush=True)
+        elif a.algo == "cpra":
             got, st = comm.cpra_multi(shards, H.PhjParams(flags=H.FLAG_UNIQUE) if a.unique else None, a.slices)
         elif a.algo == "phj":
             got, st = comm.phj_multi(shards, 0, H.PhjParams(flags=H.FLAG_UNIQUE) if a.unique else None)
@@ -174,7 +200,7 @@ def main():
                 report(s)
         elif (a.forensics or a.freeze) and s == 0:
             report(s, a.recheck_first)
-    print("%s %s world %d slices %d options %s: %d of %d steps wrong, last %.2f ms" % (a.algo, a.transport, G, a.slices, a.option + a.ctx_option + (["unique"] if a.unique else []), bad, a.steps, st["ms_wall"]), flush=True)
+    print("%s%s %s world %d slices %d options %s: %d of %d steps wrong, last %.2f ms" % (a.algo, " with rows (checked on their own)" if a.rows else "", a.transport, G, a.slices, a.option + a.ctx_option + (["unique"] if a.unique else []), bad, a.steps, st["ms_wall"]), flush=True)
     if has_dbg:
         # HJ_SCRATCH_EXPERIMENT variants 2-4: values that came back from the private segment, compared in the kernel
         d = (ctypes.c_uint64 * 40)()
