@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, review item 1d: >= 20 000 checked steps through each pipeline that runs several streams side by side, on the library of THIS
 # tree (the part stops before it measures anything when the built library is another one).  Every log starts with the library hash.
-#   tools/r06_soak.sh npj | phj | phj2 | host | grouped | cpra | cprarows | phjrows      [steps]
+#   tools/r06_soak.sh npj | phj | phj2 | host | grouped | cpra | cprarows | phjrows | phjgrouped | cpragrouped | blockgrouped      [steps]
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export GRAFT_REPO_ROOT=$PWD TMPDIR=/tmp NCCL_SOCKET_IFNAME=lo
 mkdir -p gpurun_out
@@ -29,6 +29,10 @@ phj2)    run python3 tools/stress_cpra.py --algo phj --steps $steps --world 2 --
 cpra)    run python3 tools/stress_cpra.py --algo cpra --steps $steps --slices 8 ;;
 cprarows) run python3 tools/stress_cpra.py --algo cpra --steps $steps --slices 8 --rows ;;
 phjrows) run python3 tools/stress_cpra.py --algo phj --steps $steps --rows ;;
+# grouped plans (planned on the device) as the local joins of the multi-GPU calls, and blocking on one stream
+phjgrouped)  run python3 tools/stress_cpra.py --algo phj --steps $steps --ctx-option group_from=1000 --ctx-option group_always=1 --ctx-option group_inner=16000000 ;;
+cpragrouped) run python3 tools/stress_cpra.py --algo cpra --steps $steps --slices 4 --option cpra_grouped=2 --ctx-option group_from=1000 --ctx-option group_always=1 --ctx-option group_inner=16000000 ;;
+blockgrouped) run python3 tools/stress_single.py --algo phj --steps $steps --ctx-option group_from=1000 --ctx-option group_always=1 --ctx-option group_inner=16000000 ;;
 host)    run python3 tools/stress_host_rows.py --algo phj --steps $steps ;;
 grouped) run python3 tools/stress_async_grouped.py --steps $((steps / 2)) --depth 2 ;;
 *) echo "unknown part $part"; exit 2;;
