@@ -12,6 +12,8 @@ mkdir -p gpurun_out
 quiet() { grep --line-buffered -v "amdgpu.ids\|^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl"; }
 {
 echo "# lost store or stale read, $(date -u +%FT%RZ), $(uname -r)"
+# which physical GPU this is (the rate of wrong steps differs from box to box by more than chance allows)
+/opt/rocm/bin/rocm-smi --showuniqueid --showserial --showbus 2>/dev/null | grep -i "unique\|serial\|bus" | head -6
 echo "## control: the product library, 30 steps"
 timeout -k 10 200 python3 tools/stress_cpra.py --steps 30 --slices ${3:-8} --freeze 2>&1 | quiet
 echo "## variant ${4:-plain} (tools/build_variant.py: plain = every K6 store plain, plain16 = only the 16-byte whole-line stores plain), one priority for all streams"
