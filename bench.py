@@ -650,6 +650,9 @@ def main():
         "metric": "probe Gtuples/s + % HBM roofline, PHJ |R|=64M join |S|=1G, 1/2/4/8 GPU",
         "value": round(value, 3), "unit": "Gtuples/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        # the host's share of a step: wall clock per step minus the device time between the join's first and last event (N = 1: the
+        # blocking call's enqueue lead, its copy of the state block and the synchronisation; `value` is priced on the wall clock)
+        "ms_host_per_step": round(ms_per_step - avg["ms_total"], 4) if not multi else None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s end-to-end (histogram + %s + LDS build/probe, aggregate output), "
